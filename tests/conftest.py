@@ -1,0 +1,36 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def cases():
+    with open(os.path.join(GOLDEN_DIR, "cases.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    """golden('loop_res') -> dict of arrays minted from the reference (tests/golden/make_golden.py)."""
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+                cache[name] = {k: z[k] for k in z.files}
+        return cache[name]
+
+    return load

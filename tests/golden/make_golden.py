@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Mint known-answer vectors for the DDIM hot path from the REFERENCE's own classes.
+
+Runs only in the build container (needs /root/reference; see ref_import.py).  The reference ships
+no tests or golden vectors for this path, so these fixtures ARE the pin: each
+``*.npz`` holds the OUTPUTS the reference's unmodified Python classes produced on CPU fp32 for
+inputs / weights that ``diffusiondepth_amd.synth`` re-creates bit-for-bit from a seed (so inputs
+are not stored).  Re-run:   python tests/golden/make_golden.py
+
+Cases (all eval mode, fp32, torch CPU):
+  sched.npz      DDIMScheduler tables, timesteps, step() and add_noise() outputs
+  denoise_res    ScheduledCNNRefine.forward, scalar t and per-sample t          (Res variant)
+  denoise_swin   ScheduledCNNRefine.forward of the Swin variant (UpSample_add fuse)
+  loop_res       CNNDDIMPipiline.__call__ T=5 and T=20 (x_T injected by patching torch.randn)
+  loop_swin      same for the Swin variant, T=20
+  codec          DeepDepthTransformWithUpsampling.t / inv_t (even and odd sizes)
+  head_res       full DDIMDepthEstimate_Res.forward (FPN + loop + decoder + ddim_loss), RNG injected
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from ref_import import load_reference, load_weights  # noqa: E402
+from diffusiondepth_amd import synth  # noqa: E402
+
+CASES = json.load(open(os.path.join(HERE, "cases.json")))
+
+
+class inject_rng:
+    """Make torch.randn / torch.randint return prepared tensors in call order (the reference draws
+    x_T with torch.randn (…res.py:277), the loss noise with torch.randn (:203) and the timesteps with
+    torch.randint (:207))."""
+
+    def __init__(self, randn_list=(), randint_list=()):
+        self.randn_list = [torch.from_numpy(np.asarray(a)) for a in randn_list]
+        self.randint_list = [torch.from_numpy(np.asarray(a)) for a in randint_list]
+
+    def __enter__(self):
+        self._randn, self._randint = torch.randn, torch.randint
+
+        def randn(*a, **k):
+            return self.randn_list.pop(0).clone()
+
+        def randint(*a, **k):
+            return self.randint_list.pop(0).clone()
+
+        torch.randn, torch.randint = randn, randint
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn, torch.randint = self._randn, self._randint
+        assert not self.randn_list and not self.randint_list, "unused injected RNG draws"
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def build(ref, case):
+    variant = case.get("variant", "res")
+    sd = synth.make_state_dict(case["wseed"], variant, case.get("decoder_gain", 0.05), case.get("decoder_log_scale", 0.0))
+    Model = ref.ScheduledCNNRefine if variant == "res" else ref.ScheduledCNNRefineSwin
+    model = load_weights(Model(channels_in=256, channels_noise=16).eval(), sd, "model.")
+    codec = load_weights(ref.DeepDepthTransformWithUpsampling(hidden=16).eval(), sd, "depth_transform.")
+    sched = ref.DDIMScheduler(num_train_timesteps=1000, clip_sample=False)
+    return sd, model, codec, sched
+
+
+def gen_sched(ref):
+    c = CASES["sched"]
+    s = ref.DDIMScheduler(num_train_timesteps=1000, clip_sample=False)
+    out = {"alphas_cumprod": s.alphas_cumprod.numpy().copy(), "betas": s.betas.numpy().copy()}
+    rs = np.random.RandomState(c["seed"])
+    x = rs.standard_normal(c["shape"]).astype(np.float32)
+    eps = np.abs(rs.standard_normal(c["shape"])).astype(np.float32)
+    for T in c["T"]:
+        s.set_timesteps(T)
+        out[f"timesteps_T{T}"] = s.timesteps.numpy().copy()
+        prevs = []
+        for t in s.timesteps:
+            prevs.append(t2n(s.step(torch.from_numpy(eps), t, torch.from_numpy(x), eta=0.0,
+                                    use_clipped_model_output=True)["prev_sample"]))
+        out[f"step_T{T}"] = np.stack(prevs)
+    B = len(c["add_noise_t"])
+    x0 = rs.standard_normal((B,) + tuple(c["shape"][1:])).astype(np.float32)
+    nz = rs.standard_normal((B,) + tuple(c["shape"][1:])).astype(np.float32)
+    s2 = ref.DDIMScheduler(num_train_timesteps=1000, clip_sample=False)
+    out["add_noise"] = t2n(s2.add_noise(torch.from_numpy(x0), torch.from_numpy(nz), torch.tensor(c["add_noise_t"])))
+    return out
+
+
+def gen_denoise(ref, name):
+    c = CASES[name]
+    sd, model, _, _ = build(ref, c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c.get("cond_hw"))
+    x, cond = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"])
+    out = {}
+    with torch.no_grad():
+        out["eps_scalar_t"] = t2n(model(x, torch.tensor(c["t"]), cond, None, None, None))
+        out["eps_batch_t"] = t2n(model(x, torch.from_numpy(inp["timesteps"]), cond, None, None, None))
+        out["ne_sample0_ch0_8"] = t2n(model.noise_embedding(x))[:1, :8]
+    return out
+
+
+def gen_loop(ref, name):
+    c = CASES[name]
+    sd, model, codec, sched = build(ref, c)
+    Pipe = ref.CNNDDIMPipiline if c.get("variant", "res") == "res" else ref.CNNDDIMPipilineSwin
+    pipe = Pipe(model, sched)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c.get("cond_hw"))
+    cond = torch.from_numpy(inp["cond"])
+    out = {}
+    for T in c["T"]:
+        with torch.no_grad(), inject_rng([inp["x_T"]]):
+            x0, = pipe(batch_size=c["B"], device=torch.device("cpu"), dtype=torch.float32,
+                       shape=(16, c["h"], c["w"]), input_args=(cond, None, None, None),
+                       num_inference_steps=T, return_dict=False)
+            out[f"x0_T{T}"] = t2n(x0)
+            out[f"depth_T{T}"] = t2n(codec.inv_t(x0))
+    return out
+
+
+def gen_codec(ref):
+    c = CASES["codec"]
+    sd, _, codec, _ = build(ref, c)
+    out = {}
+    for i, (B, H, W) in enumerate(c["sizes"]):
+        gt = synth.make_gt_depth(c["iseed"] + i, B, H, W)
+        with torch.no_grad():
+            lat = codec.t(torch.from_numpy(gt))
+            out[f"latent_{i}"] = t2n(lat)
+            h, w = synth.latent_hw(H, W)
+            z = np.random.RandomState(c["iseed"] + 100 + i).standard_normal((B, 16, h, w)).astype(np.float32) * c["latent_scale"]
+            out[f"depth_{i}"] = t2n(codec.inv_t(torch.from_numpy(z)))
+    return out
+
+
+def gen_head(ref):
+    c = CASES["head_res"]
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    fsd = synth.make_fpn_state_dict(c["fseed"])
+    head = ref.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=c["T"],
+                                     num_train_timesteps=1000, depth_feature_dim=16, loss_cfgs=[]).eval()
+    own = head.state_dict()
+    full = {}
+    full.update({k: torch.from_numpy(v) for k, v in sd.items()})
+    full.update({k: torch.from_numpy(v) for k, v in fsd.items()})
+    for k in own:
+        if k.endswith("num_batches_tracked"):
+            full[k] = own[k]
+    assert set(full) == set(own), (set(own) ^ set(full))
+    head.load_state_dict(full, strict=True)
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+    with torch.no_grad(), inject_rng([inp["x_T"], inp["noise"]], [inp["timesteps"]]):
+        o = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+    assert set(o) == set(c["output_keys"]), set(o)
+    # condition map for the hot-path-only tests
+    with torch.no_grad():
+        x = None
+        for i in range(4):
+            f = fp[3 - i]
+            cur = head.conv_lateral[3 - i](f)
+            if i > 0:
+                cur = cur + torch.nn.functional.adaptive_avg_pool2d(head.conv_up[3 - i](x), output_size=cur.shape[-2:])
+            x = cur
+    return {"pred": t2n(o["pred"]), "pred_init": t2n(o["pred_init"]), "ddim_loss": t2n(o["ddim_loss"]).reshape(1),
+            "cond_ch0_4": t2n(x)[:, :4], "cond_sum": np.array([float(x.double().sum())])}
+
+
+def main():
+    ref = load_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    gens = {
+        "sched": lambda: gen_sched(ref),
+        "denoise_res": lambda: gen_denoise(ref, "denoise_res"),
+        "denoise_swin": lambda: gen_denoise(ref, "denoise_swin"),
+        "loop_res": lambda: gen_loop(ref, "loop_res"),
+        "loop_res_far": lambda: gen_loop(ref, "loop_res_far"),
+        "loop_swin": lambda: gen_loop(ref, "loop_swin"),
+        "codec": lambda: gen_codec(ref),
+        "head_res": lambda: gen_head(ref),
+    }
+    only = sys.argv[1:]
+    for name, fn in gens.items():
+        if only and name not in only:
+            continue
+        out = fn()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  keys={sorted(out)}")
+
+
+if __name__ == "__main__":
+    main()

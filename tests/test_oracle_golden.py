@@ -1,0 +1,117 @@
+"""CPU: pin the NumPy oracle (oracle/ddim_oracle.py) to the known-answer vectors minted from the
+reference's own classes (tests/golden/make_golden.py).  Tolerances are fp32-vs-fp64 round-off of the
+reference's own fp32 run, scaled to the magnitude of the quantity checked."""
+import numpy as np
+import pytest
+
+from diffusiondepth_amd import synth
+from oracle import ddim_oracle as O
+
+
+def _sd(c):
+    return synth.make_state_dict(c["wseed"], c.get("variant", "res"), c.get("decoder_gain", 0.05),
+                                 c.get("decoder_log_scale", 0.0))
+
+
+def test_schedule_tables_bit_exact(golden):
+    g = golden("sched")
+    s = O.DDIMScheduleOracle()
+    assert np.array_equal(s.betas, g["betas"])
+    assert np.array_equal(s.alphas_cumprod, g["alphas_cumprod"])
+    # values quoted in BASELINE.md section 4
+    assert abs(float(s.alphas_cumprod[0]) - 0.9998999834) < 1e-9
+    assert abs(float(s.alphas_cumprod[999]) - 4.0358e-05) < 1e-9
+
+
+def test_torch_linspace_restatement_matches_torch():
+    import torch
+    for (a, b, n) in [(1e-4, 0.02, 1000), (1e-4, 0.02, 100), (0.0, 1.0, 7)]:
+        assert np.array_equal(O._torch_linspace_f32(a, b, n), torch.linspace(a, b, n, dtype=torch.float32).numpy())
+
+
+@pytest.mark.parametrize("T", [5, 20, 50])
+def test_timesteps_and_step(golden, cases, T):
+    g = golden("sched")
+    c = cases["sched"]
+    s = O.DDIMScheduleOracle()
+    ts = s.set_timesteps(T)
+    assert np.array_equal(ts, g[f"timesteps_T{T}"])
+    rs = np.random.RandomState(c["seed"])
+    x = rs.standard_normal(c["shape"]).astype(np.float32)
+    eps = np.abs(rs.standard_normal(c["shape"])).astype(np.float32)
+    for i, t in enumerate(ts):
+        lit = s.step(eps.astype(np.float64), t, x.astype(np.float64))
+        c1, c2 = s.coeffs(t)
+        closed = c1 * x + c2 * eps
+        # literal fp64 == closed form; reference fp32 step() within fp32 round-off (amplified by 1/sqrt(abar_t))
+        assert np.abs(lit - closed).max() < 1e-12
+        assert np.abs(lit - g[f"step_T{T}"][i]).max() < 2e-5
+
+
+def test_coeff_table_values_from_baseline():
+    s = O.DDIMScheduleOracle()
+    s.set_timesteps(20)
+    want = {950: (1.5963930, -0.5964435), 900: (1.5564218, -0.5565388), 500: (1.2718236, -0.2863844),
+            50: (1.0153209, -0.1660005), 0: (1.0000500, -0.0100013)}
+    for t, (c1, c2) in want.items():
+        g1, g2 = s.coeffs(t)
+        assert abs(g1 - c1) < 2e-6 and abs(g2 - c2) < 2e-6
+    prod = np.prod([s.coeffs(t)[0] for t in s.timesteps])
+    assert abs(prod - 97.109) < 5e-3
+
+
+def test_add_noise(golden, cases):
+    c = cases["sched"]
+    rs = np.random.RandomState(c["seed"])
+    rs.standard_normal(c["shape"]); rs.standard_normal(c["shape"])
+    B = len(c["add_noise_t"])
+    x0 = rs.standard_normal((B,) + tuple(c["shape"][1:])).astype(np.float32)
+    nz = rs.standard_normal((B,) + tuple(c["shape"][1:])).astype(np.float32)
+    got = O.DDIMScheduleOracle().add_noise(x0, nz, c["add_noise_t"])
+    assert np.abs(got - golden("sched")["add_noise"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["denoise_res", "denoise_swin"])
+def test_denoiser_single_call(golden, cases, name):
+    c, g = cases[name], golden(name)
+    sd = _sd(c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c.get("cond_hw"))
+    eps, mid = O.denoiser_forward(sd, inp["x_T"], c["t"], inp["cond"], c["variant"], return_intermediates=True)
+    assert np.abs(eps - g["eps_scalar_t"]).max() < 2e-5
+    assert np.abs(mid["ne"][:1, :8] - g["ne_sample0_ch0_8"]).max() < 2e-5
+    eps_b = O.denoiser_forward(sd, inp["x_T"], inp["timesteps"], inp["cond"], c["variant"])
+    assert np.abs(eps_b - g["eps_batch_t"]).max() < 2e-5
+    assert eps.min() >= 0.0          # final GN+ReLU: predicted noise is non-negative
+
+
+@pytest.mark.parametrize("name", ["loop_res", "loop_res_far", "loop_swin"])
+def test_ddim_loop_and_decode(golden, cases, name):
+    c, g = cases[name], golden(name)
+    sd = _sd(c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c.get("cond_hw"))
+    for T in c["T"]:
+        x0 = O.ddim_loop(sd, inp["x_T"], inp["cond"], T, c["variant"])
+        ref = g[f"x0_T{T}"]
+        scale = np.abs(ref).max()
+        # the reference's fp32 run carries ~1e-6 relative round-off on |x_0| ~ 1e2
+        assert np.abs(x0 - ref).max() < 3e-6 * scale, (np.abs(x0 - ref).max(), scale)
+        d = O.decode(sd, x0, dtype=np.float64)
+        dref = g[f"depth_T{T}"]
+        assert np.abs(d - dref).max() < 1e-3, np.abs(d - dref).max()      # the north-star tolerance
+        assert (np.abs(d - dref) / np.maximum(dref, 1e-2)).max() < 5e-5
+
+
+def test_codec(golden, cases):
+    c, g = cases["codec"], golden("codec")
+    sd = _sd(c)
+    for i, (B, H, W) in enumerate(c["sizes"]):
+        gt = synth.make_gt_depth(c["iseed"] + i, B, H, W)
+        lat = O.encode(sd, gt)
+        assert lat.shape == g[f"latent_{i}"].shape == (B, 16) + synth.latent_hw(H, W)
+        assert np.abs(lat - g[f"latent_{i}"]).max() < 2e-5   # fp32 round-off of pre-tanh values ~|80 m * w|
+        h, w = synth.latent_hw(H, W)
+        z = np.random.RandomState(c["iseed"] + 100 + i).standard_normal((B, 16, h, w)).astype(np.float32) * c["latent_scale"]
+        d = O.decode(sd, z)
+        dref = g[f"depth_{i}"]
+        assert d.shape == dref.shape == (B, 1, 2 * h, 2 * w)
+        assert (np.abs(d - dref) / np.maximum(np.abs(dref), 1e-2)).max() < 2e-5
