@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- depth-maps/second of the DDIM denoise hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--precision bf16] [--batch B] [--size kitti|nyu]
+
+One "step" = one pass of the hot path over one batch of B synthetic depth maps resident in HBM:
+latent encoder -> T-step DDIM loop (one hipGraph replay) -> latent decoder.  N > 1 is launched by
+torch.distributed.run, one process per GPU; the path shards by independent images, so there is no
+data-path collective (scaling "weak": B maps per GPU per step).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line (tier contract):
+  roofline      dominant kernel (conv3x3 implicit GEMM) measured live with hipEvents on the launch
+                stream (library option "layer_timing"): achieved TFLOP/s = algorithmic FLOPs per launch
+                (2*9*Cin*Cout*B*h*w) / mean launch duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline  the torch-CPU port of the reference path (oracle/torch_cpu_port.py) timed on this
+                host's cores for ONE map of the same workload (N = 1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+SIZES = {"kitti": (352, 1216), "nyu": (228, 304), "plumbing": (128, 128)}
+FLOP_PER_PIXEL_STEP = 2 * 9 * (16 * 64 + 64 * 256 + 256 * 64 + 64 * 16)       # 626 688
+LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16)}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "naive_fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "naive_fp32": "f32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=sorted(PEAK_TFLOPS))
+    ap.add_argument("--batch", type=int, default=1, help="depth maps per GPU per step (reference test(): batch 1)")
+    ap.add_argument("--size", default="kitti", choices=sorted(SIZES))
+    ap.add_argument("--T", type=int, default=20, help="DDIM inference steps (reference --inference_steps)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import diffusiondepth_amd as dda
+    from diffusiondepth_amd import synth
+
+    H, W = SIZES[args.size]
+    h, w = synth.latent_hw(H, W)
+    B, T = args.batch, args.T
+    sd = synth.make_state_dict(7240)
+    be = dda.HipDenoiser(dev)
+    be.load_state_dict(sd)
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    if args.no_graph:
+        be.set_option("graph", 0)
+    inp = synth.make_inputs(7240 + rank, B, h, w)
+    x_T = torch.from_numpy(inp["x_T"]).to(dev)
+    cond = torch.from_numpy(inp["cond"]).to(dev)
+    gt = torch.from_numpy(synth.make_gt_depth(7240 + rank, B, H, W)).to(dev)
+    x0 = torch.empty_like(x_T)
+
+    def step():
+        lat = be.encode(gt)                                   # 'pred_init' output of the head
+        be.denoise(x_T, cond, T, args.precision, out=x0)      # the T-step loop (hipGraph replay)
+        depth = be.decode(x0)
+        return lat, depth
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, depth = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(depth).all()
+
+    # ---- loop-only time of one graph replay (hipEvents on the launch stream) ----------------------
+    be.set_option("timing", 1)
+    be.denoise(x_T, cond, T, args.precision, out=x0)
+    loop_ms = be.last_loop_ms()
+    be.set_option("timing", 0)
+
+    # ---- per-kernel roofline: eager pass with an event pair around every conv launch ------------------
+    roof = None
+    if args.precision != "naive_fp32":
+        be.set_option("layer_timing", 1)
+        for _ in range(2):
+            be.denoise(x_T, cond, T, args.precision, out=x0)
+        torch.cuda.synchronize(dev)
+        per_layer = {l: be.layer_ms(l) for l in (1, 2, 3, 4)}
+        be.set_option("layer_timing", 0)
+        dom = max(per_layer, key=lambda l: per_layer[l][0])
+        tot_ms, cnt = per_layer[dom]
+        cin, cout = LAYER_DIMS[dom]
+        flops = 2.0 * 9 * cin * cout * B * h * w
+        avg_s = tot_ms / max(cnt, 1) * 1e-3
+        achieved = flops / avg_s / 1e12
+        peak = PEAK_TFLOPS[args.precision]
+        roof = {"bound": "mfma", "kernel": f"conv_igemm_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops,
+                "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
+                "loop_ms_graph": round(loop_ms, 4),
+                "loop_frac_of_peak": round(B * T * h * w * FLOP_PER_PIXEL_STEP / (loop_ms * 1e-3) / 1e12 / peak, 4) if loop_ms > 0 else None}
+
+    # ---- CPU baseline: torch-CPU port of the reference path, ONE map, this host's cores -----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_cpu_port as P
+        sdt = P.to_torch_sd(sd)
+        xc, cc = torch.from_numpy(inp["x_T"][:1]), torch.from_numpy(inp["cond"][:1])
+        with torch.no_grad():
+            P.denoiser(sdt, xc, 950, cc)                      # warm-up (thread pool, oneDNN primitives)
+            c0 = time.perf_counter()
+            lat_cpu = P.ddim_loop(sdt, xc, cc, T)
+            d_cpu = P.decode(sdt, lat_cpu)
+            cpu_s = time.perf_counter() - c0
+        cpu = {"value": round(1.0 / cpu_s, 5), "unit": "maps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+               "sample": f"1 map: {T}-step DDIM loop + decoder at latent 16x{h}x{w}, fp32 torch-CPU port of the reference ops "
+                         f"({cpu_s:.2f} s)",
+               "gflops": round(T * h * w * FLOP_PER_PIXEL_STEP / cpu_s / 1e9, 1)}
+        # parity spot check of the timed GPU configuration against the same CPU result
+        dg = depth[:1].cpu() if rank == 0 else None
+        cpu["gpu_vs_cpu_depth_rmse"] = float(torch.sqrt(torch.mean((dg - d_cpu) ** 2)))
+        cpu["gpu_vs_cpu_depth_maxabs"] = float((dg - d_cpu).abs().max())
+
+    if rank == 0:
+        maps = B * args.steps * world
+        out = {
+            "metric": f"depth-maps/sec ({T}-step DDIM, {args.size.upper()} {H}x{W} {args.precision})",
+            "value": round(maps / elapsed, 3), "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
+                                   f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
+                       "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
+                       "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FLOP_PER_PIXEL_STEP},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,19 @@
+"""diffusiondepth_amd -- MI355X-native DDIM denoise hot path of DiffusionDepth.
+
+Host side (this package, Python because the reference is Python) mirrors the reference's
+head / pipeline / scheduler / depth-transform interfaces; all arithmetic on the hot path runs in
+``libddepth_hip.so`` (hand-written HIP for gfx950, C ABI in ``include/ddepth.h``).  There is no CPU
+fallback: importing works anywhere, running needs the built library and a GPU.
+"""
+from .scheduler import DDIMScheduler
+from .backend import HipDenoiser, precision_id, library_path, load_library
+from .modules import ScheduledCNNRefine, CNNDDIMPipiline, DeepDepthTransformWithUpsampling
+from .head import DDIMDepthEstimate_Res
+from .model import Diffusion_DCbase_Model
+
+__all__ = [
+    "DDIMScheduler", "HipDenoiser", "precision_id", "library_path", "load_library",
+    "ScheduledCNNRefine", "CNNDDIMPipiline", "DeepDepthTransformWithUpsampling",
+    "DDIMDepthEstimate_Res", "Diffusion_DCbase_Model",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,266 @@
+"""ctypes binding of the C ABI in include/ddepth.h (the reference-side binding a maintainer would add;
+see INTEGRATION.md).  PyTorch is used only for device memory and the current HIP stream."""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libddepth_hip.so"
+_lib = None
+
+PRECISIONS = {"naive_fp32": 0, "fp32": 1, "bf16": 2, "f16": 3, "fp16": 3}
+VARIANTS = {"res": 0, "swin": 1}
+
+# every symbol include/ddepth.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_commit_weights",
+    "dd_set_schedule", "dd_denoise", "dd_denoise_once", "dd_add_noise", "dd_encode", "dd_decode",
+    "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch",
+]
+
+
+def precision_id(p) -> int:
+    if isinstance(p, int):
+        return p
+    try:
+        return PRECISIONS[str(p).lower()]
+    except KeyError:
+        raise ValueError(f"unknown precision {p!r}; choose one of {sorted(PRECISIONS)}") from None
+
+
+def library_path() -> str:
+    return os.environ.get("DDEPTH_LIBRARY", os.path.join(_HERE, _LIB_NAME))
+
+
+def load_library():
+    """Loads libddepth_hip.so.  Fails loudly: there is no eager / CPU fallback for the hot path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -m diffusiondepth_amd.build` (hipcc, gfx950). "
+            "diffusiondepth_amd has no fallback path for the DDIM hot loop.")
+    lib = ctypes.CDLL(path)
+    c_int, c_i64, c_vp, c_cp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
+    fp = ctypes.POINTER(ctypes.c_float)
+    sig = {
+        "dd_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_int]),
+        "dd_destroy": (c_int, [c_vp]),
+        "dd_last_error": (c_cp, [c_vp]),
+        "dd_version": (c_cp, []),
+        "dd_set_weight": (c_int, [c_vp, c_cp, c_vp, c_i64]),
+        "dd_commit_weights": (c_int, [c_vp, c_vp]),
+        "dd_set_schedule": (c_int, [c_vp, c_vp, c_int]),
+        "dd_denoise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_denoise_once": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_add_noise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_encode": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+        "dd_decode": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+        "dd_set_option": (c_int, [c_vp, c_cp, c_i64]),
+        "dd_last_loop_ms": (c_int, [c_vp, fp]),
+        "dd_get_counter": (c_int, [c_vp, c_cp, ctypes.POINTER(c_i64)]),
+        "dd_get_layer_ms": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
+        "dd_debug_fetch": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr(device) -> int:
+    torch = _torch()
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_tensor(t, name, shape=None, dtype=None):
+    torch = _torch()
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the DDIM hot path runs only on a HIP device "
+                           "(diffusiondepth_amd has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class HipDenoiser:
+    """Owner of one dd_handle_t (one per device/process).  All tensor arguments are torch CUDA
+    (= HIP) tensors, fp32 NCHW, exactly what the reference modules exchange."""
+
+    def __init__(self, device=None, variant: str = "res"):
+        torch = _torch()
+        self._lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to PyTorch: the DDIM hot path cannot run "
+                               "(diffusiondepth_amd has no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"HipDenoiser needs a HIP device, got {self.device}")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.variant = variant
+        h = ctypes.c_void_p()
+        rc = self._lib.dd_create(ctypes.byref(h), idx, VARIANTS[variant])
+        if rc != 0:
+            raise RuntimeError(f"dd_create failed ({rc}): {self._lib.dd_last_error(None).decode()}")
+        self._h = h
+        self._have_schedule = False
+        self._have_weights = False
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._lib.dd_last_error(self._h).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def version(self) -> str:
+        return self._lib.dd_version().decode()
+
+    def set_option(self, key: str, value: int):
+        self._ck(self._lib.dd_set_option(self._h, key.encode(), int(value)), f"dd_set_option({key})")
+
+    def counter(self, key: str) -> int:
+        v = ctypes.c_int64()
+        self._ck(self._lib.dd_get_counter(self._h, key.encode(), ctypes.byref(v)), f"dd_get_counter({key})")
+        return int(v.value)
+
+    def last_loop_ms(self) -> float:
+        ms = ctypes.c_float()
+        self._ck(self._lib.dd_last_loop_ms(self._h, ctypes.byref(ms)), "dd_last_loop_ms")
+        return float(ms.value)
+
+    def layer_ms(self, layer: int):
+        tot, cnt = ctypes.c_double(), ctypes.c_int64()
+        self._ck(self._lib.dd_get_layer_ms(self._h, layer, ctypes.byref(tot), ctypes.byref(cnt)), "dd_get_layer_ms")
+        return float(tot.value), int(cnt.value)
+
+    # -- parameters ---------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, object], prefix: str = ""):
+        """sd: {key: tensor | ndarray} using the reference's key names below ``prefix`` (e.g.
+        'depth_head.').  Keys the hot path does not own (FPN, backbone, num_batches_tracked) are ignored."""
+        torch = _torch()
+        n = 0
+        for k, v in sd.items():
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if not (name.startswith("model.") or name.startswith("depth_transform.")) or name.endswith("num_batches_tracked"):
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+            self._ck(self._lib.dd_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                     f"dd_set_weight({name})")
+            n += 1
+        self._ck(self._lib.dd_commit_weights(self._h, ctypes.c_void_p(_stream_ptr(self.device))), "dd_commit_weights")
+        self._have_weights = True
+        return n
+
+    def set_schedule(self, alphas_cumprod):
+        torch = _torch()
+        if isinstance(alphas_cumprod, torch.Tensor):
+            alphas_cumprod = alphas_cumprod.detach().to("cpu", torch.float32).numpy()
+        a = np.ascontiguousarray(np.asarray(alphas_cumprod, dtype=np.float32))
+        self._ck(self._lib.dd_set_schedule(self._h, a.ctypes.data_as(ctypes.c_void_p), a.size), "dd_set_schedule")
+        self._have_schedule = True
+
+    # -- hot path -----------------------------------------------------------------------------
+    def denoise(self, x_T, cond, num_inference_steps: int, precision="fp32", out=None):
+        torch = _torch()
+        x_T = _check_tensor(x_T, "x_T", dtype=torch.float32)
+        cond = _check_tensor(cond, "cond", dtype=torch.float32)
+        B, C, h, w = x_T.shape
+        if C != 16 or cond.dim() != 4 or cond.shape[0] != B or cond.shape[1] != 256:
+            raise ValueError(f"x_T must be (B,16,h,w) and cond (B,256,ch,cw); got {tuple(x_T.shape)}, {tuple(cond.shape)}")
+        out = torch.empty_like(x_T) if out is None else _check_tensor(out, "out", x_T.shape, torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_denoise(self._h, x_T.data_ptr(), cond.data_ptr(), out.data_ptr(), B, h, w,
+                                          cond.shape[2], cond.shape[3], int(num_inference_steps),
+                                          precision_id(precision), _stream_ptr(self.device)), "dd_denoise")
+        return out
+
+    def denoise_once(self, x_t, t, cond, precision="fp32"):
+        torch = _torch()
+        x_t = _check_tensor(x_t, "x_t", dtype=torch.float32)
+        cond = _check_tensor(cond, "cond", dtype=torch.float32)
+        B, C, h, w = x_t.shape
+        t = torch.as_tensor(t, device=self.device).to(torch.int64).reshape(-1)
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B)
+        t = _check_tensor(t, "t", (B,), torch.int64)
+        out = torch.empty_like(x_t)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_denoise_once(self._h, x_t.data_ptr(), t.data_ptr(), cond.data_ptr(), out.data_ptr(),
+                                               B, h, w, cond.shape[2], cond.shape[3], precision_id(precision),
+                                               _stream_ptr(self.device)), "dd_denoise_once")
+        return out
+
+    def add_noise(self, x0, noise, t):
+        torch = _torch()
+        x0 = _check_tensor(x0, "x0", dtype=torch.float32)
+        noise = _check_tensor(noise, "noise", x0.shape, torch.float32)
+        B = x0.shape[0]
+        t = _check_tensor(torch.as_tensor(t, device=self.device).to(torch.int64).reshape(-1), "t", (B,), torch.int64)
+        out = torch.empty_like(x0)
+        C, h, w = (x0.shape[1], x0.shape[2], x0.shape[3]) if x0.dim() == 4 else (1, 1, x0[0].numel())
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_add_noise(self._h, x0.data_ptr(), noise.data_ptr(), t.data_ptr(), out.data_ptr(),
+                                            B, C, h, w, _stream_ptr(self.device)), "dd_add_noise")
+        return out
+
+    def encode(self, depth):
+        torch = _torch()
+        depth = _check_tensor(depth, "depth", dtype=torch.float32)
+        B, C, H, W = depth.shape
+        if C != 1:
+            raise ValueError("depth must be (B,1,H,W)")
+        out = torch.empty((B, 16, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=depth.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_encode(self._h, depth.data_ptr(), out.data_ptr(), B, H, W, _stream_ptr(self.device)), "dd_encode")
+        return out
+
+    def decode(self, latent):
+        torch = _torch()
+        latent = _check_tensor(latent, "latent", dtype=torch.float32)
+        B, C, h, w = latent.shape
+        if C != 16:
+            raise ValueError("latent must be (B,16,h,w)")
+        out = torch.empty((B, 1, 2 * h, 2 * w), device=latent.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_decode(self._h, latent.data_ptr(), out.data_ptr(), B, h, w, _stream_ptr(self.device)), "dd_decode")
+        return out
+
+    def debug_fetch(self, name: str, B: int, h: int, w: int):
+        torch = _torch()
+        C = {"y1": 64, "y2": 256, "y3": 64, "y4": 16}[name]
+        out = torch.empty((B, C, h, w), device=self.device, dtype=torch.float32)
+        self._ck(self._lib.dd_debug_fetch(self._h, name.encode(), out.data_ptr(), out.numel(), _stream_ptr(self.device)),
+                 "dd_debug_fetch")
+        return out

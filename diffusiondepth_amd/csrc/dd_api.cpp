@@ -1,0 +1,765 @@
+// dd_api.cpp -- C ABI (include/ddepth.h) over the HIP kernels: handle, parameter packing, per-shape
+// plans (scratch + schedule tables + captured hipGraph of the T-step loop) and launch sequencing.
+#include "../../include/ddepth.h"
+#include "dd_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+using namespace dd;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  hipError_t alloc(size_t n) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline uint16_t host_f32_to_f16(float f) {
+  _Float16 hf = (_Float16)f;       // round-to-nearest-even
+  uint16_t u;
+  std::memcpy(&u, &hf, 2);
+  return u;
+}
+
+constexpr int NUM_EK = 3;
+inline int ek_of_precision(int prec) {
+  switch (prec) {
+    case DD_PREC_FP32: return EK_F32;
+    case DD_PREC_BF16: return EK_BF16;
+    case DD_PREC_F16: return EK_F16;
+    default: return -1;
+  }
+}
+inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
+
+struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
+  int cin = 0, cout = 0;
+  DevBuf wpack[NUM_EK];             // packed for the fused path
+  DevBuf bias;                      // [cout padded to 32]
+  DevBuf w_oihw;                    // naive path
+  DevBuf gamma, beta;               // GroupNorm affine [cout]
+};
+
+struct PlanKey {
+  int B, h, w, ch, cw, T, prec;
+  bool operator<(const PlanKey& o) const {
+    return std::tie(B, h, w, ch, cw, T, prec) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec);
+  }
+};
+
+struct Plan {
+  PlanKey key{};
+  int ek = EK_F32;
+  DevBuf x[2];        // fp32 NHWC state ping-pong
+  DevBuf cond;        // NHWC condition map (activation element kind; fp32 for naive)
+  DevBuf y1, y2, y3, y4;   // raw conv outputs
+  DevBuf a1, f, a3, eps;   // naive path only: normalised activations
+  DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
+  DevBuf c1c2;        // [T][2] fp32
+  DevBuf tsteps;      // [T] int64
+  size_t stats_bytes = 0;
+  hipGraphExec_t exec = nullptr;
+  bool capture_failed = false;
+  uint64_t last_use = 0;
+  ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
+  double* stat_ptr(int step, int layer) const {   // layer 0..3
+    return stats.as<double>() + ((size_t)(step * 4 + layer) * key.B) * STAT_SLOTS * STAT_STRIDE;
+  }
+};
+
+}  // namespace
+
+struct dd_handle_s {
+  int device = 0;
+  int variant = DD_VARIANT_RES;
+  std::string err;
+  std::map<std::string, std::vector<float>> host_w;
+  bool committed = false;      // denoiser group (model.*) packed
+  bool codec_committed = false; // codec group (depth_transform.*) packed
+  ConvLayer L[4];
+  DevBuf emb;
+  DevBuf codec_buf;          // all folded codec weights in one allocation
+  CodecWeights codec{};
+  DevBuf codec_tmp;          // scratch for encode/decode intermediates (grown on demand)
+  std::vector<float> acp;
+  DevBuf d_acp;
+  int n_train = 0;
+  bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
+  std::map<PlanKey, std::unique_ptr<Plan>> plans;
+  uint64_t tick = 0;
+  Plan* last_once_plan = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
+  int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
+  double layer_ms[4] = {0, 0, 0, 0};
+  int64_t layer_cnt[4] = {0, 0, 0, 0};
+  std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
+
+  int fail(int code, const std::string& m) { err = m; return code; }
+};
+
+#define DD_HIP(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess)                                                                         \
+      return h->fail(DD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));              \
+  } while (0)
+
+namespace {
+
+struct WeightSpec { const char* name; int64_t numel; };
+
+std::vector<WeightSpec> required_weights(int variant) {
+  std::vector<WeightSpec> v = {
+      {"model.noise_embedding.0.weight", 64 * 16 * 9}, {"model.noise_embedding.0.bias", 64},
+      {"model.noise_embedding.1.weight", 64}, {"model.noise_embedding.1.bias", 64},
+      {"model.noise_embedding.3.weight", 256 * 64 * 9}, {"model.noise_embedding.3.bias", 256},
+      {"model.noise_embedding.4.weight", 256}, {"model.noise_embedding.4.bias", 256},
+      {"model.time_embedding.weight", (int64_t)EMB_ROWS * COND_C},
+      {"model.pred.0.weight", 64 * 256 * 9}, {"model.pred.0.bias", 64},
+      {"model.pred.1.weight", 64}, {"model.pred.1.bias", 64},
+      {"model.pred.3.weight", 16 * 64 * 9}, {"model.pred.3.bias", 16},
+      {"model.pred.4.weight", 16}, {"model.pred.4.bias", 16},
+      {"depth_transform.conv_transform.0.0.weight", 16 * 9},
+      {"depth_transform.conv_transform.0.1.weight", 16}, {"depth_transform.conv_transform.0.1.bias", 16},
+      {"depth_transform.conv_transform.0.1.running_mean", 16}, {"depth_transform.conv_transform.0.1.running_var", 16},
+      {"depth_transform.conv_transform.1.0.weight", 16 * 16 * 9},
+      {"depth_transform.conv_transform.1.1.weight", 16}, {"depth_transform.conv_transform.1.1.bias", 16},
+      {"depth_transform.conv_transform.1.1.running_mean", 16}, {"depth_transform.conv_transform.1.1.running_var", 16},
+      {"depth_transform.conv_inv_transform.0.weight", 16 * 16 * 16}, {"depth_transform.conv_inv_transform.0.bias", 16},
+      {"depth_transform.conv_inv_transform.1.weight", 16}, {"depth_transform.conv_inv_transform.1.bias", 16},
+      {"depth_transform.conv_inv_transform.1.running_mean", 16}, {"depth_transform.conv_inv_transform.1.running_var", 16},
+      {"depth_transform.conv_inv_transform.3.0.weight", 16 * 9}, {"depth_transform.conv_inv_transform.3.0.bias", 1},
+  };
+  if (variant == DD_VARIANT_SWIN) {
+    v.push_back({"model.upsample_fuse.convA.conv.weight", 256 * 256 * 9});
+    v.push_back({"model.upsample_fuse.convA.conv.bias", 256});
+    v.push_back({"model.upsample_fuse.convB.conv.weight", 256 * 256 * 9});
+    v.push_back({"model.upsample_fuse.convB.conv.bias", 256});
+  }
+  return v;
+}
+
+// Packed layout consumed by conv_igemm_kernel:
+//   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT)
+void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, std::vector<uint8_t>& out) {
+  const int n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = 9 / g.tg;
+  const size_t n_el = (size_t)n_tiles * n_chunks * n_tg * g.tg * g.nt * g.ck;
+  const size_t esz = ek_size(ek);
+  out.assign(n_el * esz, 0);
+  size_t idx = 0;
+  for (int nt = 0; nt < n_tiles; ++nt)
+    for (int ch = 0; ch < n_chunks; ++ch)
+      for (int tg = 0; tg < n_tg; ++tg)
+        for (int t = 0; t < g.tg; ++t) {
+          const int tap = tg * g.tg + t, dy = tap / 3, dx = tap % 3;
+          for (int n = 0; n < g.nt; ++n)
+            for (int k = 0; k < g.ck; ++k, ++idx) {
+              const int co = nt * g.nt + n, ci = ch * g.ck + k;
+              const float v = (co < g.cout) ? w_oihw[(((size_t)co * g.cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+              if (ek == EK_F32) std::memcpy(&out[idx * 4], &v, 4);
+              else {
+                const uint16_t u = (ek == EK_BF16) ? host_f32_to_bf16(v) : host_f32_to_f16(v);
+                std::memcpy(&out[idx * 2], &u, 2);
+              }
+            }
+        }
+}
+
+int upload(dd_handle_t h, DevBuf& dst, const void* src, size_t bytes, hipStream_t s) {
+  if (dst.bytes < bytes || !dst.p) DD_HIP(dst.alloc(bytes));
+  DD_HIP(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, s));
+  return DD_OK;
+}
+
+int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!h->committed) return h->fail(DD_ERR_STATE, "model.* weights not committed (call dd_set_weight for every key, then dd_commit_weights)");
+  if (h->n_train <= 0) return h->fail(DD_ERR_STATE, "schedule not set (dd_set_schedule)");
+  if (B <= 0 || lh <= 0 || lw <= 0) return h->fail(DD_ERR_INVALID_ARG, "B, lat_h, lat_w must be positive");
+  if (h->variant == DD_VARIANT_RES && (ch != lh || cw != lw))
+    return h->fail(DD_ERR_INVALID_ARG, "DD_VARIANT_RES needs cond_h,cond_w == lat_h,lat_w (reference ...res.py:340 adds them elementwise)");
+  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN loop is not implemented in this build");
+  if ((long long)B * lh * lw * COND_C >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
+  return DD_OK;
+}
+
+int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
+  auto it = h->plans.find(key);
+  if (it != h->plans.end()) { it->second->last_use = ++h->tick; *out = it->second.get(); return DD_OK; }
+  // keep at most 6 plans alive: evict the least recently used
+  while (h->plans.size() >= 6) {
+    auto victim = h->plans.begin();
+    for (auto j = h->plans.begin(); j != h->plans.end(); ++j)
+      if (j->second->last_use < victim->second->last_use) victim = j;
+    if (h->last_once_plan == victim->second.get()) h->last_once_plan = nullptr;
+    DD_HIP(hipDeviceSynchronize());
+    h->plans.erase(victim);
+  }
+  std::unique_ptr<Plan> pl(new Plan());
+  pl->key = key;
+  const bool naive = key.prec == DD_PREC_NAIVE_FP32;
+  pl->ek = naive ? EK_F32 : ek_of_precision(key.prec);
+  const size_t px = (size_t)key.B * key.h * key.w;
+  const size_t es = ek_size(pl->ek);
+  DD_HIP(pl->x[0].alloc(px * LATENT_C * 4));
+  DD_HIP(pl->x[1].alloc(px * LATENT_C * 4));
+  DD_HIP(pl->cond.alloc((size_t)key.B * key.ch * key.cw * COND_C * es));
+  DD_HIP(pl->y1.alloc(px * HID_C * es));
+  DD_HIP(pl->y2.alloc(px * COND_C * es));
+  DD_HIP(pl->y3.alloc(px * HID_C * es));
+  DD_HIP(pl->y4.alloc(px * LATENT_C * 4));
+  if (naive) {
+    DD_HIP(pl->a1.alloc(px * HID_C * 4));
+    DD_HIP(pl->f.alloc(px * COND_C * 4));
+    DD_HIP(pl->a3.alloc(px * HID_C * 4));
+    DD_HIP(pl->eps.alloc(px * LATENT_C * 4));
+  }
+  const int T = key.T > 0 ? key.T : 1;
+  pl->stats_bytes = (size_t)(T + 1) * 4 * key.B * STAT_SLOTS * STAT_STRIDE * sizeof(double);
+  DD_HIP(pl->stats.alloc(pl->stats_bytes));
+  // schedule tables (reference scheduling_ddim.py:215-229 timesteps, :285-326 closed form of step())
+  std::vector<float> c1c2((size_t)T * 2, 0.f);
+  std::vector<long long> ts((size_t)T, 0);
+  if (key.T > 0) {
+    const int ratio = h->n_train / key.T;
+    for (int k = 0; k < key.T; ++k) {
+      const int t = (key.T - 1 - k) * ratio;
+      const int prev = t - ratio;
+      const double a_t = (double)h->acp[t];
+      const double a_prev = prev >= 0 ? (double)h->acp[prev] : 1.0;      // final_alpha_cumprod (set_alpha_to_one)
+      c1c2[2 * k] = (float)std::sqrt(a_prev / a_t);
+      c1c2[2 * k + 1] = (float)(std::sqrt(1.0 - a_prev) - std::sqrt(a_prev * (1.0 - a_t) / a_t));
+      ts[k] = t;
+    }
+  }
+  DD_HIP(pl->c1c2.alloc(c1c2.size() * 4));
+  DD_HIP(pl->tsteps.alloc(ts.size() * 8));
+  DD_HIP(hipMemcpy(pl->c1c2.p, c1c2.data(), c1c2.size() * 4, hipMemcpyHostToDevice));
+  DD_HIP(hipMemcpy(pl->tsteps.p, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
+  pl->last_use = ++h->tick;
+  *out = pl.get();
+  h->plans[key] = std::move(pl);
+  return DD_OK;
+}
+
+// One epsilon-network evaluation of the fused path: conv1..conv4 at loop step `step`
+// (x_in -> [update] -> conv1 ... conv4 -> y4 + GN4 statistics in stat slot `step`).
+int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, float* x_out, bool apply_update,
+                       const long long* tvec, int t_base, int t_bstride, hipStream_t s) {
+  const PlanKey& k = pl->key;
+  ConvParams p{};
+  p.B = k.B; p.h = k.h; p.w = k.w;
+  p.tiles_x = (k.w + 31) / 32;
+  p.tiles_y = (k.h + 7) / 8;
+  const int ek = pl->ek;
+  auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
+    if (!h->layer_timing) return launch_conv_igemm(layer, ek, cp, s);
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a); if (e != hipSuccess) return e;
+    e = hipEventCreate(&b); if (e != hipSuccess) return e;
+    (void)hipEventRecord(a, s);
+    e = launch_conv_igemm(layer, ek, cp, s);
+    (void)hipEventRecord(b, s);
+    h->pending_ev.emplace_back(layer - 1, a, b);
+    return e;
+  };
+  // conv1: state (+ fused DDIM update of the previous step) -> y1
+  p.in = x_in; p.wpack = h->L[0].wpack[ek].p; p.bias = h->L[0].bias.as<float>(); p.out = pl->y1.p;
+  p.stats_out = pl->stat_ptr(step, 0);
+  p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
+  p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
+  p.y4 = pl->y4.as<float>(); p.xout = x_out; p.c1c2 = pl->c1c2.as<float>(); p.step = apply_update ? step : 0;
+  DD_HIP(timed_launch(1, p));
+  // conv2: relu(gn1(y1)) -> y2
+  p.in = pl->y1.p; p.wpack = h->L[1].wpack[ek].p; p.bias = h->L[1].bias.as<float>(); p.out = pl->y2.p;
+  p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
+  p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
+  DD_HIP(timed_launch(2, p));
+  // conv3: relu(gn2(y2)) + cond + E[t] -> y3
+  p.in = pl->y2.p; p.wpack = h->L[2].wpack[ek].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+  p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
+  p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
+  p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
+  DD_HIP(timed_launch(3, p));
+  // conv4: relu(gn3(y3)) -> y4 (fp32)
+  p.in = pl->y3.p; p.wpack = h->L[3].wpack[ek].p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
+  p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
+  p.gn_gamma = h->L[2].gamma.as<float>(); p.gn_beta = h->L[2].beta.as<float>();
+  DD_HIP(timed_launch(4, p));
+  if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
+// The naive (unfused fp32) epsilon network; leaves eps in pl->eps and raw outputs in y1..y4.
+int enqueue_naive_eps(dd_handle_t h, Plan* pl, int step, const float* x_in, const long long* tvec, int t_base,
+                      int t_bstride, hipStream_t s) {
+  const PlanKey& k = pl->key;
+  const int B = k.B, hh = k.h, ww = k.w;
+  auto L = h->L;
+  DD_HIP(launch_naive_conv3x3(x_in, L[0].w_oihw.as<float>(), L[0].bias.as<float>(), pl->y1.as<float>(), B, hh, ww, LATENT_C, HID_C, s));
+  DD_HIP(launch_naive_gn_stats(pl->y1.as<float>(), pl->stat_ptr(step, 0), B, hh, ww, HID_C, s));
+  DD_HIP(launch_naive_gn_apply(pl->y1.as<float>(), pl->stat_ptr(step, 0), L[0].gamma.as<float>(), L[0].beta.as<float>(),
+                               nullptr, nullptr, nullptr, 0, 0, pl->a1.as<float>(), B, hh, ww, HID_C, s));
+  DD_HIP(launch_naive_conv3x3(pl->a1.as<float>(), L[1].w_oihw.as<float>(), L[1].bias.as<float>(), pl->y2.as<float>(), B, hh, ww, HID_C, COND_C, s));
+  DD_HIP(launch_naive_gn_stats(pl->y2.as<float>(), pl->stat_ptr(step, 1), B, hh, ww, COND_C, s));
+  DD_HIP(launch_naive_gn_apply(pl->y2.as<float>(), pl->stat_ptr(step, 1), L[1].gamma.as<float>(), L[1].beta.as<float>(),
+                               pl->cond.as<float>(), h->emb.as<float>(), tvec, t_base, t_bstride, pl->f.as<float>(), B, hh, ww, COND_C, s));
+  DD_HIP(launch_naive_conv3x3(pl->f.as<float>(), L[2].w_oihw.as<float>(), L[2].bias.as<float>(), pl->y3.as<float>(), B, hh, ww, COND_C, HID_C, s));
+  DD_HIP(launch_naive_gn_stats(pl->y3.as<float>(), pl->stat_ptr(step, 2), B, hh, ww, HID_C, s));
+  DD_HIP(launch_naive_gn_apply(pl->y3.as<float>(), pl->stat_ptr(step, 2), L[2].gamma.as<float>(), L[2].beta.as<float>(),
+                               nullptr, nullptr, nullptr, 0, 0, pl->a3.as<float>(), B, hh, ww, HID_C, s));
+  DD_HIP(launch_naive_conv3x3(pl->a3.as<float>(), L[3].w_oihw.as<float>(), L[3].bias.as<float>(), pl->y4.as<float>(), B, hh, ww, HID_C, LATENT_C, s));
+  DD_HIP(launch_naive_gn_stats(pl->y4.as<float>(), pl->stat_ptr(step, 3), B, hh, ww, LATENT_C, s));
+  DD_HIP(launch_naive_gn_apply(pl->y4.as<float>(), pl->stat_ptr(step, 3), L[3].gamma.as<float>(), L[3].beta.as<float>(),
+                               nullptr, nullptr, nullptr, 0, 0, pl->eps.as<float>(), B, hh, ww, LATENT_C, s));
+  if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
+int enqueue_loop_body(dd_handle_t h, Plan* pl, hipStream_t s) {
+  const int T = pl->key.T;
+  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  for (int k = 0; k < T; ++k) {
+    // conv1 of step k applies the update of step k-1: reads x[(k-1)&1] (k>0) / x[0] (k=0), writes x[k&1]
+    const float* xin = (k == 0) ? pl->x[0].as<float>() : pl->x[(k - 1) & 1].as<float>();
+    float* xout = pl->x[k & 1].as<float>();
+    int rc = enqueue_fused_step(h, pl, k, xin, xout, k > 0, pl->tsteps.as<long long>(), k, 0, s);
+    if (rc != DD_OK) return rc;
+  }
+  return DD_OK;
+}
+
+void drain_layer_events(dd_handle_t h) {
+  for (auto& t : h->pending_ev) {
+    float ms = 0.f;
+    if (hipEventSynchronize(std::get<2>(t)) == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(t), std::get<2>(t)) == hipSuccess) {
+      h->layer_ms[std::get<0>(t)] += ms;
+      h->layer_cnt[std::get<0>(t)] += 1;
+    }
+    (void)hipEventDestroy(std::get<1>(t));
+    (void)hipEventDestroy(std::get<2>(t));
+  }
+  h->pending_ev.clear();
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* dd_version(void) { return "ddepth 0.1 gfx950 (hip, mfma bf16/f16/f32 implicit-GEMM conv3x3+GN+ReLU, hipGraph DDIM loop)"; }
+
+const char* dd_last_error(dd_handle_t h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dd_create(dd_handle_t* out, int device, int variant) {
+  if (!out) { g_create_error = "dd_create: out is NULL"; return DD_ERR_INVALID_ARG; }
+  *out = nullptr;
+  if (variant != DD_VARIANT_RES && variant != DD_VARIANT_SWIN) { g_create_error = "dd_create: unknown variant"; return DD_ERR_INVALID_ARG; }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("dd_create: no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                     "); this library has no CPU fallback";
+    return DD_ERR_HIP;
+  }
+  if (device < 0 || device >= n) { g_create_error = "dd_create: device index out of range"; return DD_ERR_INVALID_ARG; }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return DD_ERR_HIP; }
+  dd_handle_t h = new dd_handle_s();
+  h->device = device;
+  h->variant = variant;
+  *out = h;
+  return DD_OK;
+}
+
+int dd_destroy(dd_handle_t h) {
+  if (!h) return DD_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  drain_layer_events(h);
+  h->plans.clear();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  delete h;
+  return DD_OK;
+}
+
+int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!name || !data || numel <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_set_weight: null name/data or non-positive numel");
+  for (const auto& ws : required_weights(h->variant)) {
+    if (std::strcmp(ws.name, name) == 0) {
+      if (ws.numel != numel)
+        return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight: ") + name + " expects " + std::to_string(ws.numel) +
+                                               " elements, got " + std::to_string(numel));
+      h->host_w[name].assign(data, data + numel);
+      if (std::strncmp(name, "model.", 6) == 0) h->committed = false; else h->codec_committed = false;
+      return DD_OK;
+    }
+  }
+  return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight: unknown parameter name '") + name + "'");
+}
+
+int dd_commit_weights(dd_handle_t h, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  // two independent groups: "model." (denoiser) and "depth_transform." (codec).  A group is packed when
+  // all of its keys are present; a partially provided group is an error; at least one must be complete.
+  int have[2] = {0, 0}, need[2] = {0, 0};
+  std::string first_missing[2];
+  for (const auto& ws : required_weights(h->variant)) {
+    const int grp = std::strncmp(ws.name, "model.", 6) == 0 ? 0 : 1;
+    need[grp]++;
+    if (h->host_w.count(ws.name)) have[grp]++;
+    else if (first_missing[grp].empty()) first_missing[grp] = ws.name;
+  }
+  for (int grp = 0; grp < 2; ++grp)
+    if (have[grp] != 0 && have[grp] != need[grp])
+      return h->fail(DD_ERR_STATE, "dd_commit_weights: missing parameter '" + first_missing[grp] + "'");
+  if (have[0] == 0 && have[1] == 0) return h->fail(DD_ERR_STATE, "dd_commit_weights: no parameters were set");
+  const bool do_model = have[0] == need[0], do_codec = have[1] == need[1];
+  // graphs bake weight pointers; buffers are reused when sizes match, so existing graphs stay valid,
+  // but make sure nothing is in flight while we overwrite them.
+  DD_HIP(hipDeviceSynchronize());
+  const char* conv_names[4] = {"model.noise_embedding.0", "model.noise_embedding.3", "model.pred.0", "model.pred.3"};
+  const char* gn_names[4] = {"model.noise_embedding.1", "model.noise_embedding.4", "model.pred.1", "model.pred.4"};
+  const int cins[4] = {LATENT_C, HID_C, COND_C, HID_C}, couts[4] = {HID_C, COND_C, HID_C, LATENT_C};
+  for (int l = 0; do_model && l < 4; ++l) {
+    ConvLayer& L = h->L[l];
+    L.cin = cins[l]; L.cout = couts[l];
+    const std::vector<float>& w = h->host_w[std::string(conv_names[l]) + ".weight"];
+    const std::vector<float>& b = h->host_w[std::string(conv_names[l]) + ".bias"];
+    for (int ek = 0; ek < NUM_EK; ++ek) {
+      std::vector<uint8_t> packed;
+      pack_conv_weights(w.data(), conv_pack_geom(l + 1, ek), ek, packed);
+      int rc = upload(h, L.wpack[ek], packed.data(), packed.size(), s);
+      if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));     // `packed` is a temporary
+    }
+    std::vector<float> bpad(std::max(32, L.cout), 0.f);
+    std::copy(b.begin(), b.end(), bpad.begin());
+    int rc = upload(h, L.bias, bpad.data(), bpad.size() * 4, s); if (rc) return rc;
+    rc = upload(h, L.w_oihw, w.data(), w.size() * 4, s); if (rc) return rc;
+    const std::vector<float>& gg = h->host_w[std::string(gn_names[l]) + ".weight"];
+    const std::vector<float>& gb = h->host_w[std::string(gn_names[l]) + ".bias"];
+    rc = upload(h, L.gamma, gg.data(), gg.size() * 4, s); if (rc) return rc;
+    rc = upload(h, L.beta, gb.data(), gb.size() * 4, s); if (rc) return rc;
+    DD_HIP(hipStreamSynchronize(s));
+  }
+  if (do_model) {
+    const std::vector<float>& e = h->host_w["model.time_embedding.weight"];
+    int rc = upload(h, h->emb, e.data(), e.size() * 4, s); if (rc) return rc;
+    DD_HIP(hipStreamSynchronize(s));
+    h->committed = true;
+  }
+  if (!do_codec) return DD_OK;
+  // ---- codec: fold eval-mode BatchNorm into the convolutions (reference depth_transform.py:15-26) ----
+  auto W = [&](const char* n) -> const std::vector<float>& { return h->host_w[n]; };
+  auto bn_fold = [&](const std::string& p, std::vector<float>& scale, std::vector<float>& shift) {
+    const auto &g = W((p + ".weight").c_str()), &b = W((p + ".bias").c_str()), &m = W((p + ".running_mean").c_str()),
+               &v = W((p + ".running_var").c_str());
+    scale.resize(16); shift.resize(16);
+    for (int c = 0; c < 16; ++c) {
+      const double sc = (double)g[c] / std::sqrt((double)v[c] + (double)BN_EPS);
+      scale[c] = (float)sc;
+      shift[c] = (float)((double)b[c] - (double)m[c] * sc);
+    }
+  };
+  std::vector<float> blob;
+  auto push = [&](const std::vector<float>& v) { size_t off = blob.size(); blob.insert(blob.end(), v.begin(), v.end());
+                                                 while (blob.size() % 4) blob.push_back(0.f); return off; };
+  std::vector<float> sc, sh;
+  bn_fold("depth_transform.conv_transform.0.1", sc, sh);
+  std::vector<float> e0 = W("depth_transform.conv_transform.0.0.weight");
+  for (int c = 0; c < 16; ++c) for (int k = 0; k < 9; ++k) e0[c * 9 + k] *= sc[c];
+  const size_t o_e0 = push(e0), o_eb0 = push(sh);
+  bn_fold("depth_transform.conv_transform.1.1", sc, sh);
+  std::vector<float> e1 = W("depth_transform.conv_transform.1.0.weight");
+  for (int co = 0; co < 16; ++co) for (int k = 0; k < 16 * 9; ++k) e1[co * 144 + k] *= sc[co];
+  const size_t o_e1 = push(e1), o_eb1 = push(sh);
+  bn_fold("depth_transform.conv_inv_transform.1", sc, sh);
+  std::vector<float> d0 = W("depth_transform.conv_inv_transform.0.weight");       // (in, out, 4, 4)
+  for (int ci = 0; ci < 16; ++ci) for (int co = 0; co < 16; ++co) for (int k = 0; k < 16; ++k) d0[(ci * 16 + co) * 16 + k] *= sc[co];
+  std::vector<float> db0(16);
+  { const auto& cb = W("depth_transform.conv_inv_transform.0.bias"); for (int c = 0; c < 16; ++c) db0[c] = cb[c] * sc[c] + sh[c]; }
+  const size_t o_d0 = push(d0), o_db0 = push(db0);
+  const size_t o_d1 = push(W("depth_transform.conv_inv_transform.3.0.weight"));
+  {
+    int rc = upload(h, h->codec_buf, blob.data(), blob.size() * 4, s); if (rc) return rc;
+    DD_HIP(hipStreamSynchronize(s));
+  }
+  const float* base = h->codec_buf.as<float>();
+  h->codec.enc_w0 = base + o_e0; h->codec.enc_b0 = base + o_eb0;
+  h->codec.enc_w1 = base + o_e1; h->codec.enc_b1 = base + o_eb1;
+  h->codec.dec_w0 = base + o_d0; h->codec.dec_b0 = base + o_db0;
+  h->codec.dec_w1 = base + o_d1;
+  h->codec.dec_b1 = W("depth_transform.conv_inv_transform.3.0.bias")[0];
+  h->codec_committed = true;
+  return DD_OK;
+}
+
+int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_timesteps) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!alphas_cumprod || num_train_timesteps <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_set_schedule: null table or non-positive length");
+  for (int i = 0; i < num_train_timesteps; ++i)
+    if (!(alphas_cumprod[i] > 0.f && alphas_cumprod[i] <= 1.f))
+      return h->fail(DD_ERR_INVALID_ARG, "dd_set_schedule: alphas_cumprod must lie in (0, 1]");
+  DD_HIP(hipSetDevice(h->device));
+  DD_HIP(hipDeviceSynchronize());
+  h->plans.clear();                    // tables are baked into plans
+  h->last_once_plan = nullptr;
+  h->acp.assign(alphas_cumprod, alphas_cumprod + num_train_timesteps);
+  h->n_train = num_train_timesteps;
+  DD_HIP(h->d_acp.alloc((size_t)num_train_timesteps * 4));
+  DD_HIP(hipMemcpy(h->d_acp.p, h->acp.data(), (size_t)num_train_timesteps * 4, hipMemcpyHostToDevice));
+  return DD_OK;
+}
+
+int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
+  if (!h || !key) return DD_ERR_INVALID_ARG;
+  const std::string k(key);
+  if (k == "graph") h->use_graph = value != 0;
+  else if (k == "timing") h->timing = value != 0;
+  else if (k == "debug_sync") h->debug_sync = value != 0;
+  else if (k == "layer_timing") {
+    drain_layer_events(h);
+    h->layer_timing = value != 0;
+    for (int i = 0; i < 4; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
+  } else return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: unknown key '" + k + "'");
+  return DD_OK;
+}
+
+int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
+  if (!h || !key || !value) return DD_ERR_INVALID_ARG;
+  const std::string k(key);
+  if (k == "graph_launches") *value = h->n_graph_launches;
+  else if (k == "eager_loops") *value = h->n_eager_loops;
+  else if (k == "graph_capture_failures") *value = h->n_capture_failures;
+  else if (k == "plans") *value = (int64_t)h->plans.size();
+  else return h->fail(DD_ERR_INVALID_ARG, "dd_get_counter: unknown key '" + k + "'");
+  return DD_OK;
+}
+
+int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches) {
+  if (!h || layer < 1 || layer > 4 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
+  drain_layer_events(h);
+  *total_ms = h->layer_ms[layer - 1];
+  *launches = h->layer_cnt[layer - 1];
+  return DD_OK;
+}
+
+int dd_last_loop_ms(dd_handle_t h, float* ms) {
+  if (!h || !ms) return DD_ERR_INVALID_ARG;
+  *ms = 0.f;
+  if (!h->ev_valid) return DD_OK;
+  DD_HIP(hipEventSynchronize(h->ev1));
+  DD_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return DD_OK;
+}
+
+int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
+               int cond_h, int cond_w, int T, int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  if (rc) return rc;
+  if (!x_T || !cond || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
+  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  Plan* pl = nullptr;
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision}, &pl);
+  if (rc) return rc;
+
+  DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, s));
+  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, s));
+
+  if (h->timing) {
+    if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
+    DD_HIP(hipEventRecord(h->ev0, s));
+  }
+  if (precision == DD_PREC_NAIVE_FP32) {
+    DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+    for (int k = 0; k < T; ++k) {
+      float* xc = pl->x[k & 1].as<float>();
+      float* xn = pl->x[(k + 1) & 1].as<float>();
+      rc = enqueue_naive_eps(h, pl, k, xc, pl->tsteps.as<long long>(), k, 0, s);
+      if (rc) return rc;
+      DD_HIP(launch_naive_axpby(xc, pl->eps.as<float>(), pl->c1c2.as<float>(), k, xn, (long long)B * lat_h * lat_w * LATENT_C, s));
+    }
+    h->n_eager_loops++;
+    if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    DD_HIP(launch_nhwc_to_nchw_f32(pl->x[T & 1].p, EK_F32, x_0, B, LATENT_C, lat_h, lat_w, s));
+    return DD_OK;
+  }
+
+  const bool want_graph = h->use_graph && !h->layer_timing && !h->debug_sync && !pl->capture_failed;
+  bool launched = false;
+  if (want_graph) {
+    if (!pl->exec) {
+      // first use of this plan: one eager pass sets function attributes / loads code objects and
+      // validates the launch configuration before we capture
+      rc = enqueue_loop_body(h, pl, s);
+      if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
+      hipGraph_t graph = nullptr;
+      hipError_t e = hipSuccess;
+      if (!h->cap_stream) e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        int brc = enqueue_loop_body(h, pl, h->cap_stream);
+        hipError_t e2 = hipStreamEndCapture(h->cap_stream, &graph);
+        if (brc == DD_OK && e2 == hipSuccess && graph) {
+          e = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0);
+          if (e != hipSuccess) pl->exec = nullptr;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      if (!pl->exec) {
+        (void)hipGetLastError();
+        pl->capture_failed = true;
+        h->n_capture_failures++;
+      }
+      // the eager pass above consumed x[0]: restore the input state before the real run
+      DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, s));
+      if (h->timing) DD_HIP(hipEventRecord(h->ev0, s));
+    }
+    if (pl->exec) {
+      DD_HIP(hipGraphLaunch(pl->exec, s));
+      h->n_graph_launches++;
+      launched = true;
+    }
+  }
+  if (!launched) {
+    rc = enqueue_loop_body(h, pl, s);
+    if (rc) return rc;
+    h->n_eager_loops++;
+  }
+  if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+  // x_0 = c1*x + c2*relu(gn4(y4)) of the last step, written NCHW
+  DD_HIP(launch_final(pl->x[(T - 1) & 1].as<float>(), pl->y4.as<float>(), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
+                      h->L[3].beta.as<float>(), pl->c1c2.as<float>(), T - 1, 0, x_0, B, lat_h, lat_w, s));
+  if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
+int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, float* eps, int B, int lat_h,
+                    int lat_w, int cond_h, int cond_w, int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  if (rc) return rc;
+  if (!x_t || !t || !cond || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  Plan* pl = nullptr;
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision}, &pl);
+  if (rc) return rc;
+  const long long* tv = reinterpret_cast<const long long*>(t);
+  DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, s));
+  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, s));
+  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  if (precision == DD_PREC_NAIVE_FP32) {
+    rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);
+    if (rc) return rc;
+    DD_HIP(launch_nhwc_to_nchw_f32(pl->eps.p, EK_F32, eps, B, LATENT_C, lat_h, lat_w, s));
+  } else {
+    rc = enqueue_fused_step(h, pl, 0, pl->x[0].as<float>(), pl->x[1].as<float>(), false, tv, 0, 1, s);
+    if (rc) return rc;
+    DD_HIP(launch_final(pl->x[0].as<float>(), pl->y4.as<float>(), pl->stat_ptr(0, 3), h->L[3].gamma.as<float>(),
+                        h->L[3].beta.as<float>(), pl->c1c2.as<float>(), 0, 1, eps, B, lat_h, lat_w, s));
+  }
+  h->last_once_plan = pl;
+  if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
+int dd_add_noise(dd_handle_t h, const float* x0, const float* noise, const int64_t* t, float* out, int B, int C,
+                 int lat_h, int lat_w, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (h->n_train <= 0) return h->fail(DD_ERR_STATE, "schedule not set (dd_set_schedule)");
+  if (!x0 || !noise || !t || !out || B <= 0 || C <= 0 || lat_h <= 0 || lat_w <= 0)
+    return h->fail(DD_ERR_INVALID_ARG, "dd_add_noise: null pointer or non-positive size");
+  DD_HIP(hipSetDevice(h->device));
+  DD_HIP(launch_add_noise(x0, noise, reinterpret_cast<const long long*>(t), h->d_acp.as<float>(), h->n_train, out, B,
+                          (long long)C * lat_h * lat_w, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+static int ensure_codec_tmp(dd_handle_t h, size_t bytes) {
+  if (h->codec_tmp.bytes >= bytes) return DD_OK;
+  DD_HIP(hipDeviceSynchronize());
+  DD_HIP(h->codec_tmp.alloc(bytes));
+  return DD_OK;
+}
+
+int dd_encode(dd_handle_t h, const float* depth, float* latent, int B, int H, int W, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!h->codec_committed) return h->fail(DD_ERR_STATE, "depth_transform.* weights not committed");
+  if (!depth || !latent || B <= 0 || H <= 0 || W <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_encode: null pointer or non-positive size");
+  DD_HIP(hipSetDevice(h->device));
+  const int lh = (H - 1) / 2 + 1, lw = (W - 1) / 2 + 1;
+  int rc = ensure_codec_tmp(h, (size_t)B * lh * lw * LATENT_C * 4);
+  if (rc) return rc;
+  DD_HIP(launch_encode(h->codec, depth, h->codec_tmp.as<float>(), latent, B, H, W, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h, int lat_w, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!h->codec_committed) return h->fail(DD_ERR_STATE, "depth_transform.* weights not committed");
+  if (!latent || !depth || B <= 0 || lat_h <= 0 || lat_w <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_decode: null pointer or non-positive size");
+  DD_HIP(hipSetDevice(h->device));
+  int rc = ensure_codec_tmp(h, (size_t)B * (2 * lat_h) * (2 * lat_w) * LATENT_C * 4);
+  if (rc) return rc;
+  DD_HIP(launch_decode(h->codec, latent, h->codec_tmp.as<float>(), depth, B, lat_h, lat_w, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, void* stream) {
+  if (!h || !name || !out) return DD_ERR_INVALID_ARG;
+  Plan* pl = h->last_once_plan;
+  if (!pl) return h->fail(DD_ERR_STATE, "dd_debug_fetch: no dd_denoise_once call to inspect");
+  const std::string n(name);
+  const void* src = nullptr; int C = 0; int ek = pl->ek;
+  if (n == "y1") { src = pl->y1.p; C = HID_C; }
+  else if (n == "y2") { src = pl->y2.p; C = COND_C; }
+  else if (n == "y3") { src = pl->y3.p; C = HID_C; }
+  else if (n == "y4") { src = pl->y4.p; C = LATENT_C; ek = EK_F32; }
+  else return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: unknown tensor '" + n + "'");
+  if (numel != (int64_t)pl->key.B * C * pl->key.h * pl->key.w) return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: numel mismatch");
+  DD_HIP(launch_nhwc_to_nchw_f32(src, ek, out, pl->key.B, C, pl->key.h, pl->key.w, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+}  // extern "C"

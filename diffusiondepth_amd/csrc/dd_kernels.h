@@ -1,0 +1,100 @@
+// dd_kernels.h -- device-side parameter blocks and host launchers shared by the C-ABI layer
+// (dd_api.cpp) and the kernel translation units (dd_igemm.hip, dd_naive.hip, dd_misc.hip).
+//
+// Internal data layout in HBM (DESIGN.md "Data layout"):
+//   activations  NHWC  [B][h][w][C]   element type per precision mode (bf16 / f16 / f32)
+//   state x_t    NHWC  [B][h][w][16]  fp32, ping-pong pair
+//   GroupNorm statistics  [B][DD_STAT_SLOTS][DD_STAT_STRIDE] doubles: per slot (sum, sumsq) x 4 groups
+//   packed conv weights   [n_tile][cin_chunk][tap_group][tap][NT][CK] elements (see pack_conv_weights)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dd {
+
+constexpr int LATENT_C = 16;   // depth_feature_dim   (reference src/model/diffusion_dcbase_model.py:84)
+constexpr int HID_C = 64;      // hidden width        (reference src/model/head/ddim_depth_estimate_res.py:303,315)
+constexpr int COND_C = 256;    // channels_in/fpn_dim (reference ...res.py:27-28)
+constexpr int GN_GROUPS = 4;   // nn.GroupNorm(4, C)  (reference ...res.py:305,309,317,321)
+constexpr int EMB_ROWS = 1280; // nn.Embedding(1280, 256) (reference ...res.py:313)
+constexpr float GN_EPS = 1e-5f;
+constexpr float BN_EPS = 1e-5f;
+
+// GroupNorm partial sums are spread over DD_STAT_SLOTS cache lines per sample so that the one
+// atomic per workgroup per group does not serialise on a single L2 channel.
+constexpr int STAT_SLOTS = 32;
+constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2+1]=sumsq, g<4; rest pad
+
+enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2 };
+
+enum Prologue : int {
+  PRO_X = 0,       // conv1: input = DDIM-updated state (c1*x + c2*relu(gn4(y4))), also written back
+  PRO_GN = 1,      // input = relu(gn(y))
+  PRO_GN_ADD = 2   // conv3: input = relu(gn(y)) + cond + E[t]
+};
+
+// One 3x3 convolution launch of the fused path.
+struct ConvParams {
+  const void* in;           // producing layer's raw output (NHWC, activation element type); PRO_X: x (fp32)
+  const void* wpack;        // packed weights (activation element type)
+  const float* bias;        // [COUT padded to NT multiple]
+  void* out;                // raw conv output + bias (pre-GroupNorm), NHWC
+  double* stats_out;        // [B][STAT_SLOTS][STAT_STRIDE] accumulators of THIS layer's GroupNorm
+  const double* stats_in;   // statistics the prologue normalises with (PRO_X: GN4 of the previous step)
+  const float* gn_gamma;    // affine of the GroupNorm applied in the prologue
+  const float* gn_beta;
+  const void* cond;         // PRO_GN_ADD: condition map NHWC [B][h][w][256], activation element type
+  const float* emb;         // PRO_GN_ADD: time-embedding table [1280][256] fp32
+  const long long* tvec;    // PRO_GN_ADD: timestep(s); t = tvec[t_base + b * t_bstride]
+  int t_base, t_bstride;
+  const float* y4;          // PRO_X: raw conv4 output of the previous step, fp32 NHWC [B][h][w][16]
+  float* xout;              // PRO_X: updated state written here (interior pixels of each tile)
+  const float* c1c2;        // PRO_X: [T][2] DDIM coefficients; entry (step-1) is applied when step > 0
+  int step;                 // PRO_X: 0 = no update (x is used as is)
+  int B, h, w;
+  int tiles_x, tiles_y;
+};
+
+// ---- fused implicit-GEMM path (dd_igemm.hip) -------------------------------------------------
+// layer: 1..4 (conv1 16->64, conv2 64->256, conv3 256->64, conv4 64->16); ek: element kind.
+hipError_t launch_conv_igemm(int layer, int ek, const ConvParams& p, hipStream_t s);
+// Packed-weight geometry of (layer, ek): elements and tile parameters (host side packing).
+struct PackGeom { int cin, cout, cout_pad, ck, tg, nt; };
+PackGeom conv_pack_geom(int layer, int ek);
+
+// ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
+hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, hipStream_t s);
+hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s);
+// out(NCHW) = c1*x + c2*relu(gn4(y4))  (mode 0, final DDIM update) or relu(gn4(y4)) (mode 1, eps)
+hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,
+                        const float* c1c2, int step, int mode, float* out_nchw, int B, int h, int w, hipStream_t s);
+hipError_t launch_add_noise(const float* x0, const float* noise, const long long* t, const float* acp, int n_train,
+                            float* out, int B, long long per_sample, hipStream_t s);
+struct CodecWeights {   // device pointers, BatchNorm already folded (eval mode)
+  const float* enc_w0;  // [16][9]      conv 1->16 s2, scale folded
+  const float* enc_b0;  // [16]
+  const float* enc_w1;  // [16][16][9]  conv 16->16, scale folded (OIHW)
+  const float* enc_b1;  // [16]
+  const float* dec_w0;  // [16 in][16 out][4][4] convT, scale folded over out
+  const float* dec_b0;  // [16]
+  const float* dec_w1;  // [16][9]      conv 16->1
+  float dec_b1;
+};
+hipError_t launch_encode(const CodecWeights& cw, const float* depth, float* tmp_nhwc, float* latent_nchw,
+                         int B, int H, int W, hipStream_t s);
+hipError_t launch_decode(const CodecWeights& cw, const float* latent_nchw, float* tmp_nhwc, float* depth,
+                         int B, int h, int w, hipStream_t s);
+
+// ---- naive cross-check path (dd_naive.hip) -------------------------------------------------------
+hipError_t launch_naive_conv3x3(const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc,
+                                int B, int h, int w, int cin, int cout, hipStream_t s);
+hipError_t launch_naive_gn_stats(const float* y_nhwc, double* stats, int B, int h, int w, int C, hipStream_t s);
+// out = relu(gn(y)) [+ cond + emb[t]]
+hipError_t launch_naive_gn_apply(const float* y, const double* stats, const float* gamma, const float* beta,
+                                 const float* cond, const float* emb, const long long* tvec, int t_base, int t_bstride,
+                                 float* out, int B, int h, int w, int C, hipStream_t s);
+// x_out = c1*x + c2*eps (eps already normalised)
+hipError_t launch_naive_axpby(const float* x, const float* eps, const float* c1c2, int step, float* out,
+                              long long n, hipStream_t s);
+
+}  // namespace dd

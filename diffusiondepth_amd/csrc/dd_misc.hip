@@ -1,0 +1,337 @@
+// dd_misc.hip -- layout conversion, DDIM elementwise tails, q_sample and the latent codec.
+//
+// All of these are HBM-bound streaming kernels that run once per image (or once per call), not once
+// per DDIM step; they are written for coalescing (consecutive lanes <-> consecutive addresses on the
+// wide side of every transfer), not for the matrix cores.
+#include "dd_kernels.h"
+
+namespace dd {
+
+__device__ __forceinline__ uint32_t cvt_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ uint32_t cvt_f16(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float ld_elem(const void* base, size_t idx, int ek) {
+  if (ek == EK_F32) return reinterpret_cast<const float*>(base)[idx];
+  const uint32_t u = reinterpret_cast<const uint16_t*>(base)[idx];
+  return ek == EK_BF16 ? __builtin_bit_cast(float, u << 16) : (float)__builtin_bit_cast(_Float16, (uint16_t)u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW fp32 -> NHWC (fp32 / bf16 / f16).  A 256-thread block transposes a [64 px][64 ch] tile through
+// LDS: reads are 256-B runs along pixels of one channel plane, writes are 64 channels of a pixel.
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                           int C, long long HW) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  const int px = tid & 63, cs = tid >> 6;
+  const float* s = src + ((size_t)b * C) * HW;
+#pragma unroll 4
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = cc * 4 + cs;
+    float v = 0.f;
+    if (p0 + px < HW && c0 + c < C) v = s[(size_t)(c0 + c) * HW + p0 + px];
+    tile[px][c] = v;
+  }
+  __syncthreads();
+  const int opx = tid >> 2, part = tid & 3;           // 4 threads per pixel, 16 channels each
+  if (p0 + opx >= HW) return;
+  const int cbase = c0 + part * 16;
+  if (cbase >= C) return;                              // C is a multiple of 16 for every tensor we convert
+  const size_t o = ((size_t)b * HW + p0 + opx) * C + cbase;
+  if constexpr (EK == EK_F32) {
+    float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      d[i] = make_float4(tile[opx][part * 16 + 4 * i], tile[opx][part * 16 + 4 * i + 1],
+                         tile[opx][part * 16 + 4 * i + 2], tile[opx][part * 16 + 4 * i + 3]);
+  } else {
+    uint32_t wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float lo = tile[opx][part * 16 + 2 * i], hi = tile[opx][part * 16 + 2 * i + 1];
+      wv[i] = (EK == EK_BF16) ? (cvt_bf16(lo) | (cvt_bf16(hi) << 16)) : (cvt_f16(lo) | (cvt_f16(hi) << 16));
+    }
+    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dst) + o);
+    d[0] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    d[1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+  }
+}
+
+hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, hipStream_t s) {
+  if (C % 16 != 0) return hipErrorInvalidValue;
+  const long long HW = (long long)h * w;
+  dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+  if (ek == EK_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW);
+  return hipGetLastError();
+}
+
+// NHWC (any element kind) -> NCHW fp32; debug / small tensors only (one thread per output element).
+__global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, int ek, float* __restrict__ dst, int C, long long HW,
+                                    long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long p = i % HW;
+  const long long bc = i / HW;
+  const int c = (int)(bc % C);
+  const long long b = bc / C;
+  dst[i] = ld_elem(src, (size_t)(b * HW + p) * C + c, ek);
+}
+hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s) {
+  const long long HW = (long long)h * w, total = HW * C * B;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ek, dst, C, HW, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail of the loop: x_0 = c1*x + c2*relu(gn4(y4))  (mode 0)   or   eps = relu(gn4(y4))  (mode 1),
+// NHWC fp32 in, NCHW fp32 out.  One thread per pixel: 64-B reads per lane, 16 plane-coalesced writes.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) final_kernel(const float* __restrict__ x, const float* __restrict__ y4,
+                                                    const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, const float* __restrict__ c1c2,
+                                                    int step, int mode, float* __restrict__ out, long long HW) {
+  __shared__ double s_sum[8];
+  __shared__ float s_a[LATENT_C], s_b[LATENT_C];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  if (tid < 8) {
+    const double* st = stats + (size_t)b * STAT_SLOTS * STAT_STRIDE;
+    double acc = 0.0;
+    for (int s = 0; s < STAT_SLOTS; ++s) acc += st[s * STAT_STRIDE + tid];
+    s_sum[tid] = acc;
+  }
+  __syncthreads();
+  if (tid < LATENT_C) {
+    const int grp = tid / (LATENT_C / GN_GROUPS);
+    const double cnt = (double)HW * (LATENT_C / GN_GROUPS);
+    const double mean = s_sum[grp * 2] / cnt;
+    double var = s_sum[grp * 2 + 1] / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double a = (double)gamma[tid] / sqrt(var + (double)GN_EPS);
+    s_a[tid] = (float)a;
+    s_b[tid] = (float)((double)beta[tid] - mean * a);
+  }
+  __syncthreads();
+  const long long p = (long long)blockIdx.x * blockDim.x + tid;
+  if (p >= HW) return;
+  float c1 = 0.f, c2 = 1.f;
+  if (mode == 0) { c1 = c1c2[2 * step]; c2 = c1c2[2 * step + 1]; }
+  const float4* yv = reinterpret_cast<const float4*>(y4 + ((size_t)b * HW + p) * LATENT_C);
+  const float4* xv = reinterpret_cast<const float4*>(x + ((size_t)b * HW + p) * LATENT_C);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 yy = yv[q];
+    float4 xx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mode == 0) xx = xv[q];
+    const float ys[4] = {yy.x, yy.y, yy.z, yy.w};
+    const float xs[4] = {xx.x, xx.y, xx.z, xx.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = q * 4 + i;
+      const float e = fmaxf(fmaf(s_a[c], ys[i], s_b[c]), 0.f);
+      out[((size_t)b * LATENT_C + c) * HW + p] = (mode == 0) ? (c1 * xs[i] + c2 * e) : e;
+    }
+  }
+}
+hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,
+                        const float* c1c2, int step, int mode, float* out_nchw, int B, int h, int w, hipStream_t s) {
+  const long long HW = (long long)h * w;
+  dim3 grid((unsigned)((HW + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(final_kernel, grid, dim3(256), 0, s, x, y4, stats, gamma, beta, c1c2, step, mode, out_nchw, HW);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// q_sample (reference scheduling_ddim.py:355-376): out = sqrt(abar_t)*x0 + sqrt(1-abar_t)*noise
+// ------------------------------------------------------------------------------------------------
+__global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                 const long long* __restrict__ t, const float* __restrict__ acp, int n_train,
+                                 float* __restrict__ out, long long per_sample) {
+  const int b = blockIdx.y;
+  long long tb = t[b];
+  tb = tb < 0 ? 0 : (tb >= n_train ? n_train - 1 : tb);
+  const float a = acp[tb];
+  const float sa = sqrtf(a), sb = sqrtf(1.f - a);     // fp32 pow(.,0.5) of the fp32 table, as the reference
+  const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= per_sample) return;
+  const size_t o = (size_t)b * per_sample + i4;
+  if (i4 + 4 <= per_sample && (per_sample & 3) == 0) {
+    const float4 xv = *reinterpret_cast<const float4*>(x0 + o), nv = *reinterpret_cast<const float4*>(noise + o);
+    *reinterpret_cast<float4*>(out + o) = make_float4(sa * xv.x + sb * nv.x, sa * xv.y + sb * nv.y,
+                                                      sa * xv.z + sb * nv.z, sa * xv.w + sb * nv.w);
+  } else {
+    for (long long k = i4; k < per_sample && k < i4 + 4; ++k) {
+      const size_t oo = (size_t)b * per_sample + k;
+      out[oo] = sa * x0[oo] + sb * noise[oo];
+    }
+  }
+}
+hipError_t launch_add_noise(const float* x0, const float* noise, const long long* t, const float* acp, int n_train,
+                            float* out, int B, long long per_sample, hipStream_t s) {
+  dim3 grid((unsigned)((per_sample / 4 + 256) / 256), (unsigned)B);
+  hipLaunchKernelGGL(add_noise_kernel, grid, dim3(256), 0, s, x0, noise, t, acp, n_train, out, per_sample);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// latent encoder  (reference src/model/ops/depth_transform.py:15-19, eval-mode BN folded on the host)
+//   stage 0: conv 1->16, 3x3, stride 2, pad 1 (+BN) + LeakyReLU(0.2)     -> tmp NHWC [B][h][w][16]
+//   stage 1: conv 16->16, 3x3, pad 1 (+BN) + tanh                         -> latent NCHW
+// one thread per latent pixel, all 16 channels in registers; weights are wave-uniform (scalar loads)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) enc0_kernel(const float* __restrict__ depth, const float* __restrict__ w0,
+                                                   const float* __restrict__ b0, float* __restrict__ tmp,
+                                                   int H, int W, int h, int w) {
+  const int b = blockIdx.y;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long long)h * w) return;
+  const int oy = (int)(p / w), ox = (int)(p - (long long)oy * w);
+  const float* d = depth + (size_t)b * H * W;
+  float in[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+      in[ky * 3 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? d[(size_t)iy * W + ix] : 0.f;
+    }
+  float o[LATENT_C];
+#pragma unroll
+  for (int c = 0; c < LATENT_C; ++c) {
+    float a = b0[c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) a = fmaf(w0[c * 9 + k], in[k], a);
+    o[c] = a >= 0.f ? a : 0.2f * a;
+  }
+  float4* dst = reinterpret_cast<float4*>(tmp + ((size_t)b * h * w + p) * LATENT_C);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+}
+
+__global__ void __launch_bounds__(256) enc1_kernel(const float* __restrict__ tmp, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, float* __restrict__ latent, int h, int w) {
+  const int b = blockIdx.y;
+  const long long HW = (long long)h * w;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  const int oy = (int)(p / w), ox = (int)(p - (long long)oy * w);
+  float acc[LATENT_C];
+#pragma unroll
+  for (int c = 0; c < LATENT_C; ++c) acc[c] = b1[c];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - 1 + ky;
+    if (iy < 0 || iy >= h) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox - 1 + kx;
+      if (ix < 0 || ix >= w) continue;
+      const float4* src = reinterpret_cast<const float4*>(tmp + ((size_t)b * HW + (size_t)iy * w + ix) * LATENT_C);
+      float in[LATENT_C];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float4 v = src[q]; in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w; }
+#pragma unroll
+      for (int co = 0; co < LATENT_C; ++co)
+#pragma unroll
+        for (int ci = 0; ci < LATENT_C; ++ci) acc[co] = fmaf(w1[(co * LATENT_C + ci) * 9 + ky * 3 + kx], in[ci], acc[co]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < LATENT_C; ++c) latent[((size_t)b * LATENT_C + c) * HW + p] = tanhf(acc[c]);
+}
+
+hipError_t launch_encode(const CodecWeights& cw, const float* depth, float* tmp_nhwc, float* latent_nchw,
+                         int B, int H, int W, hipStream_t s) {
+  const int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
+  dim3 grid((unsigned)(((long long)h * w + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(enc0_kernel, grid, dim3(256), 0, s, depth, cw.enc_w0, cw.enc_b0, tmp_nhwc, H, W, h, w);
+  hipLaunchKernelGGL(enc1_kernel, grid, dim3(256), 0, s, tmp_nhwc, cw.enc_w1, cw.enc_b1, latent_nchw, h, w);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// latent decoder  (reference src/model/ops/depth_transform.py:20-26,33-35, eval-mode BN folded)
+//   stage 0: ConvTranspose2d 16->16, k4 s2 p1 (+bias, BN) + ReLU -> tmp NHWC [B][2h][2w][16]
+//            out[oy][ox] = sum over ky with (oy+1-ky) even, iy=(oy+1-ky)/2 in range (same in x): 2x2 taps
+//   stage 1: conv 16->1 3x3 pad 1 (+bias) -> sigmoid -> 1/max(s,1e-6) - 1   (fp32 throughout)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dec0_kernel(const float* __restrict__ latent, const float* __restrict__ w0,
+                                                   const float* __restrict__ b0, float* __restrict__ tmp, int h, int w) {
+  const int b = blockIdx.y;
+  const int H = 2 * h, W = 2 * w;
+  const long long HW = (long long)h * w;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int oy = (int)(p / W), ox = (int)(p - (long long)oy * W);
+  float acc[LATENT_C];
+#pragma unroll
+  for (int c = 0; c < LATENT_C; ++c) acc[c] = b0[c];
+  const float* lat = latent + (size_t)b * LATENT_C * HW;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ky = ((oy + 1) & 1) + 2 * a;
+    const int iy = (oy + 1 - ky) >> 1;
+    if (iy < 0 || iy >= h) continue;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const int kx = ((ox + 1) & 1) + 2 * c2;
+      const int ix = (ox + 1 - kx) >> 1;
+      if (ix < 0 || ix >= w) continue;
+      for (int ci = 0; ci < LATENT_C; ++ci) {
+        const float v = lat[(size_t)ci * HW + (size_t)iy * w + ix];
+        const float* wr = w0 + ((size_t)ci * LATENT_C) * 16 + ky * 4 + kx;
+#pragma unroll
+        for (int co = 0; co < LATENT_C; ++co) acc[co] = fmaf(wr[co * 16], v, acc[co]);
+      }
+    }
+  }
+  float4* dst = reinterpret_cast<float4*>(tmp + ((size_t)b * H * W + p) * LATENT_C);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    dst[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
+}
+
+__global__ void __launch_bounds__(256) dec1_kernel(const float* __restrict__ tmp, const float* __restrict__ w1, float b1,
+                                                   float* __restrict__ depth, int H, int W) {
+  const int b = blockIdx.y;
+  const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long long)H * W) return;
+  const int oy = (int)(p / W), ox = (int)(p - (long long)oy * W);
+  float z = b1;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - 1 + ky;
+    if (iy < 0 || iy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox - 1 + kx;
+      if (ix < 0 || ix >= W) continue;
+      const float4* src = reinterpret_cast<const float4*>(tmp + ((size_t)b * H * W + (size_t)iy * W + ix) * LATENT_C);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = src[q];
+        const float* wk = w1 + (4 * q) * 9 + ky * 3 + kx;
+        z = fmaf(wk[0], v.x, z); z = fmaf(wk[9], v.y, z); z = fmaf(wk[18], v.z, z); z = fmaf(wk[27], v.w, z);
+      }
+    }
+  }
+  const float sg = 1.f / (1.f + expf(-z));
+  depth[(size_t)b * H * W + p] = 1.f / fmaxf(sg, 1e-6f) - 1.f;
+}
+
+hipError_t launch_decode(const CodecWeights& cw, const float* latent_nchw, float* tmp_nhwc, float* depth,
+                         int B, int h, int w, hipStream_t s) {
+  const int H = 2 * h, W = 2 * w;
+  dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)B);
+  hipLaunchKernelGGL(dec0_kernel, grid, dim3(256), 0, s, latent_nchw, cw.dec_w0, cw.dec_b0, tmp_nhwc, h, w);
+  hipLaunchKernelGGL(dec1_kernel, grid, dim3(256), 0, s, tmp_nhwc, cw.dec_w1, cw.dec_b1, depth, H, W);
+  return hipGetLastError();
+}
+
+}  // namespace dd

@@ -1,0 +1,108 @@
+"""DDIMDepthEstimate_Res: drop-in mirror of the reference head
+(reference src/model/head/ddim_depth_estimate_res.py:14-235).
+
+Same constructor keywords (the dict Diffusion_DCbase_Model passes to HEADS.build,
+reference src/model/diffusion_dcbase_model.py:77-91), same parameter tree (state_dict keys), same
+forward(fp, depth_map, depth_mask, gt_depth_map=None, return_loss=False, **kwargs) -> 13-key dict.
+The condition aggregation (conv_lateral / conv_up FPN, …res.py:108-118) stays in PyTorch-ROCm; the
+latent encoder, the T-step DDIM loop, the decoder and the ddim_loss denoiser call run in the HIP
+library.  mmcv/mmdet3d are not needed: the few factories the reference pulls from them are plain
+torch.nn layers.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .modules import CNNDDIMPipiline, DeepDepthTransformWithUpsampling, HipBound, ScheduledCNNRefine
+from .scheduler import DDIMScheduler
+
+HEADS = {}          # name -> class; stands in for the mmdet3d HEADS registry (…res.py:14)
+
+
+def register_head(cls):
+    HEADS[cls.__name__] = cls
+    return cls
+
+
+def build_head(cfg: dict):
+    cfg = dict(cfg)
+    return HEADS[cfg.pop("type")](**cfg)
+
+
+@register_head
+class DDIMDepthEstimate_Res(nn.Module):
+    def __init__(self, in_channels=(64, 128, 256, 512), up_scale_factor=1, inference_steps=20, num_train_timesteps=1000,
+                 return_indices=None, depth_transform_cfg=None, depth_feature_dim=16, detach_fp=False, loss_cfgs=(),
+                 init_cfg=None, precision=None, **kwargs):
+        super().__init__()
+        if depth_transform_cfg is not None and depth_transform_cfg.get("type", "DeepDepthTransformWithUpsampling") != \
+                "DeepDepthTransformWithUpsampling":
+            raise NotImplementedError("only DeepDepthTransformWithUpsampling is used by the reference heads (…res.py:23)")
+        fpn_dim = 256
+        in_channels = [64, 128, 256, 512]          # the reference overrides the argument the same way (…res.py:31)
+        self.detach_fp = detach_fp
+        self.loss_cfgs = list(loss_cfgs)
+        self.init_cfg = init_cfg
+        self.return_indices = return_indices
+        self.up_scale = nn.Identity() if up_scale_factor == 1 else \
+            (lambda t: F.interpolate(t, scale_factor=up_scale_factor, mode="bilinear"))
+        bound = HipBound("res")
+        self._bound = bound
+        self.depth_transform = DeepDepthTransformWithUpsampling(hidden=16, eps=1e-6, bound=bound)
+        self.model = ScheduledCNNRefine(channels_in=fpn_dim, channels_noise=depth_feature_dim, bound=bound, precision=precision)
+        self.diffusion_inference_steps = inference_steps
+        self.scheduler = DDIMScheduler(num_train_timesteps=num_train_timesteps, clip_sample=False)
+        self.pipeline = CNNDDIMPipiline(self.model, self.scheduler)
+        # present in the reference state_dict although unused in forward (…res.py:42-52)
+        self.convup_fp = nn.Sequential(nn.ConvTranspose2d(fpn_dim, fpn_dim, 2, 2, bias=False), nn.BatchNorm2d(fpn_dim), nn.ReLU(True))
+        self.conv_lateral = nn.ModuleList()
+        self.conv_up = nn.ModuleList()
+        for i, c in enumerate(in_channels):
+            self.conv_lateral.append(nn.Sequential(nn.Conv2d(c, fpn_dim, 3, 1, 1, bias=False), nn.BatchNorm2d(fpn_dim), nn.ReLU(True)))
+            if i != 0:
+                self.conv_up.append(nn.Sequential(nn.ConvTranspose2d(fpn_dim, fpn_dim, 2, 2, bias=False), nn.BatchNorm2d(fpn_dim),
+                                                  nn.ReLU(True)))
+
+    # -- condition aggregation: PyTorch-ROCm (…res.py:108-118) -----------------------------------
+    def aggregate_condition(self, fp):
+        x = None
+        n = len(fp)
+        for i in range(n):
+            f = fp[n - i - 1]
+            cur = self.conv_lateral[n - i - 1](f)
+            if i > 0:
+                cur = cur + F.adaptive_avg_pool2d(self.conv_up[n - i - 1](x), output_size=cur.shape[-2:])
+            x = cur
+        return x
+
+    def forward(self, fp, depth_map, depth_mask, gt_depth_map=None, return_loss=False, **kwargs):
+        if self.detach_fp is not False and self.detach_fp is not None:
+            if isinstance(self.detach_fp, (list, tuple, range)):
+                fp = list(fp)
+                for i in self.detach_fp:
+                    fp[i] = fp[i].detach()
+            else:
+                fp = [it.detach() for it in fp]
+        gt_map_t = self.depth_transform.t(gt_depth_map)                         # …res.py:102  (HIP encoder)
+        x = self.aggregate_condition(fp)                                        # …res.py:108-118
+        refined_depth_t, = self.pipeline(batch_size=x.shape[0], device=x.device, dtype=x.dtype, shape=gt_map_t.shape[-3:],
+                                         input_args=(x, None, None, None),
+                                         num_inference_steps=self.diffusion_inference_steps, return_dict=False)   # :124-138
+        refined_depth = self.depth_transform.inv_t(refined_depth_t)             # :140  (HIP decoder)
+        ddim_loss = self.ddim_loss(pred_depth=refined_depth, gt_depth=gt_map_t, refine_module_inputs=(x, None, None, None),
+                                   blur_depth_t=refined_depth_t, weight=1.0)    # :159-169
+        return {"pred": refined_depth, "pred_init": gt_map_t, "blur_depth_t": gt_map_t, "ddim_loss": ddim_loss,
+                "gt_map_t": gt_map_t, "pred_uncertainty": None, "pred_inter": None, "weight_map": None, "guidance": None,
+                "offset": None, "aff": None, "gamma": None, "confidence": None}
+
+    def ddim_loss(self, gt_depth, refine_module_inputs, blur_depth_t, weight, **kwargs):
+        """…res.py:201-217: same RNG draw order (CPU randn for the noise, device randint for t)."""
+        noise = torch.randn(blur_depth_t.shape).to(blur_depth_t.device)
+        bs = blur_depth_t.shape[0]
+        timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bs,), device=gt_depth.device).long()
+        be = self._bound.ensure(blur_depth_t.device, self.scheduler)
+        noisy_images = self.scheduler.add_noise(blur_depth_t, noise, timesteps, backend=be)
+        noise_pred = self.model(noisy_images, timesteps, *refine_module_inputs)
+        return F.mse_loss(noise_pred, noise)

@@ -1,0 +1,166 @@
+"""nn.Module mirrors of the reference's hot-path modules with IDENTICAL parameter names and shapes,
+so reference checkpoints (state_dict keys depth_head.model.*, depth_head.depth_transform.*) load
+unchanged.  The modules hold parameters only; their forward() calls the HIP library.
+
+  ScheduledCNNRefine                 reference src/model/head/ddim_depth_estimate_res.py:300-344
+  CNNDDIMPipiline                    reference src/model/head/ddim_depth_estimate_res.py:238-297
+  DeepDepthTransformWithUpsampling   reference src/model/ops/depth_transform.py:10-35
+"""
+from __future__ import annotations
+
+import os
+import weakref
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .backend import HipDenoiser
+from .scheduler import DDIMScheduler
+
+DEFAULT_PRECISION = os.environ.get("DDEPTH_PRECISION", "fp32")
+
+
+class HipBound:
+    """Shares one HipDenoiser between the modules of a head and re-uploads parameters when any of
+    them changed (torch bumps ``Tensor._version`` on every in-place update, e.g. optimizer.step())."""
+
+    def __init__(self, variant: str = "res"):
+        self.variant = variant
+        self.backend: Optional[HipDenoiser] = None
+        self._modules = []
+        self._sig = None
+        self._sched_sig = None
+
+    def register(self, prefix: str, module: nn.Module):
+        self._modules.append((prefix, weakref.ref(module)))
+
+    def _signature(self):
+        sig = []
+        for prefix, ref in self._modules:
+            m = ref()
+            for k, v in m.state_dict(keep_vars=True).items():
+                sig.append((prefix + k, v.data_ptr(), v._version))
+        return tuple(sig)
+
+    def ensure(self, device, scheduler: Optional[DDIMScheduler] = None) -> HipDenoiser:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"the DDIM hot path runs only on a HIP device (got tensors on {device}); "
+                               "diffusiondepth_amd has no CPU fallback")
+        if self.backend is None or self.backend.device != torch.device("cuda", device.index if device.index is not None
+                                                                       else torch.cuda.current_device()):
+            self.backend = HipDenoiser(device, self.variant)
+            self._sig = None
+            self._sched_sig = None
+        sig = self._signature()
+        if sig != self._sig:
+            sd = {}
+            for prefix, ref in self._modules:
+                sd.update({prefix + k: v for k, v in ref().state_dict().items()})
+            self.backend.load_state_dict(sd)
+            self._sig = sig
+        if scheduler is not None:
+            ssig = (id(scheduler), scheduler.config.num_train_timesteps)
+            if ssig != self._sched_sig:
+                self.backend.set_schedule(scheduler._acp_host)
+                self._sched_sig = ssig
+        return self.backend
+
+
+class ScheduledCNNRefine(nn.Module):
+    """epsilon-network: same constructor and parameter tree as the reference (…res.py:300-322)."""
+
+    def __init__(self, channels_in: int = 256, channels_noise: int = 16, bound: Optional[HipBound] = None,
+                 precision: Optional[str] = None, **kwargs):
+        super().__init__()
+        if channels_in != 256 or channels_noise != 16:
+            raise ValueError("the HIP kernels are specialised for channels_in=256, channels_noise=16 "
+                             "(the only configuration the reference heads build, …res.py:27-37)")
+        self.noise_embedding = nn.Sequential(
+            nn.Conv2d(channels_noise, 64, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, 64), nn.ReLU(True),
+            nn.Conv2d(64, channels_in, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, channels_in), nn.ReLU(True))
+        self.time_embedding = nn.Embedding(1280, channels_in)
+        self.pred = nn.Sequential(
+            nn.Conv2d(channels_in, 64, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, 64), nn.ReLU(True),
+            nn.Conv2d(64, channels_noise, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, channels_noise), nn.ReLU(True))
+        self.precision = precision or DEFAULT_PRECISION
+        self.bound = bound if bound is not None else HipBound("res")
+        self.bound.register("model.", self)
+
+    def forward(self, noisy_image, t, *args):
+        """forward(noisy_image, t, feat, blur_depth, sparse_depth, sparse_mask) -> eps (…res.py:324-344)."""
+        feat = args[0]
+        be = self.bound.ensure(noisy_image.device)
+        t = torch.as_tensor(t, device=noisy_image.device)
+        return be.denoise_once(noisy_image.float(), t, feat.float(), self.precision)
+
+
+class CNNDDIMPipiline:
+    """Same call signature as the reference pipeline (…res.py:248-297).  With eta == 0 the whole
+    T-step loop is one dd_denoise call (one hipGraph replay); otherwise it falls back to stepping
+    model / scheduler.step on the GPU."""
+
+    def __init__(self, model: ScheduledCNNRefine, scheduler: DDIMScheduler):
+        self.model = model
+        self.scheduler = scheduler
+
+    def __call__(self, batch_size, device, dtype, shape, input_args, generator=None, eta: float = 0.0,
+                 num_inference_steps: int = 50, return_dict: bool = True, x_T=None, **kwargs):
+        image_shape = (batch_size, *shape)
+        # x_T ~ N(0,1) drawn by the caller-side RNG exactly as the reference does (:277); the library never draws
+        image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
+        self.scheduler.set_timesteps(num_inference_steps)
+        why_not = self.scheduler.hip_supported(eta)
+        if why_not is None:
+            be = self.model.bound.ensure(image.device, self.scheduler)
+            image = be.denoise(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
+        else:
+            for t in self.scheduler.timesteps:
+                model_output = self.model(image, t.to(device), *input_args)
+                image = self.scheduler.step(model_output, t, image, eta=eta, use_clipped_model_output=True,
+                                            generator=generator)["prev_sample"]
+        if not return_dict:
+            return (image,)
+        return {"images": image}
+
+
+def _conv_bn_relu(ch_in, ch_out, kernel, stride=1, padding=0, bn=True, relu=True):
+    layers = [nn.Conv2d(ch_in, ch_out, kernel, stride, padding, bias=not bn)]
+    if bn:
+        layers.append(nn.BatchNorm2d(ch_out))
+    if relu:
+        layers.append(nn.LeakyReLU(0.2, inplace=True))
+    return nn.Sequential(*layers)
+
+
+class DeepDepthTransformWithUpsampling(nn.Module):
+    """Latent encoder t() / decoder inv_t() (reference depth_transform.py:10-35).  Eval-mode
+    BatchNorm (running statistics) is what the HIP kernels implement; train-mode batch statistics
+    (SyncBN in the reference's training) are out of this round's scope and raise."""
+
+    def __init__(self, hidden: int = 16, eps: float = 1e-6, bound: Optional[HipBound] = None):
+        super().__init__()
+        if hidden != 16 or eps != 1e-6:
+            raise ValueError("HIP codec kernels are specialised for hidden=16, eps=1e-6 (…res.py:23)")
+        self.conv_transform = nn.Sequential(_conv_bn_relu(1, hidden, 3, 2, 1), _conv_bn_relu(hidden, hidden, 3, 1, 1, relu=False),
+                                            nn.Tanh())
+        self.conv_inv_transform = nn.Sequential(
+            nn.ConvTranspose2d(hidden, hidden, kernel_size=4, stride=2, padding=1), nn.BatchNorm2d(hidden), nn.ReLU(inplace=True),
+            _conv_bn_relu(hidden, 1, 3, 1, 1, bn=False, relu=False), nn.Sigmoid())
+        self.eps = eps
+        self.bound = bound if bound is not None else HipBound("res")
+        self.bound.register("depth_transform.", self)
+
+    def _check_mode(self):
+        if self.training:
+            raise NotImplementedError("DeepDepthTransformWithUpsampling HIP kernels implement eval-mode BatchNorm only; "
+                                      "call .eval() (training backward is a later row of SURVEY.md 8f)")
+
+    def t(self, depth):
+        self._check_mode()
+        return self.bound.ensure(depth.device).encode(depth.float())
+
+    def inv_t(self, value):
+        self._check_mode()
+        return self.bound.ensure(value.device).decode(value.float())

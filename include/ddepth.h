@@ -1,0 +1,144 @@
+/*
+ * ddepth.h -- C ABI of the MI355X-native DDIM denoise hot path of DiffusionDepth.
+ *
+ * One shared library (diffusiondepth_amd/libddepth_hip.so, built by hipcc for gfx950) sits behind the
+ * reference's head / pipeline seam.  Every entry point below names the reference interface it
+ * replaces (paths relative to the reference tree, /root/reference).  No torch types cross this
+ * boundary: plain device pointers, sizes, a hipStream_t passed as void*.
+ *
+ * Conventions
+ *   - All tensor arguments are DEVICE pointers to contiguous fp32 NCHW data, exactly what the
+ *     reference's torch tensors hold (reference runs --opt_level O0 = fp32, src/config.py:151-154).
+ *     Timestep vectors are device int64 (torch.long), as in src/model/head/ddim_depth_estimate_res.py:207.
+ *   - The library BORROWS caller memory for the duration of a call and writes results into
+ *     caller-allocated outputs (same ownership rule as the reference's DCN extension,
+ *     src/model/deformconv/src/cuda/modulated_deform_conv_cuda.cu:78,92).  It owns only its packed
+ *     weights, scratch activations, schedule tables and captured hipGraphs (freed by dd_destroy).
+ *   - Every function returns DD_OK (0) or a dd_status error; dd_last_error() gives the message
+ *     (the reference raises C++ exceptions -> RuntimeError, modulated_deform_conv_cuda.cu:39-73; the
+ *     Python shim turns a non-zero status into RuntimeError).
+ *   - The library never draws random numbers: x_T / noise / timesteps are inputs (the reference draws
+ *     them with torch.randn / torch.randint, ...res.py:277,203,207).
+ *   - Work is enqueued on `stream` (the caller's current HIP stream, as the reference's extension
+ *     uses at::cuda::getCurrentCUDAStream(), modulated_deform_conv_cuda.cu:94); calls are
+ *     asynchronous.  One handle per device/process; a handle is not thread-safe.
+ */
+#ifndef DDEPTH_H_
+#define DDEPTH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dd_handle_s* dd_handle_t;
+
+typedef enum dd_status {
+  DD_OK = 0,
+  DD_ERR_INVALID_ARG = 1,   /* bad shape / null pointer / unknown name */
+  DD_ERR_HIP = 2,           /* a HIP runtime call failed (message carries hipGetErrorString) */
+  DD_ERR_STATE = 3,         /* weights or schedule missing, handle misuse */
+  DD_ERR_UNSUPPORTED = 4    /* valid request this build does not implement */
+} dd_status;
+
+/* Which ScheduledCNNRefine the handle implements. */
+typedef enum dd_variant {
+  DD_VARIANT_RES = 0,   /* src/model/head/ddim_depth_estimate_res.py:300-344  (f = cond + E[t] + NE(x)) */
+  DD_VARIANT_SWIN = 1   /* src/model/head/ddim_depth_estimate_res_swin_addHAHI.py:321-382 (UpSample_add fuse) */
+} dd_variant;
+
+/* Arithmetic of the convolution contractions.  State x_t, GroupNorm statistics, schedule scalars,
+ * accumulators and the decoder tail are fp32/fp64 in every mode. */
+typedef enum dd_precision {
+  DD_PREC_NAIVE_FP32 = 0,  /* unfused one-thread-per-output fp32 kernels: on-device cross-check      */
+  DD_PREC_FP32 = 1,        /* fused implicit-GEMM on v_mfma_f32_32x32x2_f32, fp32 activations (parity gate) */
+  DD_PREC_BF16 = 2,        /* fused implicit-GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations (headline)  */
+  DD_PREC_F16 = 3          /* same kernels on v_mfma_f32_32x32x16_f16 (11-bit mantissa, same rate)          */
+} dd_precision;
+
+/* ---- lifetime ---------------------------------------------------------------------------------
+ * Replaces: construction of ScheduledCNNRefine + DDIMScheduler + CNNDDIMPipiline +
+ * DeepDepthTransformWithUpsampling in DDIMDepthEstimate_Res.__init__ (…res.py:36-41). */
+int dd_create(dd_handle_t* out, int device, int variant);
+int dd_destroy(dd_handle_t h);
+
+/* Message of the last failing call on this handle (or, with h == NULL, of the last failing
+ * dd_create on this thread).  Never NULL. */
+const char* dd_last_error(dd_handle_t h);
+
+/* Library / build identification: "ddepth <version> gfx950 ...". */
+const char* dd_version(void);
+
+/* ---- parameters -------------------------------------------------------------------------------
+ * Replaces: nn.Module.load_state_dict for the keys under depth_head.model.* and
+ * depth_head.depth_transform.* (key list: SURVEY.md 8a; loaded in src/main.py:422-423).
+ * `name` is the state-dict key WITHOUT the "depth_head." prefix, e.g.
+ * "model.noise_embedding.0.weight"; `data` is a HOST pointer to `numel` contiguous fp32 values in
+ * the reference's own layout (OIHW conv weights, (in,out,kh,kw) for the ConvTranspose).
+ * Call dd_commit_weights after the last dd_set_weight (and again whenever weights changed, e.g.
+ * after an optimizer step): it validates completeness and repacks into the kernels' layouts. */
+int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel);
+int dd_commit_weights(dd_handle_t h, void* stream);
+
+/* Replaces: DDIMScheduler.__init__ (src/model/diffusers/schedulers/scheduling_ddim.py:107-157).
+ * `alphas_cumprod` is the HOST fp32 table of length num_train_timesteps that the scheduler built
+ * (torch.cumprod(1 - linspace(beta_start, beta_end))), so table bits are the reference's own. */
+int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_timesteps);
+
+/* ---- the hot loop -----------------------------------------------------------------------------
+ * Replaces: CNNDDIMPipiline.__call__ (…res.py:248-297) minus its torch.randn: `timesteps`-driven
+ * loop of  eps = model(x_t, t, cond) ; x_{t-1} = scheduler.step(eps, t, x_t, eta=0,
+ * use_clipped_model_output=True)  (DDIMScheduler.step, scheduling_ddim.py:231-353), for the
+ * T = num_inference_steps timesteps of DDIMScheduler.set_timesteps (scheduling_ddim.py:215-229).
+ *   x_T   (B,16,h,w)           initial latent noise
+ *   cond  (B,256,cond_h,cond_w) condition map (cond_h,cond_w == h,w for DD_VARIANT_RES)
+ *   x_0   (B,16,h,w)           result ("refined_depth_t", …res.py:124)
+ * The T-step loop runs as one captured hipGraph per (B,h,w,cond_h,cond_w,T,precision). */
+int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
+               int B, int lat_h, int lat_w, int cond_h, int cond_w,
+               int num_inference_steps, int precision, void* stream);
+
+/* Replaces: one ScheduledCNNRefine.forward(noisy_image, t, feat, None, None, None)
+ * (…res.py:324-344) with per-sample timesteps t[B] (device int64), as called by ddim_loss
+ * (…res.py:211).  eps (B,16,h,w) >= 0 (final GroupNorm+ReLU). */
+int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, float* eps,
+                    int B, int lat_h, int lat_w, int cond_h, int cond_w, int precision, void* stream);
+
+/* Replaces: DDIMScheduler.add_noise == q_sample (scheduling_ddim.py:355-376):
+ * out = sqrt(abar[t_b]) * x0 + sqrt(1 - abar[t_b]) * noise, t (B,) device int64, tensors (B,C,h,w). */
+int dd_add_noise(dd_handle_t h, const float* x0, const float* noise, const int64_t* t, float* out,
+                 int B, int C, int lat_h, int lat_w, void* stream);
+
+/* ---- latent codec -----------------------------------------------------------------------------
+ * Replaces: DeepDepthTransformWithUpsampling.t (src/model/ops/depth_transform.py:29-31), eval-mode
+ * BatchNorm: depth (B,1,H,W) -> latent (B,16,(H-1)/2+1,(W-1)/2+1). */
+int dd_encode(dd_handle_t h, const float* depth, float* latent, int B, int H, int W, void* stream);
+
+/* Replaces: DeepDepthTransformWithUpsampling.inv_t (depth_transform.py:33-35), eval-mode BatchNorm:
+ * latent (B,16,h,w) -> depth (B,1,2h,2w) = 1/clamp(sigmoid(.),1e-6) - 1. */
+int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h, int lat_w, void* stream);
+
+/* ---- introspection (tests, bench) ----------------------------------------------------------------
+ * Time of the last dd_denoise graph launch measured with hipEvents recorded on `stream` around
+ * the graph (0 if timing is off).  dd_set_option("timing", 1) enables it; other options:
+ * "graph" (1 = hipGraph replay [default], 0 = eager launches), "debug_sync" (1 = sync + check
+ * after every launch). */
+int dd_set_option(dd_handle_t h, const char* key, int64_t value);
+int dd_last_loop_ms(dd_handle_t h, float* ms);
+/* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans". */
+int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
+/* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
+ * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`
+ * (1..4) since the option was set (used by bench.py for the per-kernel roofline figure). */
+int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches);
+
+/* Copies an internal intermediate of the last dd_denoise_once call to a caller DEVICE buffer as
+ * fp32 NCHW: name in {"y1","y2","y3","y4"} = raw conv outputs before GroupNorm (B,C,h,w).
+ * Test hook for locating a failing layer. */
+int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDEPTH_H_ */

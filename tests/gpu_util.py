@@ -1,0 +1,48 @@
+"""Shared helpers for the `-m gpu` parity tests."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT_DIR = os.path.join(ROOT, "gpurun_out")
+_backends = {}
+
+
+def sd_for(c):
+    return synth.make_state_dict(c["wseed"], c.get("variant", "res"), c.get("decoder_gain", 0.05), c.get("decoder_log_scale", 0.0))
+
+
+def backend_for(c):
+    """One HipDenoiser per distinct weight set (cached for the session)."""
+    key = (c["wseed"], c.get("variant", "res"), c.get("decoder_gain", 0.05), c.get("decoder_log_scale", 0.0))
+    if key not in _backends:
+        be = dda.HipDenoiser(variant=c.get("variant", "res"))
+        be.load_state_dict(sd_for(c))
+        be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+        _backends[key] = be
+    return _backends[key]
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def record(name, **vals):
+    """Append a diagnostics line to gpurun_out/parity_report.jsonl (read back after the gpurun call)."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    with open(os.path.join(OUT_DIR, "parity_report.jsonl"), "a") as f:
+        f.write(json.dumps({"name": name, **{k: (float(v) if isinstance(v, (np.floating, float)) else v) for k, v in vals.items()}}) + "\n")
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+def rms(a, b):
+    d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
+    return float(np.sqrt((d * d).mean()))

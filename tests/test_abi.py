@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ddepth.h declares; the host-side
+mirrors behave like the reference's (scheduler tables / timesteps / step / add_noise vs golden,
+state_dict key names).  No compute calls into the library here (no GPU in this container)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import synth
+from diffusiondepth_amd.backend import ABI_SYMBOLS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ddepth.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(dd_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
+    lib = dda.load_library()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.dd_version()
+
+
+def test_create_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dda.HipDenoiser()
+    head = dda.DDIMDepthEstimate_Res().eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        head.depth_transform.t(torch.zeros(1, 1, 8, 8))
+
+
+def test_scheduler_matches_reference_tables(golden):
+    g = golden("sched")
+    s = dda.DDIMScheduler(num_train_timesteps=1000, clip_sample=False)
+    assert np.array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    assert np.array_equal(s.betas.numpy(), g["betas"])
+    for T in (5, 20, 50):
+        s.set_timesteps(T)
+        assert np.array_equal(s.timesteps.numpy(), g[f"timesteps_T{T}"])
+    assert s.hip_supported(0.0) is None and s.hip_supported(0.5) is not None
+
+
+def test_scheduler_step_and_add_noise_match_reference(golden, cases):
+    c, g = cases["sched"], golden("sched")
+    rs = np.random.RandomState(c["seed"])
+    x = torch.from_numpy(rs.standard_normal(c["shape"]).astype(np.float32))
+    eps = torch.from_numpy(np.abs(rs.standard_normal(c["shape"])).astype(np.float32))
+    s = dda.DDIMScheduler()
+    s.set_timesteps(20)
+    for i, t in enumerate(s.timesteps):
+        out = s.step(eps, t, x, eta=0.0, use_clipped_model_output=True)["prev_sample"]
+        assert torch.equal(out, torch.from_numpy(g["step_T20"][i]))          # same formula order -> same bits
+    B = len(c["add_noise_t"])
+    x0 = torch.from_numpy(rs.standard_normal((B,) + tuple(c["shape"][1:])).astype(np.float32))
+    nz = torch.from_numpy(rs.standard_normal((B,) + tuple(c["shape"][1:])).astype(np.float32))
+    assert torch.equal(s.add_noise(x0, nz, torch.tensor(c["add_noise_t"])), torch.from_numpy(g["add_noise"]))
+
+
+def test_head_state_dict_keys_match_reference_names():
+    head = dda.DDIMDepthEstimate_Res()
+    keys = {k for k in head.state_dict() if not k.endswith("num_batches_tracked")}
+    want = set(synth.make_state_dict(1)) | set(synth.make_fpn_state_dict(1))
+    assert keys == want, keys ^ want
+    for k, v in synth.make_state_dict(1).items():
+        assert tuple(head.state_dict()[k].shape) == v.shape, k
+
+
+def test_model_facade_builds_and_names_backbones():
+    m = dda.Diffusion_DCbase_Model(dda.model.default_args(backbone_name="mmbev_res18", inference_steps=5))
+    assert m.depth_head.diffusion_inference_steps == 5
+    feats = m.depth_backbone(torch.zeros(1, 3, 32, 48))
+    assert [f.shape[1] for f in feats] == [64, 128, 256, 512]
+    assert [tuple(f.shape[-2:]) for f in feats] == [(16, 24), (8, 12), (4, 6), (2, 3)]

@@ -115,3 +115,33 @@ def test_codec(golden, cases):
         dref = g[f"depth_{i}"]
         assert d.shape == dref.shape == (B, 1, 2 * h, 2 * w)
         assert (np.abs(d - dref) / np.maximum(np.abs(dref), 1e-2)).max() < 2e-5
+
+
+# ---- the torch-CPU port (oracle/torch_cpu_port.py: cpu_baseline + full-size checker) is pinned too ----
+def test_torch_port_loop_and_codec(golden, cases):
+    import torch
+    from oracle import torch_cpu_port as P
+    c, g = cases["loop_res"], golden("loop_res")
+    sd = P.to_torch_sd(_sd(c))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    assert torch.equal(P.make_alphas_cumprod(), torch.from_numpy(golden("sched")["alphas_cumprod"]))
+    for T in c["T"]:
+        x0 = P.ddim_loop(sd, inp["x_T"], inp["cond"], T).numpy()
+        ref = g[f"x0_T{T}"]
+        assert np.abs(x0 - ref).max() < 3e-6 * np.abs(ref).max()
+        assert np.abs(P.decode(sd, torch.from_numpy(ref)).numpy() - g[f"depth_T{T}"]).max() < 1e-5
+    cc, gc = cases["codec"], golden("codec")
+    sdc = P.to_torch_sd(_sd(cc))
+    gt = synth.make_gt_depth(cc["iseed"], *cc["sizes"][0])
+    assert np.abs(P.encode(sdc, gt).numpy() - gc["latent_0"]).max() < 2e-6
+
+
+def test_torch_port_denoiser_batch_t(golden, cases):
+    import torch
+    from oracle import torch_cpu_port as P
+    c, g = cases["denoise_res"], golden("denoise_res")
+    sd = P.to_torch_sd(_sd(c))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    with torch.no_grad():
+        e = P.denoiser(sd, torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["timesteps"]), torch.from_numpy(inp["cond"]))
+    assert np.abs(e.numpy() - g["eps_batch_t"]).max() < 1e-5
