@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--T", type=int, default=20, help="DDIM inference steps (reference --inference_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -76,6 +77,7 @@ def main():
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
     if args.no_graph:
         be.set_option("graph", 0)
+    be.set_option("kernel_version", args.kernel_version)
     inp = synth.make_inputs(7240 + rank, B, h, w)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
     cond = torch.from_numpy(inp["cond"]).to(dev)
@@ -130,7 +132,7 @@ def main():
         avg_s = tot_ms / max(cnt, 1) * 1e-3
         achieved = flops / avg_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        roof = {"bound": "mfma", "kernel": f"conv_igemm_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
+        roof = {"bound": "mfma", "kernel": f"conv_igemm{'2' if args.kernel_version == 2 else ''}_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                 "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops,
                 "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
@@ -168,7 +170,7 @@ def main():
             "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
-                       "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FLOP_PER_PIXEL_STEP},
+                       "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FLOP_PER_PIXEL_STEP},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

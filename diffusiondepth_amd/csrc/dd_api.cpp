@@ -62,16 +62,17 @@ inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
 
 struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   int cin = 0, cout = 0;
-  DevBuf wpack[NUM_EK];             // packed for the fused path
+  DevBuf wpack[NUM_EK];             // packed for the fused path, v1 kernels
+  DevBuf wpack2[NUM_EK];            // v2 kernels (pre-swizzled for LDS-DMA)
   DevBuf bias;                      // [cout padded to 32]
   DevBuf w_oihw;                    // naive path
   DevBuf gamma, beta;               // GroupNorm affine [cout]
 };
 
 struct PlanKey {
-  int B, h, w, ch, cw, T, prec;
+  int B, h, w, ch, cw, T, prec, kver;
   bool operator<(const PlanKey& o) const {
-    return std::tie(B, h, w, ch, cw, T, prec) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec);
+    return std::tie(B, h, w, ch, cw, T, prec, kver) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.kver);
   }
 };
 
@@ -113,6 +114,7 @@ struct dd_handle_s {
   DevBuf d_acp;
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
+  int kernel_version = 2;     // 1 = dd_igemm.hip, 2 = dd_igemm2.hip (pipelined)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   uint64_t tick = 0;
   Plan* last_once_plan = nullptr;
@@ -171,20 +173,26 @@ std::vector<WeightSpec> required_weights(int variant) {
 
 // Packed layout consumed by conv_igemm_kernel:
 //   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT)
-void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, std::vector<uint8_t>& out) {
+void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
   const int n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = 9 / g.tg;
   const size_t n_el = (size_t)n_tiles * n_chunks * n_tg * g.tg * g.nt * g.ck;
   const size_t esz = ek_size(ek);
   out.assign(n_el * esz, 0);
-  size_t idx = 0;
   for (int nt = 0; nt < n_tiles; ++nt)
     for (int ch = 0; ch < n_chunks; ++ch)
       for (int tg = 0; tg < n_tg; ++tg)
         for (int t = 0; t < g.tg; ++t) {
           const int tap = tg * g.tg + t, dy = tap / 3, dx = tap % 3;
+          const int rowb = g.ck * (int)esz, ppp = rowb / 16, rpb = 256 / rowb, epp = 16 / (int)esz;
+          const size_t blk0 = (((size_t)(nt * n_chunks + ch) * n_tg + tg) * g.tg + 0) * (size_t)g.nt * g.ck;
           for (int n = 0; n < g.nt; ++n)
-            for (int k = 0; k < g.ck; ++k, ++idx) {
+            for (int k = 0; k < g.ck; ++k) {
               const int co = nt * g.nt + n, ci = ch * g.ck + k;
+              // element index inside the packed image; v2 XORs the 16-B piece index with the row swizzle
+              const int row = t * g.nt + n;
+              const int piece = k / epp, within = k % epp;
+              const int piece_sw = swizzle ? (piece ^ ((row / rpb) & (ppp - 1))) : piece;
+              const size_t idx = blk0 + (size_t)row * g.ck + (size_t)piece_sw * epp + within;
               const float v = (co < g.cout) ? w_oihw[(((size_t)co * g.cin + ci) * 3 + dy) * 3 + dx] : 0.f;
               if (ek == EK_F32) std::memcpy(&out[idx * 4], &v, 4);
               else {
@@ -283,36 +291,39 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.tiles_y = (k.h + 7) / 8;
   const int ek = pl->ek;
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
-    if (!h->layer_timing) return launch_conv_igemm(layer, ek, cp, s);
+    auto launch = [&](const ConvParams& q) {
+      return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
+    };
+    if (!h->layer_timing) return launch(cp);
     hipEvent_t a, b;
     hipError_t e = hipEventCreate(&a); if (e != hipSuccess) return e;
     e = hipEventCreate(&b); if (e != hipSuccess) return e;
     (void)hipEventRecord(a, s);
-    e = launch_conv_igemm(layer, ek, cp, s);
+    e = launch(cp);
     (void)hipEventRecord(b, s);
     h->pending_ev.emplace_back(layer - 1, a, b);
     return e;
   };
   // conv1: state (+ fused DDIM update of the previous step) -> y1
-  p.in = x_in; p.wpack = h->L[0].wpack[ek].p; p.bias = h->L[0].bias.as<float>(); p.out = pl->y1.p;
+  p.in = x_in; p.wpack = (k.kver == 2 ? h->L[0].wpack2[ek] : h->L[0].wpack[ek]).p; p.bias = h->L[0].bias.as<float>(); p.out = pl->y1.p;
   p.stats_out = pl->stat_ptr(step, 0);
   p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
   p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
   p.y4 = pl->y4.as<float>(); p.xout = x_out; p.c1c2 = pl->c1c2.as<float>(); p.step = apply_update ? step : 0;
   DD_HIP(timed_launch(1, p));
   // conv2: relu(gn1(y1)) -> y2
-  p.in = pl->y1.p; p.wpack = h->L[1].wpack[ek].p; p.bias = h->L[1].bias.as<float>(); p.out = pl->y2.p;
+  p.in = pl->y1.p; p.wpack = (k.kver == 2 ? h->L[1].wpack2[ek] : h->L[1].wpack[ek]).p; p.bias = h->L[1].bias.as<float>(); p.out = pl->y2.p;
   p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
   p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
   DD_HIP(timed_launch(2, p));
   // conv3: relu(gn2(y2)) + cond + E[t] -> y3
-  p.in = pl->y2.p; p.wpack = h->L[2].wpack[ek].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+  p.in = pl->y2.p; p.wpack = (k.kver == 2 ? h->L[2].wpack2[ek] : h->L[2].wpack[ek]).p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
   DD_HIP(timed_launch(3, p));
   // conv4: relu(gn3(y3)) -> y4 (fp32)
-  p.in = pl->y3.p; p.wpack = h->L[3].wpack[ek].p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
+  p.in = pl->y3.p; p.wpack = (k.kver == 2 ? h->L[3].wpack2[ek] : h->L[3].wpack[ek]).p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
   p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
   p.gn_gamma = h->L[2].gamma.as<float>(); p.gn_beta = h->L[2].beta.as<float>();
   DD_HIP(timed_launch(4, p));
@@ -463,10 +474,14 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     const std::vector<float>& b = h->host_w[std::string(conv_names[l]) + ".bias"];
     for (int ek = 0; ek < NUM_EK; ++ek) {
       std::vector<uint8_t> packed;
-      pack_conv_weights(w.data(), conv_pack_geom(l + 1, ek), ek, packed);
+      pack_conv_weights(w.data(), conv_pack_geom(l + 1, ek), ek, false, packed);
       int rc = upload(h, L.wpack[ek], packed.data(), packed.size(), s);
       if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));     // `packed` is a temporary
+      pack_conv_weights(w.data(), conv_pack_geom2(l + 1, ek), ek, true, packed);
+      rc = upload(h, L.wpack2[ek], packed.data(), packed.size(), s);
+      if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
     }
     std::vector<float> bpad(std::max(32, L.cout), 0.f);
     std::copy(b.begin(), b.end(), bpad.begin());
@@ -553,6 +568,10 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   if (k == "graph") h->use_graph = value != 0;
   else if (k == "timing") h->timing = value != 0;
   else if (k == "debug_sync") h->debug_sync = value != 0;
+  else if (k == "kernel_version") {
+    if (value != 1 && value != 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: kernel_version must be 1 or 2");
+    h->kernel_version = (int)value;
+  }
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
@@ -599,11 +618,11 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version}, &pl);
   if (rc) return rc;
 
-  DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, s));
-  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, s));
+  DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
 
   if (h->timing) {
     if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
@@ -620,7 +639,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
     }
     h->n_eager_loops++;
     if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
-    DD_HIP(launch_nhwc_to_nchw_f32(pl->x[T & 1].p, EK_F32, x_0, B, LATENT_C, lat_h, lat_w, s));
+    DD_HIP(launch_nhwc_to_nchw_f32(pl->x[T & 1].p, EK_F32, x_0, B, LATENT_C, lat_h, lat_w, 0, s));
     return DD_OK;
   }
 
@@ -652,7 +671,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
         h->n_capture_failures++;
       }
       // the eager pass above consumed x[0]: restore the input state before the real run
-      DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, s));
+      DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
       if (h->timing) DD_HIP(hipEventRecord(h->ev0, s));
     }
     if (pl->exec) {
@@ -683,16 +702,16 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version}, &pl);
   if (rc) return rc;
   const long long* tv = reinterpret_cast<const long long*>(t);
-  DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, s));
-  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, s));
+  DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
   DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
   if (precision == DD_PREC_NAIVE_FP32) {
     rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);
     if (rc) return rc;
-    DD_HIP(launch_nhwc_to_nchw_f32(pl->eps.p, EK_F32, eps, B, LATENT_C, lat_h, lat_w, s));
+    DD_HIP(launch_nhwc_to_nchw_f32(pl->eps.p, EK_F32, eps, B, LATENT_C, lat_h, lat_w, 0, s));
   } else {
     rc = enqueue_fused_step(h, pl, 0, pl->x[0].as<float>(), pl->x[1].as<float>(), false, tv, 0, 1, s);
     if (rc) return rc;
@@ -758,7 +777,8 @@ int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, v
   else if (n == "y4") { src = pl->y4.p; C = LATENT_C; ek = EK_F32; }
   else return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: unknown tensor '" + n + "'");
   if (numel != (int64_t)pl->key.B * C * pl->key.h * pl->key.w) return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: numel mismatch");
-  DD_HIP(launch_nhwc_to_nchw_f32(src, ek, out, pl->key.B, C, pl->key.h, pl->key.w, reinterpret_cast<hipStream_t>(stream)));
+  DD_HIP(launch_nhwc_to_nchw_f32(src, ek, out, pl->key.B, C, pl->key.h, pl->key.w, pl->key.prec != DD_PREC_NAIVE_FP32,
+                                 reinterpret_cast<hipStream_t>(stream)));
   return DD_OK;
 }
 

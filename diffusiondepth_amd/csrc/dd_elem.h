@@ -1,0 +1,88 @@
+// dd_elem.h -- element-kind helpers shared by the fused convolution kernels (dd_igemm.hip = v1,
+// dd_igemm2.hip = v2): bf16/f16/f32 <-> fp32 conversion of 16-byte pieces, the MFMA step, and the
+// channel-blocked activation layout.
+#pragma once
+#include "dd_kernels.h"
+
+namespace dd {
+
+// Activations with C >= 32 channels are stored channel-blocked: [B][C/32][H][W][32] elements, so
+// that one 32-channel block of a row of pixels is contiguous (64 B per pixel in bf16/f16, 128 B in
+// fp32): conv epilogues write and conv prologues read whole contiguous row segments per block.
+// 16-channel tensors (state x, conv4 output) are plain NHWC [B][H][W][16].
+constexpr int ACT_CB = 32;
+__host__ __device__ inline size_t act_offset(int C, int h, int w, int b, int c, int y, int x) {
+  if (C < ACT_CB) return (((size_t)b * h + y) * w + x) * C + c;
+  return ((((size_t)b * (C / ACT_CB) + c / ACT_CB) * h + y) * w + x) * ACT_CB + (c % ACT_CB);
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// ------------------------------------------------------------------------------------------------
+// element helpers
+// ------------------------------------------------------------------------------------------------
+template <int EK> struct ElemSize { static constexpr int V = (EK == EK_F32) ? 4 : 2; };
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t u16) { return __builtin_bit_cast(float, u16 << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {            // round-to-nearest-even
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ float f16_to_f32(uint32_t u16) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)u16);
+}
+__device__ __forceinline__ uint32_t f32_to_f16(float f) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// 16-byte piece <-> floats.  NE = elements per piece (8 for 2-byte kinds, 4 for fp32).
+template <int EK> struct Piece {
+  static constexpr int NE = 16 / ElemSize<EK>::V;
+  static __device__ __forceinline__ void unpack(const uint4& v, float (&f)[NE]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (EK == EK_F32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, w[i]);
+    } else if constexpr (EK == EK_BF16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32(w[i] & 0xFFFFu); f[2 * i + 1] = bf16_to_f32(w[i] >> 16); }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[2 * i] = f16_to_f32(w[i] & 0xFFFFu); f[2 * i + 1] = f16_to_f32(w[i] >> 16); }
+    }
+  }
+  static __device__ __forceinline__ uint4 pack(const float (&f)[NE]) {
+    uint32_t w[4];
+    if constexpr (EK == EK_F32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(uint32_t, f[i]);
+    } else if constexpr (EK == EK_BF16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16(f[2 * i]) | (f32_to_bf16(f[2 * i + 1]) << 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w[i] = f32_to_f16(f[2 * i]) | (f32_to_f16(f[2 * i + 1]) << 16);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+template <int EK>
+__device__ __forceinline__ void mma_step(f32x16_t& acc, const uint4& wf, const uint4& pf) {
+  if constexpr (EK == EK_BF16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, pf), acc, 0, 0, 0);
+  } else if constexpr (EK == EK_F16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wf), __builtin_bit_cast(f16x8_t, pf), acc, 0, 0, 0);
+  } else {
+    // lane (i, g) holds channels 4g..4g+3 of an 8-channel group: MFMA j contracts channels {j, 4+j}
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.x), __builtin_bit_cast(float, pf.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.y), __builtin_bit_cast(float, pf.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.z), __builtin_bit_cast(float, pf.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, pf.w), acc, 0, 0, 0);
+  }
+}
+
+}  // namespace dd

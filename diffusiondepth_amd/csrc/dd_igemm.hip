@@ -13,7 +13,7 @@
 //              is staged ONCE per channel chunk and re-read from LDS for the 9 taps (so HBM/L2 sees
 //              the input ~1.3x, not 9x); weights stream through LDS per tap group,
 //   epilogue : adds the bias, accumulates this layer's GroupNorm sum / sum-of-squares (fp32 per
-//              lane -> fp64 across lanes, waves and workgroups) and stores the raw output NHWC.
+//              lane -> fp64 across lanes, waves and workgroups) and stores the raw output (channel-blocked NHWC, dd_elem.h).
 //
 // MFMA mapping (wave64): D[cout][pixel] += W[cout][k] * P[k][pixel] with the WEIGHTS as the A operand
 // and the PIXELS as the B operand of v_mfma_f32_32x32x16_{bf16,f16} (K = 16 channels) or of 4 x
@@ -21,78 +21,9 @@
 // [.. + 8*(l>>5)) of cout/pixel (l&31) from LDS rows padded by 16 B (row strides 48/80/144 B ->
 // conflict-free ds_read_b128).  In D a lane owns ONE pixel and 4 consecutive couts per register
 // quad, so the NHWC store and all per-pixel epilogue math are lane-local.
-#include "dd_kernels.h"
+#include "dd_elem.h"
 
 namespace dd {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-// ------------------------------------------------------------------------------------------------
-// element helpers
-// ------------------------------------------------------------------------------------------------
-template <int EK> struct ElemSize { static constexpr int V = (EK == EK_F32) ? 4 : 2; };
-
-__device__ __forceinline__ float bf16_to_f32(uint32_t u16) { return __builtin_bit_cast(float, u16 << 16); }
-__device__ __forceinline__ uint32_t f32_to_bf16(float f) {            // round-to-nearest-even
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
-__device__ __forceinline__ float f16_to_f32(uint32_t u16) {
-  return (float)__builtin_bit_cast(_Float16, (uint16_t)u16);
-}
-__device__ __forceinline__ uint32_t f32_to_f16(float f) {
-  return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
-}
-
-// 16-byte piece <-> floats.  NE = elements per piece (8 for 2-byte kinds, 4 for fp32).
-template <int EK> struct Piece {
-  static constexpr int NE = 16 / ElemSize<EK>::V;
-  static __device__ __forceinline__ void unpack(const uint4& v, float (&f)[NE]) {
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    if constexpr (EK == EK_F32) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f[i] = __builtin_bit_cast(float, w[i]);
-    } else if constexpr (EK == EK_BF16) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { f[2 * i] = bf16_to_f32(w[i] & 0xFFFFu); f[2 * i + 1] = bf16_to_f32(w[i] >> 16); }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { f[2 * i] = f16_to_f32(w[i] & 0xFFFFu); f[2 * i + 1] = f16_to_f32(w[i] >> 16); }
-    }
-  }
-  static __device__ __forceinline__ uint4 pack(const float (&f)[NE]) {
-    uint32_t w[4];
-    if constexpr (EK == EK_F32) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(uint32_t, f[i]);
-    } else if constexpr (EK == EK_BF16) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16(f[2 * i]) | (f32_to_bf16(f[2 * i + 1]) << 16);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = f32_to_f16(f[2 * i]) | (f32_to_f16(f[2 * i + 1]) << 16);
-    }
-    return make_uint4(w[0], w[1], w[2], w[3]);
-  }
-};
-
-template <int EK>
-__device__ __forceinline__ void mma_step(f32x16_t& acc, const uint4& wf, const uint4& pf) {
-  if constexpr (EK == EK_BF16) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, pf), acc, 0, 0, 0);
-  } else if constexpr (EK == EK_F16) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wf), __builtin_bit_cast(f16x8_t, pf), acc, 0, 0, 0);
-  } else {
-    // lane (i, g) holds channels 4g..4g+3 of an 8-channel group: MFMA j contracts channels {j, 4+j}
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.x), __builtin_bit_cast(float, pf.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.y), __builtin_bit_cast(float, pf.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.z), __builtin_bit_cast(float, pf.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, wf.w), __builtin_bit_cast(float, pf.w), acc, 0, 0, 0);
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // per-layer configuration
@@ -234,7 +165,7 @@ __global__ void __launch_bounds__(C::THREADS) conv_igemm_kernel(ConvParams p) {
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         pp_[u] = pp; j_[u] = j;
         inside[u] = (it < ITEMS) && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        goff[u] = ((size_t)gy * w + gx) * (C::CIN * IN_ESZ) + (size_t)(chunk * CK + j * EPP) * IN_ESZ;
+        goff[u] = act_offset(C::CIN, h, w, 0, chunk * CK + j * EPP, gy, gx) * IN_ESZ;     // channel-blocked for CIN >= 32
         if (inside[u]) {
 #pragma unroll
           for (int q = 0; q < NLD; ++q) raw[u][q] = *reinterpret_cast<const uint4*>(in_b + goff[u] + q * 16);
@@ -340,7 +271,6 @@ __global__ void __launch_bounds__(C::THREADS) conv_igemm_kernel(ConvParams p) {
     const int r = pix / C::TW, c = pix - r * C::TW;
     const int gy = y0 + r, gx = x0 + c;
     const bool pvalid = gy < h && gx < w;
-    char* orow = out_b + ((size_t)gy * w + gx) * (C::COUT * C::OUT_ESZ);
 #pragma unroll
     for (int n = 0; n < C::WN; ++n) {
 #pragma unroll
@@ -360,7 +290,7 @@ __global__ void __launch_bounds__(C::THREADS) conv_igemm_kernel(ConvParams p) {
           const int lg = (C::COUT == COND_C) ? (n >> 1) : (C::COUT == HID_C) ? (2 * n + (q >> 1)) : q;
           ls[lg] += s; lq[lg] += sq;
           if constexpr (C::OUT_ESZ == 4) {
-            *reinterpret_cast<float4*>(orow + (size_t)co * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 pk;
             if constexpr (EK == EK_BF16) {
@@ -370,7 +300,7 @@ __global__ void __launch_bounds__(C::THREADS) conv_igemm_kernel(ConvParams p) {
               pk.x = f32_to_f16(v[0]) | (f32_to_f16(v[1]) << 16);
               pk.y = f32_to_f16(v[2]) | (f32_to_f16(v[3]) << 16);
             }
-            *reinterpret_cast<uint2*>(orow + (size_t)co * 2) = pk;
+            *reinterpret_cast<uint2*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 2) = pk;
           }
         }
       }

@@ -61,10 +61,15 @@ hipError_t launch_conv_igemm(int layer, int ek, const ConvParams& p, hipStream_t
 // Packed-weight geometry of (layer, ek): elements and tile parameters (host side packing).
 struct PackGeom { int cin, cout, cout_pad, ck, tg, nt; };
 PackGeom conv_pack_geom(int layer, int ek);
+// v2 (dd_igemm2.hip): software-pipelined variant; weights are packed with the LDS swizzle pre-applied
+// (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
+hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
+PackGeom conv_pack_geom2(int layer, int ek);
 
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
-hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, hipStream_t s);
-hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s);
+// dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h
+hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s);
+hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, int blocked, hipStream_t s);
 // out(NCHW) = c1*x + c2*relu(gn4(y4))  (mode 0, final DDIM update) or relu(gn4(y4)) (mode 1, eps)
 hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,
                         const float* c1c2, int step, int mode, float* out_nchw, int B, int h, int w, hipStream_t s);

@@ -3,7 +3,7 @@
 // All of these are HBM-bound streaming kernels that run once per image (or once per call), not once
 // per DDIM step; they are written for coalescing (consecutive lanes <-> consecutive addresses on the
 // wide side of every transfer), not for the matrix cores.
-#include "dd_kernels.h"
+#include "dd_elem.h"
 
 namespace dd {
 
@@ -25,7 +25,7 @@ __device__ __forceinline__ float ld_elem(const void* base, size_t idx, int ek) {
 // ------------------------------------------------------------------------------------------------
 template <int EK>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst,
-                                                           int C, long long HW) {
+                                                           int C, long long HW, int blocked) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z;
   const long long p0 = (long long)blockIdx.x * 64;
@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   if (p0 + opx >= HW) return;
   const int cbase = c0 + part * 16;
   if (cbase >= C) return;                              // C is a multiple of 16 for every tensor we convert
-  const size_t o = ((size_t)b * HW + p0 + opx) * C + cbase;
+  // destination offset in the activation layout of dd_elem.h (channel-blocked when C >= 32); h*w is all that matters
+  const size_t o = (C < ACT_CB || !blocked) ? ((size_t)b * HW + p0 + opx) * C + cbase
+                                : (((size_t)b * (C / ACT_CB) + cbase / ACT_CB) * HW + p0 + opx) * ACT_CB + (cbase % ACT_CB);
   if constexpr (EK == EK_F32) {
     float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o);
 #pragma unroll
@@ -65,30 +67,32 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
-hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, hipStream_t s) {
+hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s) {
   if (C % 16 != 0) return hipErrorInvalidValue;
   const long long HW = (long long)h * w;
   dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
-  if (ek == EK_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW);
-  else if (ek == EK_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW);
-  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW);
+  if (ek == EK_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW, blocked);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW, blocked);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW, blocked);
   return hipGetLastError();
 }
 
 // NHWC (any element kind) -> NCHW fp32; debug / small tensors only (one thread per output element).
 __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, int ek, float* __restrict__ dst, int C, long long HW,
-                                    long long total) {
+                                    long long total, int blocked) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const long long p = i % HW;
   const long long bc = i / HW;
   const int c = (int)(bc % C);
   const long long b = bc / C;
-  dst[i] = ld_elem(src, (size_t)(b * HW + p) * C + c, ek);
+  const size_t o = (C < ACT_CB || !blocked) ? (size_t)(b * HW + p) * C + c
+                                            : (((size_t)b * (C / ACT_CB) + c / ACT_CB) * HW + p) * ACT_CB + (c % ACT_CB);
+  dst[i] = ld_elem(src, o, ek);
 }
-hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s) {
+hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, int blocked, hipStream_t s) {
   const long long HW = (long long)h * w, total = HW * C * B;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ek, dst, C, HW, total);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ek, dst, C, HW, total, blocked);
   return hipGetLastError();
 }
 

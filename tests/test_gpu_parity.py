@@ -23,6 +23,14 @@ EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}      #
 ALL_PREC = ["naive_fp32", "fp32", "bf16", "f16"]
 
 
+@pytest.fixture(params=[2, 1], ids=["v2", "v1"], autouse=True)
+def kver(request):
+    """Every test runs against both fused-kernel generations (dd_igemm2.hip = default, dd_igemm.hip)."""
+    import gpu_util
+    gpu_util.KVER = request.param
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def U():
     if not torch.cuda.is_available():
@@ -88,7 +96,7 @@ def test_single_denoiser_call_vs_reference(U, golden, cases, prec):
     eps_b = eps_b.cpu().numpy()
     eps_s = be.denoise_once(x, torch.tensor(c["t"], device="cuda"), cond, prec).cpu().numpy()
     eb, es = U.maxabs(eps_b, g["eps_batch_t"]), U.maxabs(eps_s, g["eps_scalar_t"])
-    U.record("denoise_once", prec=prec, eps_batch_maxabs=eb, eps_scalar_maxabs=es, eps_rms=U.rms(eps_b, g["eps_batch_t"]), **layer_err)
+    U.record("denoise_once", kver=U.KVER, prec=prec, eps_batch_maxabs=eb, eps_scalar_maxabs=es, eps_rms=U.rms(eps_b, g["eps_batch_t"]), **layer_err)
     assert eps_b.min() >= 0.0
     assert layer_err["y1"] < (1e-5 if "fp32" in prec else 2e-2)
     assert eb < EPS_TOL[prec] and es < EPS_TOL[prec], (eb, es)
@@ -109,7 +117,7 @@ def test_ddim_loop_vs_reference_golden(U, golden, cases, name, prec):
         e = U.maxabs(x0, ref)
         de = U.maxabs(depth, dref)
         drel = float((np.abs(depth - dref) / np.maximum(dref, 1e-2)).max())
-        U.record("loop", case=name, prec=prec, T=T, latent_maxabs=e, latent_scale=scale, latent_rms=U.rms(x0, ref),
+        U.record("loop", kver=U.KVER, case=name, prec=prec, T=T, latent_maxabs=e, latent_scale=scale, latent_rms=U.rms(x0, ref),
                  depth_maxabs=de, depth_rmse=U.rms(depth, dref), depth_maxrel=drel, depth_max=float(dref.max()))
         assert np.isfinite(x0).all()
         assert e < LATENT_TOL[prec] * scale, (e, scale)
@@ -130,7 +138,7 @@ def test_ragged_sizes_and_batch_vs_oracle(U, prec):
         ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], T)
         scale = float(np.abs(ref).max())
         e = U.maxabs(x0, ref)
-        U.record("ragged", prec=prec, B=B, h=h, w=w, T=T, latent_maxabs=e, latent_scale=scale)
+        U.record("ragged", kver=U.KVER, prec=prec, B=B, h=h, w=w, T=T, latent_maxabs=e, latent_scale=scale)
         assert e < LATENT_TOL[prec] * scale, (B, h, w, e, scale)
 
 
@@ -152,7 +160,7 @@ def test_graph_equals_eager_and_is_deterministic(U, cases):
         be.set_option("graph", 1)
         scale = np.abs(a).max()
         # fp64 atomics make the GroupNorm sums order-dependent only at the 1e-16 level
-        U.record("graph_vs_eager", prec=prec, rerun_maxabs=U.maxabs(a, b), eager_maxabs=U.maxabs(a, cc), scale=float(scale))
+        U.record("graph_vs_eager", kver=U.KVER, prec=prec, rerun_maxabs=U.maxabs(a, b), eager_maxabs=U.maxabs(a, cc), scale=float(scale))
         assert U.maxabs(a, b) <= tol * scale and U.maxabs(a, cc) <= tol * scale
 
 
@@ -231,7 +239,7 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
         d = be.decode(x0).cpu().numpy()
         x0 = x0.cpu().numpy()
         e, de = U.maxabs(x0, ref), U.maxabs(d, dref)
-        U.record("full_size", size=size, prec=prec, latent_maxabs=e, latent_scale=scale, latent_rms=U.rms(x0, ref),
+        U.record("full_size", kver=U.KVER, size=size, prec=prec, latent_maxabs=e, latent_scale=scale, latent_rms=U.rms(x0, ref),
                  depth_maxabs=de, depth_rmse=U.rms(d, dref), depth_max=float(dref.max()), cpu_port_seconds=cpu_s)
         assert e < LATENT_TOL[prec] * scale * (2.5 if prec == "fp32" else 1.0), (prec, e, scale)   # port itself is fp32
         if prec == "fp32":

@@ -13,7 +13,9 @@ echo "== smoke";  timeout 300 python -c "import __graft_entry__ as g; g.smoke()"
 tail -n 5 gpurun_out/smoke.log
 echo "== bench";  timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_bf16.log 2>&1; echo "bench rc=$?"
 tail -n 3 gpurun_out/bench_bf16.log
+timeout 300 python bench.py --steps 10 --warmup 2 --kernel-version 1 --no-cpu-baseline > gpurun_out/bench_bf16_v1.log 2>&1; tail -n 1 gpurun_out/bench_bf16_v1.log
 timeout 300 python bench.py --steps 10 --warmup 2 --batch 4 --no-cpu-baseline > gpurun_out/bench_bf16_b4.log 2>&1; tail -n 1 gpurun_out/bench_bf16_b4.log
+timeout 300 python bench.py --steps 10 --warmup 2 --precision f16 --no-cpu-baseline > gpurun_out/bench_f16.log 2>&1; tail -n 1 gpurun_out/bench_f16.log
 timeout 300 python bench.py --steps 5 --warmup 1 --precision fp32 --no-cpu-baseline > gpurun_out/bench_fp32.log 2>&1; tail -n 1 gpurun_out/bench_fp32.log
 echo "== rocprof"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_bf16" -o bench -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof_bf16.log" 2>&1); echo "rocprof rc=$?"
