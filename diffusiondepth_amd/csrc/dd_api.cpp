@@ -115,6 +115,7 @@ struct dd_handle_s {
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
   int kernel_version = 2;     // 1 = dd_igemm.hip, 2 = dd_igemm2.hip (pipelined)
+  int ablate = 0;             // timing experiments only (ConvParams::ablate)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   uint64_t tick = 0;
   Plan* last_once_plan = nullptr;
@@ -289,6 +290,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.B = k.B; p.h = k.h; p.w = k.w;
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + 7) / 8;
+  p.ablate = h->ablate;
   const int ek = pl->ek;
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](const ConvParams& q) {
@@ -568,6 +570,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   if (k == "graph") h->use_graph = value != 0;
   else if (k == "timing") h->timing = value != 0;
   else if (k == "debug_sync") h->debug_sync = value != 0;
+  else if (k == "ablate") h->ablate = (int)value;
   else if (k == "kernel_version") {
     if (value != 1 && value != 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: kernel_version must be 1 or 2");
     h->kernel_version = (int)value;

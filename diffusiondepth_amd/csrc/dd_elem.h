@@ -38,6 +38,16 @@ __device__ __forceinline__ uint32_t f32_to_f16(float f) {
   return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// two fp32 -> one packed dword, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+template <int EK> __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  if constexpr (EK == EK_BF16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+  else return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+
 // 16-byte piece <-> floats.  NE = elements per piece (8 for 2-byte kinds, 4 for fp32).
 template <int EK> struct Piece {
   static constexpr int NE = 16 / ElemSize<EK>::V;
@@ -59,12 +69,9 @@ template <int EK> struct Piece {
     if constexpr (EK == EK_F32) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(uint32_t, f[i]);
-    } else if constexpr (EK == EK_BF16) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = f32_to_bf16(f[2 * i]) | (f32_to_bf16(f[2 * i + 1]) << 16);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) w[i] = f32_to_f16(f[2 * i]) | (f32_to_f16(f[2 * i + 1]) << 16);
+      for (int i = 0; i < 4; ++i) w[i] = pack2<EK>(f[2 * i], f[2 * i + 1]);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   }

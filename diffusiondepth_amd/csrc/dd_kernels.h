@@ -53,6 +53,9 @@ struct ConvParams {
   int step;                 // PRO_X: 0 = no update (x is used as is)
   int B, h, w;
   int tiles_x, tiles_y;
+  int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
+                            // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
+                            // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier
 };
 
 // ---- fused implicit-GEMM path (dd_igemm.hip) -------------------------------------------------
