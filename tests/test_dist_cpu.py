@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the N>1 host path (image sharding, parameter broadcast, exact metric reduction).
+The hot path itself shards by independent images and has no data-path collective."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffusiondepth_amd import dist as ddist
+from diffusiondepth_amd import synth
+
+
+def test_shards_partition_the_items():
+    for n in (0, 1, 7, 8, 9, 33):
+        for world in (1, 2, 3, 8):
+            seen = sorted(i for r in range(world) for i in ddist.shard_indices(n, r, world))
+            assert seen == list(range(n))
+            per = {len(ddist.shard_indices(n, r, world, pad=True)) for r in range(world)}
+            assert len(per) == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    r, w = ddist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    # rank 0 "loads the checkpoint"; everybody else starts from garbage and receives the broadcast
+    sd = {k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(7240).items()}
+    if rank != 0:
+        for v in sd.values():
+            v.fill_(-1.0)
+    ddist.broadcast_state_dict(sd)
+    ref = synth.make_state_dict(7240)
+    assert all(np.array_equal(sd[k].numpy(), ref[k]) for k in ref)
+    # each rank evaluates its shard of 5 synthetic images; reduced metric sums must equal the single-process ones
+    n_img = 5
+    sums = torch.zeros(4, dtype=torch.float64)
+    for i in ddist.shard_indices(n_img, rank, world):
+        gt = torch.from_numpy(synth.make_gt_depth(100 + i, 1, 16, 24))
+        pred = gt + torch.from_numpy(np.random.RandomState(200 + i).standard_normal(gt.shape).astype(np.float32)) * 0.1
+        sums += ddist.depth_metric_sums(pred, gt)
+    tot = ddist.reduce_sums(sums)
+    if rank == 0:
+        torch.save(tot, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_broadcast_and_metric_reduction(tmp_path):
+    out = str(tmp_path / "tot.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    tot = torch.load(out)
+    ref = torch.zeros(4, dtype=torch.float64)
+    for i in range(5):
+        gt = torch.from_numpy(synth.make_gt_depth(100 + i, 1, 16, 24))
+        pred = gt + torch.from_numpy(np.random.RandomState(200 + i).standard_normal(gt.shape).astype(np.float32)) * 0.1
+        ref += ddist.depth_metric_sums(pred, gt)
+    assert torch.allclose(tot, ref, rtol=1e-12, atol=0)
+    m = ddist.finalize_metrics(tot)
+    assert 0.05 < m["rmse"] < 0.2 and m["n"] > 0
