@@ -83,6 +83,7 @@ struct Plan {
   DevBuf cond;        // NHWC condition map (activation element kind; fp32 for naive)
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
+  DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
@@ -106,6 +107,7 @@ struct dd_handle_s {
   bool committed = false;      // denoiser group (model.*) packed
   bool codec_committed = false; // codec group (depth_transform.*) packed
   ConvLayer L[4];
+  ConvLayer LA, LB;            // Swin variant: upsample_fuse.convA / convB (256->256, no norm)
   DevBuf emb;
   DevBuf codec_buf;          // all folded codec weights in one allocation
   CodecWeights codec{};
@@ -217,7 +219,7 @@ int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw) {
   if (B <= 0 || lh <= 0 || lw <= 0) return h->fail(DD_ERR_INVALID_ARG, "B, lat_h, lat_w must be positive");
   if (h->variant == DD_VARIANT_RES && (ch != lh || cw != lw))
     return h->fail(DD_ERR_INVALID_ARG, "DD_VARIANT_RES needs cond_h,cond_w == lat_h,lat_w (reference ...res.py:340 adds them elementwise)");
-  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN loop is not implemented in this build");
+  if (h->variant == DD_VARIANT_SWIN && (ch <= 0 || cw <= 0)) return h->fail(DD_ERR_INVALID_ARG, "cond_h, cond_w must be positive");
   if ((long long)B * lh * lw * COND_C >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
   return DD_OK;
 }
@@ -242,7 +244,10 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   const size_t es = ek_size(pl->ek);
   DD_HIP(pl->x[0].alloc(px * LATENT_C * 4));
   DD_HIP(pl->x[1].alloc(px * LATENT_C * 4));
-  DD_HIP(pl->cond.alloc((size_t)key.B * key.ch * key.cw * COND_C * es));
+  const bool swin = h->variant == DD_VARIANT_SWIN;
+  // Swin: the condition map is bilinearly upsampled to the latent size once per call and kept at that size
+  DD_HIP(pl->cond.alloc(swin ? px * COND_C * es : (size_t)key.B * key.ch * key.cw * COND_C * es));
+  if (swin) { DD_HIP(pl->sa.alloc(px * COND_C * es)); DD_HIP(pl->sf.alloc(px * COND_C * es)); }
   DD_HIP(pl->y1.alloc(px * HID_C * es));
   DD_HIP(pl->y2.alloc(px * COND_C * es));
   DD_HIP(pl->y3.alloc(px * HID_C * es));
@@ -303,7 +308,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     (void)hipEventRecord(a, s);
     e = launch(cp);
     (void)hipEventRecord(b, s);
-    h->pending_ev.emplace_back(layer - 1, a, b);
+    h->pending_ev.emplace_back((layer - 1) & 3, a, b);     // Swin layers 5..7 are booked under slots 0..2
     return e;
   };
   // conv1: state (+ fused DDIM update of the previous step) -> y1
@@ -318,12 +323,27 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
   p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
   DD_HIP(timed_launch(2, p));
+  if (h->variant == DD_VARIANT_SWIN) {
+    // upsample_fuse: convB(convA(relu(gn2(y2)) + up(cond) + E[t]))  then pred.0 on the raw result
+    p.in = pl->y2.p; p.wpack = h->LA.wpack2[ek].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
+    p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
+    p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
+    p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
+    DD_HIP(timed_launch(5, p));
+    p.in = pl->sa.p; p.wpack = h->LB.wpack2[ek].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
+    p.stats_in = nullptr;
+    DD_HIP(timed_launch(6, p));
+    p.in = pl->sf.p; p.wpack = h->L[2].wpack2[ek].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+    p.stats_out = pl->stat_ptr(step, 2);
+    DD_HIP(timed_launch(7, p));
+  } else {
   // conv3: relu(gn2(y2)) + cond + E[t] -> y3
   p.in = pl->y2.p; p.wpack = (k.kver == 2 ? h->L[2].wpack2[ek] : h->L[2].wpack[ek]).p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
   DD_HIP(timed_launch(3, p));
+  }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
   p.in = pl->y3.p; p.wpack = (k.kver == 2 ? h->L[3].wpack2[ek] : h->L[3].wpack[ek]).p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
   p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
@@ -495,6 +515,25 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     rc = upload(h, L.beta, gb.data(), gb.size() * 4, s); if (rc) return rc;
     DD_HIP(hipStreamSynchronize(s));
   }
+  if (do_model && h->variant == DD_VARIANT_SWIN) {
+    const char* names[2] = {"model.upsample_fuse.convA.conv", "model.upsample_fuse.convB.conv"};
+    ConvLayer* Ls[2] = {&h->LA, &h->LB};
+    for (int i = 0; i < 2; ++i) {
+      ConvLayer& L = *Ls[i];
+      L.cin = COND_C; L.cout = COND_C;
+      const std::vector<float>& w = h->host_w[std::string(names[i]) + ".weight"];
+      const std::vector<float>& b = h->host_w[std::string(names[i]) + ".bias"];
+      for (int ek = 0; ek < NUM_EK; ++ek) {
+        std::vector<uint8_t> packed;
+        pack_conv_weights(w.data(), conv_pack_geom2(5 + i, ek), ek, true, packed);
+        int rc = upload(h, L.wpack2[ek], packed.data(), packed.size(), s);
+        if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
+      int rc = upload(h, L.bias, b.data(), b.size() * 4, s); if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
+    }
+  }
   if (do_model) {
     const std::vector<float>& e = h->host_w["model.time_embedding.weight"];
     int rc = upload(h, h->emb, e.data(), e.size() * 4, s); if (rc) return rc;
@@ -570,7 +609,14 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   if (k == "graph") h->use_graph = value != 0;
   else if (k == "timing") h->timing = value != 0;
   else if (k == "debug_sync") h->debug_sync = value != 0;
-  else if (k == "ablate") h->ablate = (int)value;
+  else if (k == "ablate") {
+    if (h->ablate != (int)value) {            // kernel parameters are baked into captured graphs
+      DD_HIP(hipDeviceSynchronize());
+      h->plans.clear();
+      h->last_once_plan = nullptr;
+    }
+    h->ablate = (int)value;
+  }
   else if (k == "kernel_version") {
     if (value != 1 && value != 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: kernel_version must be 1 or 2");
     h->kernel_version = (int)value;
@@ -618,6 +664,8 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (!x_T || !cond || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
+  if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
@@ -625,7 +673,8 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (rc) return rc;
 
   DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+  if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+  else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
 
   if (h->timing) {
     if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
@@ -702,6 +751,8 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   if (rc) return rc;
   if (!x_t || !t || !cond || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
+  if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
@@ -709,7 +760,8 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   if (rc) return rc;
   const long long* tv = reinterpret_cast<const long long*>(t);
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+  if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+  else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
   DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
   if (precision == DD_PREC_NAIVE_FP32) {
     rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);

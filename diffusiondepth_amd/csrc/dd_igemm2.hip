@@ -30,12 +30,16 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int EK = EK_;
   static constexpr int LAYER = LAYER_;
   static constexpr int ESZ = ElemSize<EK>::V;
-  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2) ? HID_C : (LAYER == 3) ? COND_C : HID_C;
-  static constexpr int COUT = (LAYER == 1) ? HID_C : (LAYER == 2) ? COND_C : (LAYER == 3) ? HID_C : LATENT_C;
+  // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
+  //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
+  //   (raw input, no norm / activation in between: ConvModule(norm_cfg=None, act_cfg=None)), 7 = pred.0 256->64 on a raw input
+  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : COND_C;
+  static constexpr int COUT = (LAYER == 1 || LAYER == 3 || LAYER == 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
-  static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 3) ? (64 / ESZ) : (128 / ESZ);
-  static constexpr int TG = (LAYER == 1) ? 9 : (LAYER == 2) ? 1 : 3;
-  static constexpr int NT = (LAYER == 2) ? 128 : COUT_PAD;
+  static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
+  static constexpr int TG = (LAYER == 1) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
+  static constexpr int NT = (COUT == COND_C) ? 128 : COUT_PAD;
+  static constexpr bool STATS = !(LAYER == 5 || LAYER == 6);   // a GroupNorm follows this convolution
   static constexpr int TH = 8, TW = 32;
   // conv1 / conv4 are latency-bound (36 / 18 MFMAs per 32-pixel block): 8 waves of one block each
   // halve every wave's dependent chain; conv2 / conv3 keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
@@ -43,7 +47,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;
-  static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3) ? PRO_GN_ADD : PRO_GN;
+  static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1) ? 4 : ESZ;
   static constexpr int OUT_ESZ = (LAYER == 4) ? 4 : ESZ;
   static constexpr int PH = TH + 2, PW = TW + 2;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   const int y0 = ty * C::TH, x0 = tx * C::TW;
   const int n0 = blockIdx.y * C::NT;
   const int h = p.h, w = p.w;
-  const bool have_norm = (C::PRO != PRO_X) || (p.step > 0);
+  const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
   const int abl = p.ablate;
   if (abl & 256) return;                  // timing floor: launch + dispatch only
 
@@ -207,6 +211,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       if ((m_valid >> u) & 1u) {
+        if constexpr (C::PRO == PRO_RAW) {
+          // no normalisation between the producer and this convolution: the stored elements are the operands
+          *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[u][0] : make_uint4(0u, 0u, 0u, 0u);
+          continue;
+        }
         float v[EPP];
         if ((m_inside >> u) & 1u) {
           if constexpr (C::PRO == PRO_X) {
@@ -339,6 +348,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     int wa[NKQ];
 #pragma unroll
     for (int kq = 0; kq < NKQ; ++kq) wa[kq] = wkt[kq] + woff;
+    if (abl & 2048) __builtin_amdgcn_s_setprio(1);
     if (!(abl & 8)) {
 #pragma unroll
     for (int t = 0; t < C::TG; ++t) {
@@ -360,13 +370,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       }
     }
     }
+    if (abl & 2048) __builtin_amdgcn_s_setprio(0);
     if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES);
     // The next stage's weights (this wave's DMA pieces) must have landed before the barrier.  VMEM ops retire in
     // issue order and the DMA was issued BEFORE this stage's raw patch loads, so when those loads were issued in
     // this stage it is enough to wait until at most NRAW (= the raw loads) are outstanding: they keep flying for
     // two more stages (cdna guide T4: counted vmcnt).  Every wave issues exactly NRAW loads (clamped addresses).
-    constexpr int NRAW = NIT * NLD * ((C::PRO == PRO_GN) ? 1 : 2);
+    constexpr int NRAW = NIT * NLD * ((C::PRO == PRO_GN || C::PRO == PRO_RAW) ? 1 : 2);
     if (C::NCHUNK > 1 && tg == 0 && chunk + 1 < C::NCHUNK && C::NTG > 1 && !(abl & (2 | 128))) {
       static_assert(NRAW <= 63, "vmcnt field");
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
@@ -411,7 +422,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         const float4 bv = *reinterpret_cast<const float4*>(tab_bias + n * 32 + 8 * q + 4 * g);
         const float v[4] = {acc[n][m][q * 4 + 0] + bv.x, acc[n][m][q * 4 + 1] + bv.y,
                             acc[n][m][q * 4 + 2] + bv.z, acc[n][m][q * 4 + 3] + bv.w};
-        if (pvalid) {
+        if (C::STATS && pvalid) {
           const float s = (v[0] + v[1]) + (v[2] + v[3]);
           const float sq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
           const int lg = (C::COUT == COND_C) ? (n >> 1) : (C::COUT == HID_C) ? (2 * n + (q >> 1)) : q;
@@ -438,6 +449,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       }
     }
   }
+  if constexpr (!C::STATS) return;
   // wave-level butterfly in fp32 (64 fp32 lane partials of <= 64 values each; the cross-wave / cross-workgroup
   // accumulation below is fp64).  COUT=16: lanes of half g hold groups {g, 2+g} -> reduce inside each half only.
   constexpr int TOP = (C::COUT < 32) ? 16 : 32;
@@ -494,6 +506,9 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 2: return launch_one2<EK, 2>(p, s);
     case 3: return launch_one2<EK, 3>(p, s);
     case 4: return launch_one2<EK, 4>(p, s);
+    case 5: return launch_one2<EK, 5>(p, s);
+    case 6: return launch_one2<EK, 6>(p, s);
+    case 7: return launch_one2<EK, 7>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -515,7 +530,10 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 1: return geom2_of<EK, 1>();
     case 2: return geom2_of<EK, 2>();
     case 3: return geom2_of<EK, 3>();
-    default: return geom2_of<EK, 4>();
+    case 4: return geom2_of<EK, 4>();
+    case 5: return geom2_of<EK, 5>();
+    case 6: return geom2_of<EK, 6>();
+    default: return geom2_of<EK, 7>();
   }
 }
 PackGeom conv_pack_geom2(int layer, int ek) {

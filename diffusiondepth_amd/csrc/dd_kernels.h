@@ -30,7 +30,8 @@ enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2 };
 enum Prologue : int {
   PRO_X = 0,       // conv1: input = DDIM-updated state (c1*x + c2*relu(gn4(y4))), also written back
   PRO_GN = 1,      // input = relu(gn(y))
-  PRO_GN_ADD = 2   // conv3: input = relu(gn(y)) + cond + E[t]
+  PRO_GN_ADD = 2,  // conv3 / Swin convA: input = relu(gn(y)) + cond + E[t]
+  PRO_RAW = 3      // Swin convB / pred.0: input is used as stored (no normalisation in between)
 };
 
 // One 3x3 convolution launch of the fused path.
@@ -72,6 +73,9 @@ PackGeom conv_pack_geom2(int layer, int ek);
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
 // dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h
 hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s);
+// Swin variant: bilinear (align_corners=True) upsample of the NCHW fp32 condition map (B,C,ch,cw) to (h,w), written in the
+// channel-blocked activation layout (reference ...swin_addHAHI.py:332: F.interpolate(..., mode='bilinear', align_corners=True))
+hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s);
 hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, int blocked, hipStream_t s);
 // out(NCHW) = c1*x + c2*relu(gn4(y4))  (mode 0, final DDIM update) or relu(gn4(y4)) (mode 1, eps)
 hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,

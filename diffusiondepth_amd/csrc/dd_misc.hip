@@ -77,6 +77,78 @@ hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Swin variant: bilinear upsample (align_corners=True) NCHW fp32 (ch,cw) -> channel-blocked (h,w).  Same tiling as
+// nchw_to_nhwc_kernel: a block produces [64 output pixels][64 channels]; the 4 source taps of a pixel are read
+// along pixels of one channel plane (neighbouring lanes hit neighbouring / identical source columns).
+// torch semantics: src = dst * (in-1)/(out-1) (scale computed in fp32), i0 = floor, lambda1 = src - i0.
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__global__ void __launch_bounds__(256) upsample_to_blocked_kernel(const float* __restrict__ src, void* __restrict__ dst, int C,
+                                                                  int ch, int cw, int h, int w) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const long long HW = (long long)h * w, SHW = (long long)ch * cw;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  const int px = tid & 63, cs = tid >> 6;
+  const long long p = p0 + px;
+  const bool pin = p < HW;
+  const int oy = pin ? (int)(p / w) : 0, ox = pin ? (int)(p - (long long)oy * w) : 0;
+  const float sy = (h > 1) ? (float)(ch - 1) / (float)(h - 1) : 0.f;
+  const float sx = (w > 1) ? (float)(cw - 1) / (float)(w - 1) : 0.f;
+  const float fy = sy * (float)oy, fx = sx * (float)ox;
+  const int y0 = min((int)fy, ch - 1), x0 = min((int)fx, cw - 1);
+  const int y1 = min(y0 + 1, ch - 1), x1 = min(x0 + 1, cw - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* sb = src + (size_t)b * C * SHW;
+#pragma unroll 4
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = cc * 4 + cs;
+    float v = 0.f;
+    if (pin && c0 + c < C) {
+      const float* pl = sb + (size_t)(c0 + c) * SHW;
+      v = hy * (hx * pl[(size_t)y0 * cw + x0] + lx * pl[(size_t)y0 * cw + x1]) +
+          ly * (hx * pl[(size_t)y1 * cw + x0] + lx * pl[(size_t)y1 * cw + x1]);
+    }
+    tile[px][c] = v;
+  }
+  __syncthreads();
+  const int opx = tid >> 2, part = tid & 3;
+  if (p0 + opx >= HW) return;
+  const int cbase = c0 + part * 16;
+  if (cbase >= C) return;
+  const size_t o = (((size_t)b * (C / ACT_CB) + cbase / ACT_CB) * HW + p0 + opx) * ACT_CB + (cbase % ACT_CB);
+  if constexpr (EK == EK_F32) {
+    float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      d[i] = make_float4(tile[opx][part * 16 + 4 * i], tile[opx][part * 16 + 4 * i + 1],
+                         tile[opx][part * 16 + 4 * i + 2], tile[opx][part * 16 + 4 * i + 3]);
+  } else {
+    uint32_t wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float lo = tile[opx][part * 16 + 2 * i], hi = tile[opx][part * 16 + 2 * i + 1];
+      wv[i] = (EK == EK_BF16) ? (cvt_bf16(lo) | (cvt_bf16(hi) << 16)) : (cvt_f16(lo) | (cvt_f16(hi) << 16));
+    }
+    uint4* d = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(dst) + o);
+    d[0] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    d[1] = make_uint4(wv[4], wv[5], wv[6], wv[7]);
+  }
+}
+hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s) {
+  if (C % 64 != 0) return hipErrorInvalidValue;
+  const long long HW = (long long)h * w;
+  dim3 grid((unsigned)((HW + 63) / 64), (unsigned)(C / 64), (unsigned)B);
+  if (ek == EK_F32) hipLaunchKernelGGL(upsample_to_blocked_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, ch, cw, h, w);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(upsample_to_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, ch, cw, h, w);
+  else hipLaunchKernelGGL(upsample_to_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, ch, cw, h, w);
+  return hipGetLastError();
+}
+
 // NHWC (any element kind) -> NCHW fp32; debug / small tensors only (one thread per output element).
 __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, int ek, float* __restrict__ dst, int C, long long HW,
                                     long long total, int blocked) {

@@ -33,6 +33,9 @@ def build_head(cfg: dict):
 
 @register_head
 class DDIMDepthEstimate_Res(nn.Module):
+    _IN_CHANNELS = [64, 128, 256, 512]       # the reference overrides the constructor argument with these (…res.py:31)
+    _VARIANT = "res"
+
     def __init__(self, in_channels=(64, 128, 256, 512), up_scale_factor=1, inference_steps=20, num_train_timesteps=1000,
                  return_indices=None, depth_transform_cfg=None, depth_feature_dim=16, detach_fp=False, loss_cfgs=(),
                  init_cfg=None, precision=None, **kwargs):
@@ -41,17 +44,18 @@ class DDIMDepthEstimate_Res(nn.Module):
                 "DeepDepthTransformWithUpsampling":
             raise NotImplementedError("only DeepDepthTransformWithUpsampling is used by the reference heads (…res.py:23)")
         fpn_dim = 256
-        in_channels = [64, 128, 256, 512]          # the reference overrides the argument the same way (…res.py:31)
+        in_channels = list(self._IN_CHANNELS)
         self.detach_fp = detach_fp
         self.loss_cfgs = list(loss_cfgs)
         self.init_cfg = init_cfg
         self.return_indices = return_indices
         self.up_scale = nn.Identity() if up_scale_factor == 1 else \
             (lambda t: F.interpolate(t, scale_factor=up_scale_factor, mode="bilinear"))
-        bound = HipBound("res")
+        bound = HipBound(self._VARIANT)
         self._bound = bound
         self.depth_transform = DeepDepthTransformWithUpsampling(hidden=16, eps=1e-6, bound=bound)
-        self.model = ScheduledCNNRefine(channels_in=fpn_dim, channels_noise=depth_feature_dim, bound=bound, precision=precision)
+        self.model = ScheduledCNNRefine(channels_in=fpn_dim, channels_noise=depth_feature_dim, bound=bound, precision=precision,
+                                        variant=self._VARIANT)
         self.diffusion_inference_steps = inference_steps
         self.scheduler = DDIMScheduler(num_train_timesteps=num_train_timesteps, clip_sample=False)
         self.pipeline = CNNDDIMPipiline(self.model, self.scheduler)
@@ -106,3 +110,12 @@ class DDIMDepthEstimate_Res(nn.Module):
         noisy_images = self.scheduler.add_noise(blur_depth_t, noise, timesteps, backend=be)
         noise_pred = self.model(noisy_images, timesteps, *refine_module_inputs)
         return F.mse_loss(noise_pred, noise)
+
+
+@register_head
+class DDIMDepthEstimate_Swin_ADD(DDIMDepthEstimate_Res):
+    """Swin-L head (reference src/model/head/ddim_depth_estimate_res_swin_add.py:14-200): identical glue, backbone
+    channels [192,384,768,1536], and the UpSample_add denoiser whose stride-4 condition map is bilinearly upsampled
+    to the latent size inside the library (once per call: up(feat + E[t]) = up(feat) + E[t])."""
+    _IN_CHANNELS = [192, 384, 768, 1536]
+    _VARIANT = "swin"

@@ -68,24 +68,50 @@ class HipBound:
         return self.backend
 
 
+class _ConvModule(nn.Module):
+    """mmcv ConvModule(norm_cfg=None, act_cfg=None): a biased Conv2d stored under ``.conv`` (key names match)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=1)
+
+
+class UpSample_add(nn.Module):
+    """Parameter container of the Swin/MPViT fusion (reference …swin_addHAHI.py:321-333):
+    convB(convA(bilinear_up(feat) + noise_embedding)), no norm / activation in between."""
+
+    def __init__(self, skip_input, output_features):
+        super().__init__()
+        self.convA = _ConvModule(skip_input, output_features)
+        self.convB = _ConvModule(output_features, output_features)
+
+
 class ScheduledCNNRefine(nn.Module):
-    """epsilon-network: same constructor and parameter tree as the reference (…res.py:300-322)."""
+    """epsilon-network: same constructor and parameter tree as the reference (…res.py:300-322; with
+    variant="swin" the tree of …swin_addHAHI.py:336-362, i.e. plus ``upsample_fuse.conv{A,B}.conv``)."""
 
     def __init__(self, channels_in: int = 256, channels_noise: int = 16, bound: Optional[HipBound] = None,
-                 precision: Optional[str] = None, **kwargs):
+                 precision: Optional[str] = None, variant: str = "res", **kwargs):
         super().__init__()
+        if variant not in ("res", "swin"):
+            raise ValueError(f"unknown variant {variant!r}")
+        self.variant = variant
         if channels_in != 256 or channels_noise != 16:
             raise ValueError("the HIP kernels are specialised for channels_in=256, channels_noise=16 "
                              "(the only configuration the reference heads build, …res.py:27-37)")
         self.noise_embedding = nn.Sequential(
             nn.Conv2d(channels_noise, 64, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, 64), nn.ReLU(True),
             nn.Conv2d(64, channels_in, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, channels_in), nn.ReLU(True))
+        if variant == "swin":
+            self.upsample_fuse = UpSample_add(channels_in, channels_in)
         self.time_embedding = nn.Embedding(1280, channels_in)
         self.pred = nn.Sequential(
             nn.Conv2d(channels_in, 64, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, 64), nn.ReLU(True),
             nn.Conv2d(64, channels_noise, kernel_size=3, stride=1, padding=1), nn.GroupNorm(4, channels_noise), nn.ReLU(True))
         self.precision = precision or DEFAULT_PRECISION
-        self.bound = bound if bound is not None else HipBound("res")
+        self.bound = bound if bound is not None else HipBound(variant)
+        if self.bound.variant != variant:
+            raise ValueError("HipBound variant does not match the module variant")
         self.bound.register("model.", self)
 
     def forward(self, noisy_image, t, *args):

@@ -244,3 +244,51 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
         assert e < LATENT_TOL[prec] * scale * (2.5 if prec == "fp32" else 1.0), (prec, e, scale)   # port itself is fp32
         if prec == "fp32":
             assert de < 1e-3
+
+
+# ---- Swin / MPViT variant of the denoiser: UpSample_add fuse, stride-4 condition map ----
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):
+    if U.KVER != 2:
+        pytest.skip("the Swin variant runs on the v2 kernels only")
+    c, g = cases["denoise_swin"], golden("denoise_swin")
+    be = U.backend_for(c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c["cond_hw"])
+    x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+    eps_b = be.denoise_once(x, U.cu(inp["timesteps"]), cond, prec).cpu().numpy()
+    eps_s = be.denoise_once(x, torch.tensor(c["t"], device="cuda"), cond, prec).cpu().numpy()
+    eb, es = U.maxabs(eps_b, g["eps_batch_t"]), U.maxabs(eps_s, g["eps_scalar_t"])
+    c2, g2 = cases["loop_swin"], golden("loop_swin")
+    assert U.backend_for(c2) is be
+    inp2 = synth.make_inputs(c2["iseed"], c2["B"], c2["h"], c2["w"], c2["cond_hw"])
+    x0 = be.denoise(U.cu(inp2["x_T"]), U.cu(inp2["cond"]), 20, prec)
+    depth = be.decode(x0).cpu().numpy()
+    x0 = x0.cpu().numpy()
+    ref, dref = g2["x0_T20"], g2["depth_T20"]
+    scale = float(np.abs(ref).max())
+    e, de = U.maxabs(x0, ref), U.maxabs(depth, dref)
+    U.record("swin", prec=prec, eps_batch_maxabs=eb, eps_scalar_maxabs=es, latent_maxabs=e, latent_scale=scale,
+             depth_maxabs=de, depth_rmse=U.rms(depth, dref), depth_max=float(dref.max()))
+    assert eps_b.min() >= 0.0
+    assert eb < EPS_TOL[prec] and es < EPS_TOL[prec], (eb, es)
+    assert e < LATENT_TOL[prec] * scale, (e, scale)
+    if prec == "fp32":
+        assert de < 1e-3
+
+
+def test_swin_variant_odd_sizes_vs_oracle(U):
+    """Condition map at a non-integer scale of the latent (as Swin stride-4 maps are: 57x76 -> 114x152)."""
+    if U.KVER != 2:
+        pytest.skip("the Swin variant runs on the v2 kernels only")
+    from oracle import ddim_oracle as O
+    c = {"wseed": 7245, "variant": "swin"}
+    be = U.backend_for(c)
+    sd = U.sd_for(c)
+    for (B, h, w, ch, cw, T) in [(2, 11, 19, 6, 10, 2), (1, 20, 36, 10, 18, 2)]:
+        inp = synth.make_inputs(300 + h, B, h, w, (ch, cw))
+        x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), T, "fp32").cpu().numpy()
+        ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], T, "swin")
+        scale = float(np.abs(ref).max())
+        e = U.maxabs(x0, ref)
+        U.record("swin_ragged", B=B, h=h, w=w, ch=ch, cw=cw, latent_maxabs=e, latent_scale=scale)
+        assert e < LATENT_TOL["fp32"] * scale, (B, h, w, e, scale)
