@@ -30,8 +30,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 SIZES = {"kitti": (352, 1216), "nyu": (228, 304), "plumbing": (128, 128)}
-FLOP_PER_PIXEL_STEP = 2 * 9 * (16 * 64 + 64 * 256 + 256 * 64 + 64 * 16)       # 626 688
-LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16)}
+FLOP_PER_PIXEL_STEP = {"res": 2 * 9 * (16 * 64 + 64 * 256 + 256 * 64 + 64 * 16),                      # 626 688
+                       "swin": 2 * 9 * (16 * 64 + 64 * 256 + 2 * 256 * 256 + 256 * 64 + 64 * 16)}    # 2 985 984
+LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16), 5: (256, 256), 6: (256, 256), 7: (256, 64)}
+LAYERS = {"res": (1, 2, 3, 4), "swin": (1, 2, 5, 6, 7, 4)}
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "naive_fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "naive_fp32": "f32"}
 
@@ -48,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--variant", default="res", choices=["res", "swin"],
+                    help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,14 +75,16 @@ def main():
     H, W = SIZES[args.size]
     h, w = synth.latent_hw(H, W)
     B, T = args.batch, args.T
-    sd = synth.make_state_dict(7240)
-    be = dda.HipDenoiser(dev)
+    sd = synth.make_state_dict(7240, args.variant)
+    FPS = FLOP_PER_PIXEL_STEP[args.variant]
+    cond_hw = None if args.variant == "res" else ((H + 3) // 4, (W + 3) // 4)     # Swin stage-1 map is stride 4
+    be = dda.HipDenoiser(dev, args.variant)
     be.load_state_dict(sd)
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
     if args.no_graph:
         be.set_option("graph", 0)
     be.set_option("kernel_version", args.kernel_version)
-    inp = synth.make_inputs(7240 + rank, B, h, w)
+    inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
     cond = torch.from_numpy(inp["cond"]).to(dev)
     gt = torch.from_numpy(synth.make_gt_depth(7240 + rank, B, H, W)).to(dev)
@@ -123,7 +129,7 @@ def main():
         for _ in range(2):
             be.denoise(x_T, cond, T, args.precision, out=x0)
         torch.cuda.synchronize(dev)
-        per_layer = {l: be.layer_ms(l) for l in (1, 2, 3, 4)}
+        per_layer = {l: be.layer_ms(l) for l in LAYERS[args.variant]}
         be.set_option("layer_timing", 0)
         dom = max(per_layer, key=lambda l: per_layer[l][0])
         tot_ms, cnt = per_layer[dom]
@@ -137,7 +143,7 @@ def main():
                 "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops,
                 "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
                 "loop_ms_graph": round(loop_ms, 4),
-                "loop_frac_of_peak": round(B * T * h * w * FLOP_PER_PIXEL_STEP / (loop_ms * 1e-3) / 1e12 / peak, 4) if loop_ms > 0 else None}
+                "loop_frac_of_peak": round(B * T * h * w * FPS / (loop_ms * 1e-3) / 1e12 / peak, 4) if loop_ms > 0 else None}
 
     # ---- CPU baseline: torch-CPU port of the reference path, ONE map, this host's cores -----------
     cpu = None
@@ -146,15 +152,15 @@ def main():
         sdt = P.to_torch_sd(sd)
         xc, cc = torch.from_numpy(inp["x_T"][:1]), torch.from_numpy(inp["cond"][:1])
         with torch.no_grad():
-            P.denoiser(sdt, xc, 950, cc)                      # warm-up (thread pool, oneDNN primitives)
+            P.denoiser(sdt, xc, 950, cc, args.variant)        # warm-up (thread pool, oneDNN primitives)
             c0 = time.perf_counter()
-            lat_cpu = P.ddim_loop(sdt, xc, cc, T)
+            lat_cpu = P.ddim_loop(sdt, xc, cc, T, variant=args.variant)
             d_cpu = P.decode(sdt, lat_cpu)
             cpu_s = time.perf_counter() - c0
         cpu = {"value": round(1.0 / cpu_s, 5), "unit": "maps/s", "cores": int(torch.get_num_threads()), "kind": "port",
                "sample": f"1 map: {T}-step DDIM loop + decoder at latent 16x{h}x{w}, fp32 torch-CPU port of the reference ops "
                          f"({cpu_s:.2f} s)",
-               "gflops": round(T * h * w * FLOP_PER_PIXEL_STEP / cpu_s / 1e9, 1)}
+               "gflops": round(T * h * w * FPS / cpu_s / 1e9, 1)}
         # parity spot check of the timed GPU configuration against the same CPU result
         dg = depth[:1].cpu() if rank == 0 else None
         cpu["gpu_vs_cpu_depth_rmse"] = float(torch.sqrt(torch.mean((dg - d_cpu) ** 2)))
@@ -170,7 +176,7 @@ def main():
             "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
-                       "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FLOP_PER_PIXEL_STEP},
+                       "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

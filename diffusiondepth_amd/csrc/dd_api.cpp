@@ -125,8 +125,8 @@ struct dd_handle_s {
   bool ev_valid = false;
   hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
   int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
-  double layer_ms[4] = {0, 0, 0, 0};
-  int64_t layer_cnt[4] = {0, 0, 0, 0};
+  double layer_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse)
+  int64_t layer_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
 
   int fail(int code, const std::string& m) { err = m; return code; }
@@ -308,7 +308,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     (void)hipEventRecord(a, s);
     e = launch(cp);
     (void)hipEventRecord(b, s);
-    h->pending_ev.emplace_back((layer - 1) & 3, a, b);     // Swin layers 5..7 are booked under slots 0..2
+    h->pending_ev.emplace_back(layer - 1, a, b);
     return e;
   };
   // conv1: state (+ fused DDIM update of the previous step) -> y1
@@ -624,7 +624,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
-    for (int i = 0; i < 4; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
+    for (int i = 0; i < 8; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
   } else return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: unknown key '" + k + "'");
   return DD_OK;
 }
@@ -641,7 +641,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
 }
 
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches) {
-  if (!h || layer < 1 || layer > 4 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
+  if (!h || layer < 1 || layer > 7 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
   drain_layer_events(h);
   *total_ms = h->layer_ms[layer - 1];
   *launches = h->layer_cnt[layer - 1];

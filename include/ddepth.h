@@ -130,7 +130,7 @@ int dd_last_loop_ms(dd_handle_t h, float* ms);
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`
- * (1..4) since the option was set (used by bench.py for the per-kernel roofline figure). */
+ * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant) since the option was set (used by bench.py for the per-kernel roofline figure). */
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches);
 
 /* Copies an internal intermediate of the last dd_denoise_once call to a caller DEVICE buffer as

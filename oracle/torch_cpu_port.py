@@ -30,15 +30,21 @@ def timesteps(T, n=1000):
     return (np.arange(0, T) * (n // T)).round()[::-1].copy().astype(np.int64)   # :215-229
 
 
-def denoiser(sd, x, t, cond):
-    """ScheduledCNNRefine.forward (…res.py:324-344); t: 0-d / int or (B,) tensor."""
+def denoiser(sd, x, t, cond, variant="res"):
+    """ScheduledCNNRefine.forward (…res.py:324-344; variant="swin": …swin_addHAHI.py:364-382 with the
+    UpSample_add fuse convB(convA(bilinear_up(feat) + NE(x)))); t: 0-d / int or (B,) tensor."""
     emb = F.embedding(torch.as_tensor(t, dtype=torch.long), sd["model.time_embedding.weight"])[..., None, None]
     feat = cond + emb
     y = F.conv2d(x, sd["model.noise_embedding.0.weight"], sd["model.noise_embedding.0.bias"], padding=1)
     y = F.relu(F.group_norm(y, 4, sd["model.noise_embedding.1.weight"], sd["model.noise_embedding.1.bias"]))
     y = F.conv2d(y, sd["model.noise_embedding.3.weight"], sd["model.noise_embedding.3.bias"], padding=1)
     y = F.relu(F.group_norm(y, 4, sd["model.noise_embedding.4.weight"], sd["model.noise_embedding.4.bias"]))
-    f = feat + y
+    if variant == "res":
+        f = feat + y
+    else:
+        up = F.interpolate(feat, size=[y.size(2), y.size(3)], mode="bilinear", align_corners=True)
+        f = F.conv2d(up + y, sd["model.upsample_fuse.convA.conv.weight"], sd["model.upsample_fuse.convA.conv.bias"], padding=1)
+        f = F.conv2d(f, sd["model.upsample_fuse.convB.conv.weight"], sd["model.upsample_fuse.convB.conv.bias"], padding=1)
     y = F.conv2d(f, sd["model.pred.0.weight"], sd["model.pred.0.bias"], padding=1)
     y = F.relu(F.group_norm(y, 4, sd["model.pred.1.weight"], sd["model.pred.1.bias"]))
     y = F.conv2d(y, sd["model.pred.3.weight"], sd["model.pred.3.bias"], padding=1)
@@ -57,12 +63,12 @@ def ddim_step(acp, eps, t, x, ratio):
 
 
 @torch.no_grad()
-def ddim_loop(sd, x_T, cond, T=20, n_train=1000):
+def ddim_loop(sd, x_T, cond, T=20, n_train=1000, variant="res"):
     acp = make_alphas_cumprod(n_train)
     x = torch.as_tensor(x_T)
     cond = torch.as_tensor(cond)
     for t in timesteps(T, n_train):
-        eps = denoiser(sd, x, int(t), cond)
+        eps = denoiser(sd, x, int(t), cond, variant)
         x = ddim_step(acp, eps, int(t), x, n_train // T)
     return x
 

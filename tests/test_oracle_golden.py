@@ -145,3 +145,13 @@ def test_torch_port_denoiser_batch_t(golden, cases):
     with torch.no_grad():
         e = P.denoiser(sd, torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["timesteps"]), torch.from_numpy(inp["cond"]))
     assert np.abs(e.numpy() - g["eps_batch_t"]).max() < 1e-5
+
+
+def test_torch_port_swin_loop(golden, cases):
+    from oracle import torch_cpu_port as P
+    c, g = cases["loop_swin"], golden("loop_swin")
+    sd = P.to_torch_sd(_sd(c))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c["cond_hw"])
+    x0 = P.ddim_loop(sd, inp["x_T"], inp["cond"], 20, variant="swin").numpy()
+    ref = g["x0_T20"]
+    assert np.abs(x0 - ref).max() < 3e-6 * np.abs(ref).max()
