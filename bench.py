@@ -34,6 +34,9 @@ FLOP_PER_PIXEL_STEP = {"res": 2 * 9 * (16 * 64 + 64 * 256 + 256 * 64 + 64 * 16),
                        "swin": 2 * 9 * (16 * 64 + 64 * 256 + 2 * 256 * 256 + 256 * 64 + 64 * 16)}    # 2 985 984
 LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16), 5: (256, 256), 6: (256, 256), 7: (256, 64)}
 LAYERS = {"res": (1, 2, 3, 4), "swin": (1, 2, 5, 6, 7, 4)}
+# algorithmic HBM bytes per latent pixel per launch with 2-byte activations (fp32 mode doubles the
+# activation terms, the fp32 state / y4 terms of conv1 / conv4 are approximated the same way)
+ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640}
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "naive_fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "naive_fp32": "f32"}
 
@@ -44,7 +47,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default="bf16", choices=sorted(PEAK_TFLOPS))
-    ap.add_argument("--batch", type=int, default=1, help="depth maps per GPU per step (reference test(): batch 1)")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="depth maps per GPU per step (throughput setting; 4 = the per-GPU batch of BASELINE config 4). "
+                         "The B=1 latency of the reference's test() setting is reported alongside as `latency_b1`.")
     ap.add_argument("--size", default="kitti", choices=sorted(SIZES))
     ap.add_argument("--T", type=int, default=20, help="DDIM inference steps (reference --inference_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,11 +121,30 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(depth).all()
 
-    # ---- loop-only time of one graph replay (hipEvents on the launch stream) ----------------------
+    # ---- loop-only time of one graph replay (hipEvents on the launch stream), median of 5 ------------
     be.set_option("timing", 1)
-    be.denoise(x_T, cond, T, args.precision, out=x0)
-    loop_ms = be.last_loop_ms()
+    lm = []
+    for _ in range(5):
+        be.denoise(x_T, cond, T, args.precision, out=x0)
+        lm.append(be.last_loop_ms())
+    loop_ms = sorted(lm)[2]
     be.set_option("timing", 0)
+
+    # ---- B = 1 latency (the reference's test() feeds one image at a time, README.md:249) ----------------
+    lat = None
+    if B != 1:
+        x1, c1_, g1 = x_T[:1].contiguous(), cond[:1].contiguous(), gt[:1].contiguous()
+        o1 = torch.empty_like(x1)
+        for _ in range(3):
+            be.encode(g1); be.denoise(x1, c1_, T, args.precision, out=o1); be.decode(o1)
+        torch.cuda.synchronize(dev)
+        n1 = max(args.steps, 5)
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            be.encode(g1); be.denoise(x1, c1_, T, args.precision, out=o1); be.decode(o1)
+        torch.cuda.synchronize(dev)
+        ms1 = (time.perf_counter() - t1) / n1 * 1e3
+        lat = {"ms_per_map": round(ms1, 4), "maps_per_s": round(1e3 / ms1, 2)}
 
     # ---- per-kernel roofline: eager pass with an event pair around every conv launch ------------------
     roof = None
@@ -138,8 +162,20 @@ def main():
         avg_s = tot_ms / max(cnt, 1) * 1e-3
         achieved = flops / avg_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
+        # HBM traffic of that kernel from the committed PMC passes (tools/pmc_traffic.py), if they were taken on this config
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            want = f"--precision {args.precision} --batch {B} --size {args.size} --variant {args.variant}"
+            if pt.get("bench_args", "").strip() == want:
+                ekid = {"fp32": 0, "bf16": 1, "f16": 2}[args.precision]
+                traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": f"conv_igemm{'2' if args.kernel_version == 2 else ''}_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_traffic.json)",
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL.get(dom, 0) * ({"bf16": 1, "f16": 1, "fp32": 2}[args.precision]) * B * h * w,
                 "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops,
                 "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
                 "loop_ms_graph": round(loop_ms, 4),
@@ -177,7 +213,7 @@ def main():
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

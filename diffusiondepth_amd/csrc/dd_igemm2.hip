@@ -40,9 +40,10 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int TG = (LAYER == 1) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
   static constexpr int NT = (COUT == COND_C) ? 128 : COUT_PAD;
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6);   // a GroupNorm follows this convolution
+  // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
+  // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
+  // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
   static constexpr int TH = 8, TW = 32;
-  // conv1 / conv4 are latency-bound (36 / 18 MFMAs per 32-pixel block): 8 waves of one block each
-  // halve every wave's dependent chain; conv2 / conv3 keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
   static constexpr int WAVES = (LAYER == 1 || LAYER == 4) ? 8 : 4;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
@@ -63,10 +64,11 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int NPB = (NCHUNK > 1) ? 2 : 1;       // patch buffers
   static constexpr int PATCH_BYTES = PH * PW * ROWB;
   static constexpr int W_BYTES = TG * NT * ROWB;
+  static constexpr int NWB = (NSTAGE > 1) ? 2 : 1;       // weight ring slots
   static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
   static constexpr int CTAB = (LAYER == 1) ? LATENT_C : CIN;
   static constexpr int TAB_FLOATS = 3 * CTAB + NT;       // a, b, e of the prologue GroupNorm + this tile's bias
-  static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + 2 * W_BYTES + TAB_FLOATS * 4;
+  static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + NWB * W_BYTES + TAB_FLOATS * 4;
   static constexpr int ITEMS = PH * PW * PPP;
   static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
   static constexpr int NLD = EPP * IN_ESZ / 16;
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   constexpr int PW = C::PW, ROWB = C::ROWB, PPP = C::PPP, RPB = C::RPB, EPP = C::EPP, CK = C::CK;
   constexpr int NIT = C::NIT, NLD = C::NLD, IN_ESZ = C::IN_ESZ, NKQ = C::NKQ;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_tab = reinterpret_cast<float*>(smem + C::NPB * C::PATCH_BYTES + 2 * C::W_BYTES);
+  float* s_tab = reinterpret_cast<float*>(smem + C::NPB * C::PATCH_BYTES + C::NWB * C::W_BYTES);
   float* tab_a = s_tab;
   float* tab_b = s_tab + C::CTAB;
   float* tab_e = s_tab + 2 * C::CTAB;
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto issue_weights = [&](int s) {
     const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)blockIdx.y * C::NSTAGE + s) * (size_t)C::W_BYTES + lane * 16;
-    const unsigned dst = lds_base + C::W_OFF + (s & 1) * C::W_BYTES;
+    const unsigned dst = lds_base + C::W_OFF + (s & (C::NWB - 1)) * C::W_BYTES;
 #pragma unroll
     for (int c = 0; c < (C::W_BYTES / 1024 + C::WAVES - 1) / C::WAVES; ++c) {
       const int kc = c * C::WAVES + wave;
@@ -344,7 +346,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
     if (C::NCHUNK > 1 && tg == 0 && chunk + 1 < C::NCHUNK && !(abl & 2)) load_raw(chunk + 1);
     const int poff = (chunk & (C::NPB - 1)) * C::PATCH_BYTES;
-    const int woff = (s & 1) * C::W_BYTES;
+    const int woff = (s & (C::NWB - 1)) * C::W_BYTES;
     int wa[NKQ];
 #pragma unroll
     for (int kq = 0; kq < NKQ; ++kq) wa[kq] = wkt[kq] + woff;
@@ -523,7 +525,7 @@ hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_
 
 template <int EK, int LAYER> static PackGeom geom2_of() {
   using C = Cfg2<EK, LAYER>;
-  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT};
+  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH};
 }
 template <int EK> static PackGeom geom2_layer(int layer) {
   switch (layer) {

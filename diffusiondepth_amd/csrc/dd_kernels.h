@@ -63,7 +63,7 @@ struct ConvParams {
 // layer: 1..4 (conv1 16->64, conv2 64->256, conv3 256->64, conv4 64->16); ek: element kind.
 hipError_t launch_conv_igemm(int layer, int ek, const ConvParams& p, hipStream_t s);
 // Packed-weight geometry of (layer, ek): elements and tile parameters (host side packing).
-struct PackGeom { int cin, cout, cout_pad, ck, tg, nt; };
+struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th; };   // th = output tile height (tile width is 32)
 PackGeom conv_pack_geom(int layer, int ek);
 // v2 (dd_igemm2.hip): software-pipelined variant; weights are packed with the LDS swizzle pre-applied
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of the fused conv kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+passes as MI355X_MICROARCH.md prescribes).  Units/corrections per that guide: the counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced read -> doubled; WRITE_SIZE is taken as is.
+    python tools/pmc_traffic.py gpurun_out/pmc_c gpurun_out/pmc_d "<bench args>" > profiles/pmc_traffic.json"""
+import collections, csv, glob, json, os, re, sys
+
+
+def per_kernel(d, counter):
+    acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d), (\d)>", row.get("Kernel_Name", ""))
+            if not m:
+                continue
+            k = f"layer{m.group(2)}_ek{m.group(1)}"
+            acc[k] += float(row["Counter_Value"]); cnt[k] += 1
+    return {k: acc[k] / cnt[k] for k in acc}
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"bench_args": sys.argv[3] if len(sys.argv) > 3 else "", "note": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction), write = WRITE_SIZE KiB * 1024",
+       "kernels": {k: {"fetch_bytes": fetch[k] * 1024 * 2, "write_bytes": write.get(k, 0.0) * 1024,
+                       "hbm_bytes": fetch[k] * 1024 * 2 + write.get(k, 0.0) * 1024} for k in sorted(fetch)}}
+print(json.dumps(out, indent=1))

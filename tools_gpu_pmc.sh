@@ -4,7 +4,8 @@ cd "$(dirname "$0")"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
-ARGS="${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-graph}"
+CFG="${BENCH_CFG:---precision bf16 --batch 4 --size kitti --variant res}"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-graph $CFG"
 (cd /tmp && rocprofv3 -L > "$R/gpurun_out/counters_list.txt" 2>&1)
 grep -c . gpurun_out/counters_list.txt
 pass() {  # name, counters...
@@ -21,3 +22,4 @@ pass e SQ_WAVES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_
 ls -la gpurun_out/pmc_*/ | head -40
 python tools/pmc_summary.py gpurun_out/pmc_a gpurun_out/pmc_b gpurun_out/pmc_c gpurun_out/pmc_d gpurun_out/pmc_e > gpurun_out/pmc_summary.txt 2>&1
 cat gpurun_out/pmc_summary.txt | head -60
+python tools/pmc_traffic.py gpurun_out/pmc_c gpurun_out/pmc_d "$CFG" > gpurun_out/pmc_traffic.json; cat gpurun_out/pmc_traffic.json
