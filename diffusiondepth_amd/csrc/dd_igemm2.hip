@@ -73,6 +73,9 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
   static constexpr int NLD = EPP * IN_ESZ / 16;
   static constexpr int PIXSTRIDE = (CIN >= ACT_CB) ? ACT_CB : CIN; // elements between pixels of one channel block
+  // Placing the next chunk's prologue items between the taps (instead of one burst before the chunk's last barrier)
+  // was measured SLOWER on MI355X (conv3 181 -> 191 us at B=4: the in-loop vmcnt waits stall the MFMA stream), so off.
+  static constexpr bool INTERLEAVE = false;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
   static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);
@@ -193,8 +196,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 
   float c1 = 1.f, c2 = 0.f;
   // ---- registers -> normalise -> swizzled LDS patch buffer at byte offset pbuf_off ---------------------
-  auto transform_write = [&](int chunk, int pbuf_off) {
-    // this thread only ever touches channels [c0, c0+EPP): its slice of the GroupNorm table lives in registers
+  // One staging item (16-B piece `jfix` of patch pixel u).  This thread only ever touches channels [c0, c0+EPP), so its
+  // slice of the GroupNorm table is (re)read from LDS as three/two float4 pairs.
+  auto transform_item = [&](int chunk, int pbuf_off, int u) {
+    if (!((m_valid >> u) & 1u)) return;
+    if constexpr (C::PRO == PRO_RAW) {
+      // no normalisation between the producer and this convolution: the stored elements are the operands
+      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[u][0] : make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
     float ta[EPP], tb[EPP], te[EPP];
     const int c0 = (C::PRO == PRO_X) ? jfix * EPP : chunk * CK + jfix * EPP;
     if (have_norm) {
@@ -210,56 +220,50 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
       }
     }
+    float v[EPP];
+    if ((m_inside >> u) & 1u) {
+      if constexpr (C::PRO == PRO_X) {
+        // DDIM update of the previous step fused into the load: x <- c1*x + c2*relu(gn4(y4))
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-      if ((m_valid >> u) & 1u) {
-        if constexpr (C::PRO == PRO_RAW) {
-          // no normalisation between the producer and this convolution: the stored elements are the operands
-          *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[u][0] : make_uint4(0u, 0u, 0u, 0u);
-          continue;
-        }
-        float v[EPP];
-        if ((m_inside >> u) & 1u) {
-          if constexpr (C::PRO == PRO_X) {
-            // DDIM update of the previous step fused into the load: x <- c1*x + c2*relu(gn4(y4))
+        for (int q = 0; q < NLD; ++q) {
+          const uint32_t xw[4] = {raw[u][q].x, raw[u][q].y, raw[u][q].z, raw[u][q].w};
+          const uint32_t yw[4] = {aux[u][q].x, aux[u][q].y, aux[u][q].z, aux[u][q].w};
 #pragma unroll
-            for (int q = 0; q < NLD; ++q) {
-              const uint32_t xw[4] = {raw[u][q].x, raw[u][q].y, raw[u][q].z, raw[u][q].w};
-              const uint32_t yw[4] = {aux[u][q].x, aux[u][q].y, aux[u][q].z, aux[u][q].w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                float x = __builtin_bit_cast(float, xw[i]);
-                if (have_norm) {
-                  const float e = fmaxf(fmaf(ta[q * 4 + i], __builtin_bit_cast(float, yw[i]), tb[q * 4 + i]), 0.f);
-                  x = c1 * x + c2 * e;
-                }
-                v[q * 4 + i] = x;
-              }
+          for (int i = 0; i < 4; ++i) {
+            float x = __builtin_bit_cast(float, xw[i]);
+            if (have_norm) {
+              const float e = fmaxf(fmaf(ta[q * 4 + i], __builtin_bit_cast(float, yw[i]), tb[q * 4 + i]), 0.f);
+              x = c1 * x + c2 * e;
             }
-            if (have_norm && ((m_interior >> u) & 1u)) {
-              const size_t goff = ((size_t)pix_off[u] * LATENT_C + c0) * 4;
-#pragma unroll
-              for (int q = 0; q < NLD; ++q)
-                *reinterpret_cast<float4*>(xout_b + goff + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
-            }
-          } else {
-            Piece<EK>::unpack(raw[u][0], v);
-#pragma unroll
-            for (int i = 0; i < EPP; ++i) v[i] = fmaxf(fmaf(ta[i], v[i], tb[i]), 0.f);
-            if constexpr (C::PRO == PRO_GN_ADD) {
-              float cv[EPP];
-              Piece<EK>::unpack(aux[u][0], cv);
-#pragma unroll
-              for (int i = 0; i < EPP; ++i) v[i] = v[i] + (cv[i] + te[i]);
-            }
+            v[q * 4 + i] = x;
           }
-        } else {
-#pragma unroll
-          for (int i = 0; i < EPP; ++i) v[i] = 0.f;       // zero padding applies AFTER the normalisation
         }
-        *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = Piece<EK>::pack(v);
+        if (have_norm && ((m_interior >> u) & 1u)) {
+          const size_t goff = ((size_t)pix_off[u] * LATENT_C + c0) * 4;
+#pragma unroll
+          for (int q = 0; q < NLD; ++q)
+            *reinterpret_cast<float4*>(xout_b + goff + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+        }
+      } else {
+        Piece<EK>::unpack(raw[u][0], v);
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) v[i] = fmaxf(fmaf(ta[i], v[i], tb[i]), 0.f);
+        if constexpr (C::PRO == PRO_GN_ADD) {
+          float cv[EPP];
+          Piece<EK>::unpack(aux[u][0], cv);
+#pragma unroll
+          for (int i = 0; i < EPP; ++i) v[i] = v[i] + (cv[i] + te[i]);
+        }
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < EPP; ++i) v[i] = 0.f;       // zero padding applies AFTER the normalisation
     }
+    *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = Piece<EK>::pack(v);
+  };
+  auto transform_write = [&](int chunk, int pbuf_off) {
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) transform_item(chunk, pbuf_off, u);
   };
 
   // ---- kick off every independent load at once: weights of stage 0 (LDS-DMA), the GroupNorm partial sums
@@ -370,10 +374,21 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
           for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], wf[n], pf[m]);
       }
+      // Software interleave of the NEXT chunk's prologue with this chunk's MFMAs: the raw patch was fetched at tap 0;
+      // item (tap - (9 - NIT)) is normalised and written to the other patch buffer right behind tap `tap`, so its VALU
+      // work issues while this wave's own MFMAs occupy the matrix pipe (instead of one VALU burst before the barrier).
+      if constexpr (C::INTERLEAVE) {
+        const int tap = tg * C::TG + t;
+        if (chunk + 1 < C::NCHUNK && !(abl & 1)) {
+#pragma unroll
+          for (int u = 0; u < NIT; ++u)      // static register-array index; the (wave-uniform) tap picks the item
+            if (tap == u + (9 - NIT)) transform_item(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, u);
+        }
+      }
     }
     }
     if (abl & 2048) __builtin_amdgcn_s_setprio(0);
-    if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
+    if (!C::INTERLEAVE && C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES);
     // The next stage's weights (this wave's DMA pieces) must have landed before the barrier.  VMEM ops retire in
     // issue order and the DMA was issued BEFORE this stage's raw patch loads, so when those loads were issued in
