@@ -32,11 +32,11 @@ import torch  # noqa: E402
 SIZES = {"kitti": (352, 1216), "nyu": (228, 304), "plumbing": (128, 128)}
 FLOP_PER_PIXEL_STEP = {"res": 2 * 9 * (16 * 64 + 64 * 256 + 256 * 64 + 64 * 16),                      # 626 688
                        "swin": 2 * 9 * (16 * 64 + 64 * 256 + 2 * 256 * 256 + 256 * 64 + 64 * 16)}    # 2 985 984
-LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16), 5: (256, 256), 6: (256, 256), 7: (256, 64)}
-LAYERS = {"res": (1, 2, 3, 4), "swin": (1, 2, 5, 6, 7, 4)}
+LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16), 5: (256, 256), 6: (256, 256), 7: (256, 64), 9: (256, 64)}
+LAYERS = {"res": (1, 2, 9, 4), "res_nohoist": (1, 2, 3, 4), "swin": (1, 2, 5, 6, 7, 4)}
 # algorithmic HBM bytes per latent pixel per launch with 2-byte activations (fp32 mode doubles the
 # activation terms, the fp32 state / y4 terms of conv1 / conv4 are approximated the same way)
-ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640}
+ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640, 9: 896}     # 9: y2 512 + conv3(cond) fp32 256 + y3 128
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "naive_fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "naive_fp32": "f32"}
 
@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
     args = ap.parse_args()
@@ -89,6 +90,8 @@ def main():
     if args.no_graph:
         be.set_option("graph", 0)
     be.set_option("kernel_version", args.kernel_version)
+    be.set_option("hoist_cond", 1 if args.hoist else 0)
+    layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if (args.hoist and args.kernel_version == 2) else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
     cond = torch.from_numpy(inp["cond"]).to(dev)
@@ -153,7 +156,7 @@ def main():
         for _ in range(2):
             be.denoise(x_T, cond, T, args.precision, out=x0)
         torch.cuda.synchronize(dev)
-        per_layer = {l: be.layer_ms(l) for l in LAYERS[args.variant]}
+        per_layer = {l: be.layer_ms(l) for l in layer_set}
         be.set_option("layer_timing", 0)
         dom = max(per_layer, key=lambda l: per_layer[l][0])
         tot_ms, cnt = per_layer[dom]

@@ -70,9 +70,9 @@ struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
 };
 
 struct PlanKey {
-  int B, h, w, ch, cw, T, prec, kver;
+  int B, h, w, ch, cw, T, prec, kver, hoist;
   bool operator<(const PlanKey& o) const {
-    return std::tie(B, h, w, ch, cw, T, prec, kver) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.kver);
+    return std::tie(B, h, w, ch, cw, T, prec, kver, hoist) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.kver, o.hoist);
   }
 };
 
@@ -84,6 +84,7 @@ struct Plan {
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
+  DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 [B][2][h][w][32]
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
@@ -109,6 +110,10 @@ struct dd_handle_s {
   ConvLayer L[4];
   ConvLayer LA, LB;            // Swin variant: upsample_fuse.convA / convB (256->256, no norm)
   DevBuf emb;
+  DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
+  DevBuf zero_bias;          // 256 zeros
+  bool hoist_cond = false;   // Res variant, v2 kernels: conv3(cond) once per image instead of re-adding cond every step.
+                             // Correct (tested) but measured slower on MI355X (conv3 174 -> 183..195 us at B=4), so off by default.
   DevBuf codec_buf;          // all folded codec weights in one allocation
   CodecWeights codec{};
   DevBuf codec_tmp;          // scratch for encode/decode intermediates (grown on demand)
@@ -125,8 +130,8 @@ struct dd_handle_s {
   bool ev_valid = false;
   hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
   int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
-  double layer_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse)
-  int64_t layer_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double layer_ms[10] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3)
+  int64_t layer_cnt[10] = {0};
   std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
 
   int fail(int code, const std::string& m) { err = m; return code; }
@@ -248,6 +253,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   // Swin: the condition map is bilinearly upsampled to the latent size once per call and kept at that size
   DD_HIP(pl->cond.alloc(swin ? px * COND_C * es : (size_t)key.B * key.ch * key.cw * COND_C * es));
   if (swin) { DD_HIP(pl->sa.alloc(px * COND_C * es)); DD_HIP(pl->sf.alloc(px * COND_C * es)); }
+  if (key.hoist) DD_HIP(pl->ccond.alloc(px * HID_C * 4));
   DD_HIP(pl->y1.alloc(px * HID_C * es));
   DD_HIP(pl->y2.alloc(px * COND_C * es));
   DD_HIP(pl->y3.alloc(px * HID_C * es));
@@ -339,12 +345,13 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     p.stats_out = pl->stat_ptr(step, 2);
     DD_HIP(timed_launch(7, p));
   } else {
-  // conv3: relu(gn2(y2)) + cond + E[t] -> y3
+  // conv3: relu(gn2(y2)) + cond + E[t] -> y3   (hoisted form: conv3(relu(gn2(y2))) + [conv3(cond) + conv3(E[t])])
   p.in = pl->y2.p; p.wpack = (k.kver == 2 ? h->L[2].wpack2[ek] : h->L[2].wpack[ek]).p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
-  DD_HIP(timed_launch(3, p));
+  p.cadd = pl->ccond.as<float>(); p.etab = h->etab.as<float>();
+  DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
   p.in = pl->y3.p; p.wpack = (k.kver == 2 ? h->L[3].wpack2[ek] : h->L[3].wpack[ek]).p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
@@ -378,6 +385,19 @@ int enqueue_naive_eps(dd_handle_t h, Plan* pl, int step, const float* x_in, cons
   DD_HIP(launch_naive_gn_apply(pl->y4.as<float>(), pl->stat_ptr(step, 3), L[3].gamma.as<float>(), L[3].beta.as<float>(),
                                nullptr, nullptr, nullptr, 0, 0, pl->eps.as<float>(), B, hh, ww, LATENT_C, s));
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
+// conv3 applied once to the (already converted) condition map: the per-image part of the hoisted conv3 (layer 8)
+int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
+  const PlanKey& k = pl->key;
+  ConvParams p{};
+  p.B = k.B; p.h = k.h; p.w = k.w;
+  p.tiles_x = (k.w + 31) / 32;
+  p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
+  p.ablate = 0;
+  p.in = pl->cond.p; p.wpack = h->L[2].wpack2[pl->ek].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
+  DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
   return DD_OK;
 }
 
@@ -540,6 +560,13 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     const std::vector<float>& e = h->host_w["model.time_embedding.weight"];
     int rc = upload(h, h->emb, e.data(), e.size() * 4, s); if (rc) return rc;
     DD_HIP(hipStreamSynchronize(s));
+    if (h->etab.bytes == 0) {
+      DD_HIP(h->etab.alloc((size_t)EMB_ROWS * 10 * HID_C * 4));
+      DD_HIP(h->zero_bias.alloc(COND_C * 4));
+      DD_HIP(hipMemsetAsync(h->zero_bias.p, 0, COND_C * 4, s));
+    }
+    DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
+    DD_HIP(hipStreamSynchronize(s));
     h->committed = true;
   }
   if (!do_codec) return DD_OK;
@@ -619,6 +646,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     }
     h->ablate = (int)value;
   }
+  else if (k == "hoist_cond") h->hoist_cond = value != 0;
   else if (k == "kernel_version") {
     if (value != 1 && value != 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: kernel_version must be 1 or 2");
     h->kernel_version = (int)value;
@@ -626,7 +654,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
-    for (int i = 0; i < 8; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
+    for (int i = 0; i < 10; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
   } else return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: unknown key '" + k + "'");
   return DD_OK;
 }
@@ -643,7 +671,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
 }
 
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches) {
-  if (!h || layer < 1 || layer > 7 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
+  if (!h || layer < 1 || layer > 9 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
   drain_layer_events(h);
   *total_ms = h->layer_ms[layer - 1];
   *launches = h->layer_cnt[layer - 1];
@@ -671,12 +699,13 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version, (h->hoist_cond && h->variant == DD_VARIANT_RES && h->kernel_version == 2 && precision != DD_PREC_NAIVE_FP32) ? 1 : 0}, &pl);
   if (rc) return rc;
 
   DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
   else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+  if (pl->key.hoist) { rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
 
   if (h->timing) {
     if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
@@ -758,12 +787,13 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version, (h->hoist_cond && h->variant == DD_VARIANT_RES && h->kernel_version == 2 && precision != DD_PREC_NAIVE_FP32) ? 1 : 0}, &pl);
   if (rc) return rc;
   const long long* tv = reinterpret_cast<const long long*>(t);
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
   else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+  if (pl->key.hoist) { rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
   DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
   if (precision == DD_PREC_NAIVE_FP32) {
     rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);

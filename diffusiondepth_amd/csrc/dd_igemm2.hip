@@ -33,13 +33,16 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
   //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
   //   (raw input, no norm / activation in between: ConvModule(norm_cfg=None, act_cfg=None)), 7 = pred.0 256->64 on a raw input
+  // Res denoiser with the condition term hoisted (default): 8 = conv3 applied ONCE per image to the raw condition map (fp32
+  //   out, no bias / statistics), 9 = conv3 on relu(gn2(y2)) only, epilogue adds layer 8's output and the E[t] tap sums
   static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : COND_C;
-  static constexpr int COUT = (LAYER == 1 || LAYER == 3 || LAYER == 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
+  static constexpr int COUT = (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
   static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
   static constexpr int TG = (LAYER == 1) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
   static constexpr int NT = (COUT == COND_C) ? 128 : COUT_PAD;
-  static constexpr bool STATS = !(LAYER == 5 || LAYER == 6);   // a GroupNorm follows this convolution
+  static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8);   // a GroupNorm follows this convolution
+  static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
@@ -48,9 +51,9 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;
-  static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER >= 6) ? PRO_RAW : PRO_GN;
+  static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1) ? 4 : ESZ;
-  static constexpr int OUT_ESZ = (LAYER == 4) ? 4 : ESZ;
+  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8) ? 4 : ESZ;
   static constexpr int PH = TH + 2, PW = TW + 2;
   static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
   static constexpr int PPP = ROWB / 16;
@@ -67,7 +70,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int NWB = (NSTAGE > 1) ? 2 : 1;       // weight ring slots
   static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
   static constexpr int CTAB = (LAYER == 1) ? LATENT_C : CIN;
-  static constexpr int TAB_FLOATS = 3 * CTAB + NT;       // a, b, e of the prologue GroupNorm + this tile's bias
+  static constexpr int TAB_FLOATS = 3 * CTAB + NT + (ADD_C ? 10 * HID_C : 0);   // a, b, e of the prologue GroupNorm, this tile's bias, E[t] tap sums
   static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + NWB * W_BYTES + TAB_FLOATS * 4;
   static constexpr int ITEMS = PH * PW * PPP;
   static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
@@ -104,18 +107,31 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   float* tab_b = s_tab + C::CTAB;
   float* tab_e = s_tab + 2 * C::CTAB;
   float* tab_bias = s_tab + 3 * C::CTAB;
+  float* tab_et = tab_bias + C::NT;           // [10][64] (ADD_C only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, g = lane >> 5;
 
+  // XCD-aware workgroup -> tile map (cdna guide T1): the dispatcher places block b on XCD b % 8, each XCD has its own
+  // L2.  Remap so that every XCD owns one contiguous run of (tile, cout-split) work items: the cout halves of a tile
+  // and vertically / horizontally adjacent tiles (which share halo rows) then hit the same L2 close in time.
+  constexpr int NSPLIT = C::COUT_PAD / C::NT;
+  int wgid;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);     // bijective for any nwg
+  }
+  const int nsplit = wgid % NSPLIT;
+  const int tile = wgid / NSPLIT;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
-  const int b = blockIdx.x / tiles_per_img;
-  const int trem = blockIdx.x - b * tiles_per_img;
+  const int b = tile / tiles_per_img;
+  const int trem = tile - b * tiles_per_img;
   const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
   const int y0 = ty * C::TH, x0 = tx * C::TW;
-  const int n0 = blockIdx.y * C::NT;
+  const int n0 = nsplit * C::NT;
   const int h = p.h, w = p.w;
   const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
   const int abl = p.ablate;
@@ -134,7 +150,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // counted waits for the raw patch loads only become more conservative (cdna guide 5.7).
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto issue_weights = [&](int s) {
-    const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)blockIdx.y * C::NSTAGE + s) * (size_t)C::W_BYTES + lane * 16;
+    const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)nsplit * C::NSTAGE + s) * (size_t)C::W_BYTES + lane * 16;
     const unsigned dst = lds_base + C::W_OFF + (s & (C::NWB - 1)) * C::W_BYTES;
 #pragma unroll
     for (int c = 0; c < (C::W_BYTES / 1024 + C::WAVES - 1) / C::WAVES; ++c) {
@@ -269,7 +285,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // ---- kick off every independent load at once: weights of stage 0 (LDS-DMA), the GroupNorm partial sums
   //      of the producing layer, this thread's gamma/beta/embedding entries, the raw patch of chunk 0 ------
   issue_weights(0);
-  if (tid < C::NT) tab_bias[tid] = p.bias[blockIdx.y * C::NT + tid];     // visible after the first barrier below
+  if (tid < C::NT) tab_bias[tid] = p.bias[n0 + tid];     // visible after the first barrier below
+  if constexpr (C::ADD_C) {
+    const long long t = p.tvec[p.t_base + b * p.t_bstride];
+    for (int i = tid; i < 10 * HID_C; i += C::THREADS) tab_et[i] = p.etab[(size_t)t * 10 * HID_C + i];
+  }
   double2 sv0 = make_double2(0.0, 0.0), sv1 = make_double2(0.0, 0.0);
   float my_gamma = 0.f, my_beta = 0.f, my_emb = 0.f;
   if (have_norm) {
@@ -288,6 +308,25 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     if constexpr (C::PRO == PRO_X) { c1 = p.c1c2[2 * (p.step - 1)]; c2 = p.c1c2[2 * (p.step - 1) + 1]; }
   }
   load_raw(0);
+
+  // accumulators.  With the hoisted condition term they START at conv3(cond)[pixel][cout] (fp32, D-fragment order): the
+  // loads fly with everything else above and need no extra registers or epilogue traffic.
+  f32x16_t acc[C::WN][C::WM];
+#pragma unroll
+  for (int m = 0; m < C::WM; ++m) {
+    const int gy = y0 + wave * C::WM + m, gx = x0 + li;
+    const bool pv = gy < h && gx < w;
+#pragma unroll
+    for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (C::ADD_C) {
+          if (pv) cv = *reinterpret_cast<const float4*>(p.cadd + (size_t)b * h * w * HID_C + act_offset(HID_C, h, w, 0, n * 32 + 8 * q + 4 * g, gy, gx));
+        }
+        acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
+      }
+  }
   if (abl & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (raw[0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
@@ -316,19 +355,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       if constexpr (C::PRO == PRO_GN_ADD) tab_e[tid] = my_emb;
     }
     __syncthreads();                       // table visible
+    if constexpr (C::ADD_C) {
+      if (tid < HID_C) tab_bias[tid] += tab_et[9 * HID_C + tid];     // read again only in the epilogue (many barriers later)
+    }
   }
   transform_write(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of weight stage 0 have landed
   __syncthreads();                                    // patch 0 and weight stage 0 are in LDS for everybody
   if (abl & 1024) return;
-
-  f32x16_t acc[C::WN][C::WM];
-#pragma unroll
-  for (int n = 0; n < C::WN; ++n)
-#pragma unroll
-    for (int m = 0; m < C::WM; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][m][r] = 0.f;
 
   // per-lane LDS addressing.  Pixel block (wave*WM + m) is tile row (wave*WM + m), lane li is tile column li,
   // so tap (dy,dx) reads patch row (wave*WM + m + dy), patch column (li + dx): everything row-dependent is an
@@ -429,6 +463,12 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   for (int m = 0; m < C::WM; ++m) {
     const int gy = y0 + wave * C::WM + m, gx = x0 + li;
     const bool pvalid = gy < h && gx < w && !(abl & 16);
+    unsigned tapmask = 0x1FFu;               // ADD_C: taps of the 3x3 window that fall inside the image at this pixel
+    if constexpr (C::ADD_C) {
+      const unsigned ry = (gy >= 1 ? 1u : 0u) | 2u | (gy + 1 < h ? 4u : 0u);
+      const unsigned rx = (gx >= 1 ? 1u : 0u) | 2u | (gx + 1 < w ? 4u : 0u);
+      tapmask = ((ry & 1u) ? rx : 0u) | ((ry & 2u) ? (rx << 3) : 0u) | ((ry & 4u) ? (rx << 6) : 0u);
+    }
 #pragma unroll
     for (int n = 0; n < C::WN; ++n) {
       uint2 pk[4];
@@ -436,7 +476,20 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       for (int q = 0; q < 4; ++q) {
         if (C::COUT < 32 && q >= 2) continue;            // conv4: couts 16..31 are zero padding
         const int co = n0 + n * 32 + 8 * q + 4 * g;
-        const float4 bv = *reinterpret_cast<const float4*>(tab_bias + n * 32 + 8 * q + 4 * g);
+        float4 bv = *reinterpret_cast<const float4*>(tab_bias + n * 32 + 8 * q + 4 * g);
+        if constexpr (C::ADD_C) {
+          // tab_bias already holds bias + the full 9-tap E[t] sum; pixels on the image border take the missing taps out
+          if (tapmask != 0x1FFu) {
+            const int cl = n * 32 + 8 * q + 4 * g;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+              if (!((tapmask >> tap) & 1u)) {
+                const float4 ev = *reinterpret_cast<const float4*>(tab_et + tap * HID_C + cl);
+                bv.x -= ev.x; bv.y -= ev.y; bv.z -= ev.z; bv.w -= ev.w;
+              }
+            }
+          }
+        }
         const float v[4] = {acc[n][m][q * 4 + 0] + bv.x, acc[n][m][q * 4 + 1] + bv.y,
                             acc[n][m][q * 4 + 2] + bv.z, acc[n][m][q * 4 + 3] + bv.w};
         if (C::STATS && pvalid) {
@@ -496,7 +549,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
     for (int wv = 0; wv < C::WAVES; ++wv) tot += s_red[wv * 8 + tid];
     const int gbase = (C::COUT == COND_C) ? (n0 / (COND_C / GN_GROUPS)) : 0;
-    double* dst = p.stats_out + ((size_t)b * STAT_SLOTS + (blockIdx.x % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
+    double* dst = p.stats_out + ((size_t)b * STAT_SLOTS + (wgid % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
     atomicAdd(dst, tot);
   }
 }
@@ -512,7 +565,7 @@ static hipError_t launch_one2(const ConvParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(p.tiles_x * p.tiles_y * p.B, C::COUT_PAD / C::NT);
+  dim3 grid(p.tiles_x * p.tiles_y * p.B * (C::COUT_PAD / C::NT), 1);
   hipLaunchKernelGGL(conv_igemm2_kernel<C>, grid, dim3(C::THREADS), C::SMEM_BYTES, s, p);
   return hipGetLastError();
 }
@@ -526,6 +579,8 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 5: return launch_one2<EK, 5>(p, s);
     case 6: return launch_one2<EK, 6>(p, s);
     case 7: return launch_one2<EK, 7>(p, s);
+    case 8: return launch_one2<EK, 8>(p, s);
+    case 9: return launch_one2<EK, 9>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -550,7 +605,9 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 4: return geom2_of<EK, 4>();
     case 5: return geom2_of<EK, 5>();
     case 6: return geom2_of<EK, 6>();
-    default: return geom2_of<EK, 7>();
+    case 7: return geom2_of<EK, 7>();
+    case 8: return geom2_of<EK, 8>();
+    default: return geom2_of<EK, 9>();
   }
 }
 PackGeom conv_pack_geom2(int layer, int ek) {

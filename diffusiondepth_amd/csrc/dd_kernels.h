@@ -54,6 +54,10 @@ struct ConvParams {
   int step;                 // PRO_X: 0 = no update (x is used as is)
   int B, h, w;
   int tiles_x, tiles_y;
+  // conv3 with the condition term hoisted out of the loop (layer 9): out += cadd[pixel][cout] + sum over the taps that
+  // fall inside the image of etab[t][tap][cout]   (conv is linear: conv3(r + cond + E[t]) = conv3(r) + conv3(cond) + conv3(E[t]))
+  const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
+  const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
                             // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
                             // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier
@@ -80,6 +84,8 @@ hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, i
 // out(NCHW) = c1*x + c2*relu(gn4(y4))  (mode 0, final DDIM update) or relu(gn4(y4)) (mode 1, eps)
 hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,
                         const float* c1c2, int step, int mode, float* out_nchw, int B, int h, int w, hipStream_t s);
+// etab[t][tap][co] = sum_c w3[co][c][tap] * emb[t][c] (tap < 9), etab[t][9][co] = sum over taps; w3 = pred.0 weight OIHW (64,256,3,3)
+hipError_t launch_etab(const float* w3_oihw, const float* emb, float* etab, hipStream_t s);
 hipError_t launch_add_noise(const float* x0, const float* noise, const long long* t, const float* acp, int n_train,
                             float* out, int B, long long per_sample, hipStream_t s);
 struct CodecWeights {   // device pointers, BatchNorm already folded (eval mode)

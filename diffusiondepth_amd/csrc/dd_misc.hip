@@ -228,6 +228,27 @@ hipError_t launch_final(const float* x, const float* y4, const double* stats, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Time-embedding term of conv3 hoisted out of the DDIM loop (runs once per weight commit): the embedding E[t] is
+// spatially constant, so conv3(E[t]) at a pixel is the sum over the taps that fall inside the image of W3_tap . E[t].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) etab_kernel(const float* __restrict__ w3, const float* __restrict__ emb, float* __restrict__ etab) {
+  const int t = blockIdx.x, co = threadIdx.x;
+  const float* e = emb + (size_t)t * COND_C;
+  double tot = 0.0;
+  for (int tap = 0; tap < 9; ++tap) {
+    double acc = 0.0;
+    for (int c = 0; c < COND_C; ++c) acc += (double)w3[((size_t)co * COND_C + c) * 9 + tap] * (double)e[c];
+    etab[((size_t)t * 10 + tap) * HID_C + co] = (float)acc;
+    tot += acc;
+  }
+  etab[((size_t)t * 10 + 9) * HID_C + co] = (float)tot;
+}
+hipError_t launch_etab(const float* w3_oihw, const float* emb, float* etab, hipStream_t s) {
+  hipLaunchKernelGGL(etab_kernel, dim3(EMB_ROWS), dim3(HID_C), 0, s, w3_oihw, emb, etab);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // q_sample (reference scheduling_ddim.py:355-376): out = sqrt(abar_t)*x0 + sqrt(1-abar_t)*noise
 // ------------------------------------------------------------------------------------------------
 __global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,

@@ -123,14 +123,16 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * Time of the last dd_denoise graph launch measured with hipEvents recorded on `stream` around
  * the graph (0 if timing is off).  dd_set_option("timing", 1) enables it; other options:
  * "graph" (1 = hipGraph replay [default], 0 = eager launches), "debug_sync" (1 = sync + check
- * after every launch). */
+ * after every launch), "kernel_version" (2 = pipelined kernels [default], 1 = first-generation kernels),
+ * "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
+ * condition map is re-added in conv3's prologue every step - measured faster), "layer_timing", "ablate" (timing experiments). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans". */
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`
- * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant) since the option was set (used by bench.py for the per-kernel roofline figure). */
+ * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant; 9 = conv3 with the hoisted condition term) since the option was set (used by bench.py for the per-kernel roofline figure). */
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches);
 
 /* Copies an internal intermediate of the last dd_denoise_once call to a caller DEVICE buffer as

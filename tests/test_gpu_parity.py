@@ -292,3 +292,30 @@ def test_swin_variant_odd_sizes_vs_oracle(U):
         e = U.maxabs(x0, ref)
         U.record("swin_ragged", B=B, h=h, w=w, ch=ch, cw=cw, latent_maxabs=e, latent_scale=scale)
         assert e < LATENT_TOL["fp32"] * scale, (B, h, w, e, scale)
+
+
+def test_conv3_without_hoisting_the_condition_term(U, golden, cases):
+    """A/B switch: hoist_cond=0 re-adds cond + E[t] in conv3's prologue every step (the literal reference order);
+    the default hoists conv3(cond) + conv3(E[t]) out of the loop by linearity.  Both must match the reference."""
+    if U.KVER != 2:
+        pytest.skip("v2 kernels only")
+    from oracle import ddim_oracle as O
+    c, g = cases["loop_res"], golden("loop_res")
+    be = U.backend_for(c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    sd = U.sd_for(c)
+    rag = synth.make_inputs(55, 2, 9, 33)
+    ref_rag = O.ddim_loop(sd, rag["x_T"], rag["cond"], 3)
+    try:
+        for hoist in (0, 1):
+            be.set_option("hoist_cond", hoist)
+            for prec in ("fp32", "bf16"):
+                x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), 20, prec).cpu().numpy()
+                ref = g["x0_T20"]
+                e, scale = U.maxabs(x0, ref), float(np.abs(ref).max())
+                xr = be.denoise(U.cu(rag["x_T"]), U.cu(rag["cond"]), 3, prec).cpu().numpy()
+                er, sr = U.maxabs(xr, ref_rag), float(np.abs(ref_rag).max())
+                U.record("hoist_ab", hoist=hoist, prec=prec, latent_maxabs=e, latent_scale=scale, ragged_maxabs=er, ragged_scale=sr)
+                assert e < LATENT_TOL[prec] * scale and er < LATENT_TOL[prec] * sr
+    finally:
+        be.set_option("hoist_cond", 0)
