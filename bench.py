@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
     ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
@@ -91,6 +92,7 @@ def main():
         be.set_option("graph", 0)
     be.set_option("kernel_version", args.kernel_version)
     be.set_option("hoist_cond", 1 if args.hoist else 0)
+    be.set_option("wave_spec", 1 if args.wave_spec else 0)
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if (args.hoist and args.kernel_version == 2) else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)

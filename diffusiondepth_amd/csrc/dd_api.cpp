@@ -123,6 +123,8 @@ struct dd_handle_s {
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
   int kernel_version = 2;     // 1 = dd_igemm.hip, 2 = dd_igemm2.hip (pipelined)
   int ablate = 0;             // timing experiments only (ConvParams::ablate)
+  int wave_spec = 0;          // use the wave-specialised kernels (dd_igemm2ws.hip) where they exist.  Correct (tested);
+                              // measured on MI355X at B=4: conv3 179 -> 209 us (slower), Swin pred.0 131 -> 123 us (faster): off by default
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   uint64_t tick = 0;
   Plan* last_once_plan = nullptr;
@@ -307,6 +309,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     auto launch = [&](ConvParams q) {
       const int th = (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
       q.tiles_y = (k.h + th - 1) / th;
+      if (pl->key.kver == 2 && h->wave_spec && !h->ablate && conv_igemm2ws_supports(layer)) return launch_conv_igemm2ws(layer, ek, q, s);
       return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
@@ -647,6 +650,10 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->ablate = (int)value;
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
+  else if (k == "wave_spec") {
+    if (h->wave_spec != (int)(value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
+    h->wave_spec = value != 0;
+  }
   else if (k == "kernel_version") {
     if (value != 1 && value != 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: kernel_version must be 1 or 2");
     h->kernel_version = (int)value;

@@ -1,0 +1,78 @@
+// dd_igemm2_cfg.h -- per-layer tiling constants of the v2 fused convolution kernels, shared by dd_igemm2.hip (every
+// wave stages and computes) and dd_igemm2ws.hip (wave-specialised: 4 MFMA waves + 4 staging waves per workgroup).
+#pragma once
+#include "dd_elem.h"
+
+namespace dd {
+
+template <int EK_, int LAYER_> struct Cfg2 {
+  static constexpr int EK = EK_;
+  static constexpr int LAYER = LAYER_;
+  static constexpr int ESZ = ElemSize<EK>::V;
+  // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
+  //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
+  //   (raw input, no norm / activation in between: ConvModule(norm_cfg=None, act_cfg=None)), 7 = pred.0 256->64 on a raw input
+  // Res denoiser with the condition term hoisted (default): 8 = conv3 applied ONCE per image to the raw condition map (fp32
+  //   out, no bias / statistics), 9 = conv3 on relu(gn2(y2)) only, epilogue adds layer 8's output and the E[t] tap sums
+  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : COND_C;
+  static constexpr int COUT = (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
+  static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
+  static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
+  static constexpr int TG = (LAYER == 1) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
+  static constexpr int NT = (COUT == COND_C) ? 128 : COUT_PAD;
+  static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8);   // a GroupNorm follows this convolution
+  static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
+  // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
+  // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
+  // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
+  static constexpr int TH = 8, TW = 32;
+  static constexpr int WAVES = (LAYER == 1 || LAYER == 4) ? 8 : 4;
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int WM = (TH * TW) / (32 * WAVES);
+  static constexpr int WN = NT / 32;
+  static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
+  static constexpr int IN_ESZ = (LAYER == 1) ? 4 : ESZ;
+  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8) ? 4 : ESZ;
+  static constexpr int PH = TH + 2, PW = TW + 2;
+  static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
+  static constexpr int PPP = ROWB / 16;
+  static constexpr int LOG2_PPP = (PPP == 2) ? 1 : (PPP == 4) ? 2 : 3;
+  static constexpr int RPB = 256 / ROWB;                 // rows per 256-B LDS bank row
+  static constexpr int EPP = 16 / ESZ;
+  static constexpr int NKQ = PPP / 2;                    // MFMA k-steps per tap (16 B from each half-wave)
+  static constexpr int NCHUNK = CIN / CK;
+  static constexpr int NTG = 9 / TG;
+  static constexpr int NSTAGE = NCHUNK * NTG;
+  static constexpr int NPB = (NCHUNK > 1) ? 2 : 1;       // patch buffers
+  static constexpr int PATCH_BYTES = PH * PW * ROWB;
+  static constexpr int W_BYTES = TG * NT * ROWB;
+  static constexpr int NWB = (NSTAGE > 1) ? 2 : 1;       // weight ring slots
+  static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
+  static constexpr int CTAB = (LAYER == 1) ? LATENT_C : CIN;
+  static constexpr int TAB_FLOATS = 3 * CTAB + NT + (ADD_C ? 10 * HID_C : 0);   // a, b, e of the prologue GroupNorm, this tile's bias, E[t] tap sums
+  static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + NWB * W_BYTES + TAB_FLOATS * 4;
+  static constexpr int ITEMS = PH * PW * PPP;
+  static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
+  static constexpr int NLD = EPP * IN_ESZ / 16;
+  static constexpr int PIXSTRIDE = (CIN >= ACT_CB) ? ACT_CB : CIN; // elements between pixels of one channel block
+  // Placing the next chunk's prologue items between the taps (instead of one burst before the chunk's last barrier)
+  // was measured SLOWER on MI355X (conv3 181 -> 191 us at B=4: the in-loop vmcnt waits stall the MFMA stream), so off.
+  static constexpr bool INTERLEAVE = false;
+  // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
+  // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
+  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);
+  static_assert(CIN % CK == 0 && 9 % TG == 0 && COUT_PAD % NT == 0, "tiling");
+  static_assert(PATCH_BYTES % 16 == 0 && W_BYTES % 1024 == 0, "LDS carve / DMA granularity");
+  static_assert(PATCH_BYTES >= STAT_SLOTS * 8 * 8 + 64 + WAVES * 8 * 8, "scratch fits in the patch region");
+  static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128, "swizzle derivation");
+  static_assert(TW == 32, "one 32-pixel MFMA block == one tile row (column-only swizzle, lane == column)");
+  static_assert(THREADS % PPP == 0 && NIT <= 32, "per-thread piece index is constant; masks fit 32 bits");
+  static_assert(TG == 1 || TG == 3 || TG == 9, "tap decomposition");
+};
+
+// LDS swizzle: 16-B piece j of a row is stored at j ^ swz(k), k = the row's COLUMN index in the patch
+// (weights: the cout row index).  Any 16 lanes with distinct k mod 16 then hit 16 distinct 16-B slots of
+// the 256-B bank row, whatever the (wave-uniform) patch row is, because PW*ROWB is a multiple of 128 B.
+template <int RPB, int PPP> __device__ __forceinline__ int swz16(int k) { return ((k / RPB) & (PPP - 1)) << 4; }
+
+}  // namespace dd

@@ -73,6 +73,10 @@ PackGeom conv_pack_geom(int layer, int ek);
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
 PackGeom conv_pack_geom2(int layer, int ek);
+// wave-specialised variant (dd_igemm2ws.hip: 4 MFMA waves + 4 staging waves) of the 256->64 multi-chunk layers; same packed
+// weights and buffers as launch_conv_igemm2
+bool conv_igemm2ws_supports(int layer);
+hipError_t launch_conv_igemm2ws(int layer, int ek, const ConvParams& p, hipStream_t s);
 
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
 // dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h

@@ -125,7 +125,8 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * "graph" (1 = hipGraph replay [default], 0 = eager launches), "debug_sync" (1 = sync + check
  * after every launch), "kernel_version" (2 = pipelined kernels [default], 1 = first-generation kernels),
  * "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
- * condition map is re-added in conv3's prologue every step - measured faster), "layer_timing", "ablate" (timing experiments). */
+ * condition map is re-added in conv3's prologue every step - measured faster), "wave_spec" (1 = wave-specialised
+ * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "layer_timing", "ablate" (timing experiments). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans". */

@@ -7,7 +7,7 @@
 Tolerances (stated per north-star: <= 1e-3 abs on predicted depth):
   fp32 modes (naive_fp32, fp32): latent within 2e-5 * max|x_0| (fp32 round-off class), decoded depth within 1e-3 abs.
   bf16 / f16 operand modes: the latent error is reported (gpurun_out/parity_report.jsonl) and bounded
-  relative to max|x_0| (bf16 2e-2, f16 4e-3); they cannot meet 1e-3 abs on depth in general and are
+  relative to max|x_0| (bf16 1e-2, f16 1.5e-3); they cannot meet 1e-3 abs on depth in general and are
   judged on depth RMSE (see DESIGN.md "Precision modes").
 """
 import numpy as np
@@ -18,8 +18,8 @@ from diffusiondepth_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16": 4e-3, "bf16": 2e-2}     # x max|x_0|
-EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}      # abs on eps (values O(1..4))
+LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16": 1.5e-3, "bf16": 1e-2}   # x max|x_0|  (measured: 1e-6, 1e-6, 5e-4, 4e-3)
+EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}      # abs on eps (values O(1..4); measured 1e-5, 1e-5, 5e-3, 4e-2)
 ALL_PREC = ["naive_fp32", "fp32", "bf16", "f16"]
 
 
@@ -295,8 +295,8 @@ def test_swin_variant_odd_sizes_vs_oracle(U):
 
 
 def test_conv3_without_hoisting_the_condition_term(U, golden, cases):
-    """A/B switch: hoist_cond=0 re-adds cond + E[t] in conv3's prologue every step (the literal reference order);
-    the default hoists conv3(cond) + conv3(E[t]) out of the loop by linearity.  Both must match the reference."""
+    """A/B switches of conv3: hoist_cond (conv3(cond) + conv3(E[t]) taken out of the loop by linearity, default off) and
+    wave_spec (4 MFMA + 4 staging waves, default off).  Every combination must match the reference."""
     if U.KVER != 2:
         pytest.skip("v2 kernels only")
     from oracle import ddim_oracle as O
@@ -307,15 +307,17 @@ def test_conv3_without_hoisting_the_condition_term(U, golden, cases):
     rag = synth.make_inputs(55, 2, 9, 33)
     ref_rag = O.ddim_loop(sd, rag["x_T"], rag["cond"], 3)
     try:
-        for hoist in (0, 1):
+        for hoist, ws in ((0, 0), (1, 0), (1, 1), (0, 1)):
             be.set_option("hoist_cond", hoist)
+            be.set_option("wave_spec", ws)
             for prec in ("fp32", "bf16"):
                 x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), 20, prec).cpu().numpy()
                 ref = g["x0_T20"]
                 e, scale = U.maxabs(x0, ref), float(np.abs(ref).max())
                 xr = be.denoise(U.cu(rag["x_T"]), U.cu(rag["cond"]), 3, prec).cpu().numpy()
                 er, sr = U.maxabs(xr, ref_rag), float(np.abs(ref_rag).max())
-                U.record("hoist_ab", hoist=hoist, prec=prec, latent_maxabs=e, latent_scale=scale, ragged_maxabs=er, ragged_scale=sr)
+                U.record("hoist_ab", hoist=hoist, wave_spec=ws, prec=prec, latent_maxabs=e, latent_scale=scale, ragged_maxabs=er, ragged_scale=sr)
                 assert e < LATENT_TOL[prec] * scale and er < LATENT_TOL[prec] * sr
     finally:
         be.set_option("hoist_cond", 0)
+        be.set_option("wave_spec", 0)
