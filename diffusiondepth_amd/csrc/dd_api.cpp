@@ -307,9 +307,10 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   const int ek = pl->ek;
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](ConvParams q) {
-      const int th = (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
+      const bool ws = pl->key.kver == 2 && h->wave_spec && !h->ablate && conv_igemm2ws_supports(layer);
+      const int th = ws ? 8 : (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
       q.tiles_y = (k.h + th - 1) / th;
-      if (pl->key.kver == 2 && h->wave_spec && !h->ablate && conv_igemm2ws_supports(layer)) return launch_conv_igemm2ws(layer, ek, q, s);
+      if (ws) return launch_conv_igemm2ws(layer, ek, q, s);
       return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);

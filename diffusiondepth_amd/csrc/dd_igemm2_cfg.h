@@ -3,6 +3,12 @@
 #pragma once
 #include "dd_elem.h"
 
+// measured on MI355X: the FAT tiling (16x32 pixels, 8 waves, 9 taps per stage, one workgroup per CU) is slower than two
+// 8x32 / 4-wave workgroups per CU at B=4 (conv3 203 vs 175 us) and equal at B=1 (50 vs 52 us) -> off
+#ifndef DD_FAT_CONV3
+#define DD_FAT_CONV3 0
+#endif
+
 namespace dd {
 
 template <int EK_, int LAYER_> struct Cfg2 {
@@ -18,15 +24,18 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int COUT = (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
   static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
-  static constexpr int TG = (LAYER == 1) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
+  // FAT (conv3-shaped layers 3 / 7 / 9): one 16x32-pixel, 8-wave workgroup per CU with ALL nine taps of a channel chunk per
+  // stage -> one barrier per chunk (8 instead of 24), weights DMA'd once per 512 pixels, 1.2x instead of 1.33x halo.
+  static constexpr bool FAT = DD_FAT_CONV3 && (LAYER == 3 || LAYER == 7 || LAYER == 9);
+  static constexpr int TG = (LAYER == 1 || FAT) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
   static constexpr int NT = (COUT == COND_C) ? 128 : COUT_PAD;
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
-  static constexpr int TH = 8, TW = 32;
-  static constexpr int WAVES = (LAYER == 1 || LAYER == 4) ? 8 : 4;
+  static constexpr int TH = FAT ? 16 : 8, TW = 32;
+  static constexpr int WAVES = (LAYER == 1 || LAYER == 4 || FAT) ? 8 : 4;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;

@@ -9,6 +9,7 @@
 // same code and both fit 128 VGPRs -> 16 waves = two workgroups per CU) that execute the same number of barriers.
 // In dd_igemm2.hip every wave stops issuing MFMAs while it normalises the next chunk (VALU burst before the chunk's
 // last barrier); here that work runs on the SIMDs' VALU while the MFMA waves keep the matrix pipe busy.
+#define DD_FAT_CONV3 0      // the wave-specialised variant keeps the 8x32 / 3-taps-per-stage tiling
 #include "dd_igemm2_cfg.h"
 
 namespace dd {

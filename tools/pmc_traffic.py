@@ -7,7 +7,9 @@ import collections, csv, glob, json, os, re, sys
 
 
 def per_kernel(d, counter):
-    acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    """mean counter value per kernel over the dispatches with the LARGEST grid (the timed batch; bench.py also runs a
+    B=1 latency leg whose smaller dispatches must not be averaged in)"""
+    rows = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
@@ -15,9 +17,13 @@ def per_kernel(d, counter):
             m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d), (\d)>", row.get("Kernel_Name", ""))
             if not m:
                 continue
-            k = f"layer{m.group(2)}_ek{m.group(1)}"
-            acc[k] += float(row["Counter_Value"]); cnt[k] += 1
-    return {k: acc[k] / cnt[k] for k in acc}
+            rows[f"layer{m.group(2)}_ek{m.group(1)}"].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+    out = {}
+    for k, v in rows.items():
+        g = max(x[0] for x in v)
+        sel = [x[1] for x in v if x[0] == g]
+        out[k] = sum(sel) / len(sel)
+    return out
 
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
