@@ -18,7 +18,7 @@ VARIANTS = {"res": 0, "swin": 1}
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_commit_weights",
-    "dd_set_schedule", "dd_denoise", "dd_denoise_once", "dd_add_noise", "dd_encode", "dd_decode",
+    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_once", "dd_add_noise", "dd_encode", "dd_decode",
     "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch",
 ]
 
@@ -57,6 +57,7 @@ def load_library():
         "dd_set_weight": (c_int, [c_vp, c_cp, c_vp, c_i64]),
         "dd_commit_weights": (c_int, [c_vp, c_vp]),
         "dd_set_schedule": (c_int, [c_vp, c_vp, c_int]),
+        "dd_condition": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_vp, c_int, c_vp]),
         "dd_denoise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_add_noise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
@@ -122,6 +123,8 @@ class HipDenoiser:
         self._h = h
         self._have_schedule = False
         self._have_weights = False
+        self._have_fpn = False
+        self._cond_token = None      # (tensor, version, precision id) of the map the last condition() call returned
 
     # -- plumbing -----------------------------------------------------------------------------
     def _ck(self, rc, what):
@@ -164,15 +167,19 @@ class HipDenoiser:
     # -- parameters ---------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, object], prefix: str = ""):
         """sd: {key: tensor | ndarray} using the reference's key names below ``prefix`` (e.g.
-        'depth_head.').  Keys the hot path does not own (FPN, backbone, num_batches_tracked) are ignored."""
+        'depth_head.').  Keys the hot path does not own (backbone, convup_fp, num_batches_tracked; the FPN for the Swin
+        variant) are ignored."""
         torch = _torch()
         n = 0
+        owned = ("model.", "depth_transform.") + (("conv_lateral.", "conv_up.") if self.variant == "res" else ())
+        saw_fpn = False
         for k, v in sd.items():
             if not k.startswith(prefix):
                 continue
             name = k[len(prefix):]
-            if not (name.startswith("model.") or name.startswith("depth_transform.")) or name.endswith("num_batches_tracked"):
+            if not name.startswith(owned) or name.endswith("num_batches_tracked"):
                 continue
+            saw_fpn = saw_fpn or name.startswith("conv_")
             if isinstance(v, torch.Tensor):
                 v = v.detach().to("cpu", torch.float32).contiguous().numpy()
             a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
@@ -181,6 +188,8 @@ class HipDenoiser:
             n += 1
         self._ck(self._lib.dd_commit_weights(self._h, ctypes.c_void_p(_stream_ptr(self.device))), "dd_commit_weights")
         self._have_weights = True
+        self._have_fpn = self._have_fpn or saw_fpn
+        self._cond_token = None
         return n
 
     def set_schedule(self, alphas_cumprod):
@@ -191,17 +200,53 @@ class HipDenoiser:
         self._ck(self._lib.dd_set_schedule(self._h, a.ctypes.data_as(ctypes.c_void_p), a.size), "dd_set_schedule")
         self._have_schedule = True
 
+    # -- condition aggregation -----------------------------------------------------------------
+    def condition(self, fp, precision="fp32", export=True):
+        """The Res head's FPN (reference …res.py:108-118) on the 4 backbone maps ``fp`` (finest first).  Returns the
+        (B,256,h,w) fp32 condition map (None with export=False); the same map stays in the handle in kernel layout and
+        is picked up -- without conversion -- when the returned tensor is passed to denoise / denoise_once unchanged."""
+        torch = _torch()
+        if len(fp) != 4:
+            raise ValueError("condition() expects the 4 pyramid levels of the ResNet backbone")
+        fp = [_check_tensor(f, f"fp[{i}]", dtype=torch.float32) for i, f in enumerate(fp)]
+        B = fp[0].shape[0]
+        for i, f in enumerate(fp):
+            if f.dim() != 4 or f.shape[0] != B or f.shape[1] != 64 << i:
+                raise ValueError(f"fp[{i}] must be (B,{64 << i},h,w), got {tuple(f.shape)}")
+        ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in fp])
+        hs = (ctypes.c_int * 4)(*[f.shape[2] for f in fp])
+        ws = (ctypes.c_int * 4)(*[f.shape[3] for f in fp])
+        out = torch.empty((B, 256, fp[0].shape[2], fp[0].shape[3]), device=self.device, dtype=torch.float32) if export else None
+        pid = precision_id(precision)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_condition(self._h, ptrs, hs, ws, 4, B, out.data_ptr() if export else None, pid,
+                                            _stream_ptr(self.device)), "dd_condition")
+        self._cond_token = (out, out._version, pid) if export else None
+        return out
+
+    def _cond_arg(self, cond, precision):
+        """data pointer to hand to the library: None (= use the map dd_condition left in the handle) when ``cond`` is the
+        unmodified tensor condition() returned for this precision."""
+        tok = self._cond_token
+        if tok is not None and tok[0] is cond and tok[1] == cond._version and tok[2] == precision_id(precision):
+            return None
+        self._cond_token = None           # an explicit map overwrites the handle's copy
+        return cond.data_ptr()
+
     # -- hot path -----------------------------------------------------------------------------
     def denoise(self, x_T, cond, num_inference_steps: int, precision="fp32", out=None):
         torch = _torch()
         x_T = _check_tensor(x_T, "x_T", dtype=torch.float32)
+        cond_in = cond
         cond = _check_tensor(cond, "cond", dtype=torch.float32)
+        if cond is not cond_in:
+            self._cond_token = None
         B, C, h, w = x_T.shape
         if C != 16 or cond.dim() != 4 or cond.shape[0] != B or cond.shape[1] != 256:
             raise ValueError(f"x_T must be (B,16,h,w) and cond (B,256,ch,cw); got {tuple(x_T.shape)}, {tuple(cond.shape)}")
         out = torch.empty_like(x_T) if out is None else _check_tensor(out, "out", x_T.shape, torch.float32)
         with torch.cuda.device(self.device):
-            self._ck(self._lib.dd_denoise(self._h, x_T.data_ptr(), cond.data_ptr(), out.data_ptr(), B, h, w,
+            self._ck(self._lib.dd_denoise(self._h, x_T.data_ptr(), self._cond_arg(cond, precision), out.data_ptr(), B, h, w,
                                           cond.shape[2], cond.shape[3], int(num_inference_steps),
                                           precision_id(precision), _stream_ptr(self.device)), "dd_denoise")
         return out
@@ -217,7 +262,7 @@ class HipDenoiser:
         t = _check_tensor(t, "t", (B,), torch.int64)
         out = torch.empty_like(x_t)
         with torch.cuda.device(self.device):
-            self._ck(self._lib.dd_denoise_once(self._h, x_t.data_ptr(), t.data_ptr(), cond.data_ptr(), out.data_ptr(),
+            self._ck(self._lib.dd_denoise_once(self._h, x_t.data_ptr(), t.data_ptr(), self._cond_arg(cond, precision), out.data_ptr(),
                                                B, h, w, cond.shape[2], cond.shape[3], precision_id(precision),
                                                _stream_ptr(self.device)), "dd_denoise_once")
         return out

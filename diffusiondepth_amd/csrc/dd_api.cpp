@@ -60,6 +60,9 @@ inline int ek_of_precision(int prec) {
 }
 inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
 
+constexpr int FPN_LEVELS = 4;
+constexpr int FPN_CIN[FPN_LEVELS] = {64, 128, 256, 512};     // ResNet-34 pyramid widths (reference ...res.py:24 in_channels)
+
 struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   int cin = 0, cout = 0;
   DevBuf wpack[NUM_EK];             // packed for the fused path, v1 kernels
@@ -80,7 +83,8 @@ struct Plan {
   PlanKey key{};
   int ek = EK_F32;
   DevBuf x[2];        // fp32 NHWC state ping-pong
-  DevBuf cond;        // NHWC condition map (activation element kind; fp32 for naive)
+  std::shared_ptr<DevBuf> cond;   // condition map at latent size (activation layout / element kind; fp32 NHWC for naive); shared by every
+                                  // plan of one (B, h, w, element kind) so that dd_condition can write it in place
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
@@ -96,6 +100,15 @@ struct Plan {
   double* stat_ptr(int step, int layer) const {   // layer 0..3
     return stats.as<double>() + ((size_t)(step * 4 + layer) * key.B) * STAT_SLOTS * STAT_STRIDE;
   }
+};
+
+// workspace of dd_condition for one pyramid shape / element kind
+struct FpnWork {
+  int B = 0, ek = -1, hs[FPN_LEVELS] = {0}, ws[FPN_LEVELS] = {0};
+  DevBuf fin[FPN_LEVELS];        // backbone features, activation layout
+  DevBuf lat[FPN_LEVELS];        // levels 1..3: x_i = relu(bn(conv(f_i))) [+ top-down term]
+  DevBuf up[FPN_LEVELS - 1];     // conv_up[j](x_{j+1}) at 2h x 2w of level j+1
+  DevBuf pooled[FPN_LEVELS - 1]; // adaptive_avg_pool2d(up[j]) when 2h_{j+1} x 2w_{j+1} != h_j x w_j
 };
 
 }  // namespace
@@ -126,14 +139,22 @@ struct dd_handle_s {
   int wave_spec = 0;          // use the wave-specialised kernels (dd_igemm2ws.hip) where they exist.  Correct (tested);
                               // measured on MI355X at B=4: conv3 179 -> 209 us (slower), Swin pred.0 131 -> 123 us (faster): off by default
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
+  std::map<std::tuple<int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision) -> buffer, last use
+  // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
+  bool fpn_committed = false;
+  DevBuf fpn_lat_w[FPN_LEVELS][NUM_EK], fpn_lat_b[FPN_LEVELS];
+  DevBuf fpn_up_w[FPN_LEVELS - 1][NUM_EK], fpn_up_b[FPN_LEVELS - 1];
+  std::unique_ptr<FpnWork> fpn_work;
+  std::shared_ptr<DevBuf> fpn_cond;      // == the cond buffer dd_condition wrote last (valid until the next dd_condition / explicit cond of that shape)
+  int fpn_cond_key[4] = {0, 0, 0, -1};   // B, h, w, precision of fpn_cond
   uint64_t tick = 0;
   Plan* last_once_plan = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
   hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
   int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
-  double layer_ms[10] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3)
-  int64_t layer_cnt[10] = {0};
+  double layer_ms[16] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3, 10..14 condition FPN)
+  int64_t layer_cnt[16] = {0};
   std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
 
   int fail(int code, const std::string& m) { err = m; return code; }
@@ -148,7 +169,14 @@ struct dd_handle_s {
 
 namespace {
 
-struct WeightSpec { const char* name; int64_t numel; };
+struct WeightSpec { std::string name; int64_t numel; };
+
+// 0 = denoiser (model.*), 1 = latent codec (depth_transform.*), 2 = condition FPN (conv_lateral.* / conv_up.*)
+int weight_group(const std::string& name) {
+  if (name.compare(0, 6, "model.") == 0) return 0;
+  if (name.compare(0, 16, "depth_transform.") == 0) return 1;
+  return 2;
+}
 
 std::vector<WeightSpec> required_weights(int variant) {
   std::vector<WeightSpec> v = {
@@ -177,14 +205,28 @@ std::vector<WeightSpec> required_weights(int variant) {
     v.push_back({"model.upsample_fuse.convA.conv.bias", 256});
     v.push_back({"model.upsample_fuse.convB.conv.weight", 256 * 256 * 9});
     v.push_back({"model.upsample_fuse.convB.conv.bias", 256});
+  } else {
+    // condition aggregation FPN of the Res head (reference ...res.py:56-84): conv_lateral[i] = Conv3x3(bias=False)+BN+ReLU,
+    // conv_up[j] = ConvTranspose2d(k2,s2,bias=False)+BN+ReLU
+    const char* bn[4] = {"weight", "bias", "running_mean", "running_var"};
+    for (int i = 0; i < FPN_LEVELS; ++i) {
+      const std::string pre = "conv_lateral." + std::to_string(i);
+      v.push_back({pre + ".0.weight", (int64_t)COND_C * FPN_CIN[i] * 9});
+      for (const char* b : bn) v.push_back({pre + ".1." + b, COND_C});
+    }
+    for (int j = 0; j < FPN_LEVELS - 1; ++j) {
+      const std::string pre = "conv_up." + std::to_string(j);
+      v.push_back({pre + ".0.weight", (int64_t)COND_C * COND_C * 4});
+      for (const char* b : bn) v.push_back({pre + ".1." + b, COND_C});
+    }
   }
   return v;
 }
 
 // Packed layout consumed by conv_igemm_kernel:
-//   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT)
+//   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT; ks x ks taps)
 void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
-  const int n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = 9 / g.tg;
+  const int ks = g.ks, n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = ks * ks / g.tg;
   const size_t n_el = (size_t)n_tiles * n_chunks * n_tg * g.tg * g.nt * g.ck;
   const size_t esz = ek_size(ek);
   out.assign(n_el * esz, 0);
@@ -192,7 +234,7 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
     for (int ch = 0; ch < n_chunks; ++ch)
       for (int tg = 0; tg < n_tg; ++tg)
         for (int t = 0; t < g.tg; ++t) {
-          const int tap = tg * g.tg + t, dy = tap / 3, dx = tap % 3;
+          const int tap = tg * g.tg + t, dy = tap / ks, dx = tap % ks;
           const int rowb = g.ck * (int)esz, ppp = rowb / 16, rpb = 256 / rowb, epp = 16 / (int)esz;
           const size_t blk0 = (((size_t)(nt * n_chunks + ch) * n_tg + tg) * g.tg + 0) * (size_t)g.nt * g.ck;
           for (int n = 0; n < g.nt; ++n)
@@ -203,7 +245,7 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
               const int piece = k / epp, within = k % epp;
               const int piece_sw = swizzle ? (piece ^ ((row / rpb) & (ppp - 1))) : piece;
               const size_t idx = blk0 + (size_t)row * g.ck + (size_t)piece_sw * epp + within;
-              const float v = (co < g.cout) ? w_oihw[(((size_t)co * g.cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+              const float v = (co < g.cout) ? w_oihw[(((size_t)co * g.cin + ci) * ks + dy) * ks + dx] : 0.f;
               if (ek == EK_F32) std::memcpy(&out[idx * 4], &v, 4);
               else {
                 const uint16_t u = (ek == EK_BF16) ? host_f32_to_bf16(v) : host_f32_to_f16(v);
@@ -231,6 +273,29 @@ int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw) {
   return DD_OK;
 }
 
+// The condition map at latent size in the activation layout of `precision`: one buffer per (B, h, w, precision), shared by
+// all plans of that shape (graphs bake its address) and written in place by dd_condition.
+int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::shared_ptr<DevBuf>* out) {
+  const auto key = std::make_tuple(B, lh, lw, precision);
+  auto it = h->cond_bufs.find(key);
+  if (it == h->cond_bufs.end()) {
+    while (h->cond_bufs.size() >= 8) {           // plans keep their buffer alive through the shared_ptr
+      auto victim = h->cond_bufs.begin();
+      for (auto j = h->cond_bufs.begin(); j != h->cond_bufs.end(); ++j)
+        if (j->second.second < victim->second.second) victim = j;
+      if (h->fpn_cond == victim->second.first) { h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; }
+      h->cond_bufs.erase(victim);
+    }
+    auto buf = std::make_shared<DevBuf>();
+    const size_t es = precision == DD_PREC_NAIVE_FP32 ? 4 : ek_size(ek_of_precision(precision));
+    DD_HIP(buf->alloc((size_t)B * lh * lw * COND_C * es));
+    it = h->cond_bufs.emplace(key, std::make_pair(buf, (uint64_t)0)).first;
+  }
+  it->second.second = ++h->tick;
+  *out = it->second.first;
+  return DD_OK;
+}
+
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   auto it = h->plans.find(key);
   if (it != h->plans.end()) { it->second->last_use = ++h->tick; *out = it->second.get(); return DD_OK; }
@@ -253,7 +318,8 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   DD_HIP(pl->x[1].alloc(px * LATENT_C * 4));
   const bool swin = h->variant == DD_VARIANT_SWIN;
   // Swin: the condition map is bilinearly upsampled to the latent size once per call and kept at that size
-  DD_HIP(pl->cond.alloc(swin ? px * COND_C * es : (size_t)key.B * key.ch * key.cw * COND_C * es));
+  (void)swin;
+  { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond); if (rc) return rc; }
   if (swin) { DD_HIP(pl->sa.alloc(px * COND_C * es)); DD_HIP(pl->sf.alloc(px * COND_C * es)); }
   if (key.hoist) DD_HIP(pl->ccond.alloc(px * HID_C * 4));
   DD_HIP(pl->y1.alloc(px * HID_C * es));
@@ -340,7 +406,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     p.in = pl->y2.p; p.wpack = h->LA.wpack2[ek].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
     p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
-    p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
+    p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
     DD_HIP(timed_launch(5, p));
     p.in = pl->sa.p; p.wpack = h->LB.wpack2[ek].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
     p.stats_in = nullptr;
@@ -353,7 +419,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.in = pl->y2.p; p.wpack = (k.kver == 2 ? h->L[2].wpack2[ek] : h->L[2].wpack[ek]).p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
-  p.cond = pl->cond.p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
+  p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
   p.cadd = pl->ccond.as<float>(); p.etab = h->etab.as<float>();
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
@@ -379,7 +445,7 @@ int enqueue_naive_eps(dd_handle_t h, Plan* pl, int step, const float* x_in, cons
   DD_HIP(launch_naive_conv3x3(pl->a1.as<float>(), L[1].w_oihw.as<float>(), L[1].bias.as<float>(), pl->y2.as<float>(), B, hh, ww, HID_C, COND_C, s));
   DD_HIP(launch_naive_gn_stats(pl->y2.as<float>(), pl->stat_ptr(step, 1), B, hh, ww, COND_C, s));
   DD_HIP(launch_naive_gn_apply(pl->y2.as<float>(), pl->stat_ptr(step, 1), L[1].gamma.as<float>(), L[1].beta.as<float>(),
-                               pl->cond.as<float>(), h->emb.as<float>(), tvec, t_base, t_bstride, pl->f.as<float>(), B, hh, ww, COND_C, s));
+                               pl->cond->as<float>(), h->emb.as<float>(), tvec, t_base, t_bstride, pl->f.as<float>(), B, hh, ww, COND_C, s));
   DD_HIP(launch_naive_conv3x3(pl->f.as<float>(), L[2].w_oihw.as<float>(), L[2].bias.as<float>(), pl->y3.as<float>(), B, hh, ww, COND_C, HID_C, s));
   DD_HIP(launch_naive_gn_stats(pl->y3.as<float>(), pl->stat_ptr(step, 2), B, hh, ww, HID_C, s));
   DD_HIP(launch_naive_gn_apply(pl->y3.as<float>(), pl->stat_ptr(step, 2), L[2].gamma.as<float>(), L[2].beta.as<float>(),
@@ -400,8 +466,25 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
   p.ablate = 0;
-  p.in = pl->cond.p; p.wpack = h->L[2].wpack2[pl->ek].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
+  p.in = pl->cond->p; p.wpack = h->L[2].wpack2[pl->ek].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
   DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
+  return DD_OK;
+}
+
+// Bring the condition map into the plan's (shared) buffer: convert the caller's NCHW fp32 tensor, or -- cond == NULL --
+// check that dd_condition left its result there.
+int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
+                    int precision, hipStream_t s) {
+  if (cond) {
+    if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+    else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+    if (h->fpn_cond == pl->cond) { h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; }    // overwritten
+  } else {
+    const int* k = h->fpn_cond_key;
+    if (!h->fpn_cond || h->fpn_cond != pl->cond || k[0] != B || k[1] != lat_h || k[2] != lat_w || k[3] != precision)
+      return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, latent size and precision");
+  }
+  if (pl->key.hoist) { int rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
   return DD_OK;
 }
 
@@ -478,12 +561,13 @@ int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t nu
   if (!h) return DD_ERR_INVALID_ARG;
   if (!name || !data || numel <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_set_weight: null name/data or non-positive numel");
   for (const auto& ws : required_weights(h->variant)) {
-    if (std::strcmp(ws.name, name) == 0) {
+    if (ws.name == name) {
       if (ws.numel != numel)
         return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight: ") + name + " expects " + std::to_string(ws.numel) +
                                                " elements, got " + std::to_string(numel));
       h->host_w[name].assign(data, data + numel);
-      if (std::strncmp(name, "model.", 6) == 0) h->committed = false; else h->codec_committed = false;
+      const int grp = weight_group(name);
+      if (grp == 0) h->committed = false; else if (grp == 1) h->codec_committed = false; else h->fpn_committed = false;
       return DD_OK;
     }
   }
@@ -494,21 +578,22 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   if (!h) return DD_ERR_INVALID_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
-  // two independent groups: "model." (denoiser) and "depth_transform." (codec).  A group is packed when
-  // all of its keys are present; a partially provided group is an error; at least one must be complete.
-  int have[2] = {0, 0}, need[2] = {0, 0};
-  std::string first_missing[2];
+  // independent groups: "model." (denoiser), "depth_transform." (codec) and "conv_lateral." / "conv_up." (condition FPN,
+  // Res variant).  A group is packed when all of its keys are present; a partially provided group is an error; at least
+  // one must be complete.
+  int have[3] = {0, 0, 0}, need[3] = {0, 0, 0};
+  std::string first_missing[3];
   for (const auto& ws : required_weights(h->variant)) {
-    const int grp = std::strncmp(ws.name, "model.", 6) == 0 ? 0 : 1;
+    const int grp = weight_group(ws.name);
     need[grp]++;
     if (h->host_w.count(ws.name)) have[grp]++;
     else if (first_missing[grp].empty()) first_missing[grp] = ws.name;
   }
-  for (int grp = 0; grp < 2; ++grp)
+  for (int grp = 0; grp < 3; ++grp)
     if (have[grp] != 0 && have[grp] != need[grp])
       return h->fail(DD_ERR_STATE, "dd_commit_weights: missing parameter '" + first_missing[grp] + "'");
-  if (have[0] == 0 && have[1] == 0) return h->fail(DD_ERR_STATE, "dd_commit_weights: no parameters were set");
-  const bool do_model = have[0] == need[0], do_codec = have[1] == need[1];
+  if (have[0] == 0 && have[1] == 0 && have[2] == 0) return h->fail(DD_ERR_STATE, "dd_commit_weights: no parameters were set");
+  const bool do_model = have[0] == need[0], do_codec = have[1] == need[1], do_fpn = need[2] > 0 && have[2] == need[2];
   // graphs bake weight pointers; buffers are reused when sizes match, so existing graphs stay valid,
   // but make sure nothing is in flight while we overwrite them.
   DD_HIP(hipDeviceSynchronize());
@@ -572,6 +657,58 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
     DD_HIP(hipStreamSynchronize(s));
     h->committed = true;
+  }
+  if (do_fpn) {
+    // ---- condition FPN: fold eval-mode BatchNorm into the (bias-free) convolutions, pack for the v2 kernels ----
+    auto fold = [&](const std::string& pre, std::vector<double>& scale, std::vector<float>& shift) {
+      const auto &g = h->host_w[pre + ".weight"], &b = h->host_w[pre + ".bias"], &m = h->host_w[pre + ".running_mean"],
+                 &v = h->host_w[pre + ".running_var"];
+      scale.resize(COND_C); shift.resize(COND_C);
+      for (int c = 0; c < COND_C; ++c) {
+        scale[c] = (double)g[c] / std::sqrt((double)v[c] + (double)BN_EPS);
+        shift[c] = (float)((double)b[c] - (double)m[c] * scale[c]);
+      }
+    };
+    std::vector<double> sc; std::vector<float> sh;
+    for (int i = 0; i < FPN_LEVELS; ++i) {
+      const std::string pre = "conv_lateral." + std::to_string(i);
+      fold(pre + ".1", sc, sh);
+      std::vector<float> w = h->host_w[pre + ".0.weight"];            // [256][cin][3][3]
+      const size_t per = (size_t)FPN_CIN[i] * 9;
+      for (int co = 0; co < COND_C; ++co)
+        for (size_t k = 0; k < per; ++k) w[co * per + k] = (float)((double)w[co * per + k] * sc[co]);
+      for (int ek = 0; ek < NUM_EK; ++ek) {
+        std::vector<uint8_t> packed;
+        pack_conv_weights(w.data(), conv_pack_geom2(10 + i, ek), ek, true, packed);
+        int rc = upload(h, h->fpn_lat_w[i][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
+      int rc = upload(h, h->fpn_lat_b[i], sh.data(), sh.size() * 4, s); if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
+    }
+    for (int j = 0; j < FPN_LEVELS - 1; ++j) {
+      const std::string pre = "conv_up." + std::to_string(j);
+      fold(pre + ".1", sc, sh);
+      const std::vector<float>& wt = h->host_w[pre + ".0.weight"];     // ConvTranspose2d weight [cin][cout][2][2]
+      // as a 1x1 convolution with 4 x 256 outputs: row (dy*2+dx)*256 + co, column ci
+      std::vector<float> w((size_t)4 * COND_C * COND_C);
+      std::vector<float> b4((size_t)4 * COND_C);
+      for (int par = 0; par < 4; ++par)
+        for (int co = 0; co < COND_C; ++co) {
+          b4[par * COND_C + co] = sh[co];
+          for (int ci = 0; ci < COND_C; ++ci)
+            w[((size_t)par * COND_C + co) * COND_C + ci] = (float)((double)wt[((size_t)ci * COND_C + co) * 4 + par] * sc[co]);
+        }
+      for (int ek = 0; ek < NUM_EK; ++ek) {
+        std::vector<uint8_t> packed;
+        pack_conv_weights(w.data(), conv_pack_geom2(14, ek), ek, true, packed);
+        int rc = upload(h, h->fpn_up_w[j][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
+      int rc = upload(h, h->fpn_up_b[j], b4.data(), b4.size() * 4, s); if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
+    }
+    h->fpn_committed = true;
   }
   if (!do_codec) return DD_OK;
   // ---- codec: fold eval-mode BatchNorm into the convolutions (reference depth_transform.py:15-26) ----
@@ -662,7 +799,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
-    for (int i = 0; i < 10; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
+    for (int i = 0; i < 16; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
   } else return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: unknown key '" + k + "'");
   return DD_OK;
 }
@@ -679,7 +816,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
 }
 
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches) {
-  if (!h || layer < 1 || layer > 9 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
+  if (!h || layer < 1 || layer > 14 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
   drain_layer_events(h);
   *total_ms = h->layer_ms[layer - 1];
   *launches = h->layer_cnt[layer - 1];
@@ -695,11 +832,93 @@ int dd_last_loop_ms(dd_handle_t h, float* ms) {
   return DD_OK;
 }
 
+int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
+                 float* cond_out, int precision, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "dd_condition: the condition FPN is built for DD_VARIANT_RES only");
+  if (!h->fpn_committed) return h->fail(DD_ERR_STATE, "conv_lateral.* / conv_up.* weights not committed (dd_set_weight, dd_commit_weights)");
+  if (n_levels != FPN_LEVELS || !feats || !feat_h || !feat_w) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: expects 4 pyramid levels");
+  if (precision < DD_PREC_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16 or f16");
+  if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
+  for (int i = 0; i < FPN_LEVELS; ++i) {
+    if (!feats[i] || feat_h[i] <= 0 || feat_w[i] <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: null feature pointer or non-positive size");
+    if ((long long)B * feat_h[i] * feat_w[i] * FPN_CIN[i] >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  const int ek = ek_of_precision(precision);
+  const size_t es = ek_size(ek);
+  // workspace for this pyramid shape
+  FpnWork* fw = h->fpn_work.get();
+  bool same = fw && fw->B == B && fw->ek == ek;
+  for (int i = 0; same && i < FPN_LEVELS; ++i) same = fw->hs[i] == feat_h[i] && fw->ws[i] == feat_w[i];
+  if (!same) {
+    DD_HIP(hipDeviceSynchronize());
+    h->fpn_work.reset(new FpnWork());
+    fw = h->fpn_work.get();
+    fw->B = B; fw->ek = ek;
+    for (int i = 0; i < FPN_LEVELS; ++i) {
+      fw->hs[i] = feat_h[i]; fw->ws[i] = feat_w[i];
+      const size_t px = (size_t)B * feat_h[i] * feat_w[i];
+      DD_HIP(fw->fin[i].alloc(px * FPN_CIN[i] * es));
+      if (i > 0) {
+        DD_HIP(fw->lat[i].alloc(px * COND_C * es));
+        DD_HIP(fw->up[i - 1].alloc(px * 4 * COND_C * es));
+        if (2 * feat_h[i] != feat_h[i - 1] || 2 * feat_w[i] != feat_w[i - 1])
+          DD_HIP(fw->pooled[i - 1].alloc((size_t)B * feat_h[i - 1] * feat_w[i - 1] * COND_C * es));
+      }
+    }
+  }
+  std::shared_ptr<DevBuf> cbuf;
+  int rc = get_cond_buf(h, B, feat_h[0], feat_w[0], precision, &cbuf);
+  if (rc) return rc;
+
+  auto launch = [&](int layer, const ConvParams& q) -> hipError_t {
+    if (!h->layer_timing) return launch_conv_igemm2(layer, ek, q, s);
+    hipEvent_t a, b;
+    hipError_t e = hipEventCreate(&a); if (e != hipSuccess) return e;
+    e = hipEventCreate(&b); if (e != hipSuccess) return e;
+    (void)hipEventRecord(a, s);
+    e = launch_conv_igemm2(layer, ek, q, s);
+    (void)hipEventRecord(b, s);
+    h->pending_ev.emplace_back(layer - 1, a, b);
+    return e;
+  };
+  // top-down pass (reference ...res.py:108-118): x_3 = lat_3(f_3);  x_i = lat_i(f_i) + pool(up_i(x_{i+1}))
+  for (int i = FPN_LEVELS - 1; i >= 0; --i) {
+    const int hh = feat_h[i], ww = feat_w[i];
+    DD_HIP(launch_nchw_to_nhwc(feats[i], fw->fin[i].p, ek, B, FPN_CIN[i], hh, ww, 1, s));
+    ConvParams p{};
+    p.B = B; p.h = hh; p.w = ww;
+    p.tiles_x = (ww + 31) / 32;
+    p.tiles_y = (hh + conv_pack_geom2(10 + i, ek).th - 1) / conv_pack_geom2(10 + i, ek).th;
+    p.in = fw->fin[i].p; p.wpack = h->fpn_lat_w[i][ek].p; p.bias = h->fpn_lat_b[i].as<float>();
+    p.out = (i == 0) ? cbuf->p : fw->lat[i].p;
+    p.addend = (i == FPN_LEVELS - 1) ? nullptr : (fw->pooled[i].p ? fw->pooled[i].p : fw->up[i].p);
+    DD_HIP(launch(10 + i, p));
+    if (i > 0) {
+      ConvParams u{};
+      u.B = B; u.h = hh; u.w = ww;
+      u.tiles_x = (ww + 31) / 32;
+      u.tiles_y = (hh + conv_pack_geom2(14, ek).th - 1) / conv_pack_geom2(14, ek).th;
+      u.in = fw->lat[i].p; u.wpack = h->fpn_up_w[i - 1][ek].p; u.bias = h->fpn_up_b[i - 1].as<float>(); u.out = fw->up[i - 1].p;
+      DD_HIP(launch(14, u));
+      if (fw->pooled[i - 1].p)
+        DD_HIP(launch_adaptive_pool_blocked(fw->up[i - 1].p, fw->pooled[i - 1].p, ek, B, COND_C, 2 * hh, 2 * ww, feat_h[i - 1], feat_w[i - 1], s));
+    }
+    if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  }
+  if (cond_out) DD_HIP(launch_blocked_to_nchw(cbuf->p, ek, cond_out, B, COND_C, feat_h[0], feat_w[0], s));
+  h->fpn_cond = cbuf;
+  h->fpn_cond_key[0] = B; h->fpn_cond_key[1] = feat_h[0]; h->fpn_cond_key[2] = feat_w[0]; h->fpn_cond_key[3] = precision;
+  return DD_OK;
+}
+
 int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
                int cond_h, int cond_w, int T, int precision, void* stream) {
   int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
   if (rc) return rc;
-  if (!x_T || !cond || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
+  if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
   if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
@@ -711,9 +930,8 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (rc) return rc;
 
   DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
-  else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
-  if (pl->key.hoist) { rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  if (rc) return rc;
 
   if (h->timing) {
     if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
@@ -788,7 +1006,7 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
                     int lat_w, int cond_h, int cond_w, int precision, void* stream) {
   int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
   if (rc) return rc;
-  if (!x_t || !t || !cond || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
+  if (!x_t || !t || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
   if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
@@ -799,9 +1017,8 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   if (rc) return rc;
   const long long* tv = reinterpret_cast<const long long*>(t);
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
-  else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond.p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
-  if (pl->key.hoist) { rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  if (rc) return rc;
   DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
   if (precision == DD_PREC_NAIVE_FP32) {
     rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);

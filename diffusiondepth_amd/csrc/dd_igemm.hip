@@ -381,7 +381,7 @@ hipError_t launch_conv_igemm(int layer, int ek, const ConvParams& p, hipStream_t
 
 template <int EK, int LAYER> static PackGeom geom_of() {
   using C = Cfg<EK, LAYER>;
-  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH};
+  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH, 3};
 }
 template <int EK> static PackGeom geom_layer(int layer) {
   switch (layer) {

@@ -107,11 +107,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
     const int pp = itc >> C::LOG2_PPP;
     const int pr = pp / PW, pc = pp - pr * PW;
-    const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+    const int gy = y0 - C::HALO + pr, gx = x0 - C::HALO + pc;
     const bool inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
     if (it < C::ITEMS) m_valid |= 1u << u;
     if (inside) m_inside |= 1u << u;
-    if (inside && pr >= 1 && pr <= C::TH && pc >= 1 && pc <= C::TW) m_interior |= 1u << u;
+    if (inside && pr >= C::HALO && pr < C::HALO + C::TH && pc >= C::HALO && pc < C::HALO + C::TW) m_interior |= 1u << u;
     const int gyc = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);
     const int gxc = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
     pix_off[u] = gyc * w + gxc;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const double2 ov1 = make_double2(__shfl_xor(sv1.x, 1, 64), __shfl_xor(sv1.y, 1, 64));
     const bool hi = lane & 1;                  // this lane reduced groups 2,3 (hi) or 0,1
     const double2 g0 = hi ? ov0 : sv0, g1 = hi ? ov1 : sv1, g2 = hi ? sv0 : ov0, g3 = hi ? sv1 : ov1;
-    static_assert(C::CTAB <= C::THREADS, "one table channel per thread");
+    static_assert(C::PRO == PRO_RAW || C::CTAB <= C::THREADS, "one table channel per thread");
     if (tid < C::CTAB) {
       constexpr int CG = C::CTAB / GN_GROUPS;
       const int grp = tid / CG;
@@ -322,8 +322,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     if (!(abl & 8)) {
 #pragma unroll
     for (int t = 0; t < C::TG; ++t) {
-      const int dy = (C::TG == 9) ? t / 3 : (C::TG == 3) ? tg : tg / 3;
-      const int dx = (C::TG == 9) ? t % 3 : (C::TG == 3) ? t : tg % 3;
+      const int dy = (C::KS == 1) ? 0 : (C::TG == 9) ? t / 3 : (C::TG == 3) ? tg : tg / 3;
+      const int dx = (C::KS == 1) ? 0 : (C::TG == 9) ? t % 3 : (C::TG == 3) ? t : tg % 3;
       const int roff = poff + dy * (PW * ROWB);
 #pragma unroll
       for (int kq = 0; kq < NKQ; ++kq) {
@@ -420,8 +420,32 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             }
           }
         }
-        const float v[4] = {acc[n][m][q * 4 + 0] + bv.x, acc[n][m][q * 4 + 1] + bv.y,
-                            acc[n][m][q * 4 + 2] + bv.z, acc[n][m][q * 4 + 3] + bv.w};
+        float v[4] = {acc[n][m][q * 4 + 0] + bv.x, acc[n][m][q * 4 + 1] + bv.y,
+                      acc[n][m][q * 4 + 2] + bv.z, acc[n][m][q * 4 + 3] + bv.w};
+        if constexpr (C::RELU_OUT) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+          if constexpr (C::IS_LAT) {
+            // FPN top-down term: x = relu(bn(conv(f))) + pooled(up(pre_x))  (reference ...res.py:113-116)
+            if (p.addend != nullptr && pvalid) {
+              const char* ab = reinterpret_cast<const char*>(p.addend) + ((size_t)b * h * w * C::COUT + act_offset(C::COUT, h, w, 0, co, gy, gx)) * C::ESZ;
+              float a4[4];
+              if constexpr (C::ESZ == 4) {
+                const float4 t4 = *reinterpret_cast<const float4*>(ab);
+                a4[0] = t4.x; a4[1] = t4.y; a4[2] = t4.z; a4[3] = t4.w;
+              } else {
+                const uint2 t2 = *reinterpret_cast<const uint2*>(ab);
+                if constexpr (EK == EK_BF16) {
+                  a4[0] = bf16_to_f32(t2.x & 0xFFFFu); a4[1] = bf16_to_f32(t2.x >> 16); a4[2] = bf16_to_f32(t2.y & 0xFFFFu); a4[3] = bf16_to_f32(t2.y >> 16);
+                } else {
+                  a4[0] = f16_to_f32(t2.x & 0xFFFFu); a4[1] = f16_to_f32(t2.x >> 16); a4[2] = f16_to_f32(t2.y & 0xFFFFu); a4[3] = f16_to_f32(t2.y >> 16);
+                }
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] += a4[i];
+            }
+          }
+        }
         if (C::STATS && pvalid) {
           const float s = (v[0] + v[1]) + (v[2] + v[3]);
           const float sq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
@@ -429,7 +453,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           ls[lg] += s; lq[lg] += sq;
         }
         if constexpr (C::OUT_ESZ == 4) {
-          if (pvalid) *reinterpret_cast<float4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+          if (pvalid) {
+            if constexpr (C::SCATTER) {
+              const int par = co >> 8, cc = co & (COND_C - 1);
+              *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.out) + ((size_t)b * 4 * h * w * COND_C +
+                  act_offset(COND_C, 2 * h, 2 * w, 0, cc, 2 * gy + (par >> 1), 2 * gx + (par & 1))) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              *reinterpret_cast<float4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+          }
         } else {
           pk[q].x = pack2<EK>(v[0], v[1]);
           pk[q].y = pack2<EK>(v[2], v[3]);
@@ -443,7 +475,13 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           const auto ry = __builtin_amdgcn_permlane32_swap(pk[2 * k].y, pk[2 * k + 1].y, false, false);
           if (pvalid) {
             const int co = n0 + n * 32 + 16 * k + 8 * g;
-            *reinterpret_cast<uint4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            if constexpr (C::SCATTER) {
+              const int par = co >> 8, cc = co & (COND_C - 1);
+              *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + ((size_t)b * 4 * h * w * COND_C +
+                  act_offset(COND_C, 2 * h, 2 * w, 0, cc, 2 * gy + (par >> 1), 2 * gx + (par & 1))) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            } else {
+              *reinterpret_cast<uint4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
           }
         }
       }
@@ -511,6 +549,11 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 7: return launch_one2<EK, 7>(p, s);
     case 8: return launch_one2<EK, 8>(p, s);
     case 9: return launch_one2<EK, 9>(p, s);
+    case 10: return launch_one2<EK, 10>(p, s);
+    case 11: return launch_one2<EK, 11>(p, s);
+    case 12: return launch_one2<EK, 12>(p, s);
+    case 13: return launch_one2<EK, 13>(p, s);
+    case 14: return launch_one2<EK, 14>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -525,7 +568,7 @@ hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_
 
 template <int EK, int LAYER> static PackGeom geom2_of() {
   using C = Cfg2<EK, LAYER>;
-  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH};
+  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH, C::KS};
 }
 template <int EK> static PackGeom geom2_layer(int layer) {
   switch (layer) {
@@ -537,7 +580,12 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 6: return geom2_of<EK, 6>();
     case 7: return geom2_of<EK, 7>();
     case 8: return geom2_of<EK, 8>();
-    default: return geom2_of<EK, 9>();
+    case 9: return geom2_of<EK, 9>();
+    case 10: return geom2_of<EK, 10>();
+    case 11: return geom2_of<EK, 11>();
+    case 12: return geom2_of<EK, 12>();
+    case 13: return geom2_of<EK, 13>();
+    default: return geom2_of<EK, 14>();
   }
 }
 PackGeom conv_pack_geom2(int layer, int ek) {

@@ -18,18 +18,30 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
   //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
   //   (raw input, no norm / activation in between: ConvModule(norm_cfg=None, act_cfg=None)), 7 = pred.0 256->64 on a raw input
-  // Res denoiser with the condition term hoisted (default): 8 = conv3 applied ONCE per image to the raw condition map (fp32
+  // Res denoiser with the condition term hoisted (optional): 8 = conv3 applied ONCE per image to the raw condition map (fp32
   //   out, no bias / statistics), 9 = conv3 on relu(gn2(y2)) only, epilogue adds layer 8's output and the E[t] tap sums
-  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : COND_C;
-  static constexpr int COUT = (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
+  // Condition aggregation (FPN of the Res head, reference ...res.py:56-84,108-118; eval-mode BN folded into weights / bias):
+  //   10..13 = conv_lateral[0..3]: Conv3x3 (64|128|256|512 -> 256) + BN + ReLU, then "+ top-down term" (optional addend)
+  //   14     = conv_up[j]: ConvTranspose2d(256->256, k2, s2) + BN + ReLU written as a 1x1 conv with 4 x 256 output
+  //            "channels" (one block per output parity (dy,dx)) whose epilogue scatters to pixel (2y+dy, 2x+dx)
+  static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13);
+  static constexpr bool IS_UP = (LAYER == 14);
+  static constexpr int KS = IS_UP ? 1 : 3;                       // kernel size
+  static constexpr int HALO = KS / 2;
+  static constexpr int NTAPS = KS * KS;
+  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : IS_LAT ? (64 << (LAYER - 10)) : COND_C;
+  static constexpr int COUT = IS_UP ? 4 * COND_C : IS_LAT ? COND_C
+                            : (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
+  static constexpr bool RELU_OUT = IS_LAT || IS_UP;              // epilogue: relu(acc + bias)
+  static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
   static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
   // FAT (conv3-shaped layers 3 / 7 / 9): one 16x32-pixel, 8-wave workgroup per CU with ALL nine taps of a channel chunk per
   // stage -> one barrier per chunk (8 instead of 24), weights DMA'd once per 512 pixels, 1.2x instead of 1.33x halo.
   static constexpr bool FAT = DD_FAT_CONV3 && (LAYER == 3 || LAYER == 7 || LAYER == 9);
-  static constexpr int TG = (LAYER == 1 || FAT) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6) ? 1 : 3;
-  static constexpr int NT = (COUT == COND_C) ? 128 : COUT_PAD;
-  static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8);   // a GroupNorm follows this convolution
+  static constexpr int TG = (LAYER == 1 || FAT) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
+  static constexpr int NT = (COUT >= COND_C) ? 128 : COUT_PAD;
+  static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
@@ -42,7 +54,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1) ? 4 : ESZ;
   static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8) ? 4 : ESZ;
-  static constexpr int PH = TH + 2, PW = TW + 2;
+  static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
   static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
   static constexpr int PPP = ROWB / 16;
   static constexpr int LOG2_PPP = (PPP == 2) ? 1 : (PPP == 4) ? 2 : 3;
@@ -50,7 +62,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int EPP = 16 / ESZ;
   static constexpr int NKQ = PPP / 2;                    // MFMA k-steps per tap (16 B from each half-wave)
   static constexpr int NCHUNK = CIN / CK;
-  static constexpr int NTG = 9 / TG;
+  static constexpr int NTG = NTAPS / TG;
   static constexpr int NSTAGE = NCHUNK * NTG;
   static constexpr int NPB = (NCHUNK > 1) ? 2 : 1;       // patch buffers
   static constexpr int PATCH_BYTES = PH * PW * ROWB;
@@ -70,7 +82,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
   static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);
-  static_assert(CIN % CK == 0 && 9 % TG == 0 && COUT_PAD % NT == 0, "tiling");
+  static_assert(CIN % CK == 0 && NTAPS % TG == 0 && COUT_PAD % NT == 0, "tiling");
   static_assert(PATCH_BYTES % 16 == 0 && W_BYTES % 1024 == 0, "LDS carve / DMA granularity");
   static_assert(PATCH_BYTES >= STAT_SLOTS * 8 * 8 + 64 + WAVES * 8 * 8, "scratch fits in the patch region");
   static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128, "swizzle derivation");

@@ -58,6 +58,7 @@ struct ConvParams {
   // fall inside the image of etab[t][tap][cout]   (conv is linear: conv3(r + cond + E[t]) = conv3(r) + conv3(cond) + conv3(E[t]))
   const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
   const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
+  const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
                             // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
                             // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier
@@ -67,7 +68,7 @@ struct ConvParams {
 // layer: 1..4 (conv1 16->64, conv2 64->256, conv3 256->64, conv4 64->16); ek: element kind.
 hipError_t launch_conv_igemm(int layer, int ek, const ConvParams& p, hipStream_t s);
 // Packed-weight geometry of (layer, ek): elements and tile parameters (host side packing).
-struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th; };   // th = output tile height (tile width is 32)
+struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks; };   // th = output tile height (tile width is 32), ks = kernel size
 PackGeom conv_pack_geom(int layer, int ek);
 // v2 (dd_igemm2.hip): software-pipelined variant; weights are packed with the LDS swizzle pre-applied
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
@@ -84,6 +85,9 @@ hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C
 // Swin variant: bilinear (align_corners=True) upsample of the NCHW fp32 condition map (B,C,ch,cw) to (h,w), written in the
 // channel-blocked activation layout (reference ...swin_addHAHI.py:332: F.interpolate(..., mode='bilinear', align_corners=True))
 hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s);
+// channel-blocked activations -> NCHW fp32 (tiled through LDS), and adaptive_avg_pool2d on channel-blocked activations
+hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s);
+hipError_t launch_adaptive_pool_blocked(const void* src, void* dst, int ek, int B, int C, int ih, int iw, int oh, int ow, hipStream_t s);
 hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, int blocked, hipStream_t s);
 // out(NCHW) = c1*x + c2*relu(gn4(y4))  (mode 0, final DDIM update) or relu(gn4(y4)) (mode 1, eps)
 hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,

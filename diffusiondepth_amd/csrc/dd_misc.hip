@@ -169,6 +169,125 @@ hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Channel-blocked activations -> NCHW fp32 (the FPN's condition map handed back to the caller).  Mirror of
+// nchw_to_nhwc_kernel: a block moves [64 px][64 ch] through LDS; reads are 16-B pieces of a pixel's channel block,
+// writes are 256-B runs along pixels of one channel plane.
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__global__ void __launch_bounds__(256) blocked_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst, int C, long long HW) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const long long p0 = (long long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  const int ipx = tid >> 2, part = tid & 3;            // 4 threads per pixel, 16 channels each
+  const int cbase = c0 + part * 16;
+  if (p0 + ipx < HW && cbase < C) {
+    const size_t o = (((size_t)b * (C / ACT_CB) + cbase / ACT_CB) * HW + p0 + ipx) * ACT_CB + (cbase % ACT_CB);
+    if constexpr (EK == EK_F32) {
+      const float4* sp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 v = sp[i];
+        tile[ipx][part * 16 + 4 * i] = v.x; tile[ipx][part * 16 + 4 * i + 1] = v.y;
+        tile[ipx][part * 16 + 4 * i + 2] = v.z; tile[ipx][part * 16 + 4 * i + 3] = v.w;
+      }
+    } else {
+      const uint4* sp = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(src) + o);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 v = sp[i];
+        const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tile[ipx][part * 16 + 8 * i + 2 * j] = ld_elem(&wv[j], 0, EK);
+          tile[ipx][part * 16 + 8 * i + 2 * j + 1] = ld_elem(&wv[j], 1, EK);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int px = tid & 63, cs = tid >> 6;
+  if (p0 + px >= HW) return;
+  float* d = dst + ((size_t)b * C) * HW;
+#pragma unroll 4
+  for (int cc = 0; cc < 16; ++cc) {
+    const int c = cc * 4 + cs;
+    if (c0 + c < C) d[(size_t)(c0 + c) * HW + p0 + px] = tile[px][c];
+  }
+}
+hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s) {
+  if (C % ACT_CB != 0) return hipErrorInvalidValue;
+  const long long HW = (long long)h * w;
+  dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+  if (ek == EK_F32) hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW);
+  else hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive_avg_pool2d on channel-blocked activations (reference ...res.py:116: the 2x-upsampled top-down term is
+// pooled to the lateral map's size when the backbone sizes are odd).  torch semantics: output (oy, ox) averages input
+// rows floor(oy*IH/OH) .. ceil((oy+1)*IH/OH)-1 (same for columns), fp32 accumulation in row-major order.
+// One thread per (output pixel, 16-B piece): consecutive lanes <-> consecutive pieces of consecutive pixels.
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__global__ void __launch_bounds__(256) adaptive_pool_blocked_kernel(const void* __restrict__ src, void* __restrict__ dst,
+                                                                   int nblk, int ih, int iw, int oh, int ow, long long total) {
+  constexpr int EPP = (EK == EK_F32) ? 4 : 8;           // elements per 16-B piece
+  constexpr int PPB = ACT_CB / EPP;                     // pieces per pixel of one channel block
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int piece = (int)(i % PPB);
+  long long r = i / PPB;
+  const int ox = (int)(r % ow); r /= ow;
+  const int oy = (int)(r % oh); r /= oh;                // r = b * nblk + channel block
+  const int ys = (int)(((long long)oy * ih) / oh), ye = (int)((((long long)oy + 1) * ih + oh - 1) / oh);
+  const int xs = (int)(((long long)ox * iw) / ow), xe = (int)((((long long)ox + 1) * iw + ow - 1) / ow);
+  float acc[EPP];
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
+  const char* sb = reinterpret_cast<const char*>(src) + ((size_t)r * ih * iw) * ACT_CB * (16 / EPP) + piece * 16;
+  for (int y = ys; y < ye; ++y)
+    for (int x = xs; x < xe; ++x) {
+      const uint4 v = *reinterpret_cast<const uint4*>(sb + ((size_t)y * iw + x) * ACT_CB * (16 / EPP));
+      const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+      if constexpr (EK == EK_F32) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += __builtin_bit_cast(float, wv[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[2 * k] += ld_elem(&wv[k], 0, EK); acc[2 * k + 1] += ld_elem(&wv[k], 1, EK); }
+      }
+    }
+  const float inv = (float)((ye - ys) * (xe - xs));
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) acc[k] /= inv;
+  char* db = reinterpret_cast<char*>(dst) + (((size_t)r * oh + oy) * ow + ox) * ACT_CB * (16 / EPP) + piece * 16;
+  if constexpr (EK == EK_F32) {
+    *reinterpret_cast<float4*>(db) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  } else {
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = (EK == EK_BF16) ? (cvt_bf16(acc[2 * k]) | (cvt_bf16(acc[2 * k + 1]) << 16)) : (cvt_f16(acc[2 * k]) | (cvt_f16(acc[2 * k + 1]) << 16));
+    *reinterpret_cast<uint4*>(db) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+hipError_t launch_adaptive_pool_blocked(const void* src, void* dst, int ek, int B, int C, int ih, int iw, int oh, int ow, hipStream_t s) {
+  if (C % ACT_CB != 0) return hipErrorInvalidValue;
+  const int nblk = C / ACT_CB;
+  const int ppb = (ek == EK_F32) ? 8 : 4;
+  const long long total = (long long)B * nblk * oh * ow * ppb;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (ek == EK_F32) hipLaunchKernelGGL(adaptive_pool_blocked_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, nblk, ih, iw, oh, ow, total);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(adaptive_pool_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, nblk, ih, iw, oh, ow, total);
+  else hipLaunchKernelGGL(adaptive_pool_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, nblk, ih, iw, oh, ow, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tail of the loop: x_0 = c1*x + c2*relu(gn4(y4))  (mode 0)   or   eps = relu(gn4(y4))  (mode 1),
 // NHWC fp32 in, NCHW fp32 out.  One thread per pixel: 64-B reads per lane, 16 plane-coalesced writes.
 // ------------------------------------------------------------------------------------------------

@@ -4,9 +4,8 @@
 Same constructor keywords (the dict Diffusion_DCbase_Model passes to HEADS.build,
 reference src/model/diffusion_dcbase_model.py:77-91), same parameter tree (state_dict keys), same
 forward(fp, depth_map, depth_mask, gt_depth_map=None, return_loss=False, **kwargs) -> 13-key dict.
-The condition aggregation (conv_lateral / conv_up FPN, …res.py:108-118) stays in PyTorch-ROCm; the
-latent encoder, the T-step DDIM loop, the decoder and the ddim_loss denoiser call run in the HIP
-library.  mmcv/mmdet3d are not needed: the few factories the reference pulls from them are plain
+The latent encoder, the condition aggregation (conv_lateral / conv_up FPN, …res.py:108-118; Res head, eval
+mode), the T-step DDIM loop, the decoder and the ddim_loss denoiser call run in the HIP library.  mmcv/mmdet3d are not needed: the few factories the reference pulls from them are plain
 torch.nn layers.
 """
 from __future__ import annotations
@@ -38,7 +37,7 @@ class DDIMDepthEstimate_Res(nn.Module):
 
     def __init__(self, in_channels=(64, 128, 256, 512), up_scale_factor=1, inference_steps=20, num_train_timesteps=1000,
                  return_indices=None, depth_transform_cfg=None, depth_feature_dim=16, detach_fp=False, loss_cfgs=(),
-                 init_cfg=None, precision=None, **kwargs):
+                 init_cfg=None, precision=None, condition_backend="hip", **kwargs):
         super().__init__()
         if depth_transform_cfg is not None and depth_transform_cfg.get("type", "DeepDepthTransformWithUpsampling") != \
                 "DeepDepthTransformWithUpsampling":
@@ -68,9 +67,20 @@ class DDIMDepthEstimate_Res(nn.Module):
             if i != 0:
                 self.conv_up.append(nn.Sequential(nn.ConvTranspose2d(fpn_dim, fpn_dim, 2, 2, bias=False), nn.BatchNorm2d(fpn_dim),
                                                   nn.ReLU(True)))
+        if condition_backend not in ("hip", "torch"):
+            raise ValueError("condition_backend must be 'hip' or 'torch'")
+        # the library's FPN covers the ResNet pyramid of the Res head; the Swin/MPViT heads keep theirs in PyTorch-ROCm
+        self._hip_fpn = condition_backend == "hip" and self._VARIANT == "res"
+        if self._hip_fpn:
+            bound.register("conv_lateral.", self.conv_lateral)
+            bound.register("conv_up.", self.conv_up)
 
-    # -- condition aggregation: PyTorch-ROCm (…res.py:108-118) -----------------------------------
+    # -- condition aggregation (…res.py:108-118) --------------------------------------------------
     def aggregate_condition(self, fp):
+        if self._hip_fpn and not self.training and len(fp) == 4 and all(f.is_cuda for f in fp) and self.model.precision != "naive_fp32":
+            # eval-mode BatchNorm is folded into the convolutions inside the library (dd_condition)
+            be = self._bound.ensure(fp[0].device, self.scheduler)
+            return be.condition([f.float() for f in fp], self.model.precision)
         x = None
         n = len(fp)
         for i in range(n):

@@ -76,6 +76,9 @@ const char* dd_version(void);
  * `name` is the state-dict key WITHOUT the "depth_head." prefix, e.g.
  * "model.noise_embedding.0.weight"; `data` is a HOST pointer to `numel` contiguous fp32 values in
  * the reference's own layout (OIHW conv weights, (in,out,kh,kw) for the ConvTranspose).
+ * DD_VARIANT_RES also takes the condition FPN's parameters "conv_lateral.{0..3}.{0.weight,1.weight,1.bias,1.running_mean,
+ * 1.running_var}" and "conv_up.{0..2}.{...}" (src/model/head/ddim_depth_estimate_res.py:56-84) as a third, optional group
+ * (needed by dd_condition only).
  * Call dd_commit_weights after the last dd_set_weight (and again whenever weights changed, e.g.
  * after an optimizer step): it validates completeness and repacks into the kernels' layouts. */
 int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel);
@@ -86,13 +89,27 @@ int dd_commit_weights(dd_handle_t h, void* stream);
  * (torch.cumprod(1 - linspace(beta_start, beta_end))), so table bits are the reference's own. */
 int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_timesteps);
 
+/* ---- condition aggregation (FPN) ------------------------------------------------------------------
+ * Replaces: the top-down loop of DDIMDepthEstimate_Res.forward (src/model/head/ddim_depth_estimate_res.py:108-118)
+ *   x_3 = conv_lateral[3](f_3);   x_i = conv_lateral[i](f_i) + adaptive_avg_pool2d(conv_up[i](x_{i+1}), size of x_i)
+ * with conv_lateral = Conv3x3(bias=False)+BN+ReLU, conv_up = ConvTranspose2d(k2,s2,bias=False)+BN+ReLU, BatchNorm in
+ * eval mode (running statistics, folded into the convolutions at dd_commit_weights).
+ *   feats[i]  (B, {64,128,256,512}[i], feat_h[i], feat_w[i])  device fp32 NCHW backbone features, i = 0 finest; n_levels = 4
+ *   cond_out  (B, 256, feat_h[0], feat_w[0]) device fp32 NCHW, or NULL
+ * The result also stays inside the handle in the kernels' own layout: a following dd_denoise / dd_denoise_once with
+ * cond == NULL and the same B, lat_h == feat_h[0], lat_w == feat_w[0], precision uses it without any conversion.
+ * DD_VARIANT_RES only (the Swin/MPViT heads keep their FPN in the framework); precision fp32 / bf16 / f16. */
+int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
+                 float* cond_out, int precision, void* stream);
+
 /* ---- the hot loop -----------------------------------------------------------------------------
  * Replaces: CNNDDIMPipiline.__call__ (…res.py:248-297) minus its torch.randn: `timesteps`-driven
  * loop of  eps = model(x_t, t, cond) ; x_{t-1} = scheduler.step(eps, t, x_t, eta=0,
  * use_clipped_model_output=True)  (DDIMScheduler.step, scheduling_ddim.py:231-353), for the
  * T = num_inference_steps timesteps of DDIMScheduler.set_timesteps (scheduling_ddim.py:215-229).
  *   x_T   (B,16,h,w)           initial latent noise
- *   cond  (B,256,cond_h,cond_w) condition map (cond_h,cond_w == h,w for DD_VARIANT_RES)
+ *   cond  (B,256,cond_h,cond_w) condition map (cond_h,cond_w == h,w for DD_VARIANT_RES); NULL = the map the last
+ *                              dd_condition call left in the handle (same B, h, w, precision)
  *   x_0   (B,16,h,w)           result ("refined_depth_t", …res.py:124)
  * The T-step loop runs as one captured hipGraph per (B,h,w,cond_h,cond_w,T,precision). */
 int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
@@ -133,7 +150,7 @@ int dd_last_loop_ms(dd_handle_t h, float* ms);
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`
- * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant; 9 = conv3 with the hoisted condition term) since the option was set (used by bench.py for the per-kernel roofline figure). */
+ * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant; 9 = conv3 with the hoisted condition term; 10..13 = conv_lateral[0..3], 14 = conv_up of dd_condition) since the option was set (used by bench.py for the per-kernel roofline figure). */
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches);
 
 /* Copies an internal intermediate of the last dd_denoise_once call to a caller DEVICE buffer as

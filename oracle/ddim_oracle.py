@@ -293,6 +293,41 @@ def decode(sd, latent, eps=1e-6, dtype=np.float64):
     return 1.0 / np.maximum(s, eps) - 1.0
 
 
+def adaptive_avg_pool2d(x, out_h, out_w):
+    """F.adaptive_avg_pool2d: output (i, j) averages input rows floor(i*H/oh) .. ceil((i+1)*H/oh)-1 and the same for
+    columns (ATen AdaptiveAveragePooling.cpp start_index / end_index)."""
+    B, C, H, W = x.shape
+    if (H, W) == (out_h, out_w):
+        return x
+    out = np.empty((B, C, out_h, out_w), dtype=x.dtype)
+    for i in range(out_h):
+        ys, ye = (i * H) // out_h, -((-(i + 1) * H) // out_h)
+        for j in range(out_w):
+            xs, xe = (j * W) // out_w, -((-(j + 1) * W) // out_w)
+            out[:, :, i, j] = x[:, :, ys:ye, xs:xe].mean(axis=(2, 3))
+    return out
+
+
+def fpn_aggregate(fsd, fp, dtype=np.float64):
+    """Condition aggregation of DDIMDepthEstimate_Res.forward (reference src/model/head/ddim_depth_estimate_res.py:108-118):
+    top-down over the pyramid, x = conv_lateral[i](f_i) [+ adaptive_avg_pool2d(conv_up[i](x_prev), size of x)], with
+    conv_lateral = Conv3x3(bias=False)+BN(eval)+ReLU (...res.py:60-69) and conv_up = ConvTranspose2d(k2, s2, bias=False)
+    +BN(eval)+ReLU (...res.py:71-84).  fsd: state-dict entries "conv_lateral.*" / "conv_up.*"; fp: list of 4 NCHW maps."""
+    sd = _cast_sd(fsd, dtype)
+    n = len(fp)
+    x = None
+    for i in range(n):
+        lvl = n - i - 1
+        f = np.asarray(fp[lvl], dtype=dtype)
+        cur = relu(batch_norm_eval(conv2d(f, sd[f"conv_lateral.{lvl}.0.weight"]), *_bn_args(sd, f"conv_lateral.{lvl}.1")))
+        if i > 0:
+            up = conv_transpose2d(x, sd[f"conv_up.{lvl}.0.weight"], None, stride=2, pad=0)
+            up = relu(batch_norm_eval(up, *_bn_args(sd, f"conv_up.{lvl}.1")))
+            cur = cur + adaptive_avg_pool2d(up, cur.shape[2], cur.shape[3])
+        x = cur
+    return x
+
+
 def head_hot_path(sd, gt_depth, cond, x_T, noise, timesteps, T=20, variant="res", dtype=np.float64):
     """The hot-path part of DDIMDepthEstimate_Res.forward (…res.py:102,124-176) given the condition
     map (the FPN stays outside the hot path): encoder -> T-step loop -> decoder -> ddim_loss."""

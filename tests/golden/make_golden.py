@@ -15,6 +15,7 @@ Cases (all eval mode, fp32, torch CPU):
   loop_swin      same for the Swin variant, T=20
   codec          DeepDepthTransformWithUpsampling.t / inv_t (even and odd sizes)
   head_res       full DDIMDepthEstimate_Res.forward (FPN + loop + decoder + ddim_loss), RNG injected
+  fpn_odd        the head's condition FPN (conv_lateral / conv_up / adaptive_avg_pool2d) on an odd-sized pyramid
 """
 from __future__ import annotations
 
@@ -180,6 +181,26 @@ def gen_head(ref):
             "cond_ch0_4": t2n(x)[:, :4], "cond_sum": np.array([float(x.double().sum())])}
 
 
+def gen_fpn(ref):
+    """Condition FPN of the reference head class on an odd-sized pyramid (both adaptive_avg_pool2d size fixes are active)."""
+    c = CASES["fpn_odd"]
+    fsd = synth.make_fpn_state_dict(c["fseed"])
+    head = ref.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=2, num_train_timesteps=1000,
+                                     depth_feature_dim=16, loss_cfgs=[]).eval()
+    own = head.state_dict()
+    head.load_state_dict({k: (torch.from_numpy(fsd[k]) if k in fsd else own[k]) for k in own}, strict=True)
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(c["iseed"], c["B"], c["H"], c["W"])]
+    with torch.no_grad():
+        x = None
+        for i in range(4):                      # the loop of ...res.py:108-118, module calls are the reference's own
+            cur = head.conv_lateral[3 - i](fp[3 - i])
+            if i > 0:
+                cur = cur + torch.nn.functional.adaptive_avg_pool2d(head.conv_up[3 - i](x), output_size=cur.shape[-2:])
+            x = cur
+    return {"cond_ch0_8": t2n(x)[:, :8], "cond_chan_sum": x.double().sum(dim=(0, 2, 3)).numpy(),
+            "shape": np.array(x.shape, dtype=np.int64)}
+
+
 def main():
     ref = load_reference()
     torch.manual_seed(0)
@@ -193,6 +214,7 @@ def main():
         "loop_swin": lambda: gen_loop(ref, "loop_swin"),
         "codec": lambda: gen_codec(ref),
         "head_res": lambda: gen_head(ref),
+        "fpn_odd": lambda: gen_fpn(ref),
     }
     only = sys.argv[1:]
     for name, fn in gens.items():

@@ -155,3 +155,37 @@ def test_torch_port_swin_loop(golden, cases):
     x0 = P.ddim_loop(sd, inp["x_T"], inp["cond"], 20, variant="swin").numpy()
     ref = g["x0_T20"]
     assert np.abs(x0 - ref).max() < 3e-6 * np.abs(ref).max()
+
+
+def test_fpn_aggregate_odd_pyramid(golden, cases):
+    """Condition FPN restatement vs the reference head's own modules on an odd-sized pyramid
+    (29x39 <- 15x20 <- 8x10 <- 4x5: both adaptive_avg_pool2d size fixes are exercised)."""
+    c, g = cases["fpn_odd"], golden("fpn_odd")
+    fsd = synth.make_fpn_state_dict(c["fseed"])
+    fp = synth.make_backbone_features(c["iseed"], c["B"], c["H"], c["W"])
+    x = O.fpn_aggregate(fsd, fp)
+    assert list(x.shape) == list(g["shape"])
+    scale = float(np.abs(g["cond_ch0_8"]).max())
+    assert np.abs(x[:, :8] - g["cond_ch0_8"]).max() <= 2e-6 * scale
+    ref_sum = g["cond_chan_sum"]
+    assert np.abs(x.sum(axis=(0, 2, 3)) - ref_sum).max() <= 2e-6 * float(np.abs(ref_sum).max())
+
+
+def test_fpn_aggregate_even_pyramid(golden, cases):
+    """Same restatement vs the condition map the reference head computed inside the head_res golden run."""
+    c, g = cases["head_res"], golden("head_res")
+    fsd = synth.make_fpn_state_dict(c["fseed"])
+    fp = synth.make_backbone_features(c["iseed"], c["B"], c["H"], c["W"])
+    x = O.fpn_aggregate(fsd, fp)
+    scale = float(np.abs(g["cond_ch0_4"]).max())
+    assert np.abs(x[:, :4] - g["cond_ch0_4"]).max() <= 2e-6 * scale
+    assert abs(float(x.sum()) - float(g["cond_sum"][0])) <= 2e-6 * abs(float(g["cond_sum"][0]))
+
+
+def test_adaptive_avg_pool_matches_torch():
+    import torch
+    rs = np.random.RandomState(5)
+    for (H, W, oh, ow) in [(30, 40, 29, 39), (16, 20, 15, 20), (8, 10, 8, 10), (7, 9, 3, 4), (5, 5, 7, 6)]:
+        x = rs.standard_normal((2, 3, H, W))
+        ref = torch.nn.functional.adaptive_avg_pool2d(torch.from_numpy(x), (oh, ow)).numpy()
+        assert np.abs(O.adaptive_avg_pool2d(x, oh, ow) - ref).max() < 1e-12
