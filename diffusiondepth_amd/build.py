@@ -38,7 +38,8 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not is_stale():
         return LIB
-    cmd = [find_hipcc()] + FLAGS + ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("DDEPTH_CFLAGS", "").split()      # e.g. -DDD_ABLATE=1 for tools/ablate.py
+    cmd = [find_hipcc()] + FLAGS + extra + ["-o", LIB + ".tmp"] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[diffusiondepth_amd.build]", " ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

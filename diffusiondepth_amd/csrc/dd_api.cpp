@@ -88,7 +88,7 @@ struct Plan {
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
-  DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 [B][2][h][w][32]
+  DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
@@ -321,7 +321,11 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   (void)swin;
   { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond); if (rc) return rc; }
   if (swin) { DD_HIP(pl->sa.alloc(px * COND_C * es)); DD_HIP(pl->sf.alloc(px * COND_C * es)); }
-  if (key.hoist) DD_HIP(pl->ccond.alloc(px * HID_C * 4));
+  if (key.hoist)   // conv3(cond) in accumulator-fragment order: whole (th x 32)-pixel tiles
+  {
+    const int th = conv_pack_geom2(9, pl->ek).th;
+    DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
+  }
   DD_HIP(pl->y1.alloc(px * HID_C * es));
   DD_HIP(pl->y2.alloc(px * COND_C * es));
   DD_HIP(pl->y3.alloc(px * HID_C * es));

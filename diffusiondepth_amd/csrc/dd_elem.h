@@ -77,6 +77,30 @@ template <int EK> struct Piece {
   }
 };
 
+// relu(a*y + b) of one 16-byte piece of 2-byte elements, result packed again (the GroupNorm + ReLU prologue when nothing
+// is added behind the ReLU).  VALU diet: packed fp32 FMA (v_pk_fma_f32), hardware RNE pack, and the ReLU on the PACKED
+// pair as a signed 16-bit integer max with 0 (v_pk_max_i16: negative bf16/f16 values have the sign bit set, and rounding
+// commutes with the ReLU) -- 20 VALU per 8 elements instead of 28.
+typedef __attribute__((ext_vector_type(2))) short i16x2_t;
+template <int EK>
+__device__ __forceinline__ uint4 affine_relu_pack(const uint4& raw, const float (&ta)[8], const float (&tb)[8]) {
+  static_assert(EK != EK_F32, "2-byte element kinds only");
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2_t y;
+    if constexpr (EK == EK_BF16) { y.x = __builtin_bit_cast(float, w[i] << 16); y.y = __builtin_bit_cast(float, w[i] & 0xFFFF0000u); }
+    else { y.x = f16_to_f32(w[i] & 0xFFFFu); y.y = f16_to_f32(w[i] >> 16); }
+    const f32x2_t a = {ta[2 * i], ta[2 * i + 1]}, b = {tb[2 * i], tb[2 * i + 1]};
+    const f32x2_t u = __builtin_elementwise_fma(a, y, b);
+    const i16x2_t pk = __builtin_bit_cast(i16x2_t, pack2<EK>(u.x, u.y));
+    const i16x2_t zero = {0, 0};
+    o[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(pk, zero));
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 template <int EK>
 __device__ __forceinline__ void mma_step(f32x16_t& acc, const uint4& wf, const uint4& pf) {
   if constexpr (EK == EK_BF16) {

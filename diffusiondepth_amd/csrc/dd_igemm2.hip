@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   const int n0 = nsplit * C::NT;
   const int h = p.h, w = p.w;
   const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
-  const int abl = p.ablate;
+  const int abl = DD_ABLATE ? p.ablate : 0;   // timing experiments are compiled in with -DDD_ABLATE=1 only
   if (abl & 256) return;                  // timing floor: launch + dispatch only
 
   const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * C::CIN * IN_ESZ;
@@ -119,16 +119,17 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   }
 
   // ---- raw patch fetch of one channel chunk into registers (unconditional, clamped addresses) --------
-  uint4 raw[NIT][NLD];
+  constexpr int RD = C::RAW_DEPTH;     // raw-patch register slots: chunk c lives in slot c % RD (RD = 2: fetched two chunks ahead)
+  uint4 raw[RD][NIT][NLD];
   uint4 aux[NIT][NLD];
-  auto load_raw = [&](int chunk) {
+  auto load_raw = [&](int chunk, int slot) {
     const int cbase = chunk * CK + jfix * EPP;
     const size_t off0 = (C::CIN >= ACT_CB) ? ((size_t)(cbase >> 5) * h * w * ACT_CB + (cbase & (ACT_CB - 1))) : (size_t)cbase;
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       const size_t goff = (off0 + (size_t)pix_off[u] * C::PIXSTRIDE) * IN_ESZ;
 #pragma unroll
-      for (int q = 0; q < NLD; ++q) raw[u][q] = *reinterpret_cast<const uint4*>(in_b + goff + q * 16);
+      for (int q = 0; q < NLD; ++q) raw[slot][u][q] = *reinterpret_cast<const uint4*>(in_b + goff + q * 16);
       if constexpr (C::PRO == PRO_GN_ADD) {
         aux[u][0] = *reinterpret_cast<const uint4*>(cond_b + goff);
       } else if constexpr (C::PRO == PRO_X) {
@@ -144,11 +145,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // ---- registers -> normalise -> swizzled LDS patch buffer at byte offset pbuf_off ---------------------
   // One staging item (16-B piece `jfix` of patch pixel u).  This thread only ever touches channels [c0, c0+EPP), so its
   // slice of the GroupNorm table is (re)read from LDS as three/two float4 pairs.
-  auto transform_item = [&](int chunk, int pbuf_off, int u) {
+  auto transform_item = [&](int chunk, int pbuf_off, int u, int slot) {
     if (!((m_valid >> u) & 1u)) return;
     if constexpr (C::PRO == PRO_RAW) {
       // no normalisation between the producer and this convolution: the stored elements are the operands
-      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[u][0] : make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[slot][u][0] : make_uint4(0u, 0u, 0u, 0u);
       return;
     }
     float ta[EPP], tb[EPP], te[EPP];
@@ -172,7 +173,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         // DDIM update of the previous step fused into the load: x <- c1*x + c2*relu(gn4(y4))
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-          const uint32_t xw[4] = {raw[u][q].x, raw[u][q].y, raw[u][q].z, raw[u][q].w};
+          const uint32_t xw[4] = {raw[slot][u][q].x, raw[slot][u][q].y, raw[slot][u][q].z, raw[slot][u][q].w};
           const uint32_t yw[4] = {aux[u][q].x, aux[u][q].y, aux[u][q].z, aux[u][q].w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -191,7 +192,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             *reinterpret_cast<float4*>(xout_b + goff + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
         }
       } else {
-        Piece<EK>::unpack(raw[u][0], v);
+        if constexpr (C::PRO == PRO_GN && EK != EK_F32) {
+          *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = affine_relu_pack<EK>(raw[slot][u][0], ta, tb);
+          return;
+        }
+        Piece<EK>::unpack(raw[slot][u][0], v);
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = fmaxf(fmaf(ta[i], v[i], tb[i]), 0.f);
         if constexpr (C::PRO == PRO_GN_ADD) {
@@ -207,9 +212,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     }
     *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = Piece<EK>::pack(v);
   };
-  auto transform_write = [&](int chunk, int pbuf_off) {
+  auto transform_write = [&](int chunk, int pbuf_off, int slot) {
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) transform_item(chunk, pbuf_off, u);
+    for (int u = 0; u < NIT; ++u) transform_item(chunk, pbuf_off, u, slot);
   };
 
   // ---- kick off every independent load at once: weights of stage 0 (LDS-DMA), the GroupNorm partial sums
@@ -237,7 +242,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     }
     if constexpr (C::PRO == PRO_X) { c1 = p.c1c2[2 * (p.step - 1)]; c2 = p.c1c2[2 * (p.step - 1) + 1]; }
   }
-  load_raw(0);
+  load_raw(0, 0);
+  if constexpr (RD == 2 && C::NCHUNK > 1) load_raw(1, 1);
 
   // accumulators.  With the hoisted condition term they START at conv3(cond)[pixel][cout] (fp32, D-fragment order): the
   // loads fly with everything else above and need no extra registers or epilogue traffic.
@@ -252,12 +258,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       for (int q = 0; q < 4; ++q) {
         float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (C::ADD_C) {
-          if (pv) cv = *reinterpret_cast<const float4*>(p.cadd + (size_t)b * h * w * HID_C + act_offset(HID_C, h, w, 0, n * 32 + 8 * q + 4 * g, gy, gx));
+          // layer 8 stored conv3(cond) in accumulator-fragment order: every load is one contiguous KiB per wave
+          (void)pv;
+          cv = reinterpret_cast<const float4*>(p.cadd)[((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane];
         }
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }
   }
-  if (abl & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (raw[0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
+  if (abl & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
   if (have_norm) {
@@ -289,7 +297,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       if (tid < HID_C) tab_bias[tid] += tab_et[9 * HID_C + tid];     // read again only in the epilogue (many barriers later)
     }
   }
-  transform_write(0, 0);
+  transform_write(0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of weight stage 0 have landed
   __syncthreads();                                    // patch 0 and weight stage 0 are in LDS for everybody
   if (abl & 1024) return;
@@ -308,59 +316,84 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
   for (int kq = 0; kq < NKQ; ++kq) wkt[kq] = C::W_OFF + li * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li));
 
-  auto stage = [&](int chunk, int tg) {
+  // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
+  auto mfma_block = [&](int chunk, int tg) {
     const int s = chunk * C::NTG + tg;
-    if (s + 1 < C::NSTAGE && !(abl & 4)) issue_weights(s + 1);
-    asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
-    if (C::NCHUNK > 1 && tg == 0 && chunk + 1 < C::NCHUNK && !(abl & 2)) load_raw(chunk + 1);
     const int poff = (chunk & (C::NPB - 1)) * C::PATCH_BYTES;
     const int woff = (s & (C::NWB - 1)) * C::W_BYTES;
     int wa[NKQ];
 #pragma unroll
     for (int kq = 0; kq < NKQ; ++kq) wa[kq] = wkt[kq] + woff;
-    if (abl & 2048) __builtin_amdgcn_s_setprio(1);
-    if (!(abl & 8)) {
+    {
+      // Software-pipelined fragment stream: the ds_reads of group g+1 (one (tap, k-step) = WM pixel + WN weight fragments)
+      // are issued between the MFMAs of group g, into the other half of a two-deep register buffer, so a wave's MFMA
+      // stream does not wait for LDS latency inside a stage (only the first group of a stage is exposed).
+      constexpr int NG = C::TG * NKQ;          // fragment groups per stage
+      constexpr int NF = C::WM + C::WN;        // fragments (ds_read_b128) per group
+      constexpr int NM = C::WM * C::WN * ((EK == EK_F32) ? 4 : 1);   // MFMA instructions per group
+      constexpr int FD = C::FRAG_DEPTH;        // register buffers: FD-1 groups of ds_reads are in flight ahead of the MFMAs
+      uint4 fr[FD][NF];
+      auto load_group = [&](int gi, uint4 (&f)[NF]) {
+        const int t = gi / NKQ, kq = gi % NKQ;
+        const int dy = (C::KS == 1) ? 0 : (C::TG == 9) ? t / 3 : (C::TG == 3) ? tg : tg / 3;
+        const int dx = (C::KS == 1) ? 0 : (C::TG == 9) ? t % 3 : (C::TG == 3) ? t : tg % 3;
+        const int pa = colt[dx][kq] + poff + dy * (PW * ROWB);
 #pragma unroll
-    for (int t = 0; t < C::TG; ++t) {
-      const int dy = (C::KS == 1) ? 0 : (C::TG == 9) ? t / 3 : (C::TG == 3) ? tg : tg / 3;
-      const int dx = (C::KS == 1) ? 0 : (C::TG == 9) ? t % 3 : (C::TG == 3) ? t : tg % 3;
-      const int roff = poff + dy * (PW * ROWB);
+        for (int m = 0; m < C::WM; ++m) f[m] = *reinterpret_cast<const uint4*>(smem + pa + m * (PW * ROWB));
 #pragma unroll
-      for (int kq = 0; kq < NKQ; ++kq) {
-        const int pa = colt[dx][kq] + roff;
-        uint4 pf[C::WM], wf[C::WN];
+        for (int n = 0; n < C::WN; ++n) f[C::WM + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + (t * C::NT + n * 32) * ROWB);
+      };
+      if constexpr (FD > 1) {
 #pragma unroll
-        for (int m = 0; m < C::WM; ++m) pf[m] = *reinterpret_cast<const uint4*>(smem + pa + m * (PW * ROWB));
+        for (int pg = 0; pg < FD - 1 && pg < NG; ++pg) load_group(pg, fr[pg % FD]);
+        __builtin_amdgcn_sched_group_barrier(0x100, NF * ((FD - 1 < NG) ? FD - 1 : NG), 0);
+      }
 #pragma unroll
-        for (int n = 0; n < C::WN; ++n) wf[n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + (t * C::NT + n * 32) * ROWB);
+      for (int gi = 0; gi < NG; ++gi) {
+        const bool pre = FD > 1 && gi + FD - 1 < NG;
+        if constexpr (FD > 1) {
+          if (pre) load_group(gi + FD - 1, fr[(gi + FD - 1) % FD]);
+        } else {
+          load_group(gi, fr[0]);
+        }
 #pragma unroll
         for (int n = 0; n < C::WN; ++n)
 #pragma unroll
-          for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], wf[n], pf[m]);
-      }
-      // Software interleave of the NEXT chunk's prologue with this chunk's MFMAs: the raw patch was fetched at tap 0;
-      // item (tap - (9 - NIT)) is normalised and written to the other patch buffer right behind tap `tap`, so its VALU
-      // work issues while this wave's own MFMAs occupy the matrix pipe (instead of one VALU burst before the barrier).
-      if constexpr (C::INTERLEAVE) {
-        const int tap = tg * C::TG + t;
-        if (chunk + 1 < C::NCHUNK && !(abl & 1)) {
+          for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][C::WM + n], fr[gi % FD][m]);
+        if constexpr (FD == 1) {
+        } else if (pre) {
+          // one ds_read behind each of the first NF MFMAs, the rest of the MFMAs after them
+          constexpr int PER = (NM >= NF) ? 1 : (NF + NM - 1) / NM;
 #pragma unroll
-          for (int u = 0; u < NIT; ++u)      // static register-array index; the (wave-uniform) tap picks the item
-            if (tap == u + (9 - NIT)) transform_item(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, u);
+          for (int i = 0; i < ((NM >= NF) ? NF : NM); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+          }
+          if (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
         }
       }
     }
-    }
-    if (abl & 2048) __builtin_amdgcn_s_setprio(0);
+  };
+
+  constexpr int NRAW = NIT * NLD * ((C::PRO == PRO_GN || C::PRO == PRO_RAW) ? 1 : 2);   // raw-patch loads per load_raw()
+  static_assert(NRAW <= 63, "vmcnt field");
+
+  // par = chunk % RD as a compile-time constant at every call site (static register indexing of the raw slots)
+  auto stage = [&](int chunk, int tg, int par) {
+    const int s = chunk * C::NTG + tg;
+    if (s + 1 < C::NSTAGE && !(abl & 4)) issue_weights(s + 1);
+    asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
+    if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && !(abl & 2)) load_raw(chunk + RD, par);
+    if (!(abl & 8)) mfma_block(chunk, tg);
     if (!C::INTERLEAVE && C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
-      transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES);
+      transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, (par + 1) % RD);
     // The next stage's weights (this wave's DMA pieces) must have landed before the barrier.  VMEM ops retire in
     // issue order and the DMA was issued BEFORE this stage's raw patch loads, so when those loads were issued in
     // this stage it is enough to wait until at most NRAW (= the raw loads) are outstanding: they keep flying for
     // two more stages (cdna guide T4: counted vmcnt).  Every wave issues exactly NRAW loads (clamped addresses).
-    constexpr int NRAW = NIT * NLD * ((C::PRO == PRO_GN || C::PRO == PRO_RAW) ? 1 : 2);
-    if (C::NCHUNK > 1 && tg == 0 && chunk + 1 < C::NCHUNK && C::NTG > 1 && !(abl & (2 | 128))) {
-      static_assert(NRAW <= 63, "vmcnt field");
+    if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && (C::NTG > 1 || RD == 2) && !(abl & (2 | 128))) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -370,18 +403,74 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     asm volatile("" ::: "memory");
   };
 
-  if constexpr (C::TG == 1) {
+  if constexpr (C::PINGPONG) {
+    // Ping-pong halves (MI355X guide "two waves per SIMD"): the 8 waves are two 4-wave halves, one wave of each per SIMD.
+    // Every channel chunk runs as two barrier-separated phases; in phase 1 half A issues its 72 MFMAs while half B
+    // normalises ITS items of the next chunk's patch (VALU / VMEM / LDS-write work only), in phase 2 the roles swap.  Each
+    // SIMD's matrix pipe therefore always has exactly one wave feeding it and that wave's partner never competes for it.
+    //   patch buffer (chunk+1)&1 : written in both phases of `chunk` (B's items, then A's), last read in chunk-1
+    //   weight slot  (chunk+1)&1 : DMA issued at the top of `chunk`, awaited before its closing barrier
+    //   raw registers            : A loads at the top of phase 1 (consumed in phase 2); B loads the chunk after next at the
+    //                              top of phase 2 (consumed in phase 1 of the following chunk)
+    static_assert(C::NTG == 1 && C::WAVES == 8 && C::NPB == 2 && C::NWB == 2, "ping-pong layout");
+    const int half = wave >> 2;
+    static_assert(RD == 1, "ping-pong keeps one raw slot");
+    if (half == 1 && C::NCHUNK > 1) load_raw(1, 0);
+#pragma unroll 1
+    for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
+      const bool more = chunk + 1 < C::NCHUNK;
+      const int nbuf = ((chunk + 1) & 1) * C::PATCH_BYTES;
+      if (half == 0) {
+        if (more) { issue_weights(chunk + 1); asm volatile("" ::: "memory"); load_raw(chunk + 1, 0); }
+        mfma_block(chunk, 0);
+      } else if (more) {
+        transform_write(chunk + 1, nbuf, 0);
+        asm volatile("" ::: "memory");
+        issue_weights(chunk + 1);           // behind the transform: its compiler-counted vmcnt waits then do not cover the DMA
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (half == 1) {
+        if (chunk + 2 < C::NCHUNK) load_raw(chunk + 2, 0);
+        mfma_block(chunk, 0);
+        if (chunk + 2 < C::NCHUNK) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");   // DMA landed, raw loads fly on
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        if (more) transform_write(chunk + 1, nbuf, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  } else if constexpr (RD == 2) {
+    // two raw slots: the chunk loop advances two chunks per trip so that the slot index is a constant
+    static_assert(C::NCHUNK % 2 == 0, "even number of channel chunks");
+#pragma unroll 1
+    for (int chunk = 0; chunk < C::NCHUNK; chunk += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        if constexpr (C::TG == 1) {
+#pragma unroll
+          for (int tg = 0; tg < C::NTG; ++tg) stage(chunk + par, tg, par);
+        } else {
+#pragma unroll 1
+          for (int tg = 0; tg < C::NTG; ++tg) stage(chunk + par, tg, par);
+        }
+      }
+    }
+  } else if constexpr (C::TG == 1) {
     // one tap per stage: unroll the nine stages of a chunk so that (dy, dx) are compile-time
 #pragma unroll 1
     for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
 #pragma unroll
-      for (int tg = 0; tg < C::NTG; ++tg) stage(chunk, tg);
+      for (int tg = 0; tg < C::NTG; ++tg) stage(chunk, tg, 0);
     }
   } else {
 #pragma unroll 1
     for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
 #pragma unroll 1
-      for (int tg = 0; tg < C::NTG; ++tg) stage(chunk, tg);
+      for (int tg = 0; tg < C::NTG; ++tg) stage(chunk, tg, 0);
     }
   }
 
@@ -452,7 +541,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           const int lg = (C::COUT == COND_C) ? (n >> 1) : (C::COUT == HID_C) ? (2 * n + (q >> 1)) : q;
           ls[lg] += s; lq[lg] += sq;
         }
-        if constexpr (C::OUT_ESZ == 4) {
+        if constexpr (C::LAYER == 8) {
+          // hoisted condition term: fp32, accumulator-fragment order [tile][wave][n][m][q][lane] (read back by layer 9 only)
+          reinterpret_cast<float4*>(p.out)[((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane] =
+              make_float4(v[0], v[1], v[2], v[3]);
+        } else if constexpr (C::OUT_ESZ == 4) {
           if (pvalid) {
             if constexpr (C::SCATTER) {
               const int par = co >> 8, cc = co & (COND_C - 1);

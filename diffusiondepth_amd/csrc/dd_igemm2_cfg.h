@@ -9,6 +9,21 @@
 #define DD_FAT_CONV3 0
 #endif
 
+// ConvParams::ablate (timing experiments: skip parts of the kernel) is honoured only in builds with -DDD_ABLATE=1;
+// the default build folds every check away so the main loop is straight-line code.
+#ifndef DD_PINGPONG
+#define DD_PINGPONG 1
+#endif
+#ifndef DD_FRAG_DEPTH
+#define DD_FRAG_DEPTH 2
+#endif
+#ifndef DD_RAW_DEPTH
+#define DD_RAW_DEPTH 2
+#endif
+#ifndef DD_ABLATE
+#define DD_ABLATE 0
+#endif
+
 namespace dd {
 
 template <int EK_, int LAYER_> struct Cfg2 {
@@ -38,7 +53,8 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
   // FAT (conv3-shaped layers 3 / 7 / 9): one 16x32-pixel, 8-wave workgroup per CU with ALL nine taps of a channel chunk per
   // stage -> one barrier per chunk (8 instead of 24), weights DMA'd once per 512 pixels, 1.2x instead of 1.33x halo.
-  static constexpr bool FAT = DD_FAT_CONV3 && (LAYER == 3 || LAYER == 7 || LAYER == 9);
+  static constexpr bool FAT = DD_FAT_CONV3 && (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);   // 8 shares 9's tile geometry
+  static constexpr bool PINGPONG = FAT && DD_PINGPONG;          // the two 4-wave halves alternate MFMA / staging phases
   static constexpr int TG = (LAYER == 1 || FAT) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
@@ -79,6 +95,12 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // Placing the next chunk's prologue items between the taps (instead of one burst before the chunk's last barrier)
   // was measured SLOWER on MI355X (conv3 181 -> 191 us at B=4: the in-loop vmcnt waits stall the MFMA stream), so off.
   static constexpr bool INTERLEAVE = false;
+  // two-deep fragment registers in the MFMA loop (next group's ds_reads issued between this group's MFMAs); the Swin convA
+  // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
+  // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
+  // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7) && !(FAT && DD_PINGPONG)) ? 2 : 1;
+  static constexpr int FRAG_DEPTH = (LAYER == 5) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
   static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);

@@ -232,7 +232,8 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
       for (int q = 0; q < 4; ++q) {
         float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (C::ADD_C) {
-          if (pv) cv = *reinterpret_cast<const float4*>(p.cadd + (size_t)b * h * w * HID_C + act_offset(HID_C, h, w, 0, n * 32 + 8 * q + 4 * g, gy, gx));
+          (void)pv;   // accumulator-fragment order written by layer 8 (dd_igemm2.hip), 4 MFMA-role waves per tile
+          cv = reinterpret_cast<const float4*>(p.cadd)[((((size_t)tile * 4 + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane];
         }
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }

@@ -17,7 +17,7 @@ x, cond = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cud
 names = {0: "full", 1: "-transform", 3: "-transform-rawload", 4: "-weightDMA", 7: "-all staging", 8: "-MFMA", 16: "-stores", 32: "-stats",
          48: "-stores-stats", 64: "-barrier", 15: "-staging-MFMA", 63: "only prologue+sync", 127: "only prologue", 256: "return at entry", 512: "return after loads", 1024: "return after patch0", 119: "prologue+MFMA+epi-novmem"}
 out = {}
-for mask in [0, 4, 1, 3, 7, 64, 8, 16, 32, 119, 127, 0]:
+for mask in ([int(m) for m in os.environ["ABL_MASKS"].split(",")] if os.environ.get("ABL_MASKS") else [0, 4, 1, 3, 7, 64, 8, 16, 32, 119, 127, 0]):
     be.set_option("ablate", mask)
     be.set_option("layer_timing", 1)
     for _ in range(2):
