@@ -167,11 +167,10 @@ class HipDenoiser:
     # -- parameters ---------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, object], prefix: str = ""):
         """sd: {key: tensor | ndarray} using the reference's key names below ``prefix`` (e.g.
-        'depth_head.').  Keys the hot path does not own (backbone, convup_fp, num_batches_tracked; the FPN for the Swin
-        variant) are ignored."""
+        'depth_head.').  Keys the library does not own (backbone, convup_fp, num_batches_tracked) are ignored."""
         torch = _torch()
         n = 0
-        owned = ("model.", "depth_transform.") + (("conv_lateral.", "conv_up.") if self.variant == "res" else ())
+        owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.")
         saw_fpn = False
         for k, v in sd.items():
             if not k.startswith(prefix):
@@ -202,17 +201,19 @@ class HipDenoiser:
 
     # -- condition aggregation -----------------------------------------------------------------
     def condition(self, fp, precision="fp32", export=True):
-        """The Res head's FPN (reference …res.py:108-118) on the 4 backbone maps ``fp`` (finest first).  Returns the
-        (B,256,h,w) fp32 condition map (None with export=False); the same map stays in the handle in kernel layout and
-        is picked up -- without conversion -- when the returned tensor is passed to denoise / denoise_once unchanged."""
+        """The head's FPN (reference …res.py:108-118, …res_swin_add.py:117-127) on the 4 backbone maps ``fp`` (finest
+        first; widths 64..512 for the Res variant, 192..1536 for Swin).  Returns the (B,256,h,w) fp32 condition map (None
+        with export=False); the same map stays in the handle in kernel layout and is picked up -- without conversion --
+        when the returned tensor is passed to denoise / denoise_once unchanged."""
         torch = _torch()
         if len(fp) != 4:
             raise ValueError("condition() expects the 4 pyramid levels of the ResNet backbone")
         fp = [_check_tensor(f, f"fp[{i}]", dtype=torch.float32) for i, f in enumerate(fp)]
         B = fp[0].shape[0]
+        c0 = 192 if self.variant == "swin" else 64
         for i, f in enumerate(fp):
-            if f.dim() != 4 or f.shape[0] != B or f.shape[1] != 64 << i:
-                raise ValueError(f"fp[{i}] must be (B,{64 << i},h,w), got {tuple(f.shape)}")
+            if f.dim() != 4 or f.shape[0] != B or f.shape[1] != c0 << i:
+                raise ValueError(f"fp[{i}] must be (B,{c0 << i},h,w), got {tuple(f.shape)}")
         ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in fp])
         hs = (ctypes.c_int * 4)(*[f.shape[2] for f in fp])
         ws = (ctypes.c_int * 4)(*[f.shape[3] for f in fp])

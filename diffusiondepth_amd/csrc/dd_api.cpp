@@ -61,7 +61,10 @@ inline int ek_of_precision(int prec) {
 inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
 
 constexpr int FPN_LEVELS = 4;
-constexpr int FPN_CIN[FPN_LEVELS] = {64, 128, 256, 512};     // ResNet-34 pyramid widths (reference ...res.py:24 in_channels)
+constexpr int FPN_CIN_RES[FPN_LEVELS] = {64, 128, 256, 512};       // ResNet pyramid widths (reference ...res.py:31 in_channels)
+constexpr int FPN_CIN_SWIN[FPN_LEVELS] = {192, 384, 768, 1536};   // Swin-L pyramid widths (reference ...res_swin_add.py:31)
+inline const int* fpn_cin(int variant) { return variant == DD_VARIANT_SWIN ? FPN_CIN_SWIN : FPN_CIN_RES; }
+inline int fpn_lat_layer(int variant, int level) { return (variant == DD_VARIANT_SWIN ? 15 : 10) + level; }   // kernel layer id
 
 struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   int cin = 0, cout = 0;
@@ -145,6 +148,7 @@ struct dd_handle_s {
   DevBuf fpn_lat_w[FPN_LEVELS][NUM_EK], fpn_lat_b[FPN_LEVELS];
   DevBuf fpn_up_w[FPN_LEVELS - 1][NUM_EK], fpn_up_b[FPN_LEVELS - 1];
   std::unique_ptr<FpnWork> fpn_work;
+  std::shared_ptr<DevBuf> fpn_out;       // Swin: FPN result at the pyramid's finest size (activation layout), upsampled per dd_denoise
   std::shared_ptr<DevBuf> fpn_cond;      // == the cond buffer dd_condition wrote last (valid until the next dd_condition / explicit cond of that shape)
   int fpn_cond_key[4] = {0, 0, 0, -1};   // B, h, w, precision of fpn_cond
   uint64_t tick = 0;
@@ -205,13 +209,14 @@ std::vector<WeightSpec> required_weights(int variant) {
     v.push_back({"model.upsample_fuse.convA.conv.bias", 256});
     v.push_back({"model.upsample_fuse.convB.conv.weight", 256 * 256 * 9});
     v.push_back({"model.upsample_fuse.convB.conv.bias", 256});
-  } else {
-    // condition aggregation FPN of the Res head (reference ...res.py:56-84): conv_lateral[i] = Conv3x3(bias=False)+BN+ReLU,
+  }
+  {
+    // condition aggregation FPN of the Res / Swin heads (reference ...res.py:56-84): conv_lateral[i] = Conv3x3(bias=False)+BN+ReLU,
     // conv_up[j] = ConvTranspose2d(k2,s2,bias=False)+BN+ReLU
     const char* bn[4] = {"weight", "bias", "running_mean", "running_var"};
     for (int i = 0; i < FPN_LEVELS; ++i) {
       const std::string pre = "conv_lateral." + std::to_string(i);
-      v.push_back({pre + ".0.weight", (int64_t)COND_C * FPN_CIN[i] * 9});
+      v.push_back({pre + ".0.weight", (int64_t)COND_C * fpn_cin(variant)[i] * 9});
       for (const char* b : bn) v.push_back({pre + ".1." + b, COND_C});
     }
     for (int j = 0; j < FPN_LEVELS - 1; ++j) {
@@ -483,6 +488,11 @@ int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h
     if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
     else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
     if (h->fpn_cond == pl->cond) { h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; }    // overwritten
+  } else if (h->variant == DD_VARIANT_SWIN) {
+    const int* k = h->fpn_cond_key;
+    if (!h->fpn_cond || h->fpn_cond != h->fpn_out || k[0] != B || k[1] != cond_h || k[2] != cond_w || k[3] != precision)
+      return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, condition size and precision");
+    DD_HIP(launch_upsample_blocked(h->fpn_out->p, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
   } else {
     const int* k = h->fpn_cond_key;
     if (!h->fpn_cond || h->fpn_cond != pl->cond || k[0] != B || k[1] != lat_h || k[2] != lat_w || k[3] != precision)
@@ -678,12 +688,12 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       const std::string pre = "conv_lateral." + std::to_string(i);
       fold(pre + ".1", sc, sh);
       std::vector<float> w = h->host_w[pre + ".0.weight"];            // [256][cin][3][3]
-      const size_t per = (size_t)FPN_CIN[i] * 9;
+      const size_t per = (size_t)fpn_cin(h->variant)[i] * 9;
       for (int co = 0; co < COND_C; ++co)
         for (size_t k = 0; k < per; ++k) w[co * per + k] = (float)((double)w[co * per + k] * sc[co]);
       for (int ek = 0; ek < NUM_EK; ++ek) {
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(10 + i, ek), ek, true, packed);
+        pack_conv_weights(w.data(), conv_pack_geom2(fpn_lat_layer(h->variant, i), ek), ek, true, packed);
         int rc = upload(h, h->fpn_lat_w[i][ek], packed.data(), packed.size(), s); if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
@@ -839,14 +849,13 @@ int dd_last_loop_ms(dd_handle_t h, float* ms) {
 int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
                  float* cond_out, int precision, void* stream) {
   if (!h) return DD_ERR_INVALID_ARG;
-  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "dd_condition: the condition FPN is built for DD_VARIANT_RES only");
   if (!h->fpn_committed) return h->fail(DD_ERR_STATE, "conv_lateral.* / conv_up.* weights not committed (dd_set_weight, dd_commit_weights)");
   if (n_levels != FPN_LEVELS || !feats || !feat_h || !feat_w) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: expects 4 pyramid levels");
   if (precision < DD_PREC_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16 or f16");
   if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
   for (int i = 0; i < FPN_LEVELS; ++i) {
     if (!feats[i] || feat_h[i] <= 0 || feat_w[i] <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: null feature pointer or non-positive size");
-    if ((long long)B * feat_h[i] * feat_w[i] * FPN_CIN[i] >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
+    if ((long long)B * feat_h[i] * feat_w[i] * fpn_cin(h->variant)[i] >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
@@ -864,7 +873,7 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
     for (int i = 0; i < FPN_LEVELS; ++i) {
       fw->hs[i] = feat_h[i]; fw->ws[i] = feat_w[i];
       const size_t px = (size_t)B * feat_h[i] * feat_w[i];
-      DD_HIP(fw->fin[i].alloc(px * FPN_CIN[i] * es));
+      DD_HIP(fw->fin[i].alloc(px * fpn_cin(h->variant)[i] * es));
       if (i > 0) {
         DD_HIP(fw->lat[i].alloc(px * COND_C * es));
         DD_HIP(fw->up[i - 1].alloc(px * 4 * COND_C * es));
@@ -873,9 +882,19 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
       }
     }
   }
+  // Res: the result IS the plan's condition buffer (latent size).  Swin: the map stays at the pyramid's finest size here
+  // and is bilinearly upsampled into the plan's buffer by dd_denoise (cond == NULL), which knows the latent size.
   std::shared_ptr<DevBuf> cbuf;
-  int rc = get_cond_buf(h, B, feat_h[0], feat_w[0], precision, &cbuf);
-  if (rc) return rc;
+  int rc = DD_OK;
+  const bool swin = h->variant == DD_VARIANT_SWIN;
+  if (swin) {
+    const size_t need = (size_t)B * feat_h[0] * feat_w[0] * COND_C * es;
+    if (!h->fpn_out || h->fpn_out->bytes < need) { h->fpn_out = std::make_shared<DevBuf>(); DD_HIP(h->fpn_out->alloc(need)); }
+    cbuf = h->fpn_out;
+  } else {
+    rc = get_cond_buf(h, B, feat_h[0], feat_w[0], precision, &cbuf);
+    if (rc) return rc;
+  }
 
   auto launch = [&](int layer, const ConvParams& q) -> hipError_t {
     if (!h->layer_timing) return launch_conv_igemm2(layer, ek, q, s);
@@ -891,15 +910,16 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   // top-down pass (reference ...res.py:108-118): x_3 = lat_3(f_3);  x_i = lat_i(f_i) + pool(up_i(x_{i+1}))
   for (int i = FPN_LEVELS - 1; i >= 0; --i) {
     const int hh = feat_h[i], ww = feat_w[i];
-    DD_HIP(launch_nchw_to_nhwc(feats[i], fw->fin[i].p, ek, B, FPN_CIN[i], hh, ww, 1, s));
+    DD_HIP(launch_nchw_to_nhwc(feats[i], fw->fin[i].p, ek, B, fpn_cin(h->variant)[i], hh, ww, 1, s));
+    const int lat_layer = fpn_lat_layer(h->variant, i);
     ConvParams p{};
     p.B = B; p.h = hh; p.w = ww;
     p.tiles_x = (ww + 31) / 32;
-    p.tiles_y = (hh + conv_pack_geom2(10 + i, ek).th - 1) / conv_pack_geom2(10 + i, ek).th;
+    p.tiles_y = (hh + conv_pack_geom2(lat_layer, ek).th - 1) / conv_pack_geom2(lat_layer, ek).th;
     p.in = fw->fin[i].p; p.wpack = h->fpn_lat_w[i][ek].p; p.bias = h->fpn_lat_b[i].as<float>();
     p.out = (i == 0) ? cbuf->p : fw->lat[i].p;
     p.addend = (i == FPN_LEVELS - 1) ? nullptr : (fw->pooled[i].p ? fw->pooled[i].p : fw->up[i].p);
-    DD_HIP(launch(10 + i, p));
+    DD_HIP(launch(lat_layer, p));
     if (i > 0) {
       ConvParams u{};
       u.B = B; u.h = hh; u.w = ww;

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const double2 g0 = hi ? ov0 : sv0, g1 = hi ? ov1 : sv1, g2 = hi ? sv0 : ov0, g3 = hi ? sv1 : ov1;
     static_assert(C::PRO == PRO_RAW || C::CTAB <= C::THREADS, "one table channel per thread");
     if (tid < C::CTAB) {
-      constexpr int CG = C::CTAB / GN_GROUPS;
+      constexpr int CG = (C::CTAB > 0) ? C::CTAB / GN_GROUPS : 1;
       const int grp = tid / CG;
       const double2 gs = grp == 0 ? g0 : grp == 1 ? g1 : grp == 2 ? g2 : g3;
       const double inv_cnt = 1.0 / ((double)h * (double)w * (double)CG);
@@ -647,6 +647,10 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 12: return launch_one2<EK, 12>(p, s);
     case 13: return launch_one2<EK, 13>(p, s);
     case 14: return launch_one2<EK, 14>(p, s);
+    case 15: return launch_one2<EK, 15>(p, s);
+    case 16: return launch_one2<EK, 16>(p, s);
+    case 17: return launch_one2<EK, 17>(p, s);
+    case 18: return launch_one2<EK, 18>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -678,7 +682,11 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 11: return geom2_of<EK, 11>();
     case 12: return geom2_of<EK, 12>();
     case 13: return geom2_of<EK, 13>();
-    default: return geom2_of<EK, 14>();
+    case 14: return geom2_of<EK, 14>();
+    case 15: return geom2_of<EK, 15>();
+    case 16: return geom2_of<EK, 16>();
+    case 17: return geom2_of<EK, 17>();
+    default: return geom2_of<EK, 18>();
   }
 }
 PackGeom conv_pack_geom2(int layer, int ek) {

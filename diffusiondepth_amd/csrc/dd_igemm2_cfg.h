@@ -39,12 +39,13 @@ template <int EK_, int LAYER_> struct Cfg2 {
   //   10..13 = conv_lateral[0..3]: Conv3x3 (64|128|256|512 -> 256) + BN + ReLU, then "+ top-down term" (optional addend)
   //   14     = conv_up[j]: ConvTranspose2d(256->256, k2, s2) + BN + ReLU written as a 1x1 conv with 4 x 256 output
   //            "channels" (one block per output parity (dy,dx)) whose epilogue scatters to pixel (2y+dy, 2x+dx)
-  static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13);
+  //   15..18 = the same lateral convs for the Swin-L pyramid (192|384|768|1536 -> 256; reference ...res_swin_add.py:31,57-84)
+  static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18);
   static constexpr bool IS_UP = (LAYER == 14);
   static constexpr int KS = IS_UP ? 1 : 3;                       // kernel size
   static constexpr int HALO = KS / 2;
   static constexpr int NTAPS = KS * KS;
-  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : IS_LAT ? (64 << (LAYER - 10)) : COND_C;
+  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : IS_LAT ? (LAYER >= 15 ? (192 << (LAYER - 15)) : (64 << (LAYER - 10))) : COND_C;
   static constexpr int COUT = IS_UP ? 4 * COND_C : IS_LAT ? COND_C
                             : (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
   static constexpr bool RELU_OUT = IS_LAT || IS_UP;              // epilogue: relu(acc + bias)
@@ -85,7 +86,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int W_BYTES = TG * NT * ROWB;
   static constexpr int NWB = (NSTAGE > 1) ? 2 : 1;       // weight ring slots
   static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
-  static constexpr int CTAB = (LAYER == 1) ? LATENT_C : CIN;
+  static constexpr int CTAB = (PRO == PRO_RAW) ? 0 : (LAYER == 1) ? LATENT_C : CIN;   // channels of the prologue GroupNorm table
   static constexpr int TAB_FLOATS = 3 * CTAB + NT + (ADD_C ? 10 * HID_C : 0);   // a, b, e of the prologue GroupNorm, this tile's bias, E[t] tap sums
   static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + NWB * W_BYTES + TAB_FLOATS * 4;
   static constexpr int ITEMS = PH * PW * PPP;

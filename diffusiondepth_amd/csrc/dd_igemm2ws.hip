@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
     for (int i = tid; i < 10 * HID_C; i += 256) tab_et[i] = p.etab[(size_t)t * 10 * HID_C + i];
   }
   if constexpr (have_norm) {
-    static_assert(C::CTAB == 256, "one table channel per MFMA-role thread");
+    static_assert(C::PRO == PRO_RAW || C::CTAB == 256, "one table channel per MFMA-role thread");
     const double* st = p.stats_in + (size_t)b * STAT_SLOTS * STAT_STRIDE + (lane >> 1) * STAT_STRIDE + (lane & 1) * 4;
     double2 sv0 = *reinterpret_cast<const double2*>(st);
     double2 sv1 = *reinterpret_cast<const double2*>(st + 2);
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
     const double2 ov1 = make_double2(__shfl_xor(sv1.x, 1, 64), __shfl_xor(sv1.y, 1, 64));
     const bool hi = lane & 1;
     const double2 g0 = hi ? ov0 : sv0, g1 = hi ? ov1 : sv1, g2 = hi ? sv0 : ov0, g3 = hi ? sv1 : ov1;
-    constexpr int CG = C::CTAB / GN_GROUPS;
+    constexpr int CG = (C::CTAB > 0) ? C::CTAB / GN_GROUPS : 1;
     const int grp = tid / CG;
     const double2 gs = grp == 0 ? g0 : grp == 1 ? g1 : grp == 2 ? g2 : g3;
     const double inv_cnt = 1.0 / ((double)h * (double)w * (double)CG);

@@ -88,6 +88,8 @@ hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B
 // channel-blocked activations -> NCHW fp32 (tiled through LDS), and adaptive_avg_pool2d on channel-blocked activations
 hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s);
 hipError_t launch_adaptive_pool_blocked(const void* src, void* dst, int ek, int B, int C, int ih, int iw, int oh, int ow, hipStream_t s);
+// bilinear upsample (align_corners=True) between two channel-blocked tensors (Swin condition map kept in the handle)
+hipError_t launch_upsample_blocked(const void* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s);
 hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, int C, int h, int w, int blocked, hipStream_t s);
 // out(NCHW) = c1*x + c2*relu(gn4(y4))  (mode 0, final DDIM update) or relu(gn4(y4)) (mode 1, eps)
 hipError_t launch_final(const float* x, const float* y4, const double* stats, const float* gamma, const float* beta,

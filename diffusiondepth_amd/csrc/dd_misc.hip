@@ -149,6 +149,68 @@ hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Swin variant, condition map already in the activation layout (written by dd_condition at stride 4): bilinear upsample
+// (align_corners=True, same fp32 formula as upsample_to_blocked_kernel) blocked (ch,cw) -> blocked (h,w).
+// One thread per (output pixel, 16-B piece): 4 taps of 16 B each.
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__global__ void __launch_bounds__(256) upsample_blocked_kernel(const void* __restrict__ src, void* __restrict__ dst, int nblk,
+                                                              int ch, int cw, int h, int w, long long total) {
+  constexpr int EPP = (EK == EK_F32) ? 4 : 8;
+  constexpr int PPB = ACT_CB / EPP;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int piece = (int)(i % PPB);
+  long long r = i / PPB;
+  const int ox = (int)(r % w); r /= w;
+  const int oy = (int)(r % h); r /= h;                  // r = b * nblk + channel block
+  const float sy = (h > 1) ? (float)(ch - 1) / (float)(h - 1) : 0.f;
+  const float sx = (w > 1) ? (float)(cw - 1) / (float)(w - 1) : 0.f;
+  const float fy = sy * (float)oy, fx = sx * (float)ox;
+  const int y0 = min((int)fy, ch - 1), x0 = min((int)fx, cw - 1);
+  const int y1 = min(y0 + 1, ch - 1), x1 = min(x0 + 1, cw - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const char* sb = reinterpret_cast<const char*>(src) + ((size_t)r * ch * cw) * ACT_CB * (16 / EPP) + piece * 16;
+  auto tap = [&](int y, int x, float (&f)[EPP]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(sb + ((size_t)y * cw + x) * ACT_CB * (16 / EPP));
+    const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (EK == EK_F32) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) f[k] = __builtin_bit_cast(float, wv[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { f[2 * k] = ld_elem(&wv[k], 0, EK); f[2 * k + 1] = ld_elem(&wv[k], 1, EK); }
+    }
+  };
+  float a[EPP], b[EPP], c[EPP], d[EPP], o[EPP];
+  tap(y0, x0, a); tap(y0, x1, b); tap(y1, x0, c); tap(y1, x1, d);
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) o[k] = hy * (hx * a[k] + lx * b[k]) + ly * (hx * c[k] + lx * d[k]);
+  char* db = reinterpret_cast<char*>(dst) + (((size_t)r * h + oy) * w + ox) * ACT_CB * (16 / EPP) + piece * 16;
+  if constexpr (EK == EK_F32) {
+    *reinterpret_cast<float4*>(db) = make_float4(o[0], o[1], o[2], o[3]);
+  } else {
+    uint32_t q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      q[k] = (EK == EK_BF16) ? (cvt_bf16(o[2 * k]) | (cvt_bf16(o[2 * k + 1]) << 16)) : (cvt_f16(o[2 * k]) | (cvt_f16(o[2 * k + 1]) << 16));
+    *reinterpret_cast<uint4*>(db) = make_uint4(q[0], q[1], q[2], q[3]);
+  }
+}
+hipError_t launch_upsample_blocked(const void* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s) {
+  if (C % ACT_CB != 0) return hipErrorInvalidValue;
+  const int nblk = C / ACT_CB;
+  const int ppb = (ek == EK_F32) ? 8 : 4;
+  const long long total = (long long)B * nblk * h * w * ppb;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (ek == EK_F32) hipLaunchKernelGGL(upsample_blocked_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, nblk, ch, cw, h, w, total);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(upsample_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, nblk, ch, cw, h, w, total);
+  else hipLaunchKernelGGL(upsample_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, nblk, ch, cw, h, w, total);
+  return hipGetLastError();
+}
+
 // NHWC (any element kind) -> NCHW fp32; debug / small tensors only (one thread per output element).
 __global__ void nhwc_to_nchw_kernel(const void* __restrict__ src, int ek, float* __restrict__ dst, int C, long long HW,
                                     long long total, int blocked) {

@@ -69,8 +69,7 @@ class DDIMDepthEstimate_Res(nn.Module):
                                                   nn.ReLU(True)))
         if condition_backend not in ("hip", "torch"):
             raise ValueError("condition_backend must be 'hip' or 'torch'")
-        # the library's FPN covers the ResNet pyramid of the Res head; the Swin/MPViT heads keep theirs in PyTorch-ROCm
-        self._hip_fpn = condition_backend == "hip" and self._VARIANT == "res"
+        self._hip_fpn = condition_backend == "hip"
         if self._hip_fpn:
             bound.register("conv_lateral.", self.conv_lateral)
             bound.register("conv_up.", self.conv_up)

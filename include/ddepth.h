@@ -76,9 +76,10 @@ const char* dd_version(void);
  * `name` is the state-dict key WITHOUT the "depth_head." prefix, e.g.
  * "model.noise_embedding.0.weight"; `data` is a HOST pointer to `numel` contiguous fp32 values in
  * the reference's own layout (OIHW conv weights, (in,out,kh,kw) for the ConvTranspose).
- * DD_VARIANT_RES also takes the condition FPN's parameters "conv_lateral.{0..3}.{0.weight,1.weight,1.bias,1.running_mean,
- * 1.running_var}" and "conv_up.{0..2}.{...}" (src/model/head/ddim_depth_estimate_res.py:56-84) as a third, optional group
- * (needed by dd_condition only).
+ * The condition FPN's parameters "conv_lateral.{0..3}.{0.weight,1.weight,1.bias,1.running_mean,1.running_var}" and
+ * "conv_up.{0..2}.{...}" (src/model/head/ddim_depth_estimate_res.py:56-84, ..._res_swin_add.py:57-84) form a third,
+ * optional group (needed by dd_condition only); lateral input widths are 64/128/256/512 for DD_VARIANT_RES and
+ * 192/384/768/1536 for DD_VARIANT_SWIN.
  * Call dd_commit_weights after the last dd_set_weight (and again whenever weights changed, e.g.
  * after an optimizer step): it validates completeness and repacks into the kernels' layouts. */
 int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel);
@@ -94,11 +95,13 @@ int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_ti
  *   x_3 = conv_lateral[3](f_3);   x_i = conv_lateral[i](f_i) + adaptive_avg_pool2d(conv_up[i](x_{i+1}), size of x_i)
  * with conv_lateral = Conv3x3(bias=False)+BN+ReLU, conv_up = ConvTranspose2d(k2,s2,bias=False)+BN+ReLU, BatchNorm in
  * eval mode (running statistics, folded into the convolutions at dd_commit_weights).
- *   feats[i]  (B, {64,128,256,512}[i], feat_h[i], feat_w[i])  device fp32 NCHW backbone features, i = 0 finest; n_levels = 4
+ *   feats[i]  (B, C_i, feat_h[i], feat_w[i])  device fp32 NCHW backbone features, i = 0 finest; n_levels = 4;
+ *             C = {64,128,256,512} (DD_VARIANT_RES) or {192,384,768,1536} (DD_VARIANT_SWIN)
  *   cond_out  (B, 256, feat_h[0], feat_w[0]) device fp32 NCHW, or NULL
  * The result also stays inside the handle in the kernels' own layout: a following dd_denoise / dd_denoise_once with
- * cond == NULL and the same B, lat_h == feat_h[0], lat_w == feat_w[0], precision uses it without any conversion.
- * DD_VARIANT_RES only (the Swin/MPViT heads keep their FPN in the framework); precision fp32 / bf16 / f16. */
+ * cond == NULL, the same B and precision and cond_h == feat_h[0], cond_w == feat_w[0] (== lat_h, lat_w for
+ * DD_VARIANT_RES; for DD_VARIANT_SWIN the map is upsampled to the latent size there) uses it without any conversion.
+ * precision fp32 / bf16 / f16. */
 int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
                  float* cond_out, int precision, void* stream);
 
