@@ -18,7 +18,7 @@ VARIANTS = {"res": 0, "swin": 1}
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_commit_weights",
-    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_once", "dd_add_noise", "dd_encode", "dd_decode",
+    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_once", "dd_denoise_once_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
     "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch",
 ]
 
@@ -60,6 +60,9 @@ def load_library():
         "dd_condition": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_vp, c_int, c_vp]),
         "dd_denoise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_denoise_once_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_zero_grad": (c_int, [c_vp, c_vp]),
+        "dd_get_grad": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
         "dd_add_noise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
         "dd_encode": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
         "dd_decode": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
@@ -267,6 +270,54 @@ class HipDenoiser:
                                                B, h, w, cond.shape[2], cond.shape[3], precision_id(precision),
                                                _stream_ptr(self.device)), "dd_denoise_once")
         return out
+
+    # -- training: backward of one denoiser call ---------------------------------------------------
+    PARAM_SHAPES = {
+        "model.noise_embedding.0.weight": (64, 16, 3, 3), "model.noise_embedding.0.bias": (64,),
+        "model.noise_embedding.1.weight": (64,), "model.noise_embedding.1.bias": (64,),
+        "model.noise_embedding.3.weight": (256, 64, 3, 3), "model.noise_embedding.3.bias": (256,),
+        "model.noise_embedding.4.weight": (256,), "model.noise_embedding.4.bias": (256,),
+        "model.time_embedding.weight": (1280, 256),
+        "model.pred.0.weight": (64, 256, 3, 3), "model.pred.0.bias": (64,),
+        "model.pred.1.weight": (64,), "model.pred.1.bias": (64,),
+        "model.pred.3.weight": (16, 64, 3, 3), "model.pred.3.bias": (16,),
+        "model.pred.4.weight": (16,), "model.pred.4.bias": (16,),
+    }
+
+    def denoise_once_backward(self, x_t, t, cond, grad_eps, precision="naive_fp32", need_grad_x=True, need_grad_cond=True):
+        """VJP of one ScheduledCNNRefine.forward (what autograd computes for ``self.model(...)`` in the reference's
+        training step): returns (grad_x, grad_cond); parameter gradients accumulate in the handle (``grads()``)."""
+        torch = _torch()
+        x_t = _check_tensor(x_t, "x_t", dtype=torch.float32)
+        cond = _check_tensor(cond, "cond", dtype=torch.float32)
+        grad_eps = _check_tensor(grad_eps, "grad_eps", x_t.shape, torch.float32)
+        B, C, h, w = x_t.shape
+        t = torch.as_tensor(t, device=self.device).to(torch.int64).reshape(-1)
+        if t.numel() == 1 and B > 1:
+            t = t.expand(B)
+        t = _check_tensor(t, "t", (B,), torch.int64)
+        gx = torch.empty_like(x_t) if need_grad_x else None
+        gc = torch.empty_like(cond) if need_grad_cond else None
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_denoise_once_backward(
+                self._h, x_t.data_ptr(), t.data_ptr(), cond.data_ptr(), grad_eps.data_ptr(),
+                gx.data_ptr() if gx is not None else None, gc.data_ptr() if gc is not None else None,
+                B, h, w, cond.shape[2], cond.shape[3], precision_id(precision), _stream_ptr(self.device)), "dd_denoise_once_backward")
+        self._cond_token = None
+        return gx, gc
+
+    def zero_grad(self):
+        self._ck(self._lib.dd_zero_grad(self._h, _stream_ptr(self.device)), "dd_zero_grad")
+
+    def grad(self, name: str):
+        torch = _torch()
+        out = torch.empty(self.PARAM_SHAPES[name], device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_get_grad(self._h, name.encode(), out.data_ptr(), out.numel(), _stream_ptr(self.device)), f"dd_get_grad({name})")
+        return out
+
+    def grads(self):
+        return {k: self.grad(k) for k in self.PARAM_SHAPES}
 
     def add_noise(self, x0, noise, t):
         torch = _torch()

@@ -72,6 +72,7 @@ struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   DevBuf wpack2[NUM_EK];            // v2 kernels (pre-swizzled for LDS-DMA)
   DevBuf bias;                      // [cout padded to 32]
   DevBuf w_oihw;                    // naive path
+  DevBuf wT_oihw;                   // naive backward: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (dgrad as a forward conv)
   DevBuf gamma, beta;               // GroupNorm affine [cout]
 };
 
@@ -91,6 +92,8 @@ struct Plan {
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
+  DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
+  DevBuf dgb;              // backward: per (sample, channel) sums [B][256][2] doubles (dbeta, dgamma terms)
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
@@ -142,6 +145,7 @@ struct dd_handle_s {
   int wave_spec = 0;          // use the wave-specialised kernels (dd_igemm2ws.hip) where they exist.  Correct (tested);
                               // measured on MI355X at B=4: conv3 179 -> 209 us (slower), Swin pred.0 131 -> 123 us (faster): off by default
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
+  std::map<std::string, std::unique_ptr<DevBuf>> grads;   // parameter gradients (fp32, reference shapes), accumulated like torch .grad
   std::map<std::tuple<int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
   bool fpn_committed = false;
@@ -174,6 +178,10 @@ struct dd_handle_s {
 namespace {
 
 struct WeightSpec { std::string name; int64_t numel; };
+
+const char* const kConvNames[4] = {"model.noise_embedding.0", "model.noise_embedding.3", "model.pred.0", "model.pred.3"};
+const char* const kGnNames[4] = {"model.noise_embedding.1", "model.noise_embedding.4", "model.pred.1", "model.pred.4"};
+constexpr int kCins[4] = {LATENT_C, HID_C, COND_C, HID_C}, kCouts[4] = {HID_C, COND_C, HID_C, LATENT_C};
 
 // 0 = denoiser (model.*), 1 = latent codec (depth_transform.*), 2 = condition FPN (conv_lateral.* / conv_up.*)
 int weight_group(const std::string& name) {
@@ -634,6 +642,14 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     std::copy(b.begin(), b.end(), bpad.begin());
     int rc = upload(h, L.bias, bpad.data(), bpad.size() * 4, s); if (rc) return rc;
     rc = upload(h, L.w_oihw, w.data(), w.size() * 4, s); if (rc) return rc;
+    {
+      std::vector<float> wt(w.size());
+      for (int co = 0; co < L.cout; ++co)
+        for (int ci = 0; ci < L.cin; ++ci)
+          for (int k = 0; k < 9; ++k) wt[((size_t)ci * L.cout + co) * 9 + (8 - k)] = w[((size_t)co * L.cin + ci) * 9 + k];
+      rc = upload(h, L.wT_oihw, wt.data(), wt.size() * 4, s); if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
+    }
     const std::vector<float>& gg = h->host_w[std::string(gn_names[l]) + ".weight"];
     const std::vector<float>& gb = h->host_w[std::string(gn_names[l]) + ".bias"];
     rc = upload(h, L.gamma, gg.data(), gg.size() * 4, s); if (rc) return rc;
@@ -1056,6 +1072,110 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   }
   h->last_once_plan = pl;
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
+namespace {
+
+float* grad_buf(dd_handle_t h, const std::string& name, size_t numel, hipStream_t s, hipError_t* err) {
+  auto it = h->grads.find(name);
+  if (it == h->grads.end()) {
+    std::unique_ptr<DevBuf> b(new DevBuf());
+    *err = b->alloc(numel * 4);
+    if (*err != hipSuccess) return nullptr;
+    *err = hipMemsetAsync(b->p, 0, numel * 4, s);
+    it = h->grads.emplace(name, std::move(b)).first;
+  }
+  return it->second->as<float>();
+}
+
+}  // namespace
+
+int dd_zero_grad(dd_handle_t h, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  DD_HIP(hipSetDevice(h->device));
+  for (auto& kv : h->grads) DD_HIP(hipMemsetAsync(kv.second->p, 0, kv.second->bytes, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+int dd_get_grad(dd_handle_t h, const char* name, float* dst, int64_t numel, void* stream) {
+  if (!h || !name || !dst) return h ? h->fail(DD_ERR_INVALID_ARG, "dd_get_grad: null argument") : DD_ERR_INVALID_ARG;
+  auto it = h->grads.find(name);
+  if (it == h->grads.end()) return h->fail(DD_ERR_STATE, std::string("dd_get_grad: no gradient accumulated for '") + name + "'");
+  if ((size_t)numel * 4 != it->second->bytes)
+    return h->fail(DD_ERR_INVALID_ARG, std::string("dd_get_grad: '") + name + "' has " + std::to_string(it->second->bytes / 4) + " elements");
+  DD_HIP(hipSetDevice(h->device));
+  DD_HIP(hipMemcpyAsync(dst, it->second->p, it->second->bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, const float* grad_eps,
+                             float* grad_x, float* grad_cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
+                             int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  if (rc) return rc;
+  if (!x_t || !t || !grad_eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: null pointer");
+  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: DD_VARIANT_RES only");
+  if (precision != DD_PREC_NAIVE_FP32)
+    return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: only the unfused fp32 path (DD_PREC_NAIVE_FP32) is built so far");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  Plan* pl = nullptr;
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version, 0}, &pl);
+  if (rc) return rc;
+  const long long HW = (long long)lat_h * lat_w;
+  const size_t px = (size_t)B * HW;
+  if (!pl->gA.p) {
+    DD_HIP(pl->gA.alloc(px * COND_C * 4));
+    DD_HIP(pl->gY.alloc(px * COND_C * 4));
+    DD_HIP(pl->dgb.alloc((size_t)B * COND_C * 2 * sizeof(double)));
+  }
+  const long long* tv = reinterpret_cast<const long long*>(t);
+  // ---- recompute the forward pass: y1..y4, a1, f, a3 and the GroupNorm sums stay in the plan ----
+  DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  if (rc) return rc;
+  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);
+  if (rc) return rc;
+  // ---- backward, last layer first ----
+  DD_HIP(launch_nchw_to_nhwc(grad_eps, pl->gA.p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  const DevBuf* ybuf[4] = {&pl->y1, &pl->y2, &pl->y3, &pl->y4};
+  const void* inbuf[4] = {pl->x[0].p, pl->a1.p, pl->f.p, pl->a3.p};          // the conv's input activation
+  hipError_t e = hipSuccess;
+  for (int l = 3; l >= 0; --l) {
+    const int C = kCouts[l], CI = kCins[l];
+    const ActView yv{ybuf[l]->p, EK_F32, 0, C, HW}, gav{pl->gA.p, EK_F32, 0, C, HW}, gyv{pl->gY.p, EK_F32, 0, C, HW};
+    const ActView none{nullptr, EK_F32, 0, C, HW};
+    const float* gamma = h->L[l].gamma.as<float>();
+    const float* beta = h->L[l].beta.as<float>();
+    DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
+    DD_HIP(launch_gn_bwd_reduce(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, s));
+    DD_HIP(launch_gn_bwd_apply(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), gyv, none, none, nullptr, nullptr, 0, 0, B, s));
+    float* dgam = grad_buf(h, std::string(kGnNames[l]) + ".weight", C, s, &e); DD_HIP(e);
+    float* dbet = grad_buf(h, std::string(kGnNames[l]) + ".bias", C, s, &e); DD_HIP(e);
+    DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
+    float* dbias = grad_buf(h, std::string(kConvNames[l]) + ".bias", C, s, &e); DD_HIP(e);
+    DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
+    float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e); DD_HIP(e);
+    const ActView inv{inbuf[l], EK_F32, 0, CI, HW};
+    DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));
+    // dgrad: g_in = conv3x3(g_y, W^T flipped): C -> CI channels
+    DD_HIP(launch_naive_conv3x3(pl->gY.as<float>(), h->L[l].wT_oihw.as<float>(), nullptr, pl->gA.as<float>(), B, lat_h, lat_w, C, CI, s));
+    if (l == 2) {
+      // gA = dLoss/df, f = relu(gn2(y2)) + cond + E[t]  (reference ...res.py:330-340): the same gradient reaches cond, E[t] and a2
+      const ActView gf{pl->gA.p, EK_F32, 0, COND_C, HW};
+      if (grad_cond) DD_HIP(launch_view_to_nchw(gf, grad_cond, B, 0, s));
+      float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e);
+      DD_HIP(launch_channel_sum(gf, demb, tv, 0, 1, B, s));
+    }
+    if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  }
+  if (grad_x) {
+    const ActView gx{pl->gA.p, EK_F32, 0, LATENT_C, HW};
+    DD_HIP(launch_view_to_nchw(gx, grad_x, B, 0, s));
+  }
+  h->last_once_plan = pl;
   return DD_OK;
 }
 

@@ -113,6 +113,20 @@ hipError_t launch_encode(const CodecWeights& cw, const float* depth, float* tmp_
 hipError_t launch_decode(const CodecWeights& cw, const float* latent_nchw, float* tmp_nhwc, float* depth,
                          int B, int h, int w, hipStream_t s);
 
+// ---- backward pieces (dd_bwd.hip): SURVEY.md 8f rank 2 -------------------------------------------------
+// An activation tensor as the kernels above store it: C channels, HW pixels per sample; blocked = channel-blocked layout
+// of dd_elem.h (C >= 32), otherwise plain NHWC.
+struct ActView { const void* p; int ek; int blocked; int C; long long HW; };
+hipError_t launch_gn_bwd_reduce(const ActView& ga, const ActView& y, const double* stats, const float* gamma, const float* beta,
+                                double* out_bc2, int B, hipStream_t s);
+hipError_t launch_gn_bwd_apply(const ActView& ga, const ActView& y, const double* stats, const float* gamma, const float* beta,
+                               const double* dgb, const ActView& gy, const ActView& act, const ActView& cond, const float* emb,
+                               const long long* tvec, int t_base, int t_bstride, int B, hipStream_t s);
+hipError_t launch_channel_sum(const ActView& v, float* out, const long long* rows, int t_base, int t_bstride, int B, hipStream_t s);
+hipError_t launch_gn_param_grad(const double* dgb, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
+hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oihw, int B, int h, int w, hipStream_t s);
+hipError_t launch_view_to_nchw(const ActView& v, float* dst, int B, int accumulate, hipStream_t s);
+
 // ---- naive cross-check path (dd_naive.hip) -------------------------------------------------------
 hipError_t launch_naive_conv3x3(const float* in_nhwc, const float* w_oihw, const float* bias, float* out_nhwc,
                                 int B, int h, int w, int cin, int cout, hipStream_t s);

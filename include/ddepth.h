@@ -125,6 +125,22 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
 int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, float* eps,
                     int B, int lat_h, int lat_w, int cond_h, int cond_w, int precision, void* stream);
 
+/* ---- training: backward of one epsilon-network evaluation -----------------------------
+ * Replaces: what torch autograd does for  noise_pred = self.model(noisy_images, timesteps, *inputs)  when the reference
+ * trains (ddim_loss, src/model/head/ddim_depth_estimate_res.py:201-217; loss.backward(), src/main.py:232-241): the
+ * vector-Jacobian product of ScheduledCNNRefine.forward (...res.py:324-344) at (x_t, t, cond) with grad_eps (B,16,h,w).
+ *   grad_x    (B,16,h,w)   dLoss/dx_t, or NULL
+ *   grad_cond (B,256,h,w)  dLoss/dcond (overwritten), or NULL
+ * Parameter gradients ACCUMULATE inside the handle (like Tensor.grad) under the state-dict names of dd_set_weight
+ * ("model.pred.0.weight", "model.time_embedding.weight", ...) in the reference's own shapes; dd_get_grad copies one to a
+ * caller DEVICE buffer, dd_zero_grad clears all.  The forward pass is recomputed internally (no stash from
+ * dd_denoise_once is needed).  DD_VARIANT_RES; precision: DD_PREC_NAIVE_FP32 (unfused fp32 kernels) so far. */
+int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, const float* grad_eps,
+                             float* grad_x, float* grad_cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
+                             int precision, void* stream);
+int dd_zero_grad(dd_handle_t h, void* stream);
+int dd_get_grad(dd_handle_t h, const char* name, float* dst, int64_t numel, void* stream);
+
 /* Replaces: DDIMScheduler.add_noise == q_sample (scheduling_ddim.py:355-376):
  * out = sqrt(abar[t_b]) * x0 + sqrt(1 - abar[t_b]) * noise, t (B,) device int64, tensors (B,C,h,w). */
 int dd_add_noise(dd_handle_t h, const float* x0, const float* noise, const int64_t* t, float* out,

@@ -93,3 +93,16 @@ def decode(sd, latent, eps=1e-6):
     y = F.relu(_bn(sd, p + "1", y))
     y = torch.sigmoid(F.conv2d(y, sd[p + "3.0.weight"], sd[p + "3.0.bias"], padding=1))
     return 1.0 / y.clamp(eps) - 1
+
+
+def denoiser_vjp(sd, x, t, cond, grad_eps, variant="res"):
+    """Vector-Jacobian product of `denoiser` by torch autograd (what loss.backward() sends through one call of the
+    reference's ScheduledCNNRefine, ...res.py:211 / src/main.py:232-241).  Returns (eps, grad_x, grad_cond, {name: grad})."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("model.")}
+    full = dict(sd)
+    full.update(params)
+    x = torch.as_tensor(x).clone().requires_grad_(True)
+    cond = torch.as_tensor(cond).clone().requires_grad_(True)
+    eps = denoiser(full, x, t, cond, variant)
+    eps.backward(torch.as_tensor(grad_eps))
+    return eps.detach(), x.grad, cond.grad, {k: v.grad for k, v in params.items() if v.grad is not None}

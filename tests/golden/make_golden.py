@@ -15,6 +15,7 @@ Cases (all eval mode, fp32, torch CPU):
   loop_swin      same for the Swin variant, T=20
   codec          DeepDepthTransformWithUpsampling.t / inv_t (even and odd sizes)
   head_res       full DDIMDepthEstimate_Res.forward (FPN + loop + decoder + ddim_loss), RNG injected
+  denoise_bwd_res  autograd of ScheduledCNNRefine.forward (g_x, g_cond, all parameter gradients) for a seeded upstream gradient
   fpn_odd        the head's condition FPN (conv_lateral / conv_up / adaptive_avg_pool2d) on an odd-sized pyramid
 """
 from __future__ import annotations
@@ -109,6 +110,38 @@ def gen_denoise(ref, name):
         out["eps_scalar_t"] = t2n(model(x, torch.tensor(c["t"]), cond, None, None, None))
         out["eps_batch_t"] = t2n(model(x, torch.from_numpy(inp["timesteps"]), cond, None, None, None))
         out["ne_sample0_ch0_8"] = t2n(model.noise_embedding(x))[:1, :8]
+    return out
+
+
+def gen_denoise_bwd(ref, name):
+    """Autograd of the reference's ScheduledCNNRefine (the gradients ddim_loss / the depth loss send through one call,
+    ...res.py:211 + loss.backward()): g_x, g_cond and every parameter gradient for a seeded upstream gradient."""
+    c = CASES[name]
+    sd, model, _, _ = build(ref, c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], c.get("cond_hw"))
+    x = torch.from_numpy(inp["x_T"]).requires_grad_(True)
+    cond = torch.from_numpy(inp["cond"]).requires_grad_(True)
+    g = torch.from_numpy(np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32))
+    model.zero_grad()
+    eps = model(x, torch.from_numpy(inp["timesteps"]), cond, None, None, None)
+    eps.backward(g)
+    out = {"eps": t2n(eps), "grad_x": t2n(x.grad), "grad_cond_ch0_8": t2n(cond.grad)[:, :8],
+           "grad_cond_chan_sum": cond.grad.double().sum(dim=(0, 2, 3)).numpy()}
+    for k, v in model.state_dict(keep_vars=True).items():
+        if v.grad is None:
+            continue
+        gnp = t2n(v.grad)
+        if k == "time_embedding.weight":
+            rows = sorted(set(int(t) for t in inp["timesteps"]))
+            out["grad.model." + k + ".rows"] = np.array(rows, dtype=np.int64)
+            out["grad.model." + k] = gnp[rows]
+            assert float(np.abs(gnp).sum()) == float(np.abs(gnp[rows]).sum())
+        elif gnp.size > 20000:
+            # the two 147k-element conv gradients: every 7th element plus two checksums keep the fixture small
+            out["grad.model." + k + ".stride7"] = gnp.reshape(-1)[::7].copy()
+            out["grad.model." + k + ".sums"] = np.array([gnp.astype(np.float64).sum(), np.abs(gnp.astype(np.float64)).sum()])
+        else:
+            out["grad.model." + k] = gnp
     return out
 
 
@@ -209,6 +242,7 @@ def main():
         "sched": lambda: gen_sched(ref),
         "denoise_res": lambda: gen_denoise(ref, "denoise_res"),
         "denoise_swin": lambda: gen_denoise(ref, "denoise_swin"),
+        "denoise_bwd_res": lambda: gen_denoise_bwd(ref, "denoise_bwd_res"),
         "loop_res": lambda: gen_loop(ref, "loop_res"),
         "loop_res_far": lambda: gen_loop(ref, "loop_res_far"),
         "loop_swin": lambda: gen_loop(ref, "loop_swin"),

@@ -189,3 +189,28 @@ def test_adaptive_avg_pool_matches_torch():
         x = rs.standard_normal((2, 3, H, W))
         ref = torch.nn.functional.adaptive_avg_pool2d(torch.from_numpy(x), (oh, ow)).numpy()
         assert np.abs(O.adaptive_avg_pool2d(x, oh, ow) - ref).max() < 1e-12
+
+
+def test_torch_port_denoiser_vjp_matches_reference_autograd(golden, cases):
+    """The differentiable torch port (backward oracle) vs autograd of the reference's own ScheduledCNNRefine."""
+    import torch
+    from oracle import torch_cpu_port as P
+    c, g = cases["denoise_bwd_res"], golden("denoise_bwd_res")
+    sd = P.to_torch_sd(synth.make_state_dict(c["wseed"], "res"))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    ge = np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32)
+    eps, gx, gc, grads = P.denoiser_vjp(sd, inp["x_T"], torch.from_numpy(inp["timesteps"]), inp["cond"], ge)
+    assert np.abs(eps.numpy() - g["eps"]).max() <= 1e-5
+    assert np.abs(gx.numpy() - g["grad_x"]).max() <= 2e-5 * np.abs(g["grad_x"]).max()
+    assert np.abs(gc.numpy()[:, :8] - g["grad_cond_ch0_8"]).max() <= 2e-5 * np.abs(g["grad_cond_ch0_8"]).max()
+    for k in list(g):
+        if not k.startswith("grad.model.") or k.endswith((".rows", ".sums")):
+            continue
+        name = k[len("grad."):]
+        if name.endswith(".stride7"):
+            got = grads[name[:-len(".stride7")]].numpy().reshape(-1)[::7]
+        elif name == "model.time_embedding.weight":
+            got = grads[name].numpy()[g[k + ".rows"]]
+        else:
+            got = grads[name].numpy()
+        assert np.abs(got - g[k]).max() <= 5e-5 * max(1e-6, np.abs(g[k]).max()), name
