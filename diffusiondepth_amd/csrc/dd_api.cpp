@@ -72,6 +72,7 @@ struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   DevBuf wpack2[NUM_EK];            // v2 kernels (pre-swizzled for LDS-DMA)
   DevBuf bias;                      // [cout padded to 32]
   DevBuf w_oihw;                    // naive path
+  DevBuf wpackT[NUM_EK];            // fused backward: W' packed for the dgrad layer (23 - conv index) of dd_igemm2.hip
   DevBuf wT_oihw;                   // naive backward: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (dgrad as a forward conv)
   DevBuf gamma, beta;               // GroupNorm affine [cout]
 };
@@ -92,6 +93,7 @@ struct Plan {
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
+  DevBuf bX, bA1, bF, bA3; // fused backward: the four convs' input activations, materialised for the weight gradients
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums [B][256][2] doubles (dbeta, dgamma terms)
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
@@ -142,6 +144,7 @@ struct dd_handle_s {
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
   int kernel_version = 2;     // 1 = dd_igemm.hip, 2 = dd_igemm2.hip (pipelined)
   int ablate = 0;             // timing experiments only (ConvParams::ablate)
+  int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
   int wave_spec = 0;          // use the wave-specialised kernels (dd_igemm2ws.hip) where they exist.  Correct (tested);
                               // measured on MI355X at B=4: conv3 179 -> 209 us (slower), Swin pred.0 131 -> 123 us (faster): off by default
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
@@ -649,6 +652,12 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
           for (int k = 0; k < 9; ++k) wt[((size_t)ci * L.cout + co) * 9 + (8 - k)] = w[((size_t)co * L.cin + ci) * 9 + k];
       rc = upload(h, L.wT_oihw, wt.data(), wt.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
+      for (int ek = 0; ek < NUM_EK; ++ek) {
+        std::vector<uint8_t> packed;
+        pack_conv_weights(wt.data(), conv_pack_geom2(23 - l, ek), ek, true, packed);
+        rc = upload(h, L.wpackT[ek], packed.data(), packed.size(), s); if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
     }
     const std::vector<float>& gg = h->host_w[std::string(gn_names[l]) + ".weight"];
     const std::vector<float>& gb = h->host_w[std::string(gn_names[l]) + ".bias"];
@@ -818,6 +827,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->ablate = (int)value;
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
+  else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
   else if (k == "wave_spec") {
     if (h->wave_spec != (int)(value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
     h->wave_spec = value != 0;
@@ -1116,8 +1126,9 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   if (rc) return rc;
   if (!x_t || !t || !grad_eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: null pointer");
   if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: DD_VARIANT_RES only");
-  if (precision != DD_PREC_NAIVE_FP32)
-    return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: only the unfused fp32 path (DD_PREC_NAIVE_FP32) is built so far");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: unknown precision");
+  const bool naive = precision == DD_PREC_NAIVE_FP32;
+  if (!naive && h->kernel_version != 2) return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: the fused path needs kernel_version 2");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
@@ -1125,46 +1136,86 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   if (rc) return rc;
   const long long HW = (long long)lat_h * lat_w;
   const size_t px = (size_t)B * HW;
+  const int ek = pl->ek;
+  const size_t es = ek_size(ek);
   if (!pl->gA.p) {
     DD_HIP(pl->gA.alloc(px * COND_C * 4));
     DD_HIP(pl->gY.alloc(px * COND_C * 4));
     DD_HIP(pl->dgb.alloc((size_t)B * COND_C * 2 * sizeof(double)));
+    if (!naive) {
+      DD_HIP(pl->bX.alloc(px * LATENT_C * es));
+      DD_HIP(pl->bA1.alloc(px * HID_C * es));
+      DD_HIP(pl->bF.alloc(px * COND_C * es));
+      DD_HIP(pl->bA3.alloc(px * HID_C * es));
+    }
   }
   const long long* tv = reinterpret_cast<const long long*>(t);
-  // ---- recompute the forward pass: y1..y4, a1, f, a3 and the GroupNorm sums stay in the plan ----
+  // ---- recompute the forward pass: y1..y4 and the GroupNorm sums (and, unfused, a1 / f / a3) stay in the plan ----
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
   if (rc) return rc;
   DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
-  rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);
-  if (rc) return rc;
+  const int lay = naive ? 0 : 1;                    // activation layout flag of the views: plain NHWC fp32 / channel-blocked
+  const ActView nothing{nullptr, EK_F32, 0, 1, HW};
+  if (naive) {
+    rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);
+    if (rc) return rc;
+  } else {
+    rc = enqueue_fused_step(h, pl, 0, pl->x[0].as<float>(), pl->x[1].as<float>(), false, tv, 0, 1, s);
+    if (rc) return rc;
+    // the convs' input activations in the kernels' own element kind: x, a1 = relu(gn1(y1)), f = relu(gn2(y2)) + cond + E[t],
+    // a3 = relu(gn3(y3))  (the weight gradients contract the conv-output gradients with these)
+    DD_HIP(launch_view_copy(ActView{pl->x[0].p, EK_F32, 0, LATENT_C, HW}, ActView{pl->bX.p, ek, 0, LATENT_C, HW}, B, s));
+    const DevBuf* ys[3] = {&pl->y1, &pl->y2, &pl->y3};
+    const DevBuf* as[3] = {&pl->bA1, &pl->bF, &pl->bA3};
+    for (int l = 0; l < 3; ++l) {
+      const int C = kCouts[l];
+      const ActView yv{ys[l]->p, ek, 1, C, HW}, av{as[l]->p, ek, 1, C, HW};
+      const ActView cv = (l == 1) ? ActView{pl->cond->p, ek, 1, C, HW} : nothing;
+      DD_HIP(launch_gn_bwd_apply(nothing, yv, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(), pl->dgb.as<double>(),
+                                 nothing, av, cv, h->emb.as<float>(), tv, 0, 1, B, s));
+    }
+  }
   // ---- backward, last layer first ----
   DD_HIP(launch_nchw_to_nhwc(grad_eps, pl->gA.p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   const DevBuf* ybuf[4] = {&pl->y1, &pl->y2, &pl->y3, &pl->y4};
-  const void* inbuf[4] = {pl->x[0].p, pl->a1.p, pl->f.p, pl->a3.p};          // the conv's input activation
+  const void* inbuf[4] = {naive ? pl->x[0].p : pl->bX.p, naive ? pl->a1.p : pl->bA1.p, naive ? pl->f.p : pl->bF.p,
+                          naive ? pl->a3.p : pl->bA3.p};                     // the conv's input activation
   hipError_t e = hipSuccess;
   for (int l = 3; l >= 0; --l) {
     const int C = kCouts[l], CI = kCins[l];
-    const ActView yv{ybuf[l]->p, EK_F32, 0, C, HW}, gav{pl->gA.p, EK_F32, 0, C, HW}, gyv{pl->gY.p, EK_F32, 0, C, HW};
-    const ActView none{nullptr, EK_F32, 0, C, HW};
+    // conv4's output y4 and the incoming grad_eps are fp32 NHWC in every mode; everything else is in the plan's element kind
+    const int ek_y = (naive || l == 3) ? EK_F32 : ek, ek_g = naive ? EK_F32 : ek;
+    const ActView yv{ybuf[l]->p, ek_y, lay, C, HW}, gav{pl->gA.p, (l == 3) ? (int)EK_F32 : ek_g, lay, C, HW}, gyv{pl->gY.p, ek_g, lay, C, HW};
     const float* gamma = h->L[l].gamma.as<float>();
     const float* beta = h->L[l].beta.as<float>();
     DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
     DD_HIP(launch_gn_bwd_reduce(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, s));
-    DD_HIP(launch_gn_bwd_apply(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), gyv, none, none, nullptr, nullptr, 0, 0, B, s));
+    DD_HIP(launch_gn_bwd_apply(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), gyv, nothing, nothing, nullptr, nullptr, 0, 0, B, s));
     float* dgam = grad_buf(h, std::string(kGnNames[l]) + ".weight", C, s, &e); DD_HIP(e);
     float* dbet = grad_buf(h, std::string(kGnNames[l]) + ".bias", C, s, &e); DD_HIP(e);
     DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
     float* dbias = grad_buf(h, std::string(kConvNames[l]) + ".bias", C, s, &e); DD_HIP(e);
     DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
     float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e); DD_HIP(e);
-    const ActView inv{inbuf[l], EK_F32, 0, CI, HW};
-    DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));
+    const ActView inv{inbuf[l], ek_g, lay, CI, HW};
+    if (!naive && ek != EK_F32 && !h->naive_wgrad) DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, ek, C, CI, B, lat_h, lat_w, s));
+    else DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));     // fp32 operands: the unfused kernel (parity modes)
     // dgrad: g_in = conv3x3(g_y, W^T flipped): C -> CI channels
-    DD_HIP(launch_naive_conv3x3(pl->gY.as<float>(), h->L[l].wT_oihw.as<float>(), nullptr, pl->gA.as<float>(), B, lat_h, lat_w, C, CI, s));
+    if (naive) {
+      DD_HIP(launch_naive_conv3x3(pl->gY.as<float>(), h->L[l].wT_oihw.as<float>(), nullptr, pl->gA.as<float>(), B, lat_h, lat_w, C, CI, s));
+    } else {
+      const int layer = 23 - l;
+      ConvParams q{};
+      q.B = B; q.h = lat_h; q.w = lat_w;
+      q.tiles_x = (lat_w + 31) / 32;
+      q.tiles_y = (lat_h + conv_pack_geom2(layer, ek).th - 1) / conv_pack_geom2(layer, ek).th;
+      q.in = pl->gY.p; q.wpack = h->L[l].wpackT[ek].p; q.bias = h->zero_bias.as<float>(); q.out = pl->gA.p;
+      DD_HIP(launch_conv_igemm2(layer, ek, q, s));
+    }
     if (l == 2) {
       // gA = dLoss/df, f = relu(gn2(y2)) + cond + E[t]  (reference ...res.py:330-340): the same gradient reaches cond, E[t] and a2
-      const ActView gf{pl->gA.p, EK_F32, 0, COND_C, HW};
+      const ActView gf{pl->gA.p, ek_g, lay, COND_C, HW};
       if (grad_cond) DD_HIP(launch_view_to_nchw(gf, grad_cond, B, 0, s));
       float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e);
       DD_HIP(launch_channel_sum(gf, demb, tv, 0, 1, B, s));

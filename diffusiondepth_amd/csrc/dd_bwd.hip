@@ -231,6 +231,21 @@ hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oih
   return hipGetLastError();
 }
 
+// dst view = src view (layout / element-kind conversion of small tensors: the fp32 state as a conv operand)
+__global__ void view_copy_kernel(ActView src, ActView dst, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % src.C);
+  const long long bp = i / src.C;
+  const long long p = bp % src.HW, b = bp / src.HW;
+  view_store(dst, b, p, c, view_load(src, b, p, c));
+}
+hipError_t launch_view_copy(const ActView& src, const ActView& dst, int B, hipStream_t s) {
+  const long long total = (long long)B * src.C * src.HW;
+  hipLaunchKernelGGL(view_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, total);
+  return hipGetLastError();
+}
+
 // dst[b][c][p] (+)= src view  (NCHW fp32 gradient handed back to the caller: g_x, g_cond)
 __global__ void view_to_nchw_kernel(ActView v, float* __restrict__ dst, int accumulate, long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

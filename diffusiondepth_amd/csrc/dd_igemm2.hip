@@ -651,6 +651,10 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 16: return launch_one2<EK, 16>(p, s);
     case 17: return launch_one2<EK, 17>(p, s);
     case 18: return launch_one2<EK, 18>(p, s);
+    case 20: return launch_one2<EK, 20>(p, s);
+    case 21: return launch_one2<EK, 21>(p, s);
+    case 22: return launch_one2<EK, 22>(p, s);
+    case 23: return launch_one2<EK, 23>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -686,7 +690,11 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 15: return geom2_of<EK, 15>();
     case 16: return geom2_of<EK, 16>();
     case 17: return geom2_of<EK, 17>();
-    default: return geom2_of<EK, 18>();
+    case 18: return geom2_of<EK, 18>();
+    case 20: return geom2_of<EK, 20>();
+    case 21: return geom2_of<EK, 21>();
+    case 22: return geom2_of<EK, 22>();
+    default: return geom2_of<EK, 23>();
   }
 }
 PackGeom conv_pack_geom2(int layer, int ek) {

@@ -40,23 +40,28 @@ template <int EK_, int LAYER_> struct Cfg2 {
   //   14     = conv_up[j]: ConvTranspose2d(256->256, k2, s2) + BN + ReLU written as a 1x1 conv with 4 x 256 output
   //            "channels" (one block per output parity (dy,dx)) whose epilogue scatters to pixel (2y+dy, 2x+dx)
   //   15..18 = the same lateral convs for the Swin-L pyramid (192|384|768|1536 -> 256; reference ...res_swin_add.py:31,57-84)
+  // Backward: 20..23 = data gradients of conv4, conv3, conv2, conv1 -- the same implicit GEMM with
+  //   W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] on the raw GroupNorm-backward result: 16->64, 64->256, 256->64, 64->16
   static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18);
+  static constexpr bool IS_DGRAD = (LAYER >= 20 && LAYER <= 23);
   static constexpr bool IS_UP = (LAYER == 14);
   static constexpr int KS = IS_UP ? 1 : 3;                       // kernel size
   static constexpr int HALO = KS / 2;
   static constexpr int NTAPS = KS * KS;
-  static constexpr int CIN = (LAYER == 1) ? LATENT_C : (LAYER == 2 || LAYER == 4) ? HID_C : IS_LAT ? (LAYER >= 15 ? (192 << (LAYER - 15)) : (64 << (LAYER - 10))) : COND_C;
+  static constexpr int CIN = (LAYER == 1 || LAYER == 20) ? LATENT_C : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? HID_C : IS_LAT ? (LAYER >= 15 ? (192 << (LAYER - 15)) : (64 << (LAYER - 10))) : COND_C;
   static constexpr int COUT = IS_UP ? 4 * COND_C : IS_LAT ? COND_C
+                            : (LAYER == 21) ? COND_C : (LAYER == 23) ? LATENT_C
                             : (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
   static constexpr bool RELU_OUT = IS_LAT || IS_UP;              // epilogue: relu(acc + bias)
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
-  static constexpr int CK = (LAYER == 1) ? 16 : (LAYER == 2 || LAYER == 4) ? (128 / ESZ) : (64 / ESZ);
+  static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (64 / ESZ);
   // FAT (conv3-shaped layers 3 / 7 / 9): one 16x32-pixel, 8-wave workgroup per CU with ALL nine taps of a channel chunk per
   // stage -> one barrier per chunk (8 instead of 24), weights DMA'd once per 512 pixels, 1.2x instead of 1.33x halo.
   static constexpr bool FAT = DD_FAT_CONV3 && (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);   // 8 shares 9's tile geometry
   static constexpr bool PINGPONG = FAT && DD_PINGPONG;          // the two 4-wave halves alternate MFMA / staging phases
-  static constexpr int TG = (LAYER == 1 || FAT) ? 9 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
+  static constexpr int TG = (LAYER == 1 || LAYER == 20 || FAT) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
+                          : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
@@ -64,13 +69,13 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
   static constexpr int TH = FAT ? 16 : 8, TW = 32;
-  static constexpr int WAVES = (LAYER == 1 || LAYER == 4 || FAT) ? 8 : 4;
+  static constexpr int WAVES = (LAYER == 1 || LAYER == 4 || LAYER == 20 || LAYER == 23 || FAT) ? 8 : 4;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;
   static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1) ? 4 : ESZ;
-  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8) ? 4 : ESZ;
+  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8 || LAYER == 23) ? 4 : ESZ;
   static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
   static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
   static constexpr int PPP = ROWB / 16;
@@ -100,7 +105,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
   // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
   // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
-  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7) && !(FAT && DD_PINGPONG)) ? 2 : 1;
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22) && !(FAT && DD_PINGPONG)) ? 2 : 1;
   static constexpr int FRAG_DEPTH = (LAYER == 5) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)

@@ -1,0 +1,172 @@
+// dd_wgrad.hip -- weight gradient of a 3x3 convolution on the matrix cores (what autograd's
+// conv2d backward-weight does for the four convs of ScheduledCNNRefine, reference
+// src/model/head/ddim_depth_estimate_res.py:303-322, when the reference trains):
+//
+//     dW[co][ci][ky][kx] += sum_{b, y, x} g_y[b][y][x][co] * a[b][y+ky-1][x+kx-1][ci]
+//
+// As a GEMM the contraction index is the PIXEL: D[co][ci] += sum_k A[co][k] * B[k][ci] with k = pixel.  The MFMA operand
+// registers of a lane hold 8 consecutive k for one row, but both tensors are stored channel-last (a pixel's channels are
+// contiguous), so every tile is transposed on its way into LDS:
+//
+//   gT [64 co][264]          g_y of one 8x32-pixel tile, pixel-contiguous rows (pitch 264: rows shift by 16 B -> conflict-free b128)
+//   aT [32 ci][10][40]+pad   the (8+2)x(32+2) input patch, pixel-contiguous rows, channel pitch 520 elements
+//
+// A workgroup = 6 waves owns (64 output channels) x (32 input channels) x (all 9 taps) and walks a strided set of pixel
+// tiles, accumulating in registers; wave (ib, ky) = (32-co half, kernel row) holds the three kx taps (48 accumulators).
+// Per 16-pixel k-step a wave reads ONE A fragment and TWO aligned 16-B pieces of the patch row; the kx = 1, 2 operands
+// are those two pieces shifted by 2 / 4 bytes in registers (v_alignbyte / renaming), so no unaligned LDS access is needed:
+// 3 ds_read_b128 per 3 MFMAs.  At the end every lane adds its 48 values to dW with fp32 atomics (slabs x 18 432 per type).
+// bf16 / f16 operands, fp32 accumulation.
+#include "dd_elem.h"
+
+namespace dd {
+
+constexpr int WG_THREADS = 384;
+constexpr int GT_PITCH = 264;                    // elements per gT row (256 pixels + 8)
+constexpr int AT_ROW = 40;                       // elements per patch row (34 used)
+constexpr int AT_PITCH = 520;                    // elements per aT channel (10 x 40 = 400, padded so that rows shift by 16 B)
+constexpr int WGRAD_LDS = (64 * GT_PITCH + 32 * AT_PITCH) * 2;
+
+struct WgradParams {
+  const void* gy;      // conv-output gradient, activation layout, CO channels
+  const void* a;       // conv input activation, activation layout, CI channels
+  float* dw;           // [CO][CI][3][3] fp32, accumulated
+  int CO, CI, B, h, w, tiles_x, tiles_y, slabs;
+};
+
+template <int EK>
+__global__ void __launch_bounds__(WG_THREADS) wgrad_mfma_kernel(WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint16_t* gT = reinterpret_cast<uint16_t*>(smem);
+  uint16_t* aT = gT + 64 * GT_PITCH;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ib = wave / 3, ky = wave - ib * 3;
+  const int li = lane & 31, g = lane >> 5;
+  const int n_cib = (p.CI + 31) / 32;
+  const int cog = blockIdx.y / n_cib, cib = blockIdx.y - cog * n_cib;      // 64-co group, 32-ci block
+  const int co0 = cog * 64, ci0 = cib * 32;
+  const long long HW = (long long)p.h * p.w;
+  const int n_tiles = p.B * p.tiles_y * p.tiles_x;
+
+  f32x16_t acc[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  // rows of the LDS images that no channel maps to (CO = 16, CI = 16) stay zero for the whole kernel
+  for (int i = tid; i < (64 * GT_PITCH + 32 * AT_PITCH) / 2; i += WG_THREADS) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
+  __syncthreads();
+
+  const int co_pieces = min(64, p.CO - co0) / 8;            // 16-B pieces (8 channels) per pixel of the g_y tile: 8 or 2
+  const int ci_pieces = min(32, p.CI - ci0) / 8;            // ... of the patch: 4 or 2
+  for (int tile = blockIdx.x; tile < n_tiles; tile += p.slabs) {
+    const int b = tile / (p.tiles_y * p.tiles_x);
+    const int trem = tile - b * p.tiles_y * p.tiles_x;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * 8, x0 = tx * 32;
+    // ---- g_y tile -> gT (transposed): item = (pixel, piece); consecutive lanes = consecutive pieces of consecutive pixels ----
+    for (int it = tid; it < 256 * co_pieces; it += WG_THREADS) {
+      const int q = it % co_pieces, px = it / co_pieces;
+      const int r = px >> 5, c = px & 31;
+      const int gyy = y0 + r, gxx = x0 + c;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gyy < p.h && gxx < p.w) {
+        const int ch = co0 + q * 8;
+        const size_t off = (p.CO >= ACT_CB) ? ((((size_t)b * (p.CO / ACT_CB) + ch / ACT_CB) * HW + (size_t)gyy * p.w + gxx) * ACT_CB + (ch % ACT_CB))
+                                            : (((size_t)b * HW + (size_t)gyy * p.w + gxx) * p.CO + ch);
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gy) + off);
+      }
+      uint16_t* dst = gT + (q * 8) * GT_PITCH + px;
+      const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dst[(2 * k) * GT_PITCH] = (uint16_t)(wv[k] & 0xFFFFu);
+        dst[(2 * k + 1) * GT_PITCH] = (uint16_t)(wv[k] >> 16);
+      }
+    }
+    // ---- input patch (10 x 34 pixels, zero outside the image) -> aT (transposed) ----
+    for (int it = tid; it < 340 * ci_pieces; it += WG_THREADS) {
+      const int q = it % ci_pieces, pp = it / ci_pieces;
+      const int pr = pp / 34, pc = pp - pr * 34;
+      const int gyy = y0 - 1 + pr, gxx = x0 - 1 + pc;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gyy >= 0 && gyy < p.h && gxx >= 0 && gxx < p.w) {
+        const int ch = ci0 + q * 8;
+        const size_t off = (p.CI >= ACT_CB) ? ((((size_t)b * (p.CI / ACT_CB) + ch / ACT_CB) * HW + (size_t)gyy * p.w + gxx) * ACT_CB + (ch % ACT_CB))
+                                            : (((size_t)b * HW + (size_t)gyy * p.w + gxx) * p.CI + ch);
+        v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.a) + off);
+      }
+      uint16_t* dst = aT + (q * 8) * AT_PITCH + pr * AT_ROW + pc;
+      const uint32_t wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dst[(2 * k) * AT_PITCH] = (uint16_t)(wv[k] & 0xFFFFu);
+        dst[(2 * k + 1) * AT_PITCH] = (uint16_t)(wv[k] >> 16);
+      }
+    }
+    __syncthreads();
+    // ---- 16 k-steps of 16 pixels: tile row r = s / 2, columns c0 = 16 (s % 2) + 8 g .. + 7 ----
+    // byte offsets from the 16-B aligned LDS base (so that the fragment reads are single ds_read_b128)
+    const int arow = ((ib * 32 + li) * GT_PITCH + 8 * g) * 2;
+    const int brow = (64 * GT_PITCH + li * AT_PITCH + ky * AT_ROW + 8 * g) * 2;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int r = s >> 1, c0 = (s & 1) * 16;
+      const uint4 af = *reinterpret_cast<const uint4*>(smem + arow + (r * 32 + c0) * 2);
+      const uint4 lo = *reinterpret_cast<const uint4*>(smem + brow + (r * AT_ROW + c0) * 2);
+      const uint4 hi = *reinterpret_cast<const uint4*>(smem + brow + (r * AT_ROW + c0 + 8) * 2);
+      // patch columns c0+8g+kx .. +7: kx = 0 is `lo`, kx = 1 the 2-byte shift of (lo, hi), kx = 2 the 4-byte shift
+      const uint4 b1 = make_uint4(__builtin_amdgcn_alignbyte(lo.y, lo.x, 2), __builtin_amdgcn_alignbyte(lo.z, lo.y, 2),
+                                  __builtin_amdgcn_alignbyte(lo.w, lo.z, 2), __builtin_amdgcn_alignbyte(hi.x, lo.w, 2));
+      const uint4 b2 = make_uint4(lo.y, lo.z, lo.w, hi.x);
+      mma_step<EK>(acc[0], af, lo);
+      mma_step<EK>(acc[1], af, b1);
+      mma_step<EK>(acc[2], af, b2);
+    }
+    __syncthreads();                     // everybody is done reading before the next tile overwrites the images
+  }
+  // ---- flush: D[row co][col ci], lane owns column li and rows 8q + 4g + r ----
+  const int ci = ci0 + li;
+  if (ci < p.CI) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + ib * 32 + 8 * q + 4 * g + r;
+          if (co < p.CO) atomicAdd(p.dw + (((size_t)co * p.CI + ci) * 3 + ky) * 3 + kx, acc[kx][q * 4 + r]);
+        }
+  }
+}
+
+hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, int ek, int CO, int CI, int B, int h, int w, hipStream_t s) {
+  if (ek != EK_BF16 && ek != EK_F16) return hipErrorInvalidValue;
+  if (CO % 8 != 0 || CI % 8 != 0) return hipErrorInvalidValue;
+  WgradParams p{};
+  p.gy = gy; p.a = a; p.dw = dw_oihw; p.CO = CO; p.CI = CI; p.B = B; p.h = h; p.w = w;
+  p.tiles_x = (w + 31) / 32; p.tiles_y = (h + 7) / 8;
+  const int types = ((CO + 63) / 64) * ((CI + 31) / 32);
+  const int n_tiles = B * p.tiles_x * p.tiles_y;
+  int slabs = (512 + types - 1) / types;                  // about two workgroups per CU over all types
+  if (slabs > n_tiles) slabs = n_tiles;
+  if (slabs < 1) slabs = 1;
+  p.slabs = slabs;
+  static bool attr_set[2] = {false, false};
+  const int idx = ek == EK_BF16 ? 0 : 1;
+  const void* fn = ek == EK_BF16 ? reinterpret_cast<const void*>(&wgrad_mfma_kernel<EK_BF16>) : reinterpret_cast<const void*>(&wgrad_mfma_kernel<EK_F16>);
+  if (!attr_set[idx]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS);
+    if (e != hipSuccess) return e;
+    attr_set[idx] = true;
+  }
+  dim3 grid((unsigned)slabs, (unsigned)types);
+  if (ek == EK_BF16) hipLaunchKernelGGL(wgrad_mfma_kernel<EK_BF16>, grid, dim3(WG_THREADS), WGRAD_LDS, s, p);
+  else hipLaunchKernelGGL(wgrad_mfma_kernel<EK_F16>, grid, dim3(WG_THREADS), WGRAD_LDS, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace dd

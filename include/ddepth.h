@@ -162,7 +162,8 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * after every launch), "kernel_version" (2 = pipelined kernels [default], 1 = first-generation kernels),
  * "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
  * condition map is re-added in conv3's prologue every step - measured faster), "wave_spec" (1 = wave-specialised
- * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "layer_timing", "ablate" (timing experiments). */
+ * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "layer_timing", "ablate" (timing experiments), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
+ * instead of the MFMA kernel, A/B check). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans". */

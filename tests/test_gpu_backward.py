@@ -4,8 +4,14 @@ the C ABI against
   (2) torch autograd of the CPU port on other seeded shapes (ragged sizes, batch > 1, repeated timesteps),
   (3) properties: gradients accumulate across calls and clear with zero_grad; linear in grad_eps.
 
-Tolerance (fp32 path): 1e-4 x max|reference gradient| per tensor (fp32 sums over up to B*h*w*9*Cin products in a
-different order than torch's).
+Tolerances per gradient tensor: fp32 paths (unfused `naive_fp32`, fused `fp32`): max|err| <= 1e-4 x max|reference| (fp32
+sums over up to B*h*w*9*Cin products in a different order than torch's).  bf16 / f16 operand modes (activations AND
+gradients stored in 16 bits between the kernels): relative L2 error ||got - ref|| / ||ref|| <= 0.2 / 0.06 (measured
+0.03-0.09 / 0.03-0.04 on the golden case, up to 0.17 for bf16 on a 9x33 single image).  A 16-bit forward flips the ReLU mask of the ~0.3 % of elements whose pre-activation is within
+rounding of zero; under the RANDOM upstream gradient used here every gradient is a sum of random-sign terms, so those few
+flips move it by sqrt(flipped / kept) ~ 5 % however fine the arithmetic is (the last layer's dbeta, a plain masked sum of
+grad_eps, shows it in isolation).  The fused fp32 mode, same kernels and layouts, matches to 2e-6.  Measured values are
+recorded in parity_report.jsonl.
 """
 import numpy as np
 import pytest
@@ -15,7 +21,8 @@ from diffusiondepth_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
+TOL = {"naive_fp32": 1e-4, "fp32": 1e-4, "f16": 6e-2, "bf16": 2e-1}
+PRECS = ["naive_fp32", "fp32", "bf16", "f16"]
 
 
 @pytest.fixture(scope="module")
@@ -27,20 +34,23 @@ def U():
     return gpu_util
 
 
-def _rel(a, b):
-    b = np.asarray(b, dtype=np.float64)
-    return float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(1e-12, np.abs(b).max()))
+def _rel(a, b, prec="fp32"):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if prec in ("bf16", "f16"):
+        return float(np.sqrt(((a - b) ** 2).sum()) / max(1e-30, np.sqrt((b ** 2).sum())))
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-def test_backward_matches_reference_autograd_golden(U, golden, cases):
+@pytest.mark.parametrize("prec", PRECS)
+def test_backward_matches_reference_autograd_golden(U, golden, cases, prec):
     c, g = cases["denoise_bwd_res"], golden("denoise_bwd_res")
     be = U.backend_for(c)
     inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
     ge = np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32)
     be.zero_grad()
-    gx, gc = be.denoise_once_backward(U.cu(inp["x_T"]), U.cu(inp["timesteps"]), U.cu(inp["cond"]), U.cu(ge), "naive_fp32")
-    errs = {"grad_x": _rel(gx.cpu().numpy(), g["grad_x"]), "grad_cond": _rel(gc.cpu().numpy()[:, :8], g["grad_cond_ch0_8"]),
-            "grad_cond_sum": _rel(gc.double().sum(dim=(0, 2, 3)).cpu().numpy(), g["grad_cond_chan_sum"])}
+    gx, gc = be.denoise_once_backward(U.cu(inp["x_T"]), U.cu(inp["timesteps"]), U.cu(inp["cond"]), U.cu(ge), prec)
+    errs = {"grad_x": _rel(gx.cpu().numpy(), g["grad_x"], prec), "grad_cond": _rel(gc.cpu().numpy()[:, :8], g["grad_cond_ch0_8"], prec),
+            "grad_cond_sum": _rel(gc.double().sum(dim=(0, 2, 3)).cpu().numpy(), g["grad_cond_chan_sum"], prec)}
     for k in list(g):
         if not k.startswith("grad.model.") or k.endswith((".rows", ".sums")):
             continue
@@ -53,14 +63,15 @@ def test_backward_matches_reference_autograd_golden(U, golden, cases):
             assert float(np.abs(full).sum()) == pytest.approx(float(np.abs(got).sum()), rel=1e-6)      # no other row touched
         else:
             got = be.grad(name).cpu().numpy()
-        errs[name] = _rel(got, g[k])
-    U.record("bwd_golden", **{k.replace("model.", ""): v for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if v > TOL}
+        errs[name] = _rel(got, g[k], prec)
+    U.record("bwd_golden", prec=prec, **{k.replace("model.", ""): v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v > TOL[prec]}
     assert not bad, bad
 
 
+@pytest.mark.parametrize("prec", ["naive_fp32", "fp32", "bf16"])
 @pytest.mark.parametrize("B,h,w,tt", [(1, 9, 33, [500]), (3, 16, 20, [7, 7, 999])])
-def test_backward_matches_torch_port_autograd(U, cases, B, h, w, tt):
+def test_backward_matches_torch_port_autograd(U, cases, B, h, w, tt, prec):
     from oracle import torch_cpu_port as P
     c = cases["denoise_bwd_res"]
     be = U.backend_for(c)
@@ -70,12 +81,12 @@ def test_backward_matches_torch_port_autograd(U, cases, B, h, w, tt):
     t = torch.tensor(tt)
     _, rgx, rgc, rgrads = P.denoiser_vjp(sd, inp["x_T"], t, inp["cond"], ge)
     be.zero_grad()
-    gx, gc = be.denoise_once_backward(U.cu(inp["x_T"]), t.cuda(), U.cu(inp["cond"]), U.cu(ge), "naive_fp32")
-    errs = {"grad_x": _rel(gx.cpu().numpy(), rgx.numpy()), "grad_cond": _rel(gc.cpu().numpy(), rgc.numpy())}
+    gx, gc = be.denoise_once_backward(U.cu(inp["x_T"]), t.cuda(), U.cu(inp["cond"]), U.cu(ge), prec)
+    errs = {"grad_x": _rel(gx.cpu().numpy(), rgx.numpy(), prec), "grad_cond": _rel(gc.cpu().numpy(), rgc.numpy(), prec)}
     for name, ref in rgrads.items():
-        errs[name] = _rel(be.grad(name).cpu().numpy(), ref.numpy())
-    U.record("bwd_port", B=B, h=h, w=w, **{k.replace("model.", ""): v for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if v > TOL}
+        errs[name] = _rel(be.grad(name).cpu().numpy(), ref.numpy(), prec)
+    U.record("bwd_port", prec=prec, B=B, h=h, w=w, **{k.replace("model.", ""): v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v > TOL[prec]}
     assert not bad, bad
 
 
@@ -94,5 +105,27 @@ def test_gradients_accumulate_and_clear(U, cases):
     assert _rel(g3, 3.0 * g1) < 1e-5
     be.zero_grad()
     assert float(be.grad("model.pred.0.weight").abs().max()) == 0.0
-    with pytest.raises(RuntimeError, match="unfused fp32"):
-        be.denoise_once_backward(*args, U.cu(ge), "bf16")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        be.denoise_once_backward(inp_cpu := torch.from_numpy(inp["x_T"]), torch.tensor([321]), torch.from_numpy(inp["cond"]), torch.from_numpy(ge))
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_mfma_wgrad_equals_unfused_wgrad(U, cases, prec):
+    """dd_wgrad.hip (MFMA, transposed LDS images, fp32 atomics) against the one-thread-per-weight kernel on the SAME 16-bit
+    operands: only the summation order differs.  Ragged size (tiles overhang the image), batch 2, all four layer shapes."""
+    c = cases["denoise_bwd_res"]
+    be = U.backend_for(c)
+    inp = synth.make_inputs(17, 2, 19, 45)
+    ge = np.random.RandomState(2).standard_normal(inp["x_T"].shape).astype(np.float32)
+    args = (U.cu(inp["x_T"]), torch.tensor([100, 900]).cuda(), U.cu(inp["cond"]), U.cu(ge), prec)
+    names = ["model.noise_embedding.0.weight", "model.noise_embedding.3.weight", "model.pred.0.weight", "model.pred.3.weight"]
+    be.zero_grad(); be.denoise_once_backward(*args)
+    fast = {n: be.grad(n).cpu().numpy() for n in names}
+    be.set_option("naive_wgrad", 1)
+    try:
+        be.zero_grad(); be.denoise_once_backward(*args)
+        slow = {n: be.grad(n).cpu().numpy() for n in names}
+    finally:
+        be.set_option("naive_wgrad", 0)
+    for n in names:
+        assert _rel(fast[n], slow[n]) < 2e-5, n
