@@ -95,7 +95,7 @@ struct Plan {
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
   DevBuf bX, bA1, bF, bA3; // fused backward: the four convs' input activations, materialised for the weight gradients
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
-  DevBuf dgb;              // backward: per (sample, channel) sums [B][256][2] doubles (dbeta, dgamma terms)
+  DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
@@ -1141,7 +1141,7 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   if (!pl->gA.p) {
     DD_HIP(pl->gA.alloc(px * COND_C * 4));
     DD_HIP(pl->gY.alloc(px * COND_C * 4));
-    DD_HIP(pl->dgb.alloc((size_t)B * COND_C * 2 * sizeof(double)));
+    DD_HIP(pl->dgb.alloc((size_t)B * COND_C * 4 * sizeof(double)));
     if (!naive) {
       DD_HIP(pl->bX.alloc(px * LATENT_C * es));
       DD_HIP(pl->bA1.alloc(px * HID_C * es));
@@ -1170,6 +1170,11 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
     const DevBuf* as[3] = {&pl->bA1, &pl->bF, &pl->bA3};
     for (int l = 0; l < 3; ++l) {
       const int C = kCouts[l];
+      if (ek != EK_F32) {
+        DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l]->p, ek, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
+                                           nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond->p : nullptr, h->emb.as<float>(), tv, 0, 1, B, C, HW, s));
+        continue;
+      }
       const ActView yv{ys[l]->p, ek, 1, C, HW}, av{as[l]->p, ek, 1, C, HW};
       const ActView cv = (l == 1) ? ActView{pl->cond->p, ek, 1, C, HW} : nothing;
       DD_HIP(launch_gn_bwd_apply(nothing, yv, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(), pl->dgb.as<double>(),
@@ -1189,14 +1194,26 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
     const ActView yv{ybuf[l]->p, ek_y, lay, C, HW}, gav{pl->gA.p, (l == 3) ? (int)EK_F32 : ek_g, lay, C, HW}, gyv{pl->gY.p, ek_g, lay, C, HW};
     const float* gamma = h->L[l].gamma.as<float>();
     const float* beta = h->L[l].beta.as<float>();
-    DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
-    DD_HIP(launch_gn_bwd_reduce(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, s));
-    DD_HIP(launch_gn_bwd_apply(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), gyv, nothing, nothing, nullptr, nullptr, 0, 0, B, s));
     float* dgam = grad_buf(h, std::string(kGnNames[l]) + ".weight", C, s, &e); DD_HIP(e);
     float* dbet = grad_buf(h, std::string(kGnNames[l]) + ".bias", C, s, &e); DD_HIP(e);
-    DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
     float* dbias = grad_buf(h, std::string(kConvNames[l]) + ".bias", C, s, &e); DD_HIP(e);
-    DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
+    // 16-bit channel-blocked tensors (layers 0..2 of the fused bf16 / f16 modes): vectorised kernels, one pass for all sums
+    const bool vec = !naive && ek != EK_F32 && l < 3;
+    if (vec) {
+      DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 4 * sizeof(double), s));
+      DD_HIP(launch_gn_bwd_reduce_blocked(pl->gA.p, ybuf[l]->p, ek, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, C, HW, s));
+      DD_HIP(launch_gn_bwd_apply_blocked(pl->gA.p, ybuf[l]->p, ek, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), pl->gY.p, nullptr,
+                                         nullptr, nullptr, nullptr, 0, 0, B, C, HW, s));
+      float* demb = nullptr;
+      if (l == 1) { demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e); }
+      DD_HIP(launch_gn_param_grad4(pl->dgb.as<double>(), pl->stat_ptr(0, l), gamma, dgam, dbet, dbias, demb, tv, 0, 1, B, C, HW, s));
+    } else {
+      DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
+      DD_HIP(launch_gn_bwd_reduce(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, s));
+      DD_HIP(launch_gn_bwd_apply(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), gyv, nothing, nothing, nullptr, nullptr, 0, 0, B, s));
+      DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
+      DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
+    }
     float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e); DD_HIP(e);
     const ActView inv{inbuf[l], ek_g, lay, CI, HW};
     if (!naive && ek != EK_F32 && !h->naive_wgrad) DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, ek, C, CI, B, lat_h, lat_w, s));
@@ -1216,9 +1233,14 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
     if (l == 2) {
       // gA = dLoss/df, f = relu(gn2(y2)) + cond + E[t]  (reference ...res.py:330-340): the same gradient reaches cond, E[t] and a2
       const ActView gf{pl->gA.p, ek_g, lay, COND_C, HW};
-      if (grad_cond) DD_HIP(launch_view_to_nchw(gf, grad_cond, B, 0, s));
-      float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e);
-      DD_HIP(launch_channel_sum(gf, demb, tv, 0, 1, B, s));
+      if (grad_cond) {
+        if (!naive && ek != EK_F32) DD_HIP(launch_blocked_to_nchw(pl->gA.p, ek, grad_cond, B, COND_C, lat_h, lat_w, s));
+        else DD_HIP(launch_view_to_nchw(gf, grad_cond, B, 0, s));
+      }
+      if (naive || ek == EK_F32) {     // (16-bit modes: the layer-1 reduction pass below also sums g_f per channel)
+        float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e);
+        DD_HIP(launch_channel_sum(gf, demb, tv, 0, 1, B, s));
+      }
     }
     if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   }

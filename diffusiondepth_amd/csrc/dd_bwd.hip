@@ -183,6 +183,196 @@ hipError_t launch_channel_sum(const ActView& v, float* out, const long long* row
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Vectorised forms for the fused path's channel-blocked 2-byte tensors (C = 64 / 256): a thread owns one 16-byte piece
+// (8 channels) of a pixel, 4 threads cover a 32-channel block of that pixel, consecutive lanes = consecutive addresses.
+// grid (pixel slabs, C / 32, B), 256 threads = 64 pixels x 4 pieces per pass.
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) { Piece<EK>::unpack(v, f); }
+
+// per (b, c):  out[0] += sum g_z,  out[1] += sum g_z * yh,  out[2] += sum y  (for the analytic conv-bias gradient),
+// out[3] += sum g_a (unmasked: the time-embedding gradient when g_a is dLoss/df)
+template <int EK>
+__global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16_t* __restrict__ ga, const uint16_t* __restrict__ y,
+                                                                    const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, double* __restrict__ out, int C,
+                                                                    long long HW, int slab) {
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS];
+  __shared__ float s_red[64][4][33];                       // [pixel lane][sum kind][channel of the block] (+1 pad)
+  const int tid = threadIdx.x;
+  const long long b = blockIdx.z;
+  const int cb = blockIdx.y;
+  if (tid < GN_GROUPS) group_moments(stats, b, tid, (double)HW * (C / GN_GROUPS), s_mean[tid], s_rstd[tid]);
+  __syncthreads();
+  const int q = tid & 3, pl = tid >> 2;
+  const int c0 = cb * ACT_CB + q * 8;
+  const int grp = c0 / (C / GN_GROUPS);                    // 8 channels never straddle a group (C/4 >= 16)
+  const float mean = s_mean[grp], rstd = s_rstd[grp];
+  float gm[8], bt[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { gm[k] = gamma[c0 + k]; bt[k] = beta[c0 + k]; }
+  float a0[8], a1[8], a2[8], a3[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a0[k] = 0.f; a1[k] = 0.f; a2[k] = 0.f; a3[k] = 0.f; }
+  const size_t base = ((size_t)b * (C / ACT_CB) + cb) * HW * ACT_CB + q * 8;
+  const long long p0 = (long long)blockIdx.x * slab, p1 = min(p0 + slab, HW);
+  for (long long p = p0 + pl; p < p1; p += 64) {
+    const uint4 gv = *reinterpret_cast<const uint4*>(ga + base + (size_t)p * ACT_CB);
+    const uint4 yv = *reinterpret_cast<const uint4*>(y + base + (size_t)p * ACT_CB);
+    float g[8], yy[8];
+    unpack8<EK>(gv, g); unpack8<EK>(yv, yy);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float yh = (yy[k] - mean) * rstd;
+      const float gz = fmaf(gm[k], yh, bt[k]) > 0.f ? g[k] : 0.f;
+      a0[k] += gz; a1[k] = fmaf(gz, yh, a1[k]); a2[k] += yy[k]; a3[k] += g[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s_red[pl][0][q * 8 + k] = a0[k]; s_red[pl][1][q * 8 + k] = a1[k]; s_red[pl][2][q * 8 + k] = a2[k]; s_red[pl][3][q * 8 + k] = a3[k]; }
+  __syncthreads();
+  if (tid < 128) {                                         // (kind, channel): sum the 64 pixel lanes in fp64
+    const int kind = tid >> 5, c = tid & 31;
+    double t = 0.0;
+    for (int l = 0; l < 64; ++l) t += (double)s_red[l][kind][c];
+    atomicAdd(out + ((size_t)b * C + cb * ACT_CB + c) * 4 + kind, t);
+  }
+}
+hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+                                        double* out_bc4, int B, int C, long long HW, hipStream_t s) {
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16)) return hipErrorInvalidValue;
+  const int slab = 1024;                                   // 16 passes of 64 pixels: fp32 partials of <= 16 values per thread
+  dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
+  if (ek == EK_BF16) hipLaunchKernelGGL(gn_bwd_reduce_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
+                                        reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
+  else hipLaunchKernelGGL(gn_bwd_reduce_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
+                          reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
+  return hipGetLastError();
+}
+
+// g_y = A_c g_z + P_g + Q_g y   with A_c = gamma_c rstd_g,  Q_g = -rstd^2 S2/N,  P_g = -rstd S1/N - mean Q_g  (the same
+// expression as gn_bwd_apply_kernel, regrouped);  optional  act = relu(A_c y + B_c) [+ cond + E[t]].   sums: [b][c][4].
+template <int EK>
+__global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_t* __restrict__ ga, const uint16_t* __restrict__ y,
+                                                                   const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const double* __restrict__ sums,
+                                                                   uint16_t* __restrict__ gy, uint16_t* __restrict__ act,
+                                                                   const uint16_t* __restrict__ cond, const float* __restrict__ emb,
+                                                                   const long long* __restrict__ tvec, int t_base, int t_bstride, int C,
+                                                                   long long HW, int slab) {
+  __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS], s_p[GN_GROUPS], s_q[GN_GROUPS];
+  const int tid = threadIdx.x;
+  const long long b = blockIdx.z;
+  const int cb = blockIdx.y;
+  const int CG = C / GN_GROUPS;
+  if (tid < GN_GROUPS) {
+    float mean, rstd;
+    group_moments(stats, b, tid, (double)HW * CG, mean, rstd);
+    double s1 = 0.0, s2 = 0.0;
+    if (gy) {
+      for (int c = tid * CG; c < (tid + 1) * CG; ++c) {
+        s1 += (double)gamma[c] * sums[((size_t)b * C + c) * 4];
+        s2 += (double)gamma[c] * sums[((size_t)b * C + c) * 4 + 1];
+      }
+    }
+    const double inv_n = 1.0 / ((double)HW * CG);
+    const float qg = -(rstd * rstd) * (float)(s2 * inv_n);
+    s_mean[tid] = mean; s_rstd[tid] = rstd;
+    s_q[tid] = qg;
+    s_p[tid] = -rstd * (float)(s1 * inv_n) - mean * qg;
+  }
+  __syncthreads();
+  const int q = tid & 3, pl = tid >> 2;
+  const int c0 = cb * ACT_CB + q * 8;
+  const int grp = c0 / CG;
+  const float mean = s_mean[grp], rstd = s_rstd[grp], pg = s_p[grp], qg = s_q[grp];
+  float ta[8], tb[8], te[8];
+  const long long t = tvec ? tvec[t_base + b * t_bstride] : 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    ta[k] = gamma[c0 + k] * rstd;
+    tb[k] = beta[c0 + k] - ta[k] * mean;
+    te[k] = (cond && emb) ? emb[(size_t)t * C + c0 + k] : 0.f;
+  }
+  const size_t base = ((size_t)b * (C / ACT_CB) + cb) * HW * ACT_CB + q * 8;
+  const long long p0 = (long long)blockIdx.x * slab, p1 = min(p0 + slab, HW);
+  for (long long p = p0 + pl; p < p1; p += 64) {
+    const size_t off = base + (size_t)p * ACT_CB;
+    float yy[8];
+    unpack8<EK>(*reinterpret_cast<const uint4*>(y + off), yy);
+    if (gy) {
+      float g[8], o[8];
+      unpack8<EK>(*reinterpret_cast<const uint4*>(ga + off), g);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float gz = fmaf(ta[k], yy[k], tb[k]) > 0.f ? g[k] : 0.f;
+        o[k] = fmaf(ta[k], gz, fmaf(qg, yy[k], pg));
+      }
+      *reinterpret_cast<uint4*>(gy + off) = Piece<EK>::pack(o);
+    }
+    if (act) {
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaf(ta[k], yy[k], tb[k]), 0.f);
+      if (cond) {
+        float cv[8];
+        unpack8<EK>(*reinterpret_cast<const uint4*>(cond + off), cv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = o[k] + (cv[k] + te[k]);
+      }
+      *reinterpret_cast<uint4*>(act + off) = Piece<EK>::pack(o);
+    }
+  }
+}
+hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+                                       const double* sums_bc4, void* gy, void* act, const void* cond, const float* emb,
+                                       const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s) {
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16)) return hipErrorInvalidValue;
+  const int slab = 512;
+  dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
+  auto U16 = [](const void* p) { return reinterpret_cast<const uint16_t*>(p); };
+  if (ek == EK_BF16) hipLaunchKernelGGL(gn_bwd_apply_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
+                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
+  else hipLaunchKernelGGL(gn_bwd_apply_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
+                          reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
+  return hipGetLastError();
+}
+
+// Parameter gradients of one layer from the per (b, c) sums [B][C][4] of gn_bwd_reduce_blocked_kernel:
+//   dbeta_c += sum_b s0,  dgamma_c += sum_b s1,  dbias_c += sum_b sum_p g_y = sum_b (A_c s0 + HW P_g + Q_g s2)   (g_y as above),
+//   demb[t_b][c] += s3 (only when demb != NULL).
+__global__ void gn_param_grad4_kernel(const double* __restrict__ sums, const double* __restrict__ stats, const float* __restrict__ gamma,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ demb,
+                                      const long long* __restrict__ tvec, int t_base, int t_bstride, int B, int C, long long HW) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int CG = C / GN_GROUPS, grp = c / CG;
+  double sb = 0.0, sg = 0.0, sbias = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double* sc = sums + ((size_t)b * C + c) * 4;
+    sb += sc[0]; sg += sc[1];
+    float mean, rstd;
+    group_moments(stats, b, grp, (double)HW * CG, mean, rstd);
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = grp * CG; k < (grp + 1) * CG; ++k) { s1 += (double)gamma[k] * sums[((size_t)b * C + k) * 4]; s2 += (double)gamma[k] * sums[((size_t)b * C + k) * 4 + 1]; }
+    const double inv_n = 1.0 / ((double)HW * CG);
+    const double qg = -(double)rstd * rstd * s2 * inv_n;
+    const double pg = -(double)rstd * s1 * inv_n - (double)mean * qg;
+    sbias += (double)gamma[c] * rstd * sc[0] + (double)HW * pg + qg * sc[2];
+    if (demb) atomicAdd(demb + (size_t)tvec[t_base + b * t_bstride] * C + c, (float)sc[3]);
+  }
+  dbeta[c] += (float)sb;
+  dgamma[c] += (float)sg;
+  dbias[c] += (float)sbias;
+}
+hipError_t launch_gn_param_grad4(const double* sums_bc4, const double* stats, const float* gamma, float* dgamma, float* dbeta, float* dbias,
+                                 float* demb, const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s) {
+  hipLaunchKernelGGL(gn_param_grad4_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums_bc4, stats, gamma, dgamma, dbeta, dbias, demb, tvec,
+                     t_base, t_bstride, B, C, HW);
+  return hipGetLastError();
+}
+
 // dgamma_c += sum_b dgb[b][c][1],  dbeta_c += sum_b dgb[b][c][0]
 __global__ void gn_param_grad_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -122,6 +122,14 @@ hipError_t launch_gn_bwd_reduce(const ActView& ga, const ActView& y, const doubl
 hipError_t launch_gn_bwd_apply(const ActView& ga, const ActView& y, const double* stats, const float* gamma, const float* beta,
                                const double* dgb, const ActView& gy, const ActView& act, const ActView& cond, const float* emb,
                                const long long* tvec, int t_base, int t_bstride, int B, hipStream_t s);
+// vectorised forms for channel-blocked bf16 / f16 tensors with C = 64 / 256; sums are [B][C][4] doubles (see dd_bwd.hip)
+hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+                                        double* out_bc4, int B, int C, long long HW, hipStream_t s);
+hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+                                       const double* sums_bc4, void* gy, void* act, const void* cond, const float* emb,
+                                       const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s);
+hipError_t launch_gn_param_grad4(const double* sums_bc4, const double* stats, const float* gamma, float* dgamma, float* dbeta, float* dbias,
+                                 float* demb, const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s);
 hipError_t launch_channel_sum(const ActView& v, float* out, const long long* rows, int t_base, int t_bstride, int B, hipStream_t s);
 hipError_t launch_gn_param_grad(const double* dgb, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
 hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oihw, int B, int h, int w, hipStream_t s);
