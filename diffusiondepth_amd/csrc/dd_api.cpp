@@ -148,6 +148,7 @@ struct dd_handle_s {
   int wave_spec = 0;          // use the wave-specialised kernels (dd_igemm2ws.hip) where they exist.  Correct (tested);
                               // measured on MI355X at B=4: conv3 179 -> 209 us (slower), Swin pred.0 131 -> 123 us (faster): off by default
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
+  DevBuf wgrad_ws;            // per-slab partial weight gradients of dd_wgrad.hip
   std::map<std::string, std::unique_ptr<DevBuf>> grads;   // parameter gradients (fp32, reference shapes), accumulated like torch .grad
   std::map<std::tuple<int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
@@ -1216,7 +1217,11 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
     }
     float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e); DD_HIP(e);
     const ActView inv{inbuf[l], ek_g, lay, CI, HW};
-    if (!naive && ek != EK_F32 && !h->naive_wgrad) DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, ek, C, CI, B, lat_h, lat_w, s));
+    if (!naive && ek != EK_F32 && !h->naive_wgrad) {
+      const size_t need = wgrad_workspace_bytes(C, CI, B, lat_h, lat_w);
+      if (h->wgrad_ws.bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws.alloc(need)); }
+      DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, h->wgrad_ws.as<float>(), ek, C, CI, B, lat_h, lat_w, s));
+    }
     else DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));     // fp32 operands: the unfused kernel (parity modes)
     // dgrad: g_in = conv3x3(g_y, W^T flipped): C -> CI channels
     if (naive) {

@@ -134,7 +134,8 @@ hipError_t launch_channel_sum(const ActView& v, float* out, const long long* row
 hipError_t launch_gn_param_grad(const double* dgb, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
 hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oihw, int B, int h, int w, hipStream_t s);
 // MFMA weight gradient (dd_wgrad.hip), bf16 / f16 operands in the activation layouts, fp32 atomics into dw [CO][CI][3][3]
-hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, int ek, int CO, int CI, int B, int h, int w, hipStream_t s);
+size_t wgrad_workspace_bytes(int CO, int CI, int B, int h, int w);     // per-slab partial sums
+hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, float* workspace, int ek, int CO, int CI, int B, int h, int w, hipStream_t s);
 hipError_t launch_view_copy(const ActView& src, const ActView& dst, int B, hipStream_t s);
 hipError_t launch_view_to_nchw(const ActView& v, float* dst, int B, int accumulate, hipStream_t s);
 
