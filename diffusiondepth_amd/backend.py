@@ -18,7 +18,7 @@ VARIANTS = {"res": 0, "swin": 1}
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_commit_weights",
-    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_once", "dd_denoise_once_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
+    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
     "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch",
 ]
 
@@ -61,6 +61,7 @@ def load_library():
         "dd_denoise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_denoise_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_zero_grad": (c_int, [c_vp, c_vp]),
         "dd_get_grad": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
         "dd_add_noise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
@@ -303,6 +304,24 @@ class HipDenoiser:
                 self._h, x_t.data_ptr(), t.data_ptr(), cond.data_ptr(), grad_eps.data_ptr(),
                 gx.data_ptr() if gx is not None else None, gc.data_ptr() if gc is not None else None,
                 B, h, w, cond.shape[2], cond.shape[3], precision_id(precision), _stream_ptr(self.device)), "dd_denoise_once_backward")
+        self._cond_token = None
+        return gx, gc
+
+    def denoise_backward(self, x_T, cond, grad_x0, num_inference_steps: int, precision="naive_fp32", need_grad_xT=False, need_grad_cond=True):
+        """Backward of the whole DDIM loop (autograd through ``self.pipeline(...)`` in the reference's training step):
+        returns (grad_xT, grad_cond); parameter gradients accumulate in the handle."""
+        torch = _torch()
+        x_T = _check_tensor(x_T, "x_T", dtype=torch.float32)
+        cond = _check_tensor(cond, "cond", dtype=torch.float32)
+        grad_x0 = _check_tensor(grad_x0, "grad_x0", x_T.shape, torch.float32)
+        B, C, h, w = x_T.shape
+        gx = torch.empty_like(x_T) if need_grad_xT else None
+        gc = torch.empty_like(cond) if need_grad_cond else None
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_denoise_backward(
+                self._h, x_T.data_ptr(), cond.data_ptr(), grad_x0.data_ptr(), gx.data_ptr() if gx is not None else None,
+                gc.data_ptr() if gc is not None else None, B, h, w, cond.shape[2], cond.shape[3], int(num_inference_steps),
+                precision_id(precision), _stream_ptr(self.device)), "dd_denoise_backward")
         self._cond_token = None
         return gx, gc
 

@@ -94,6 +94,7 @@ struct Plan {
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
   DevBuf bX, bA1, bF, bA3; // fused backward: the four convs' input activations, materialised for the weight gradients
+  DevBuf xstash;           // loop backward: the T states entering each step + the running gradient, fp32 NHWC16
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
@@ -959,7 +960,7 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
     }
     if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   }
-  if (cond_out) DD_HIP(launch_blocked_to_nchw(cbuf->p, ek, cond_out, B, COND_C, feat_h[0], feat_w[0], s));
+  if (cond_out) DD_HIP(launch_blocked_to_nchw(cbuf->p, ek, cond_out, B, COND_C, feat_h[0], feat_w[0], 0, s));
   h->fpn_cond = cbuf;
   h->fpn_cond_key[0] = B; h->fpn_cond_key[1] = feat_h[0]; h->fpn_cond_key[2] = feat_w[0]; h->fpn_cond_key[3] = precision;
   return DD_OK;
@@ -1120,72 +1121,66 @@ int dd_get_grad(dd_handle_t h, const char* name, float* dst, int64_t numel, void
   return DD_OK;
 }
 
-int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, const float* grad_eps,
-                             float* grad_x, float* grad_cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
-                             int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
-  if (rc) return rc;
-  if (!x_t || !t || !grad_eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: null pointer");
-  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: DD_VARIANT_RES only");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: unknown precision");
-  const bool naive = precision == DD_PREC_NAIVE_FP32;
-  if (!naive && h->kernel_version != 2) return h->fail(DD_ERR_UNSUPPORTED, "dd_denoise_once_backward: the fused path needs kernel_version 2");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  DD_HIP(hipSetDevice(h->device));
-  Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version, 0}, &pl);
-  if (rc) return rc;
-  const long long HW = (long long)lat_h * lat_w;
-  const size_t px = (size_t)B * HW;
-  const int ek = pl->ek;
-  const size_t es = ek_size(ek);
-  if (!pl->gA.p) {
-    DD_HIP(pl->gA.alloc(px * COND_C * 4));
-    DD_HIP(pl->gY.alloc(px * COND_C * 4));
-    DD_HIP(pl->dgb.alloc((size_t)B * COND_C * 4 * sizeof(double)));
-    if (!naive) {
-      DD_HIP(pl->bX.alloc(px * LATENT_C * es));
-      DD_HIP(pl->bA1.alloc(px * HID_C * es));
-      DD_HIP(pl->bF.alloc(px * COND_C * es));
-      DD_HIP(pl->bA3.alloc(px * HID_C * es));
-    }
+namespace {
+
+int ensure_bwd_buffers(dd_handle_t h, Plan* pl) {
+  if (pl->gA.p) return DD_OK;
+  const size_t px = (size_t)pl->key.B * pl->key.h * pl->key.w;
+  const size_t es = ek_size(pl->ek);
+  DD_HIP(pl->gA.alloc(px * COND_C * 4));
+  DD_HIP(pl->gY.alloc(px * COND_C * 4));
+  DD_HIP(pl->dgb.alloc((size_t)pl->key.B * COND_C * 4 * sizeof(double)));
+  if (pl->key.prec != DD_PREC_NAIVE_FP32) {
+    DD_HIP(pl->bX.alloc(px * LATENT_C * es));
+    DD_HIP(pl->bA1.alloc(px * HID_C * es));
+    DD_HIP(pl->bF.alloc(px * COND_C * es));
+    DD_HIP(pl->bA3.alloc(px * HID_C * es));
   }
-  const long long* tv = reinterpret_cast<const long long*>(t);
-  // ---- recompute the forward pass: y1..y4 and the GroupNorm sums (and, unfused, a1 / f / a3) stay in the plan ----
-  DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
-  if (rc) return rc;
-  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  return DD_OK;
+}
+
+// Backward of one epsilon-network evaluation at state x (fp32 NHWC, device), timesteps tv[t_base + b * t_bstride], with the
+// condition map already staged in the plan.  On entry pl->gA holds dLoss/deps (fp32 NHWC16); on exit it holds dLoss/dx
+// (fp32 NHWC16).  Recomputes the forward pass (GroupNorm sums in stat slot 0), accumulates the parameter gradients into
+// h->grads, writes (or accumulates) dLoss/dcond as NCHW fp32 into grad_cond when that is not NULL.
+int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, int t_base, int t_bstride, float* grad_cond,
+             int accumulate_cond, hipStream_t s) {
+  const int B = pl->key.B, lat_h = pl->key.h, lat_w = pl->key.w, precision = pl->key.prec;
+  const bool naive = precision == DD_PREC_NAIVE_FP32;
+  const long long HW = (long long)lat_h * lat_w;
+  const int ek = pl->ek;
+  int rc = DD_OK;
+  DD_HIP(hipMemsetAsync(pl->stat_ptr(0, 0), 0, (size_t)4 * B * STAT_SLOTS * STAT_STRIDE * sizeof(double), s));
   const int lay = naive ? 0 : 1;                    // activation layout flag of the views: plain NHWC fp32 / channel-blocked
   const ActView nothing{nullptr, EK_F32, 0, 1, HW};
   if (naive) {
-    rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);
+    rc = enqueue_naive_eps(h, pl, 0, x_nhwc, tv, t_base, t_bstride, s);
     if (rc) return rc;
   } else {
-    rc = enqueue_fused_step(h, pl, 0, pl->x[0].as<float>(), pl->x[1].as<float>(), false, tv, 0, 1, s);
+    rc = enqueue_fused_step(h, pl, 0, x_nhwc, pl->x[1].as<float>(), false, tv, t_base, t_bstride, s);
     if (rc) return rc;
     // the convs' input activations in the kernels' own element kind: x, a1 = relu(gn1(y1)), f = relu(gn2(y2)) + cond + E[t],
     // a3 = relu(gn3(y3))  (the weight gradients contract the conv-output gradients with these)
-    DD_HIP(launch_view_copy(ActView{pl->x[0].p, EK_F32, 0, LATENT_C, HW}, ActView{pl->bX.p, ek, 0, LATENT_C, HW}, B, s));
+    DD_HIP(launch_view_copy(ActView{x_nhwc, EK_F32, 0, LATENT_C, HW}, ActView{pl->bX.p, ek, 0, LATENT_C, HW}, B, s));
     const DevBuf* ys[3] = {&pl->y1, &pl->y2, &pl->y3};
     const DevBuf* as[3] = {&pl->bA1, &pl->bF, &pl->bA3};
     for (int l = 0; l < 3; ++l) {
       const int C = kCouts[l];
       if (ek != EK_F32) {
         DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l]->p, ek, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
-                                           nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond->p : nullptr, h->emb.as<float>(), tv, 0, 1, B, C, HW, s));
+                                           nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond->p : nullptr, h->emb.as<float>(), tv, t_base,
+                                           t_bstride, B, C, HW, s));
         continue;
       }
       const ActView yv{ys[l]->p, ek, 1, C, HW}, av{as[l]->p, ek, 1, C, HW};
       const ActView cv = (l == 1) ? ActView{pl->cond->p, ek, 1, C, HW} : nothing;
       DD_HIP(launch_gn_bwd_apply(nothing, yv, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(), pl->dgb.as<double>(),
-                                 nothing, av, cv, h->emb.as<float>(), tv, 0, 1, B, s));
+                                 nothing, av, cv, h->emb.as<float>(), tv, t_base, t_bstride, B, s));
     }
   }
   // ---- backward, last layer first ----
-  DD_HIP(launch_nchw_to_nhwc(grad_eps, pl->gA.p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   const DevBuf* ybuf[4] = {&pl->y1, &pl->y2, &pl->y3, &pl->y4};
-  const void* inbuf[4] = {naive ? pl->x[0].p : pl->bX.p, naive ? pl->a1.p : pl->bA1.p, naive ? pl->f.p : pl->bF.p,
+  const void* inbuf[4] = {naive ? (const void*)x_nhwc : pl->bX.p, naive ? pl->a1.p : pl->bA1.p, naive ? pl->f.p : pl->bF.p,
                           naive ? pl->a3.p : pl->bA3.p};                     // the conv's input activation
   hipError_t e = hipSuccess;
   for (int l = 3; l >= 0; --l) {
@@ -1207,7 +1202,7 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
                                          nullptr, nullptr, nullptr, 0, 0, B, C, HW, s));
       float* demb = nullptr;
       if (l == 1) { demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e); }
-      DD_HIP(launch_gn_param_grad4(pl->dgb.as<double>(), pl->stat_ptr(0, l), gamma, dgam, dbet, dbias, demb, tv, 0, 1, B, C, HW, s));
+      DD_HIP(launch_gn_param_grad4(pl->dgb.as<double>(), pl->stat_ptr(0, l), gamma, dgam, dbet, dbias, demb, tv, t_base, t_bstride, B, C, HW, s));
     } else {
       DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
       DD_HIP(launch_gn_bwd_reduce(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, s));
@@ -1221,8 +1216,9 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
       const size_t need = wgrad_workspace_bytes(C, CI, B, lat_h, lat_w);
       if (h->wgrad_ws.bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws.alloc(need)); }
       DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, h->wgrad_ws.as<float>(), ek, C, CI, B, lat_h, lat_w, s));
+    } else {
+      DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));     // fp32 operands: the unfused kernel (parity modes)
     }
-    else DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));     // fp32 operands: the unfused kernel (parity modes)
     // dgrad: g_in = conv3x3(g_y, W^T flipped): C -> CI channels
     if (naive) {
       DD_HIP(launch_naive_conv3x3(pl->gY.as<float>(), h->L[l].wT_oihw.as<float>(), nullptr, pl->gA.as<float>(), B, lat_h, lat_w, C, CI, s));
@@ -1239,21 +1235,105 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
       // gA = dLoss/df, f = relu(gn2(y2)) + cond + E[t]  (reference ...res.py:330-340): the same gradient reaches cond, E[t] and a2
       const ActView gf{pl->gA.p, ek_g, lay, COND_C, HW};
       if (grad_cond) {
-        if (!naive && ek != EK_F32) DD_HIP(launch_blocked_to_nchw(pl->gA.p, ek, grad_cond, B, COND_C, lat_h, lat_w, s));
-        else DD_HIP(launch_view_to_nchw(gf, grad_cond, B, 0, s));
+        if (!naive && ek != EK_F32) DD_HIP(launch_blocked_to_nchw(pl->gA.p, ek, grad_cond, B, COND_C, lat_h, lat_w, accumulate_cond, s));
+        else DD_HIP(launch_view_to_nchw(gf, grad_cond, B, accumulate_cond, s));
       }
       if (naive || ek == EK_F32) {     // (16-bit modes: the layer-1 reduction pass below also sums g_f per channel)
         float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e);
-        DD_HIP(launch_channel_sum(gf, demb, tv, 0, 1, B, s));
+        DD_HIP(launch_channel_sum(gf, demb, tv, t_base, t_bstride, B, s));
       }
     }
     if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   }
-  if (grad_x) {
-    const ActView gx{pl->gA.p, EK_F32, 0, LATENT_C, HW};
-    DD_HIP(launch_view_to_nchw(gx, grad_x, B, 0, s));
-  }
+  return DD_OK;
+}
+
+int check_bwd(dd_handle_t h, int precision, const char* who) {
+  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_RES only");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
+  if (precision != DD_PREC_NAIVE_FP32 && h->kernel_version != 2) return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": the fused path needs kernel_version 2");
+  return DD_OK;
+}
+
+}  // namespace
+
+int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, const float* grad_eps,
+                             float* grad_x, float* grad_cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
+                             int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  if (rc) return rc;
+  if (!x_t || !t || !grad_eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: null pointer");
+  rc = check_bwd(h, precision, "dd_denoise_once_backward");
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  Plan* pl = nullptr;
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version, 0}, &pl);
+  if (rc) return rc;
+  rc = ensure_bwd_buffers(h, pl);
+  if (rc) return rc;
+  DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  if (rc) return rc;
+  DD_HIP(launch_nchw_to_nhwc(grad_eps, pl->gA.p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  rc = bwd_core(h, pl, pl->x[0].as<float>(), reinterpret_cast<const long long*>(t), 0, 1, grad_cond, 0, s);
+  if (rc) return rc;
+  if (grad_x) DD_HIP(launch_nhwc_to_nchw_f32(pl->gA.p, EK_F32, grad_x, B, LATENT_C, lat_h, lat_w, 0, s));
   h->last_once_plan = pl;
+  return DD_OK;
+}
+
+int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
+                        int B, int lat_h, int lat_w, int cond_h, int cond_w, int T, int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  if (rc) return rc;
+  if (!x_T || !grad_x0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: null pointer");
+  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: num_inference_steps must be in [1, num_train_timesteps]");
+  rc = check_bwd(h, precision, "dd_denoise_backward");
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  Plan* pl = nullptr;
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version, 0}, &pl);
+  if (rc) return rc;
+  rc = ensure_bwd_buffers(h, pl);
+  if (rc) return rc;
+  const bool naive = precision == DD_PREC_NAIVE_FP32;
+  const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
+  if (pl->xstash.bytes < (size_t)(T + 1) * n16 * 4) DD_HIP(pl->xstash.alloc((size_t)(T + 1) * n16 * 4));
+  float* X = pl->xstash.as<float>();                 // X[k] = state entering step k (k < T); X[T] = running dLoss/dx
+  float* G = X + (size_t)T * n16;
+  const long long* ts = pl->tsteps.as<long long>();
+  // ---- forward loop again, keeping every intermediate state (16 channels: T x 6.8 MB per KITTI image) ----
+  DD_HIP(launch_nchw_to_nhwc(x_T, X, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  if (rc) return rc;
+  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  for (int k = 0; k + 1 < T; ++k) {                  // the last step's epsilon is recomputed by its backward pass
+    if (naive) {
+      rc = enqueue_naive_eps(h, pl, k, X + (size_t)k * n16, ts, k, 0, s);
+      if (rc) return rc;
+      DD_HIP(launch_naive_axpby(X + (size_t)k * n16, pl->eps.as<float>(), pl->c1c2.as<float>(), k, X + (size_t)(k + 1) * n16, (long long)n16, s));
+    } else {
+      // conv1 of step k applies the update of step k-1 (reads X[k-1], y4 of step k-1) and writes X[k]
+      rc = enqueue_fused_step(h, pl, k, (k == 0) ? X : X + (size_t)(k - 1) * n16, X + (size_t)k * n16, k > 0, ts, k, 0, s);
+      if (rc) return rc;
+    }
+  }
+  if (!naive && T > 1) {
+    // X[T-1] = update of step T-2 applied to X[T-2]: the fused path does that inside the NEXT step's conv1
+    rc = enqueue_fused_step(h, pl, T - 1, X + (size_t)(T - 2) * n16, X + (size_t)(T - 1) * n16, true, ts, T - 1, 0, s);
+    if (rc) return rc;
+  }
+  // ---- backward through the chain x_{k+1} = c1_k x_k + c2_k eps(x_k, t_k, cond) ----
+  DD_HIP(launch_nchw_to_nhwc(grad_x0, G, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  for (int k = T - 1; k >= 0; --k) {
+    DD_HIP(launch_bwd_chain(G, pl->gA.as<float>(), pl->c1c2.as<float>(), k, 0, (long long)n16, s));          // gA = c2_k G
+    rc = bwd_core(h, pl, X + (size_t)k * n16, ts, k, 0, grad_cond, k < T - 1 ? 1 : 0, s);
+    if (rc) return rc;
+    DD_HIP(launch_bwd_chain(G, pl->gA.as<float>(), pl->c1c2.as<float>(), k, 1, (long long)n16, s));          // G = c1_k G + gA
+  }
+  if (grad_xT) DD_HIP(launch_nhwc_to_nchw_f32(G, EK_F32, grad_xT, B, LATENT_C, lat_h, lat_w, 0, s));
   return DD_OK;
 }
 

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(ActView ga, ActView 
 hipError_t launch_gn_bwd_reduce(const ActView& ga, const ActView& y, const double* stats, const float* gamma, const float* beta,
                                 double* out_bc2, int B, hipStream_t s) {
   if (256 % y.C != 0) return hipErrorInvalidValue;
-  const int slab = 2048;
+  const int slab = (y.C <= 16) ? 256 : 2048;            // 16-channel tensors: 16 pixel lanes per block, keep the grid large
   dim3 grid((unsigned)((y.HW + slab - 1) / slab), (unsigned)B);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, grid, dim3(256), 0, s, ga, y, stats, gamma, beta, out_bc2, slab);
   return hipGetLastError();
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(ActView v, float* __re
 }
 hipError_t launch_channel_sum(const ActView& v, float* out, const long long* rows, int t_base, int t_bstride, int B, hipStream_t s) {
   if (256 % v.C != 0) return hipErrorInvalidValue;
-  const int slab = 2048;
+  const int slab = (v.C <= 16) ? 256 : 2048;
   dim3 grid((unsigned)((v.HW + slab - 1) / slab), (unsigned)B);
   hipLaunchKernelGGL(channel_sum_kernel, grid, dim3(256), 0, s, v, out, rows, t_base, t_bstride, slab);
   return hipGetLastError();
@@ -418,6 +418,17 @@ hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oih
   const int rows_per_slab = 16;
   dim3 grid((unsigned)((n + 255) / 256), (unsigned)((B * h + rows_per_slab - 1) / rows_per_slab));
   hipLaunchKernelGGL(naive_wgrad_kernel, grid, dim3(256), 0, s, gy, a, dw_oihw, h, w, B, rows_per_slab);
+  return hipGetLastError();
+}
+
+__global__ void bwd_chain_kernel(float* __restrict__ g, float* __restrict__ ga, const float* __restrict__ c1c2, int k, int mode, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 0) ga[i] = c1c2[2 * k + 1] * g[i];
+  else g[i] = fmaf(c1c2[2 * k], g[i], ga[i]);
+}
+hipError_t launch_bwd_chain(float* g, float* ga, const float* c1c2, int k, int mode, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(bwd_chain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, ga, c1c2, k, mode, n);
   return hipGetLastError();
 }
 

@@ -86,7 +86,7 @@ hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C
 // channel-blocked activation layout (reference ...swin_addHAHI.py:332: F.interpolate(..., mode='bilinear', align_corners=True))
 hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s);
 // channel-blocked activations -> NCHW fp32 (tiled through LDS), and adaptive_avg_pool2d on channel-blocked activations
-hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s);
+hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, int accumulate, hipStream_t s);
 hipError_t launch_adaptive_pool_blocked(const void* src, void* dst, int ek, int B, int C, int ih, int iw, int oh, int ow, hipStream_t s);
 // bilinear upsample (align_corners=True) between two channel-blocked tensors (Swin condition map kept in the handle)
 hipError_t launch_upsample_blocked(const void* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s);
@@ -136,6 +136,8 @@ hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oih
 // MFMA weight gradient (dd_wgrad.hip), bf16 / f16 operands in the activation layouts, fp32 atomics into dw [CO][CI][3][3]
 size_t wgrad_workspace_bytes(int CO, int CI, int B, int h, int w);     // per-slab partial sums
 hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, float* workspace, int ek, int CO, int CI, int B, int h, int w, hipStream_t s);
+// chain rule of x_{k+1} = c1_k x_k + c2_k eps: mode 0: ga = c2_k * g;  mode 1: g = c1_k * g + ga   (c1c2 = [T][2] device table)
+hipError_t launch_bwd_chain(float* g, float* ga, const float* c1c2, int k, int mode, long long n, hipStream_t s);
 hipError_t launch_view_copy(const ActView& src, const ActView& dst, int B, hipStream_t s);
 hipError_t launch_view_to_nchw(const ActView& v, float* dst, int B, int accumulate, hipStream_t s);
 

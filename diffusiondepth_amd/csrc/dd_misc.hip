@@ -236,7 +236,7 @@ hipError_t launch_nhwc_to_nchw_f32(const void* src, int ek, float* dst, int B, i
 // writes are 256-B runs along pixels of one channel plane.
 // ------------------------------------------------------------------------------------------------
 template <int EK>
-__global__ void __launch_bounds__(256) blocked_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst, int C, long long HW) {
+__global__ void __launch_bounds__(256) blocked_to_nchw_kernel(const void* __restrict__ src, float* __restrict__ dst, int C, long long HW, int accumulate) {
   __shared__ float tile[64][65];
   const int b = blockIdx.z;
   const long long p0 = (long long)blockIdx.x * 64;
@@ -275,16 +275,19 @@ __global__ void __launch_bounds__(256) blocked_to_nchw_kernel(const void* __rest
 #pragma unroll 4
   for (int cc = 0; cc < 16; ++cc) {
     const int c = cc * 4 + cs;
-    if (c0 + c < C) d[(size_t)(c0 + c) * HW + p0 + px] = tile[px][c];
+    if (c0 + c < C) {
+      float* o = d + (size_t)(c0 + c) * HW + p0 + px;
+      *o = accumulate ? *o + tile[px][c] : tile[px][c];
+    }
   }
 }
-hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, hipStream_t s) {
+hipError_t launch_blocked_to_nchw(const void* src, int ek, float* dst, int B, int C, int h, int w, int accumulate, hipStream_t s) {
   if (C % ACT_CB != 0) return hipErrorInvalidValue;
   const long long HW = (long long)h * w;
   dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
-  if (ek == EK_F32) hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW);
-  else if (ek == EK_BF16) hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW);
-  else hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW);
+  if (ek == EK_F32) hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW, accumulate);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW, accumulate);
+  else hipLaunchKernelGGL(blocked_to_nchw_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW, accumulate);
   return hipGetLastError();
 }
 

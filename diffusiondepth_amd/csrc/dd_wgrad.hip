@@ -191,8 +191,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   const int n = 9 * CO * CI;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;          // index into [tap][co][ci]: consecutive threads = consecutive ci
   if (i >= n) return;
-  float acc = 0.f;
-  for (int sl = 0; sl < slabs; ++sl) acc += part[(size_t)sl * n + i];
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;          // four independent chains: the loads of a chain are issued together
+  int sl = 0;
+  for (; sl + 4 <= slabs; sl += 4) {
+    a0 += part[(size_t)sl * n + i]; a1 += part[(size_t)(sl + 1) * n + i];
+    a2 += part[(size_t)(sl + 2) * n + i]; a3 += part[(size_t)(sl + 3) * n + i];
+  }
+  for (; sl < slabs; ++sl) a0 += part[(size_t)sl * n + i];
+  const float acc = (a0 + a1) + (a2 + a3);
   const int ci = i % CI, co = (i / CI) % CO, tap = i / (CI * CO);
   dw[((size_t)co * CI + ci) * 9 + tap] += acc;
 }

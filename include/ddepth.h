@@ -134,10 +134,20 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
  * Parameter gradients ACCUMULATE inside the handle (like Tensor.grad) under the state-dict names of dd_set_weight
  * ("model.pred.0.weight", "model.time_embedding.weight", ...) in the reference's own shapes; dd_get_grad copies one to a
  * caller DEVICE buffer, dd_zero_grad clears all.  The forward pass is recomputed internally (no stash from
- * dd_denoise_once is needed).  DD_VARIANT_RES; precision: DD_PREC_NAIVE_FP32 (unfused fp32 kernels) so far. */
+ * dd_denoise_once is needed).  DD_VARIANT_RES.  precision: naive_fp32 = unfused fp32 kernels (cross-check); fp32 / bf16 / f16 =
+ * data gradients on the fused convolution kernels (transposed, flipped weights), weight gradients on the matrix cores
+ * (bf16 / f16; the fp32 mode keeps the unfused weight-gradient kernel), GroupNorm backward fused into two passes per layer. */
 int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, const float* grad_eps,
                              float* grad_x, float* grad_cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
                              int precision, void* stream);
+/* Backward of the whole T-step loop (what autograd does for  refined_depth_t = self.pipeline(...)  in the reference's
+ * training step: the loop output is NOT detached, the depth losses back-propagate through all T denoiser calls,
+ * ...res.py:124-169).  Given grad_x0 = dLoss/dx_0 (B,16,h,w) it re-runs the forward loop keeping the T
+ * intermediate states (16 channels each), then walks the chain x_{k+1} = c1_k x_k + c2_k eps(x_k, t_k, cond) backwards,
+ * recomputing each step's activations instead of stashing them:
+ *   grad_xT (B,16,h,w) or NULL;  grad_cond (B,256,h,w) = sum over the T steps, or NULL;  parameter gradients accumulate. */
+int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
+                        int B, int lat_h, int lat_w, int cond_h, int cond_w, int num_inference_steps, int precision, void* stream);
 int dd_zero_grad(dd_handle_t h, void* stream);
 int dd_get_grad(dd_handle_t h, const char* name, float* dst, int64_t numel, void* stream);
 

@@ -106,3 +106,20 @@ def denoiser_vjp(sd, x, t, cond, grad_eps, variant="res"):
     eps = denoiser(full, x, t, cond, variant)
     eps.backward(torch.as_tensor(grad_eps))
     return eps.detach(), x.grad, cond.grad, {k: v.grad for k, v in params.items() if v.grad is not None}
+
+
+def ddim_loop_vjp(sd, x_T, cond, grad_x0, T=20, n_train=1000, variant="res"):
+    """Autograd through the whole T-step loop (the reference trains through it: the pipeline output is not detached,
+    ...res.py:124-169).  Returns (x_0, grad_xT, grad_cond, {name: grad})."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("model.")}
+    full = dict(sd)
+    full.update(params)
+    acp = make_alphas_cumprod(n_train)
+    x = torch.as_tensor(x_T).clone().requires_grad_(True)
+    cond = torch.as_tensor(cond).clone().requires_grad_(True)
+    cur = x
+    for t in timesteps(T, n_train):
+        eps = denoiser(full, cur, int(t), cond, variant)
+        cur = ddim_step(acp, eps, int(t), cur, n_train // T)
+    cur.backward(torch.as_tensor(grad_x0))
+    return cur.detach(), x.grad, cond.grad, {k: v.grad for k, v in params.items() if v.grad is not None}

@@ -16,6 +16,7 @@ Cases (all eval mode, fp32, torch CPU):
   codec          DeepDepthTransformWithUpsampling.t / inv_t (even and odd sizes)
   head_res       full DDIMDepthEstimate_Res.forward (FPN + loop + decoder + ddim_loss), RNG injected
   denoise_bwd_res  autograd of ScheduledCNNRefine.forward (g_x, g_cond, all parameter gradients) for a seeded upstream gradient
+  loop_bwd_res   autograd through the whole T-step CNNDDIMPipiline for a seeded dLoss/dx_0
   fpn_odd        the head's condition FPN (conv_lateral / conv_up / adaptive_avg_pool2d) on an odd-sized pyramid
 """
 from __future__ import annotations
@@ -145,6 +146,42 @@ def gen_denoise_bwd(ref, name):
     return out
 
 
+def gen_loop_bwd(ref, name):
+    """Autograd through the reference's CNNDDIMPipiline (the loop output is not detached in training, ...res.py:124-169):
+    dLoss/dcond, dLoss/dx_T and parameter gradients for a seeded dLoss/dx_0."""
+    c = CASES[name]
+    sd, model, codec, sched = build(ref, c)
+    pipe = ref.CNNDDIMPipiline(model, sched)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    cond = torch.from_numpy(inp["cond"]).requires_grad_(True)
+    xT = torch.from_numpy(inp["x_T"]).requires_grad_(True)
+    g = torch.from_numpy(np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32))
+    model.zero_grad()
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: xT                     # the pipeline's own draw (...res.py:277) returns OUR leaf tensor
+    try:
+        x0, = pipe(batch_size=c["B"], device=torch.device("cpu"), dtype=torch.float32, shape=(16, c["h"], c["w"]),
+                   input_args=(cond, None, None, None), num_inference_steps=c["T"], return_dict=False)
+    finally:
+        torch.randn = real_randn
+    x0.backward(g)
+    out = {"x0": t2n(x0), "grad_xT": t2n(xT.grad), "grad_cond_ch0_8": t2n(cond.grad)[:, :8],
+           "grad_cond_chan_sum": cond.grad.double().sum(dim=(0, 2, 3)).numpy()}
+    for k, v in model.state_dict(keep_vars=True).items():
+        if v.grad is None:
+            continue
+        gnp = t2n(v.grad)
+        if k == "time_embedding.weight":
+            rows = sorted(set(int(t) for t in sched.timesteps))
+            out["grad.model." + k + ".rows"] = np.array(rows, dtype=np.int64)
+            out["grad.model." + k] = gnp[rows]
+        elif gnp.size > 20000:
+            out["grad.model." + k + ".stride7"] = gnp.reshape(-1)[::7].copy()
+        else:
+            out["grad.model." + k] = gnp
+    return out
+
+
 def gen_loop(ref, name):
     c = CASES[name]
     sd, model, codec, sched = build(ref, c)
@@ -243,6 +280,7 @@ def main():
         "denoise_res": lambda: gen_denoise(ref, "denoise_res"),
         "denoise_swin": lambda: gen_denoise(ref, "denoise_swin"),
         "denoise_bwd_res": lambda: gen_denoise_bwd(ref, "denoise_bwd_res"),
+        "loop_bwd_res": lambda: gen_loop_bwd(ref, "loop_bwd_res"),
         "loop_res": lambda: gen_loop(ref, "loop_res"),
         "loop_res_far": lambda: gen_loop(ref, "loop_res_far"),
         "loop_swin": lambda: gen_loop(ref, "loop_swin"),

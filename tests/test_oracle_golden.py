@@ -214,3 +214,28 @@ def test_torch_port_denoiser_vjp_matches_reference_autograd(golden, cases):
         else:
             got = grads[name].numpy()
         assert np.abs(got - g[k]).max() <= 5e-5 * max(1e-6, np.abs(g[k]).max()), name
+
+
+def test_torch_port_loop_vjp_matches_reference_autograd(golden, cases):
+    """Differentiable loop of the torch port (loop-backward oracle) vs autograd through the reference's CNNDDIMPipiline."""
+    from oracle import torch_cpu_port as P
+    c, g = cases["loop_bwd_res"], golden("loop_bwd_res")
+    sd = P.to_torch_sd(synth.make_state_dict(c["wseed"], "res"))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    ge = np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32)
+    x0, gx, gc, grads = P.ddim_loop_vjp(sd, inp["x_T"], inp["cond"], ge, T=c["T"])
+    rel = lambda a, b: float(np.abs(np.asarray(a) - b).max() / max(1e-12, np.abs(b).max()))
+    assert rel(x0.numpy(), g["x0"]) < 1e-5
+    assert rel(gx.numpy(), g["grad_xT"]) < 1e-4
+    assert rel(gc.numpy()[:, :8], g["grad_cond_ch0_8"]) < 1e-4
+    for k in list(g):
+        if not k.startswith("grad.model.") or k.endswith(".rows"):
+            continue
+        name = k[len("grad."):]
+        if name.endswith(".stride7"):
+            got = grads[name[:-len(".stride7")]].numpy().reshape(-1)[::7]
+        elif name == "model.time_embedding.weight":
+            got = grads[name].numpy()[g[k + ".rows"]]
+        else:
+            got = grads[name].numpy()
+        assert rel(got, g[k]) < 2e-4, name
