@@ -86,6 +86,62 @@ class UpSample_add(nn.Module):
         self.convB = _ConvModule(output_features, output_features)
 
 
+_PARAM_ORDER = list(HipDenoiser.PARAM_SHAPES)          # "model.<name>" in the order the Functions below return gradients
+
+
+def _ordered_params(model: nn.Module):
+    named = dict(model.named_parameters())
+    return [named[n[len("model."):]] for n in _PARAM_ORDER]
+
+
+class _DenoiseOnceFn(torch.autograd.Function):
+    """autograd node of one epsilon-network call: forward dd_denoise_once, backward dd_denoise_once_backward (what
+    loss.backward() sends through ``self.model(...)`` in the reference's training step, …res.py:211, src/main.py:232-241)."""
+
+    @staticmethod
+    def forward(ctx, be, precision, x, t, cond, *params):
+        ctx.be, ctx.precision = be, precision
+        ctx.save_for_backward(x, t, cond)
+        return be.denoise_once(x, t, cond, precision)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t, cond = ctx.saved_tensors
+        be = ctx.be
+        be.zero_grad()
+        gx, gc = be.denoise_once_backward(x, t, cond, g.contiguous().float(), ctx.precision,
+                                          need_grad_x=ctx.needs_input_grad[2], need_grad_cond=ctx.needs_input_grad[4])
+        grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_PARAM_ORDER)]
+        return (None, None, gx, None, gc, *grads)
+
+
+class _DenoiseLoopFn(torch.autograd.Function):
+    """autograd node of the whole T-step loop: forward dd_denoise (one hipGraph), backward dd_denoise_backward (the reference
+    does not detach the loop output: its depth losses back-propagate through all T calls, …res.py:124-169)."""
+
+    @staticmethod
+    def forward(ctx, be, precision, T, x_T, cond, *params):
+        ctx.be, ctx.precision, ctx.T = be, precision, T
+        ctx.save_for_backward(x_T, cond)
+        return be.denoise(x_T, cond, T, precision)
+
+    @staticmethod
+    def backward(ctx, g):
+        x_T, cond = ctx.saved_tensors
+        be = ctx.be
+        be.zero_grad()
+        gx, gc = be.denoise_backward(x_T, cond, g.contiguous().float(), ctx.T, ctx.precision,
+                                     need_grad_xT=ctx.needs_input_grad[3], need_grad_cond=ctx.needs_input_grad[4])
+        grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_PARAM_ORDER)]
+        return (None, None, None, gx, gc, *grads)
+
+
+def _wants_grad(model: nn.Module, *tensors) -> bool:
+    """Record an autograd node?  Yes in .train() mode or when an input carries gradient, under enabled grad mode (an .eval()
+    module fed plain tensors runs the bare kernels even outside torch.no_grad())."""
+    return torch.is_grad_enabled() and (model.training or any(t is not None and t.requires_grad for t in tensors))
+
+
 class ScheduledCNNRefine(nn.Module):
     """epsilon-network: same constructor and parameter tree as the reference (…res.py:300-322; with
     variant="swin" the tree of …swin_addHAHI.py:336-362, i.e. plus ``upsample_fuse.conv{A,B}.conv``)."""
@@ -119,6 +175,15 @@ class ScheduledCNNRefine(nn.Module):
         feat = args[0]
         be = self.bound.ensure(noisy_image.device)
         t = torch.as_tensor(t, device=noisy_image.device)
+        if _wants_grad(self, noisy_image, feat):
+            if self.variant != "res":
+                raise NotImplementedError("the HIP backward is built for the Res denoiser (SURVEY.md 8f rank 2); wrap the Swin "
+                                          "variant in torch.no_grad() or train it with the PyTorch modules")
+            tt = t.to(torch.int64).reshape(-1)
+            if tt.numel() == 1 and noisy_image.shape[0] > 1:
+                tt = tt.expand(noisy_image.shape[0])
+            return _DenoiseOnceFn.apply(be, self.precision, noisy_image.float().contiguous(), tt.contiguous(), feat.float().contiguous(),
+                                        *_ordered_params(self))
         return be.denoise_once(noisy_image.float(), t, feat.float(), self.precision)
 
 
@@ -140,7 +205,11 @@ class CNNDDIMPipiline:
         why_not = self.scheduler.hip_supported(eta)
         if why_not is None:
             be = self.model.bound.ensure(image.device, self.scheduler)
-            image = be.denoise(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
+            if _wants_grad(self.model, image, input_args[0]) and self.model.variant == "res":
+                image = _DenoiseLoopFn.apply(be, self.model.precision, int(num_inference_steps), image.float().contiguous(),
+                                             input_args[0].float().contiguous(), *_ordered_params(self.model)).to(dtype)
+            else:
+                image = be.denoise(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
         else:
             for t in self.scheduler.timesteps:
                 model_output = self.model(image, t.to(device), *input_args)
@@ -161,9 +230,9 @@ def _conv_bn_relu(ch_in, ch_out, kernel, stride=1, padding=0, bn=True, relu=True
 
 
 class DeepDepthTransformWithUpsampling(nn.Module):
-    """Latent encoder t() / decoder inv_t() (reference depth_transform.py:10-35).  Eval-mode
-    BatchNorm (running statistics) is what the HIP kernels implement; train-mode batch statistics
-    (SyncBN in the reference's training) are out of this round's scope and raise."""
+    """Latent encoder t() / decoder inv_t() (reference depth_transform.py:10-35).  Eval-mode BatchNorm (running statistics)
+    is what the HIP kernels implement; in .train() mode (batch statistics, autograd into the codec weights) the same torch
+    modules run in PyTorch-ROCm -- the codec is ~1 GFLOP per image."""
 
     def __init__(self, hidden: int = 16, eps: float = 1e-6, bound: Optional[HipBound] = None):
         super().__init__()
@@ -178,15 +247,15 @@ class DeepDepthTransformWithUpsampling(nn.Module):
         self.bound = bound if bound is not None else HipBound("res")
         self.bound.register("depth_transform.", self)
 
-    def _check_mode(self):
-        if self.training:
-            raise NotImplementedError("DeepDepthTransformWithUpsampling HIP kernels implement eval-mode BatchNorm only; "
-                                      "call .eval() (training backward is a later row of SURVEY.md 8f)")
+    def _torch_path(self, x) -> bool:
+        return self.training or (torch.is_grad_enabled() and x.requires_grad)
 
     def t(self, depth):
-        self._check_mode()
+        if self._torch_path(depth):
+            return self.conv_transform(depth)                                        # depth_transform.py:29-31
         return self.bound.ensure(depth.device).encode(depth.float())
 
     def inv_t(self, value):
-        self._check_mode()
+        if self._torch_path(value):
+            return 1.0 / self.conv_inv_transform(value).clamp(self.eps) - 1          # depth_transform.py:33-35
         return self.bound.ensure(value.device).decode(value.float())

@@ -200,3 +200,49 @@ def test_loop_backward_t1_equals_single_call(U, cases):
     assert _rel(gc_loop.cpu().numpy(), gc_once.cpu().numpy()) < 1e-5
     assert _rel(w_loop, w_once) < 1e-5
     assert _rel(gx_loop.cpu().numpy(), (c1 * g + gx_once).cpu().numpy()) < 1e-5
+
+
+def test_autograd_through_head_modules_matches_torch_port(U, cases):
+    """loss.backward() through the drop-in modules (ScheduledCNNRefine + CNNDDIMPipiline in .train() mode, fp32 kernels):
+    parameter .grad, cond.grad and the loss value against torch autograd of the CPU port on the same tensors -- the wiring
+    the reference's training step relies on (…res.py:124-169, 201-217; src/main.py:232-241)."""
+    import diffusiondepth_amd as dda
+    from oracle import torch_cpu_port as P
+    c = cases["loop_bwd_res"]
+    sd = synth.make_state_dict(c["wseed"], "res")
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    T = c["T"]
+    # reference side (CPU, torch autograd): loss = sum(w * x_0) + mse(eps(x_q, t), noise)
+    wts = torch.from_numpy(np.random.RandomState(3).standard_normal(inp["x_T"].shape).astype(np.float32))
+    sdt = P.to_torch_sd(sd)
+    params = {k: v.clone().requires_grad_(True) for k, v in sdt.items() if k.startswith("model.")}
+    full = dict(sdt); full.update(params)
+    cond_r = torch.from_numpy(inp["cond"]).clone().requires_grad_(True)
+    acp = P.make_alphas_cumprod()
+    cur = torch.from_numpy(inp["x_T"])
+    for t in P.timesteps(T):
+        cur = P.ddim_step(acp, P.denoiser(full, cur, int(t), cond_r), int(t), cur, 1000 // T)
+    tq = torch.from_numpy(inp["timesteps"])
+    eps_q = P.denoiser(full, torch.from_numpy(inp["noise"]), tq, cond_r)
+    loss_r = (wts * cur).sum() + torch.nn.functional.mse_loss(eps_q, torch.from_numpy(inp["noise"]))
+    loss_r.backward()
+    # product side
+    model = dda.ScheduledCNNRefine(precision="fp32")
+    model.load_state_dict({k[len("model."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("model.")})
+    model = model.cuda().train()
+    sched = dda.DDIMScheduler()
+    pipe = dda.CNNDDIMPipiline(model, sched)
+    cond = U.cu(inp["cond"]).requires_grad_(True)
+    x0, = pipe(batch_size=c["B"], device=cond.device, dtype=torch.float32, shape=(16, c["h"], c["w"]), input_args=(cond, None, None, None),
+               num_inference_steps=T, return_dict=False, x_T=U.cu(inp["x_T"]))
+    eps = model(U.cu(inp["noise"]), U.cu(inp["timesteps"]), cond, None, None, None)
+    loss = (wts.cuda() * x0).sum() + torch.nn.functional.mse_loss(eps, U.cu(inp["noise"]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-4 * abs(float(loss_r.detach()))
+    errs = {"cond": _rel(cond.grad.cpu().numpy(), cond_r.grad.numpy())}
+    named = dict(model.named_parameters())
+    for k, v in params.items():
+        errs[k] = _rel(named[k[len("model."):]].grad.cpu().numpy(), v.grad.numpy())
+    U.record("autograd_modules", **{k.replace("model.", ""): v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v > 5e-3}
+    assert not bad, bad
