@@ -17,6 +17,7 @@ Cases (all eval mode, fp32, torch CPU):
   head_res       full DDIMDepthEstimate_Res.forward (FPN + loop + decoder + ddim_loss), RNG injected
   denoise_bwd_res  autograd of ScheduledCNNRefine.forward (g_x, g_cond, all parameter gradients) for a seeded upstream gradient
   loop_bwd_res   autograd through the whole T-step CNNDDIMPipiline for a seeded dLoss/dx_0
+  head_train_res one training-mode forward + backward of the whole reference head (loss, sampled gradients)
   fpn_odd        the head's condition FPN (conv_lateral / conv_up / adaptive_avg_pool2d) on an odd-sized pyramid
 """
 from __future__ import annotations
@@ -271,6 +272,38 @@ def gen_fpn(ref):
             "shape": np.array(x.shape, dtype=np.int64)}
 
 
+def gen_head_train(ref):
+    """One training-mode forward + backward of the reference head (BatchNorm on batch statistics in the FPN and the codec,
+    autograd through the T-step loop and ddim_loss; RNG draws injected): loss value and a sample of parameter gradients."""
+    c = CASES["head_train_res"]
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    fsd = synth.make_fpn_state_dict(c["fseed"])
+    head = ref.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=c["T"], num_train_timesteps=1000,
+                                     depth_feature_dim=16, loss_cfgs=[]).train()
+    own = head.state_dict()
+    full = {k: torch.from_numpy(v) for k, v in {**sd, **fsd}.items()}
+    for k in own:
+        if k.endswith("num_batches_tracked"):
+            full[k] = own[k]
+    head.load_state_dict(full, strict=True)
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [torch.from_numpy(f).requires_grad_(True) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+    with inject_rng([inp["x_T"], inp["noise"]], [inp["timesteps"]]):
+        o = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+        loss = (o["pred"] - gt).abs().mean() + o["ddim_loss"]
+    loss.backward()
+    out = {"loss": np.array([float(loss)]), "ddim_loss": np.array([float(o["ddim_loss"])]), "pred": t2n(o["pred"]),
+           "grad_fp3": t2n(fp[3].grad), "grad_fp0_ch0_4": t2n(fp[0].grad)[:, :4]}
+    for k in c["grad_keys"]:
+        p = dict(head.named_parameters())[k]
+        gnp = t2n(p.grad)
+        out["grad." + k] = gnp.reshape(-1)[::c["grad_stride"]].copy() if gnp.size > 5000 else gnp
+    return out
+
+
 def main():
     ref = load_reference()
     torch.manual_seed(0)
@@ -287,6 +320,7 @@ def main():
         "codec": lambda: gen_codec(ref),
         "head_res": lambda: gen_head(ref),
         "fpn_odd": lambda: gen_fpn(ref),
+        "head_train_res": lambda: gen_head_train(ref),
     }
     only = sys.argv[1:]
     for name, fn in gens.items():

@@ -246,3 +246,51 @@ def test_autograd_through_head_modules_matches_torch_port(U, cases):
     U.record("autograd_modules", **{k.replace("model.", ""): v for k, v in errs.items()})
     bad = {k: v for k, v in errs.items() if v > 5e-3}
     assert not bad, bad
+
+
+def test_head_training_step_matches_reference_golden(U, golden, cases):
+    """One training-mode step of the drop-in head (BatchNorm on batch statistics in the PyTorch-ROCm FPN / codec, the DDIM
+    loop and ddim_loss through the HIP forward AND backward, RNG draws injected) against the same step of the reference head
+    run under autograd on CPU (head_train_res.npz): loss, prediction, gradients w.r.t. the backbone features and a sample of
+    parameter gradients from every part of the head.  Tolerance 1e-2 of max per tensor (ReLU ties, see module docstring;
+    MIOpen vs oneDNN convolutions in the torch-side FPN / codec), loss 1e-4."""
+    import diffusiondepth_amd as dda
+    c, g = cases["head_train_res"], golden("head_train_res")
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    head = dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=c["T"], num_train_timesteps=1000,
+                                     depth_feature_dim=16, loss_cfgs=[], precision="fp32")
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected
+    head = head.cuda().train()
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [U.cu(f).requires_grad_(True) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+    draws = [U.cu(inp["x_T"]), torch.from_numpy(inp["noise"])]
+    real_randn, real_randint = torch.randn, torch.randint
+    torch.randn = lambda *a, **k: draws.pop(0)
+    torch.randint = lambda *a, **k: U.cu(inp["timesteps"])
+    prev = torch.backends.cudnn.allow_tf32
+    torch.backends.cudnn.allow_tf32 = False
+    try:
+        out = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+        loss = (out["pred"] - gt).abs().mean() + out["ddim_loss"]
+        loss.backward()
+    finally:
+        torch.randn, torch.randint = real_randn, real_randint
+        torch.backends.cudnn.allow_tf32 = prev
+    lv = float(loss.detach())
+    assert abs(lv - float(g["loss"][0])) <= 1e-4 * abs(float(g["loss"][0]))
+    errs = {"pred": _rel(out["pred"].detach().cpu().numpy(), g["pred"]),
+            "grad_fp3": _rel(fp[3].grad.cpu().numpy(), g["grad_fp3"]), "grad_fp0": _rel(fp[0].grad.cpu().numpy()[:, :4], g["grad_fp0_ch0_4"])}
+    named = dict(head.named_parameters())
+    for k in c["grad_keys"]:
+        got = named[k].grad.cpu().numpy()
+        if got.size > 5000:
+            got = got.reshape(-1)[::c["grad_stride"]]
+        errs[k] = _rel(got, g["grad." + k])
+    U.record("head_train", loss=lv, **errs)
+    bad = {k: v for k, v in errs.items() if v > 1e-2}
+    assert not bad, bad
