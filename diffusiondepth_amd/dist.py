@@ -4,6 +4,9 @@ hipGraph.  What the reference does across ranks on this path (reference src/main
   * DistributedSampler shards the image indices by rank              -> shard_indices()
   * rank 0 loads the checkpoint, apex DDP broadcasts parameters      -> broadcast_state_dict()
   * metrics are only logged for rank 0's shard (no reduction)        -> reduce_sums() (we do reduce)
+  * training: apex DDP averages the gradients of all parameters      -> allreduce_gradients(): the ONE exchange step per
+    iteration, as a few large flat buckets -- xGMI is point-to-point (7 links x ~153 GB/s per GPU), ring
+    collectives are per-link bound, so bucket size is chosen for bandwidth (default 64 MiB), not for NVSwitch latency
 Backend 'nccl' == RCCL on ROCm (GPU tensors); 'gloo' on CPU is used by the tests.
 """
 from __future__ import annotations
@@ -49,6 +52,42 @@ def reduce_sums(sums: torch.Tensor) -> torch.Tensor:
         sums = sums.clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     return sums
+
+
+def allreduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = True) -> int:
+    """Averages .grad of `params` over all ranks (gradient all-reduce of data-parallel training, reference
+    src/main.py:106-114 via apex DDP).  Gradients are packed into flat buckets of ~bucket_bytes in parameter order (the
+    same order on every rank), one all_reduce per bucket, and unpacked in place.  Parameters without .grad contribute
+    zeros so that the collective sequence is identical on every rank.  Returns the number of collectives issued."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return 0
+    world = dist.get_world_size()
+    params = [p for p in params if p.requires_grad]
+    n_coll = 0
+    i = 0
+    while i < len(params):
+        j, nbytes = i, 0
+        while j < len(params) and (j == i or nbytes + params[j].numel() * 4 <= bucket_bytes):
+            nbytes += params[j].numel() * 4
+            j += 1
+        group = params[i:j]
+        dev = group[0].device
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in group]).to(dev)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        n_coll += 1
+        if average:
+            flat /= world
+        off = 0
+        for p in group:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        i = j
+    return n_coll
 
 
 def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0) -> Dict[str, torch.Tensor]:

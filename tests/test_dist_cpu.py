@@ -67,3 +67,31 @@ def test_two_rank_gloo_broadcast_and_metric_reduction(tmp_path):
     assert torch.allclose(tot, ref, rtol=1e-12, atol=0)
     m = ddist.finalize_metrics(tot)
     assert 0.05 < m["rmse"] < 0.2 and m["n"] > 0
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    ddist.init_from_env("gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(64, 16, 3, 3), (64,), (256, 64, 3, 3), (1280, 256), (16,)]]
+    for k, p in enumerate(params):
+        if k == 4 and rank == 1:
+            continue                                   # a parameter that received no gradient on this rank
+        p.grad = torch.full_like(p, float(rank + 1) * (k + 1))
+    n = ddist.allreduce_gradients(params, bucket_bytes=1 << 20)      # 1 MiB buckets -> several collectives
+    if rank == 0:
+        torch.save({"n": n, "g": [p.grad.clone() for p in params]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce(tmp_path):
+    """Bucketed gradient averaging (the one exchange step of data-parallel training): rank r holds grad = (r+1)(k+1) for
+    parameter k -> the average is 1.5 (k+1); the last parameter has a gradient on rank 0 only -> 2.5."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r["n"] >= 2
+    for k, g in enumerate(r["g"]):
+        want = 1.5 * (k + 1) if k < 4 else 2.5
+        assert torch.allclose(g, torch.full_like(g, want)), k
