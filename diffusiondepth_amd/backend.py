@@ -285,6 +285,17 @@ class HipDenoiser:
         "model.pred.4.weight": (16,), "model.pred.4.bias": (16,),
     }
 
+    SWIN_PARAM_SHAPES = {
+        "model.upsample_fuse.convA.conv.weight": (256, 256, 3, 3), "model.upsample_fuse.convA.conv.bias": (256,),
+        "model.upsample_fuse.convB.conv.weight": (256, 256, 3, 3), "model.upsample_fuse.convB.conv.bias": (256,),
+    }
+
+    def param_shapes(self):
+        d = dict(self.PARAM_SHAPES)
+        if self.variant == "swin":
+            d.update(self.SWIN_PARAM_SHAPES)
+        return d
+
     def denoise_once_backward(self, x_t, t, cond, grad_eps, precision="naive_fp32", need_grad_x=True, need_grad_cond=True):
         """VJP of one ScheduledCNNRefine.forward (what autograd computes for ``self.model(...)`` in the reference's
         training step): returns (grad_x, grad_cond); parameter gradients accumulate in the handle (``grads()``)."""
@@ -330,13 +341,13 @@ class HipDenoiser:
 
     def grad(self, name: str):
         torch = _torch()
-        out = torch.empty(self.PARAM_SHAPES[name], device=self.device, dtype=torch.float32)
+        out = torch.empty(self.param_shapes()[name], device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             self._ck(self._lib.dd_get_grad(self._h, name.encode(), out.data_ptr(), out.numel(), _stream_ptr(self.device)), f"dd_get_grad({name})")
         return out
 
     def grads(self):
-        return {k: self.grad(k) for k in self.PARAM_SHAPES}
+        return {k: self.grad(k) for k in self.param_shapes()}
 
     def add_noise(self, x0, noise, t):
         torch = _torch()

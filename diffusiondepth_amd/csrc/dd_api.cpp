@@ -684,6 +684,17 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
       int rc = upload(h, L.bias, b.data(), b.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
+      // backward: data gradient of a 256->256 conv = the convB kernel (layer 6: raw input, no norm) on W^T flipped
+      std::vector<float> wt(w.size());
+      for (int co = 0; co < COND_C; ++co)
+        for (int ci = 0; ci < COND_C; ++ci)
+          for (int k = 0; k < 9; ++k) wt[((size_t)ci * COND_C + co) * 9 + (8 - k)] = w[((size_t)co * COND_C + ci) * 9 + k];
+      for (int ek = 0; ek < NUM_EK; ++ek) {
+        std::vector<uint8_t> packed;
+        pack_conv_weights(wt.data(), conv_pack_geom2(6, ek), ek, true, packed);
+        rc = upload(h, L.wpackT[ek], packed.data(), packed.size(), s); if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
     }
   }
   if (do_model) {
@@ -1180,8 +1191,10 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   }
   // ---- backward, last layer first ----
   const DevBuf* ybuf[4] = {&pl->y1, &pl->y2, &pl->y3, &pl->y4};
-  const void* inbuf[4] = {naive ? (const void*)x_nhwc : pl->bX.p, naive ? pl->a1.p : pl->bA1.p, naive ? pl->f.p : pl->bF.p,
-                          naive ? pl->a3.p : pl->bA3.p};                     // the conv's input activation
+  const bool swin = h->variant == DD_VARIANT_SWIN;     // fused modes only (checked by the callers)
+  // the conv's input activation; Swin: pred.0 reads the raw convB output sf (and convB reads sa, convA reads bF = u)
+  const void* inbuf[4] = {naive ? (const void*)x_nhwc : pl->bX.p, naive ? pl->a1.p : pl->bA1.p,
+                          naive ? pl->f.p : (swin ? pl->sf.p : pl->bF.p), naive ? pl->a3.p : pl->bA3.p};
   hipError_t e = hipSuccess;
   for (int l = 3; l >= 0; --l) {
     const int C = kCouts[l], CI = kCins[l];
@@ -1231,10 +1244,41 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       q.in = pl->gY.p; q.wpack = h->L[l].wpackT[ek].p; q.bias = h->zero_bias.as<float>(); q.out = pl->gA.p;
       DD_HIP(launch_conv_igemm2(layer, ek, q, s));
     }
+    if (l == 2 && swin) {
+      // Swin fuse (reference ...swin_addHAHI.py:321-333,378): sf = convB(sa), sa = convA(u), u = relu(gn2(y2)) + up(cond) + E[t];
+      // no norm / activation in between.  gA = dLoss/dsf on entry, dLoss/du on exit (gY is the scratch in between).
+      const char* fuse[2] = {"model.upsample_fuse.convB.conv", "model.upsample_fuse.convA.conv"};
+      ConvLayer* FL[2] = {&h->LB, &h->LA};
+      const void* fin[2] = {pl->sa.p, pl->bF.p};           // convB's input, convA's input
+      void* gbuf[3] = {pl->gA.p, pl->gY.p, pl->gA.p};      // gradient w.r.t. sf -> sa -> u
+      for (int i = 0; i < 2; ++i) {
+        const ActView gout{gbuf[i], ek, 1, COND_C, HW}, fv{fin[i], ek, 1, COND_C, HW};
+        float* db = grad_buf(h, std::string(fuse[i]) + ".bias", COND_C, s, &e); DD_HIP(e);
+        float* dwf = grad_buf(h, std::string(fuse[i]) + ".weight", (size_t)COND_C * COND_C * 9, s, &e); DD_HIP(e);
+        if (ek != EK_F32) DD_HIP(launch_channel_sum_blocked(gbuf[i], ek, db, B, COND_C, HW, s));
+        else DD_HIP(launch_channel_sum(gout, db, nullptr, 0, 0, B, s));
+        if (ek != EK_F32 && !h->naive_wgrad) {
+          const size_t need = wgrad_workspace_bytes(COND_C, COND_C, B, lat_h, lat_w);
+          if (h->wgrad_ws.bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws.alloc(need)); }
+          DD_HIP(launch_wgrad_mfma(gbuf[i], fin[i], dwf, h->wgrad_ws.as<float>(), ek, COND_C, COND_C, B, lat_h, lat_w, s));
+        } else {
+          DD_HIP(launch_naive_wgrad(gout, fv, dwf, B, lat_h, lat_w, s));
+        }
+        ConvParams q{};
+        q.B = B; q.h = lat_h; q.w = lat_w;
+        q.tiles_x = (lat_w + 31) / 32;
+        q.tiles_y = (lat_h + conv_pack_geom2(6, ek).th - 1) / conv_pack_geom2(6, ek).th;
+        q.in = gbuf[i]; q.wpack = FL[i]->wpackT[ek].p; q.bias = h->zero_bias.as<float>(); q.out = gbuf[i + 1];
+        DD_HIP(launch_conv_igemm2(6, ek, q, s));
+      }
+    }
     if (l == 2) {
       // gA = dLoss/df, f = relu(gn2(y2)) + cond + E[t]  (reference ...res.py:330-340): the same gradient reaches cond, E[t] and a2
+      // (Swin: gA = dLoss/du and cond enters through the bilinear upsample, whose adjoint maps the gradient back to (ch, cw))
       const ActView gf{pl->gA.p, ek_g, lay, COND_C, HW};
-      if (grad_cond) {
+      if (grad_cond && swin) {
+        DD_HIP(launch_upsample_adjoint(pl->gA.p, ek, grad_cond, B, COND_C, pl->key.ch, pl->key.cw, lat_h, lat_w, accumulate_cond, s));
+      } else if (grad_cond) {
         if (!naive && ek != EK_F32) DD_HIP(launch_blocked_to_nchw(pl->gA.p, ek, grad_cond, B, COND_C, lat_h, lat_w, accumulate_cond, s));
         else DD_HIP(launch_view_to_nchw(gf, grad_cond, B, accumulate_cond, s));
       }
@@ -1249,7 +1293,8 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
 }
 
 int check_bwd(dd_handle_t h, int precision, const char* who) {
-  if (h->variant != DD_VARIANT_RES) return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_RES only");
+  if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_SWIN has no unfused path (use fp32 / bf16 / f16)");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
   if (precision != DD_PREC_NAIVE_FP32 && h->kernel_version != 2) return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": the fused path needs kernel_version 2");
   return DD_OK;

@@ -373,6 +373,146 @@ hipError_t launch_gn_param_grad4(const double* sums_bc4, const double* stats, co
   return hipGetLastError();
 }
 
+// out[c] += sum_{b,p} v[b][p][c] for a channel-blocked 2-byte tensor (conv bias gradients of the Swin fuse convs, which have
+// no GroupNorm behind them).  Same thread mapping as gn_bwd_reduce_blocked_kernel.
+template <int EK>
+__global__ void __launch_bounds__(256) channel_sum_blocked_kernel(const uint16_t* __restrict__ v, float* __restrict__ out, int C, long long HW, int slab) {
+  __shared__ float s_red[64][33];
+  const int tid = threadIdx.x;
+  const long long b = blockIdx.z;
+  const int cb = blockIdx.y, q = tid & 3, pl = tid >> 2;
+  float a[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = 0.f;
+  const size_t base = ((size_t)b * (C / ACT_CB) + cb) * HW * ACT_CB + q * 8;
+  const long long p0 = (long long)blockIdx.x * slab, p1 = min(p0 + slab, HW);
+  for (long long p = p0 + pl; p < p1; p += 64) {
+    float f[8];
+    unpack8<EK>(*reinterpret_cast<const uint4*>(v + base + (size_t)p * ACT_CB), f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += f[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s_red[pl][q * 8 + k] = a[k];
+  __syncthreads();
+  if (tid < 32) {
+    double t = 0.0;
+    for (int l = 0; l < 64; ++l) t += (double)s_red[l][tid];
+    atomicAdd(out + cb * ACT_CB + tid, (float)t);
+  }
+}
+hipError_t launch_channel_sum_blocked(const void* v, int ek, float* out, int B, int C, long long HW, hipStream_t s) {
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16)) return hipErrorInvalidValue;
+  const int slab = 1024;
+  dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
+  if (ek == EK_BF16) hipLaunchKernelGGL(channel_sum_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(v), out, C, HW, slab);
+  else hipLaunchKernelGGL(channel_sum_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(v), out, C, HW, slab);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adjoint of the bilinear upsample (align_corners=True) of the Swin condition map: dst[b][c][sy][sx] (NCHW fp32, (ch, cw))
+// (+)= sum over the latent pixels (oy, ox) whose interpolation stencil contains (sy, sx) of weight * g[b][oy][ox][c].
+// Gather form (no atomics): the candidate rows / columns of a source pixel are an interval, the weights are recomputed with
+// exactly the forward's fp32 expressions (upsample_to_blocked_kernel).  One thread per (source pixel, 8-channel piece).
+// ------------------------------------------------------------------------------------------------
+template <int EK>
+__global__ void __launch_bounds__(256) upsample_adjoint_kernel(const uint16_t* __restrict__ g, float* __restrict__ dst, int C, int ch, int cw,
+                                                              int h, int w, int accumulate, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int npc = C / 8;
+  const int piece = (int)(i % npc);
+  long long r = i / npc;
+  const int sx = (int)(r % cw); r /= cw;
+  const int sy = (int)(r % ch);
+  const long long b = r / ch;
+  const float fsy = (h > 1) ? (float)(ch - 1) / (float)(h - 1) : 0.f;
+  const float fsx = (w > 1) ? (float)(cw - 1) / (float)(w - 1) : 0.f;
+  // destination rows whose y0 or y1 can equal sy: fy = fsy * oy in (sy - 1, sy + 1)
+  const int oy_lo = (fsy > 0.f) ? max(0, (int)floorf((float)(sy - 1) / fsy)) : 0;
+  const int oy_hi = (fsy > 0.f) ? min(h - 1, (int)ceilf((float)(sy + 1) / fsy)) : h - 1;
+  const int ox_lo = (fsx > 0.f) ? max(0, (int)floorf((float)(sx - 1) / fsx)) : 0;
+  const int ox_hi = (fsx > 0.f) ? min(w - 1, (int)ceilf((float)(sx + 1) / fsx)) : w - 1;
+  const int c0 = piece * 8;
+  const size_t gbase = ((size_t)b * (C / ACT_CB) + c0 / ACT_CB) * (size_t)h * w * ACT_CB + (c0 % ACT_CB);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float fy = fsy * (float)oy;
+    const int y0 = min((int)fy, ch - 1), y1 = min(y0 + 1, ch - 1);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float wy = (y0 == sy ? hy : 0.f) + (y1 == sy ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = fsx * (float)ox;
+      const int x0 = min((int)fx, cw - 1), x1 = min(x0 + 1, cw - 1);
+      const float lx = fx - (float)x0, hx = 1.f - lx;
+      const float wx = (x0 == sx ? hx : 0.f) + (x1 == sx ? lx : 0.f);
+      if (wx == 0.f) continue;
+      float f[8];
+      unpack8<EK>(*reinterpret_cast<const uint4*>(g + gbase + ((size_t)oy * w + ox) * ACT_CB), f);
+      const float wt = wy * wx;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(wt, f[k], acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float* o = dst + (((size_t)b * C + c0 + k) * ch + sy) * cw + sx;
+    *o = accumulate ? *o + acc[k] : acc[k];
+  }
+}
+// generic (any element kind, one thread per output element): the fp32 parity mode
+__global__ void upsample_adjoint_view_kernel(ActView g, float* __restrict__ dst, int ch, int cw, int h, int w, int accumulate, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int sx = (int)(i % cw);
+  long long r = i / cw;
+  const int sy = (int)(r % ch); r /= ch;
+  const int c = (int)(r % g.C);
+  const long long b = r / g.C;
+  const float fsy = (h > 1) ? (float)(ch - 1) / (float)(h - 1) : 0.f;
+  const float fsx = (w > 1) ? (float)(cw - 1) / (float)(w - 1) : 0.f;
+  const int oy_lo = (fsy > 0.f) ? max(0, (int)floorf((float)(sy - 1) / fsy)) : 0;
+  const int oy_hi = (fsy > 0.f) ? min(h - 1, (int)ceilf((float)(sy + 1) / fsy)) : h - 1;
+  const int ox_lo = (fsx > 0.f) ? max(0, (int)floorf((float)(sx - 1) / fsx)) : 0;
+  const int ox_hi = (fsx > 0.f) ? min(w - 1, (int)ceilf((float)(sx + 1) / fsx)) : w - 1;
+  float acc = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float fy = fsy * (float)oy;
+    const int y0 = min((int)fy, ch - 1), y1 = min(y0 + 1, ch - 1);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float wy = (y0 == sy ? hy : 0.f) + (y1 == sy ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float fx = fsx * (float)ox;
+      const int x0 = min((int)fx, cw - 1), x1 = min(x0 + 1, cw - 1);
+      const float lx = fx - (float)x0, hx = 1.f - lx;
+      const float wx = (x0 == sx ? hx : 0.f) + (x1 == sx ? lx : 0.f);
+      if (wx == 0.f) continue;
+      acc = fmaf(wy * wx, view_load(g, b, (long long)oy * w + ox, c), acc);
+    }
+  }
+  dst[i] = accumulate ? dst[i] + acc : acc;
+}
+
+hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int C, int ch, int cw, int h, int w, int accumulate, hipStream_t s) {
+  if (C % ACT_CB != 0) return hipErrorInvalidValue;
+  if (ek == EK_F32) {
+    const long long total = (long long)B * C * ch * cw;
+    hipLaunchKernelGGL(upsample_adjoint_view_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       ActView{g, EK_F32, 1, C, (long long)h * w}, dst, ch, cw, h, w, accumulate, total);
+    return hipGetLastError();
+  }
+  const long long total = (long long)B * ch * cw * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (ek == EK_BF16) hipLaunchKernelGGL(upsample_adjoint_kernel<EK_BF16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(g), dst, C, ch, cw, h, w, accumulate, total);
+  else hipLaunchKernelGGL(upsample_adjoint_kernel<EK_F16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(g), dst, C, ch, cw, h, w, accumulate, total);
+  return hipGetLastError();
+}
+
 // dgamma_c += sum_b dgb[b][c][1],  dbeta_c += sum_b dgb[b][c][0]
 __global__ void gn_param_grad_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -86,12 +86,14 @@ class UpSample_add(nn.Module):
         self.convB = _ConvModule(output_features, output_features)
 
 
-_PARAM_ORDER = list(HipDenoiser.PARAM_SHAPES)          # "model.<name>" in the order the Functions below return gradients
+def _param_order(variant: str):
+    """"model.<name>" in the order the Functions below return gradients."""
+    return list(HipDenoiser.PARAM_SHAPES) + (list(HipDenoiser.SWIN_PARAM_SHAPES) if variant == "swin" else [])
 
 
 def _ordered_params(model: nn.Module):
     named = dict(model.named_parameters())
-    return [named[n[len("model."):]] for n in _PARAM_ORDER]
+    return [named[n[len("model."):]] for n in _param_order(model.variant)]
 
 
 class _DenoiseOnceFn(torch.autograd.Function):
@@ -111,7 +113,7 @@ class _DenoiseOnceFn(torch.autograd.Function):
         be.zero_grad()
         gx, gc = be.denoise_once_backward(x, t, cond, g.contiguous().float(), ctx.precision,
                                           need_grad_x=ctx.needs_input_grad[2], need_grad_cond=ctx.needs_input_grad[4])
-        grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_PARAM_ORDER)]
+        grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_param_order(be.variant))]
         return (None, None, gx, None, gc, *grads)
 
 
@@ -132,7 +134,7 @@ class _DenoiseLoopFn(torch.autograd.Function):
         be.zero_grad()
         gx, gc = be.denoise_backward(x_T, cond, g.contiguous().float(), ctx.T, ctx.precision,
                                      need_grad_xT=ctx.needs_input_grad[3], need_grad_cond=ctx.needs_input_grad[4])
-        grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_PARAM_ORDER)]
+        grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_param_order(be.variant))]
         return (None, None, None, gx, gc, *grads)
 
 
@@ -176,9 +178,6 @@ class ScheduledCNNRefine(nn.Module):
         be = self.bound.ensure(noisy_image.device)
         t = torch.as_tensor(t, device=noisy_image.device)
         if _wants_grad(self, noisy_image, feat):
-            if self.variant != "res":
-                raise NotImplementedError("the HIP backward is built for the Res denoiser (SURVEY.md 8f rank 2); wrap the Swin "
-                                          "variant in torch.no_grad() or train it with the PyTorch modules")
             tt = t.to(torch.int64).reshape(-1)
             if tt.numel() == 1 and noisy_image.shape[0] > 1:
                 tt = tt.expand(noisy_image.shape[0])
@@ -205,7 +204,7 @@ class CNNDDIMPipiline:
         why_not = self.scheduler.hip_supported(eta)
         if why_not is None:
             be = self.model.bound.ensure(image.device, self.scheduler)
-            if _wants_grad(self.model, image, input_args[0]) and self.model.variant == "res":
+            if _wants_grad(self.model, image, input_args[0]):
                 image = _DenoiseLoopFn.apply(be, self.model.precision, int(num_inference_steps), image.float().contiguous(),
                                              input_args[0].float().contiguous(), *_ordered_params(self.model)).to(dtype)
             else:

@@ -140,7 +140,8 @@ def gen_denoise_bwd(ref, name):
             assert float(np.abs(gnp).sum()) == float(np.abs(gnp[rows]).sum())
         elif gnp.size > 20000:
             # the two 147k-element conv gradients: every 7th element plus two checksums keep the fixture small
-            out["grad.model." + k + ".stride7"] = gnp.reshape(-1)[::7].copy()
+            st = 7 if gnp.size <= 200000 else 31
+            out["grad.model." + k + f".stride{st}"] = gnp.reshape(-1)[::st].copy()
             out["grad.model." + k + ".sums"] = np.array([gnp.astype(np.float64).sum(), np.abs(gnp.astype(np.float64)).sum()])
         else:
             out["grad.model." + k] = gnp
@@ -314,6 +315,7 @@ def main():
         "denoise_swin": lambda: gen_denoise(ref, "denoise_swin"),
         "denoise_bwd_res": lambda: gen_denoise_bwd(ref, "denoise_bwd_res"),
         "loop_bwd_res": lambda: gen_loop_bwd(ref, "loop_bwd_res"),
+        "denoise_bwd_swin": lambda: gen_denoise_bwd(ref, "denoise_bwd_swin"),
         "loop_res": lambda: gen_loop(ref, "loop_res"),
         "loop_res_far": lambda: gen_loop(ref, "loop_res_far"),
         "loop_swin": lambda: gen_loop(ref, "loop_swin"),

@@ -294,3 +294,42 @@ def test_head_training_step_matches_reference_golden(U, golden, cases):
     U.record("head_train", loss=lv, **errs)
     bad = {k: v for k, v in errs.items() if v > 1e-2}
     assert not bad, bad
+
+
+def _golden_param_errs(be, g, prec):
+    """{name: error} of every 'grad.model.*' entry of a golden file (strided samples / embedding rows handled)."""
+    import re
+    errs = {}
+    for k in list(g):
+        if not k.startswith("grad.model.") or k.endswith((".rows", ".sums")):
+            continue
+        name = k[len("grad."):]
+        m = re.match(r"(.*)\.stride(\d+)$", name)
+        if m:
+            got = be.grad(m.group(1)).cpu().numpy().reshape(-1)[::int(m.group(2))]
+        elif name == "model.time_embedding.weight":
+            got = be.grad(name).cpu().numpy()[g[k + ".rows"]]
+        else:
+            got = be.grad(name).cpu().numpy()
+        errs[name] = _rel(got, g[k], prec)
+    return errs
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_swin_backward_matches_reference_autograd_golden(U, golden, cases, prec):
+    """Swin / MPViT denoiser (UpSample_add fuse: two 256->256 convs without norm, bilinearly upsampled stride-4 condition map):
+    gradients vs autograd of the reference's own class (denoise_bwd_swin.npz), incl. the adjoint of the upsample (grad_cond at
+    the condition map's own size) and the convA / convB parameter gradients."""
+    c, g = cases["denoise_bwd_swin"], golden("denoise_bwd_swin")
+    be = U.backend_for(c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], tuple(c["cond_hw"]))
+    ge = np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32)
+    be.zero_grad()
+    gx, gc = be.denoise_once_backward(U.cu(inp["x_T"]), U.cu(inp["timesteps"]), U.cu(inp["cond"]), U.cu(ge), prec)
+    assert tuple(gc.shape) == tuple(inp["cond"].shape)
+    errs = {"grad_x": _rel(gx.cpu().numpy(), g["grad_x"], prec), "grad_cond": _rel(gc.cpu().numpy()[:, :8], g["grad_cond_ch0_8"], prec),
+            "grad_cond_sum": _rel(gc.double().sum(dim=(0, 2, 3)).cpu().numpy(), g["grad_cond_chan_sum"], prec)}
+    errs.update(_golden_param_errs(be, g, prec))
+    U.record("bwd_swin_golden", prec=prec, **{k.replace("model.", ""): v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v > TOL[prec]}
+    assert not bad, bad

@@ -216,6 +216,31 @@ def test_torch_port_denoiser_vjp_matches_reference_autograd(golden, cases):
         assert np.abs(got - g[k]).max() <= 5e-5 * max(1e-6, np.abs(g[k]).max()), name
 
 
+def test_torch_port_swin_denoiser_vjp_matches_reference_autograd(golden, cases):
+    import re
+    import torch
+    from oracle import torch_cpu_port as P
+    c, g = cases["denoise_bwd_swin"], golden("denoise_bwd_swin")
+    sd = P.to_torch_sd(synth.make_state_dict(c["wseed"], "swin"))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], tuple(c["cond_hw"]))
+    ge = np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32)
+    eps, gx, gc, grads = P.denoiser_vjp(sd, inp["x_T"], torch.from_numpy(inp["timesteps"]), inp["cond"], ge, variant="swin")
+    rel = lambda a, b: float(np.abs(np.asarray(a) - b).max() / max(1e-12, np.abs(b).max()))
+    assert rel(gx.numpy(), g["grad_x"]) < 5e-5 and rel(gc.numpy()[:, :8], g["grad_cond_ch0_8"]) < 5e-5
+    for k in list(g):
+        if not k.startswith("grad.model.") or k.endswith((".rows", ".sums")):
+            continue
+        name = k[len("grad."):]
+        m = re.match(r"(.*)\.stride(\d+)$", name)
+        if m:
+            got = grads[m.group(1)].numpy().reshape(-1)[::int(m.group(2))]
+        elif name == "model.time_embedding.weight":
+            got = grads[name].numpy()[g[k + ".rows"]]
+        else:
+            got = grads[name].numpy()
+        assert rel(got, g[k]) < 1e-4, name
+
+
 def test_torch_port_loop_vjp_matches_reference_autograd(golden, cases):
     """Differentiable loop of the torch port (loop-backward oracle) vs autograd through the reference's CNNDDIMPipiline."""
     from oracle import torch_cpu_port as P
