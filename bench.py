@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--T", type=int, default=20, help="DDIM inference steps (reference --inference_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-latency-b1", action="store_true", help="skip the B=1 latency extra (keeps a profile to one launch shape)")
+    ap.add_argument("--no-train-extra", action="store_true", help="skip the training-step timing (loop forward + backward, batch 1)")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
     ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
     ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
@@ -137,7 +139,7 @@ def main():
 
     # ---- B = 1 latency (the reference's test() feeds one image at a time, README.md:249) ----------------
     lat = None
-    if B != 1:
+    if B != 1 and not args.no_latency_b1:
         x1, c1_, g1 = x_T[:1].contiguous(), cond[:1].contiguous(), gt[:1].contiguous()
         o1 = torch.empty_like(x1)
         for _ in range(3):
@@ -207,6 +209,26 @@ def main():
         cpu["gpu_vs_cpu_depth_rmse"] = float(torch.sqrt(torch.mean((dg - d_cpu) ** 2)))
         cpu["gpu_vs_cpu_depth_maxabs"] = float((dg - d_cpu).abs().max())
 
+    # ---- training extra: one T-step loop forward + backward (dd_denoise + dd_denoise_backward) ----
+    train = None
+    if rank == 0 and world == 1 and args.precision in ("bf16", "f16") and args.variant == "res" and not args.no_train_extra:
+        g0 = torch.randn_like(x_T[:1])
+        xb, cb = x_T[:1].contiguous(), cond[:1].contiguous()
+
+        def train_step():
+            be.zero_grad()
+            be.denoise(xb, cb, T, args.precision)
+            be.denoise_backward(xb, cb, g0, T, args.precision)
+        train_step()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(3):
+            train_step()
+        torch.cuda.synchronize(dev)
+        tms = (time.perf_counter() - t2) / 3 * 1e3
+        train = {"what": f"{T}-step loop forward + backward (per-step recompute), batch 1, {args.precision}", "ms": round(tms, 3),
+                 "tflops_fwd_recompute_dgrad_wgrad": round(4.0 * T * h * w * FPS / tms / 1e9, 1)}
+
     if rank == 0:
         maps = B * args.steps * world
         out = {
@@ -218,7 +240,7 @@ def main():
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant},
-            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat,
+            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

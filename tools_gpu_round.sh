@@ -20,7 +20,7 @@ for b in 1 4; do timeout 300 python tools/head_timing.py $b bf16 2>&1 | grep "B=
 timeout 300 python bench.py --steps 10 --warmup 2 --precision f16 --no-cpu-baseline > gpurun_out/bench_f16.log 2>&1; tail -n 1 gpurun_out/bench_f16.log
 timeout 300 python bench.py --steps 5 --warmup 1 --precision fp32 --no-cpu-baseline > gpurun_out/bench_fp32.log 2>&1; tail -n 1 gpurun_out/bench_fp32.log
 echo "== rocprof"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_bf16" -o bench --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OLDPWD/gpurun_out/rocprof_bf16.log" 2>&1); echo "rocprof rc=$?"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_bf16" -o bench --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-train-extra --no-latency-b1 > "$OLDPWD/gpurun_out/rocprof_bf16.log" 2>&1); echo "rocprof rc=$?"
 find gpurun_out/prof_bf16 -name "*stats*" | head; 
 for f in $(find gpurun_out/prof_bf16 -name "*kernel_stats.csv" | head -1); do head -n 20 "$f"; done
 # keep the merge-back small: drop the raw traces, keep the stats
