@@ -793,6 +793,10 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   std::vector<float> db0(16);
   { const auto& cb = W("depth_transform.conv_inv_transform.0.bias"); for (int c = 0; c < 16; ++c) db0[c] = cb[c] * sc[c] + sh[c]; }
   const size_t o_d0 = push(d0), o_db0 = push(db0);
+  // the same weights tap-major [ky][kx][ci][co] for the fused decoder kernel (a wave reads one (tap, ci) row of 16 couts uniformly)
+  std::vector<float> d0t(4096);
+  for (int ci = 0; ci < 16; ++ci) for (int co = 0; co < 16; ++co) for (int k = 0; k < 16; ++k) d0t[(k * 16 + ci) * 16 + co] = d0[(ci * 16 + co) * 16 + k];
+  const size_t o_d0t = push(d0t);
   const size_t o_d1 = push(W("depth_transform.conv_inv_transform.3.0.weight"));
   {
     int rc = upload(h, h->codec_buf, blob.data(), blob.size() * 4, s); if (rc) return rc;
@@ -801,7 +805,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   const float* base = h->codec_buf.as<float>();
   h->codec.enc_w0 = base + o_e0; h->codec.enc_b0 = base + o_eb0;
   h->codec.enc_w1 = base + o_e1; h->codec.enc_b1 = base + o_eb1;
-  h->codec.dec_w0 = base + o_d0; h->codec.dec_b0 = base + o_db0;
+  h->codec.dec_w0 = base + o_d0; h->codec.dec_b0 = base + o_db0; h->codec.dec_w0t = base + o_d0t;
   h->codec.dec_w1 = base + o_d1;
   h->codec.dec_b1 = W("depth_transform.conv_inv_transform.3.0.bias")[0];
   h->codec_committed = true;

@@ -606,9 +606,102 @@ __global__ void __launch_bounds__(256) dec1_kernel(const float* __restrict__ tmp
   depth[(size_t)b * H * W + p] = 1.f / fmaxf(sg, 1e-6f) - 1.f;
 }
 
+// Fused decoder: one workgroup produces a 16x32 tile of the depth map.  The (8+2)x(16+2) latent patch and the ReLU'd
+// transposed-convolution output of the (16+2)x(32+2) region (the 3x3 conv's halo) live in LDS, so the 16-channel full
+// resolution intermediate (110 MB per B=4 KITTI batch) never goes to HBM.  Wave w computes the region pixels of output
+// parity class w = ((oy+1)&1, (ox+1)&1): its 2x2 live taps of the 4x4 kernel are wave-uniform, so the weights are scalar
+// operands (tap-major copy dec_w0t).
+constexpr int DT_H = 16, DT_W = 32;                 // output tile
+constexpr int DR_H = DT_H + 2, DR_W = DT_W + 2;     // region of the intermediate (halo 1)
+constexpr int DL_H = DT_H / 2 + 2, DL_W = DT_W / 2 + 2, DL_P = DL_W + 1;   // latent patch rows / cols / padded row pitch
+__global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict__ latent, const float* __restrict__ w0t,
+                                                        const float* __restrict__ b0, const float* __restrict__ w1, float b1,
+                                                        float* __restrict__ depth, int h, int w) {
+  __shared__ float s_lat[LATENT_C][DL_H][DL_P];
+  __shared__ __attribute__((aligned(16))) float s_mid[DR_H][DR_W][LATENT_C];
+  const int b = blockIdx.z;
+  const int H = 2 * h, W = 2 * w;
+  const int Y0 = blockIdx.y * DT_H, X0 = blockIdx.x * DT_W;
+  const int iy0 = Y0 / 2 - 1, ix0 = X0 / 2 - 1;                 // latent coordinates of patch (0, 0)
+  const int tid = threadIdx.x;
+  const long long HWl = (long long)h * w;
+  const float* lat = latent + (size_t)b * LATENT_C * HWl;
+  for (int i = tid; i < LATENT_C * DL_H * DL_W; i += 256) {
+    const int c = i / (DL_H * DL_W), rem = i - c * (DL_H * DL_W);
+    const int r = rem / DL_W, q = rem - r * DL_W;
+    const int iy = iy0 + r, ix = ix0 + q;
+    s_lat[c][r][q] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? lat[(size_t)c * HWl + (size_t)iy * w + ix] : 0.f;
+  }
+  __syncthreads();
+  // ---- transposed conv (k4 s2 p1) + bias + ReLU over the region; region (r, c) <-> output (Y0 - 1 + r, X0 - 1 + c).
+  //      Y0, X0 are even, so (oy + 1) & 1 == r & 1: live taps ky = (r & 1) + {0, 2}, latent patch row (r - ky) / 2 + 1.
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int pr = wave >> 1, pc = wave & 1;                      // this wave's parity class
+  constexpr int NR = DR_H / 2, NC = DR_W / 2;                   // 9 x 17 pixels per class
+  for (int idx = lane; idx < NR * NC; idx += 64) {
+    const int rr = idx / NC, cc = idx - rr * NC;
+    const int r = 2 * rr + pr, c = 2 * cc + pc;
+    const int oy = Y0 - 1 + r, ox = X0 - 1 + c;
+    float acc[LATENT_C];
+#pragma unroll
+    for (int co = 0; co < LATENT_C; ++co) acc[co] = b0[co];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = pr + 2 * a;
+      const int lr = (r - ky) / 2 + 1;                          // exact: r - ky is even
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int kx = pc + 2 * d;
+        const int lc = (c - kx) / 2 + 1;
+        const float* wt = w0t + (size_t)(ky * 4 + kx) * LATENT_C * LATENT_C;     // wave-uniform
+#pragma unroll 4
+        for (int ci = 0; ci < LATENT_C; ++ci) {
+          const float v = s_lat[ci][lr][lc];
+#pragma unroll
+          for (int co = 0; co < LATENT_C; ++co) acc[co] = fmaf(wt[ci * LATENT_C + co], v, acc[co]);
+        }
+      }
+    }
+    const bool inside = oy >= 0 && oy < H && ox >= 0 && ox < W;   // the 3x3 conv zero-pads OUTSIDE the image
+    float4* dst = reinterpret_cast<float4*>(&s_mid[r][c][0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      dst[q] = inside ? make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  // ---- conv 16 -> 1 3x3 (+bias) -> sigmoid -> 1 / max(s, 1e-6) - 1 ----
+  for (int i = tid; i < DT_H * DT_W; i += 256) {
+    const int ty = i / DT_W, tx = i - ty * DT_W;
+    const int oy = Y0 + ty, ox = X0 + tx;
+    if (oy >= H || ox >= W) continue;
+    float z = b1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4* src = reinterpret_cast<const float4*>(&s_mid[ty + ky][tx + kx][0]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = src[q];
+          const float* wk = w1 + (4 * q) * 9 + ky * 3 + kx;
+          z = fmaf(wk[0], v.x, z); z = fmaf(wk[9], v.y, z); z = fmaf(wk[18], v.z, z); z = fmaf(wk[27], v.w, z);
+        }
+      }
+    const float sg = 1.f / (1.f + expf(-z));
+    depth[(size_t)b * H * W + (size_t)oy * W + ox] = 1.f / fmaxf(sg, 1e-6f) - 1.f;
+  }
+}
+
 hipError_t launch_decode(const CodecWeights& cw, const float* latent_nchw, float* tmp_nhwc, float* depth,
                          int B, int h, int w, hipStream_t s) {
   const int H = 2 * h, W = 2 * w;
+  if (cw.dec_w0t != nullptr) {
+    (void)tmp_nhwc;
+    dim3 grid((unsigned)((W + DT_W - 1) / DT_W), (unsigned)((H + DT_H - 1) / DT_H), (unsigned)B);
+    hipLaunchKernelGGL(dec_fused_kernel, grid, dim3(256), 0, s, latent_nchw, cw.dec_w0t, cw.dec_b0, cw.dec_w1, cw.dec_b1, depth, h, w);
+    return hipGetLastError();
+  }
   dim3 grid((unsigned)(((long long)H * W + 255) / 256), (unsigned)B);
   hipLaunchKernelGGL(dec0_kernel, grid, dim3(256), 0, s, latent_nchw, cw.dec_w0, cw.dec_b0, tmp_nhwc, h, w);
   hipLaunchKernelGGL(dec1_kernel, grid, dim3(256), 0, s, tmp_nhwc, cw.dec_w1, cw.dec_b1, depth, H, W);
