@@ -211,7 +211,8 @@ def main():
 
     # ---- training extra: one T-step loop forward + backward (dd_denoise + dd_denoise_backward) ----
     train = None
-    if rank == 0 and world == 1 and args.precision in ("bf16", "f16") and args.variant == "res" and not args.no_train_extra:
+    if (rank == 0 and world == 1 and args.precision in ("bf16", "f16") and args.variant == "res" and args.kernel_version == 2
+            and not args.no_train_extra):
         g0 = torch.randn_like(x_T[:1])
         xb, cb = x_T[:1].contiguous(), cond[:1].contiguous()
 
