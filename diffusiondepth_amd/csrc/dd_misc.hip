@@ -619,6 +619,7 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
                                                         float* __restrict__ depth, int h, int w) {
   __shared__ float s_lat[LATENT_C][DL_H][DL_P];
   __shared__ __attribute__((aligned(16))) float s_mid[DR_H][DR_W][LATENT_C];
+  __shared__ __attribute__((aligned(16))) float s_w1[9][LATENT_C];     // 3x3 conv weights, tap-major (144 scalars would spill the SGPR file)
   const int b = blockIdx.z;
   const int H = 2 * h, W = 2 * w;
   const int Y0 = blockIdx.y * DT_H, X0 = blockIdx.x * DT_W;
@@ -626,6 +627,7 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
   const int tid = threadIdx.x;
   const long long HWl = (long long)h * w;
   const float* lat = latent + (size_t)b * LATENT_C * HWl;
+  if (tid < 9 * LATENT_C) s_w1[tid / LATENT_C][tid % LATENT_C] = w1[(tid % LATENT_C) * 9 + tid / LATENT_C];
   for (int i = tid; i < LATENT_C * DL_H * DL_W; i += 256) {
     const int c = i / (DL_H * DL_W), rem = i - c * (DL_H * DL_W);
     const int r = rem / DL_W, q = rem - r * DL_W;
@@ -645,16 +647,18 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
     float acc[LATENT_C];
 #pragma unroll
     for (int co = 0; co < LATENT_C; ++co) acc[co] = b0[co];
-#pragma unroll
+    // (tap and channel loops stay rolled: each (tap, ci) row of 16 weights is one s_load_dwordx16; unrolling them made the
+    //  compiler hold 256 scalar weights and spill SGPRs through v_readlane / v_writelane)
+#pragma unroll 1
     for (int a = 0; a < 2; ++a) {
       const int ky = pr + 2 * a;
       const int lr = (r - ky) / 2 + 1;                          // exact: r - ky is even
-#pragma unroll
+#pragma unroll 1
       for (int d = 0; d < 2; ++d) {
         const int kx = pc + 2 * d;
         const int lc = (c - kx) / 2 + 1;
         const float* wt = w0t + (size_t)(ky * 4 + kx) * LATENT_C * LATENT_C;     // wave-uniform
-#pragma unroll 4
+#pragma unroll 2
         for (int ci = 0; ci < LATENT_C; ++ci) {
           const float v = s_lat[ci][lr][lc];
 #pragma unroll
@@ -681,11 +685,11 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const float4* src = reinterpret_cast<const float4*>(&s_mid[ty + ky][tx + kx][0]);
+        const float4* wk = reinterpret_cast<const float4*>(&s_w1[ky * 3 + kx][0]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 v = src[q];
-          const float* wk = w1 + (4 * q) * 9 + ky * 3 + kx;
-          z = fmaf(wk[0], v.x, z); z = fmaf(wk[9], v.y, z); z = fmaf(wk[18], v.z, z); z = fmaf(wk[27], v.w, z);
+          const float4 v = src[q], wv = wk[q];
+          z = fmaf(wv.x, v.x, z); z = fmaf(wv.y, v.y, z); z = fmaf(wv.z, v.z, z); z = fmaf(wv.w, v.w, z);
         }
       }
     const float sg = 1.f / (1.f + expf(-z));

@@ -1,6 +1,6 @@
 #!/bin/bash
 # minimal iteration: v2 parity tests + bench lines (bf16 B=1, B=4)
-cd "$(dirname "$0")"; mkdir -p gpurun_out; export TMPDIR=/tmp
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out; export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.jsonl
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider -k "v2" > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/pytest_gpu.log
 for cfg in bf16,1,res bf16,4,res ${EXTRA_CFG}; do IFS=, read -r a b c <<< "$cfg"; set -- $a $b $c

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes (separate runs, kernel-trace only) over a short eager bf16 bench; summaries land in gpurun_out/pmc_*.
-cd "$(dirname "$0")"
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"

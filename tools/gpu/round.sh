@@ -2,7 +2,7 @@
 # One gpurun call: diagnostics -> parity tests (separate processes per group so a device fault in one
 # precision mode cannot take the others down) -> smoke -> bench -> rocprofv3 kernel stats.
 # Everything is logged under gpurun_out/ (merged back into the build container).
-cd "$(dirname "$0")"
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/parity_report.jsonl

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library build variants (build_variants/lib_<name>.so): bench lines only, parity on the first
-cd "$(dirname "$0")"; mkdir -p gpurun_out; export TMPDIR=/tmp
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out; export TMPDIR=/tmp
 for lib in build_variants/lib_*.so; do
   name=$(basename $lib .so); export DDEPTH_LIBRARY=$PWD/$lib
   if [ "$PARITY" = "1" ]; then timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider -k "v2 and (golden or oracle)" 2>&1 | tail -n 2; fi
