@@ -54,23 +54,32 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);     // bijective for any nwg
   }
-  const int nsplit = wgid % NSPLIT;
-  const int tile = wgid / NSPLIT;
+  // PERSIST (conv1 / conv4): the grid is one resident wave of workgroups and each walks tiles wgid, wgid + gridDim.x, ...;
+  // otherwise one workgroup per (tile, cout split).  Everything below that depends on the tile is (re)set by set_tile().
+  const int nsplit = C::PERSIST ? 0 : wgid % NSPLIT;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
-  const int b = tile / tiles_per_img;
-  const int trem = tile - b * tiles_per_img;
-  const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-  const int y0 = ty * C::TH, x0 = tx * C::TW;
+  const int n_work = tiles_per_img * p.B;             // tiles of this launch (PERSIST: the loop bound)
   const int n0 = nsplit * C::NT;
   const int h = p.h, w = p.w;
   const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
   const int abl = DD_ABLATE ? p.ablate : 0;   // timing experiments are compiled in with -DDD_ABLATE=1 only
   if (abl & 256) return;                  // timing floor: launch + dispatch only
-
-  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * C::CIN * IN_ESZ;
-  const char* cond_b = (C::PRO == PRO_GN_ADD) ? reinterpret_cast<const char*>(p.cond) + (size_t)b * h * w * C::CIN * IN_ESZ : nullptr;
-  const char* y4_b = (C::PRO == PRO_X) ? reinterpret_cast<const char*>(p.y4) + (size_t)b * h * w * LATENT_C * 4 : nullptr;
-  char* xout_b = (C::PRO == PRO_X) ? reinterpret_cast<char*>(p.xout) + (size_t)b * h * w * LATENT_C * 4 : nullptr;
+  int tile = C::PERSIST ? wgid : wgid / NSPLIT;
+  int b, y0, x0;
+  const char *in_b, *cond_b, *y4_b;
+  char* xout_b;
+  auto set_tile_base = [&](int t) {
+    tile = t;
+    b = t / tiles_per_img;
+    const int trem = t - b * tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    y0 = ty * C::TH; x0 = tx * C::TW;
+    in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * C::CIN * IN_ESZ;
+    cond_b = (C::PRO == PRO_GN_ADD) ? reinterpret_cast<const char*>(p.cond) + (size_t)b * h * w * C::CIN * IN_ESZ : nullptr;
+    y4_b = (C::PRO == PRO_X) ? reinterpret_cast<const char*>(p.y4) + (size_t)b * h * w * LATENT_C * 4 : nullptr;
+    xout_b = (C::PRO == PRO_X) ? reinterpret_cast<char*>(p.xout) + (size_t)b * h * w * LATENT_C * 4 : nullptr;
+  };
+  set_tile_base(tile);
 
   // ---- weight stage s -> ring slot (s & 1) by LDS-DMA: wave `wave` copies KiB-chunks wave, wave+WAVES, ... ----
   // Issued through inline asm (M0 = wave-uniform LDS destination, lane l lands at M0 + 16*l): with the
@@ -101,22 +110,26 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   int lds_off[NIT];            // byte offset of the (swizzled) piece inside a patch buffer
   int pix_off[NIT];            // clamped global pixel index gy*w+gx
   unsigned m_valid = 0, m_inside = 0, m_interior = 0;
+  auto set_tile_geometry = [&]() {
+    m_valid = 0; m_inside = 0; m_interior = 0;
 #pragma unroll
-  for (int u = 0; u < NIT; ++u) {
-    const int it = u * C::THREADS + tid;
-    const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
-    const int pp = itc >> C::LOG2_PPP;
-    const int pr = pp / PW, pc = pp - pr * PW;
-    const int gy = y0 - C::HALO + pr, gx = x0 - C::HALO + pc;
-    const bool inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
-    if (it < C::ITEMS) m_valid |= 1u << u;
-    if (inside) m_inside |= 1u << u;
-    if (inside && pr >= C::HALO && pr < C::HALO + C::TH && pc >= C::HALO && pc < C::HALO + C::TW) m_interior |= 1u << u;
-    const int gyc = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);
-    const int gxc = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
-    pix_off[u] = gyc * w + gxc;
-    lds_off[u] = pp * ROWB + ((jfix << 4) ^ swz16<RPB, PPP>(pc));
-  }
+    for (int u = 0; u < NIT; ++u) {
+      const int it = u * C::THREADS + tid;
+      const int itc = it < C::ITEMS ? it : C::ITEMS - 1;
+      const int pp = itc >> C::LOG2_PPP;
+      const int pr = pp / PW, pc = pp - pr * PW;
+      const int gy = y0 - C::HALO + pr, gx = x0 - C::HALO + pc;
+      const bool inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
+      if (it < C::ITEMS) m_valid |= 1u << u;
+      if (inside) m_inside |= 1u << u;
+      if (inside && pr >= C::HALO && pr < C::HALO + C::TH && pc >= C::HALO && pc < C::HALO + C::TW) m_interior |= 1u << u;
+      const int gyc = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);
+      const int gxc = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
+      pix_off[u] = gyc * w + gxc;
+      lds_off[u] = pp * ROWB + ((jfix << 4) ^ swz16<RPB, PPP>(pc));
+    }
+  };
+  set_tile_geometry();
 
   // ---- raw patch fetch of one channel chunk into registers (unconditional, clamped addresses) --------
   constexpr int RD = C::RAW_DEPTH;     // raw-patch register slots: chunk c lives in slot c % RD (RD = 2: fetched two chunks ahead)
@@ -227,7 +240,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   }
   double2 sv0 = make_double2(0.0, 0.0), sv1 = make_double2(0.0, 0.0);
   float my_gamma = 0.f, my_beta = 0.f, my_emb = 0.f;
-  if (have_norm) {
+  auto load_norm_inputs = [&]() {          // everything the GroupNorm table of image b is built from
+    if (!have_norm) return;
     // 32 slots x 4 groups x (sum, sumsq): lane l takes slot l>>1, groups 2*(l&1) and 2*(l&1)+1 (every wave redundantly)
     const double* st = p.stats_in + (size_t)b * STAT_SLOTS * STAT_STRIDE + (lane >> 1) * STAT_STRIDE + (lane & 1) * 4;
     sv0 = *reinterpret_cast<const double2*>(st);
@@ -241,13 +255,35 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       }
     }
     if constexpr (C::PRO == PRO_X) { c1 = p.c1c2[2 * (p.step - 1)]; c2 = p.c1c2[2 * (p.step - 1) + 1]; }
-  }
+  };
+  load_norm_inputs();
   load_raw(0, 0);
   if constexpr (RD == 2 && C::NCHUNK > 1) load_raw(1, 1);
 
+  // per-lane LDS addressing.  Pixel block (wave*WM + m) is tile row (wave*WM + m), lane li is tile column li,
+  // so tap (dy,dx) reads patch row (wave*WM + m + dy), patch column (li + dx): everything row-dependent is an
+  // immediate or a wave-uniform scalar; only the column term (3 variants of dx) lives in VGPRs.
+  const int g16 = g << 4;
+  int colt[3][NKQ];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int kq = 0; kq < NKQ; ++kq)
+      colt[dx][kq] = wave * (C::WM * PW * ROWB) + (li + dx) * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li + dx));
+  int wkt[NKQ];
+#pragma unroll
+  for (int kq = 0; kq < NKQ; ++kq) wkt[kq] = C::W_OFF + li * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li));
+
+  // ---- tile loop: a single pass, or (PERSIST) tiles tile, tile + gridDim.x, ... ------------------------------------------
+  int tab_img = b;                 // image whose GroupNorm table is in LDS
+  bool first_tile = true;
+  bool has_next = false;           // PERSIST: another tile follows, its raw patch is being prefetched
+  int e_b = b, e_y0 = y0, e_x0 = x0, e_tile = tile;     // the tile the accumulators / epilogue belong to
+  f32x16_t acc[C::WN][C::WM];
+  do {
+  if (C::PERSIST && !first_tile && b != tab_img) load_norm_inputs();
   // accumulators.  With the hoisted condition term they START at conv3(cond)[pixel][cout] (fp32, D-fragment order): the
   // loads fly with everything else above and need no extra registers or epilogue traffic.
-  f32x16_t acc[C::WN][C::WM];
 #pragma unroll
   for (int m = 0; m < C::WM; ++m) {
     const int gy = y0 + wave * C::WM + m, gx = x0 + li;
@@ -268,7 +304,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   if (abl & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
-  if (have_norm) {
+  if (have_norm && (first_tile || b != tab_img)) {
+    tab_img = b;
 #pragma unroll
     for (int off = 2; off <= 32; off <<= 1) {
       sv0.x += __shfl_xor(sv0.x, off, 64); sv0.y += __shfl_xor(sv0.y, off, 64);
@@ -301,20 +338,19 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of weight stage 0 have landed
   __syncthreads();                                    // patch 0 and weight stage 0 are in LDS for everybody
   if (abl & 1024) return;
-
-  // per-lane LDS addressing.  Pixel block (wave*WM + m) is tile row (wave*WM + m), lane li is tile column li,
-  // so tap (dy,dx) reads patch row (wave*WM + m + dy), patch column (li + dx): everything row-dependent is an
-  // immediate or a wave-uniform scalar; only the column term (3 variants of dx) lives in VGPRs.
-  const int g16 = g << 4;
-  int colt[3][NKQ];
-#pragma unroll
-  for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-    for (int kq = 0; kq < NKQ; ++kq)
-      colt[dx][kq] = wave * (C::WM * PW * ROWB) + (li + dx) * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li + dx));
-  int wkt[NKQ];
-#pragma unroll
-  for (int kq = 0; kq < NKQ; ++kq) wkt[kq] = C::W_OFF + li * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li));
+  e_b = b; e_y0 = y0; e_x0 = x0; e_tile = tile;
+  if constexpr (C::PERSIST) {
+    // the current tile's raw registers and staging geometry are free now: point them at the next tile and (single-stage
+    // layers) start its loads; conv4 issues them behind its last weight DMA instead (VMEM retires in order: a later wait
+    // for a weight stage would otherwise drain them)
+    const int next = tile + (int)gridDim.x;
+    has_next = next < n_work;
+    if (has_next) {
+      set_tile_base(next);
+      set_tile_geometry();
+      if constexpr (C::NSTAGE == 1) load_raw(0, 0);
+    }
+  }
 
   // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
   auto mfma_block = [&](int chunk, int tg) {
@@ -386,6 +422,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     if (s + 1 < C::NSTAGE && !(abl & 4)) issue_weights(s + 1);
     asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
     if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && !(abl & 2)) load_raw(chunk + RD, par);
+    // PERSIST with several weight stages (conv4): the next tile's raw patch is requested right behind the LAST weight DMA
+    constexpr bool PF_HERE = C::PERSIST && C::NSTAGE > 1;
+    if (PF_HERE && s == C::NSTAGE - 2 && has_next) load_raw(0, 0);
     if (!(abl & 8)) mfma_block(chunk, tg);
     if (!C::INTERLEAVE && C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, (par + 1) % RD);
@@ -395,6 +434,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     // two more stages (cdna guide T4: counted vmcnt).  Every wave issues exactly NRAW loads (clamped addresses).
     if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && (C::NTG > 1 || RD == 2) && !(abl & (2 | 128))) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
+    } else if (PF_HERE && s == C::NSTAGE - 2 && has_next) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");      // last weight stage landed, prefetch flies on
+    } else if (C::PERSIST && s == C::NSTAGE - 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // no DMA pending: leave the prefetch alone
     } else {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
@@ -477,10 +520,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // ---- epilogue: bias, GroupNorm partial sums, store --------------------------------------------------
   constexpr int NG_LOCAL = (C::COUT == COND_C) ? C::NT / (COND_C / GN_GROUPS) : 4;
   float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
-  char* out_b = reinterpret_cast<char*>(p.out) + (size_t)b * h * w * C::COUT * C::OUT_ESZ;
+  char* out_b = reinterpret_cast<char*>(p.out) + (size_t)e_b * h * w * C::COUT * C::OUT_ESZ;
 #pragma unroll
   for (int m = 0; m < C::WM; ++m) {
-    const int gy = y0 + wave * C::WM + m, gx = x0 + li;
+    const int gy = e_y0 + wave * C::WM + m, gx = e_x0 + li;
     const bool pvalid = gy < h && gx < w && !(abl & 16);
     unsigned tapmask = 0x1FFu;               // ADD_C: taps of the 3x3 window that fall inside the image at this pixel
     if constexpr (C::ADD_C) {
@@ -517,7 +560,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           if constexpr (C::IS_LAT) {
             // FPN top-down term: x = relu(bn(conv(f))) + pooled(up(pre_x))  (reference ...res.py:113-116)
             if (p.addend != nullptr && pvalid) {
-              const char* ab = reinterpret_cast<const char*>(p.addend) + ((size_t)b * h * w * C::COUT + act_offset(C::COUT, h, w, 0, co, gy, gx)) * C::ESZ;
+              const char* ab = reinterpret_cast<const char*>(p.addend) + ((size_t)e_b * h * w * C::COUT + act_offset(C::COUT, h, w, 0, co, gy, gx)) * C::ESZ;
               float a4[4];
               if constexpr (C::ESZ == 4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(ab);
@@ -543,13 +586,13 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
         if constexpr (C::LAYER == 8) {
           // hoisted condition term: fp32, accumulator-fragment order [tile][wave][n][m][q][lane] (read back by layer 9 only)
-          reinterpret_cast<float4*>(p.out)[((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane] =
+          reinterpret_cast<float4*>(p.out)[((((size_t)e_tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane] =
               make_float4(v[0], v[1], v[2], v[3]);
         } else if constexpr (C::OUT_ESZ == 4) {
           if (pvalid) {
             if constexpr (C::SCATTER) {
               const int par = co >> 8, cc = co & (COND_C - 1);
-              *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.out) + ((size_t)b * 4 * h * w * COND_C +
+              *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.out) + ((size_t)e_b * 4 * h * w * COND_C +
                   act_offset(COND_C, 2 * h, 2 * w, 0, cc, 2 * gy + (par >> 1), 2 * gx + (par & 1))) * 4) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
               *reinterpret_cast<float4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -570,7 +613,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             const int co = n0 + n * 32 + 16 * k + 8 * g;
             if constexpr (C::SCATTER) {
               const int par = co >> 8, cc = co & (COND_C - 1);
-              *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + ((size_t)b * 4 * h * w * COND_C +
+              *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + ((size_t)e_b * 4 * h * w * COND_C +
                   act_offset(COND_C, 2 * h, 2 * w, 0, cc, 2 * gy + (par >> 1), 2 * gx + (par & 1))) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             } else {
               *reinterpret_cast<uint4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
@@ -610,9 +653,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
     for (int wv = 0; wv < C::WAVES; ++wv) tot += s_red[wv * 8 + tid];
     const int gbase = (C::COUT == COND_C) ? (n0 / (COND_C / GN_GROUPS)) : 0;
-    double* dst = p.stats_out + ((size_t)b * STAT_SLOTS + (wgid % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
+    double* dst = p.stats_out + ((size_t)e_b * STAT_SLOTS + ((C::PERSIST ? e_tile : wgid) % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
     atomicAdd(dst, tot);
   }
+  first_tile = false;
+  if (!(C::PERSIST && has_next)) break;
+  __syncthreads();                                  // the statistics scratch and every LDS image of this tile are done with
+  if constexpr (C::NSTAGE > 1) issue_weights(0);    // restart the weight ring for the next tile (slot 0 was read by the last stage)
+  } while (true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -626,7 +674,17 @@ static hipError_t launch_one2(const ConvParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  dim3 grid(p.tiles_x * p.tiles_y * p.B * (C::COUT_PAD / C::NT), 1);
+  unsigned n_wg = (unsigned)(p.tiles_x * p.tiles_y * p.B * (C::COUT_PAD / C::NT));
+  if constexpr (C::PERSIST) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const unsigned resident = (unsigned)(n_cu * C::PERSIST_WGS_PER_CU);      // one resident wave of workgroups, each walks several tiles
+    if (n_wg > resident) n_wg = resident;
+  }
+  dim3 grid(n_wg, 1);
   hipLaunchKernelGGL(conv_igemm2_kernel<C>, grid, dim3(C::THREADS), C::SMEM_BYTES, s, p);
   return hipGetLastError();
 }

@@ -20,6 +20,9 @@
 #ifndef DD_RAW_DEPTH
 #define DD_RAW_DEPTH 2
 #endif
+#ifndef DD_PERSIST
+#define DD_PERSIST 0
+#endif
 #ifndef DD_ABLATE
 #define DD_ABLATE 0
 #endif
@@ -100,6 +103,12 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int PIXSTRIDE = (CIN >= ACT_CB) ? ACT_CB : CIN; // elements between pixels of one channel block
   // Placing the next chunk's prologue items between the taps (instead of one burst before the chunk's last barrier)
   // was measured SLOWER on MI355X (conv3 181 -> 191 us at B=4: the in-loop vmcnt waits stall the MFMA stream), so off.
+  // conv1 / conv4 (one channel chunk, latency-bound at 2-3 workgroups per CU): persistent workgroups that walk several
+  // tiles and fetch the next tile's raw patch while the current tile computes and stores.  Measured on MI355X (B=4):
+  // conv1 39 -> 51 us, conv4 38 -> 55 us (the hardware dispatcher's own tile queue overlaps better than one resident wave of
+  // workgroups with 5-25 spilled registers), so off by default (-DDD_PERSIST=1 to build it; parity-tested)
+  static constexpr bool PERSIST = DD_PERSIST && (LAYER == 1 || LAYER == 4);
+  static constexpr int PERSIST_WGS_PER_CU = (LAYER == 1) ? 3 : 2;
   static constexpr bool INTERLEAVE = false;
   // two-deep fragment registers in the MFMA loop (next group's ds_reads issued between this group's MFMAs); the Swin convA
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
