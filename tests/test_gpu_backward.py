@@ -333,3 +333,23 @@ def test_swin_backward_matches_reference_autograd_golden(U, golden, cases, prec)
     U.record("bwd_swin_golden", prec=prec, **{k.replace("model.", ""): v for k, v in errs.items()})
     bad = {k: v for k, v in errs.items() if v > TOL[prec]}
     assert not bad, bad
+
+
+def test_swin_loop_backward_matches_torch_port_autograd(U, cases):
+    """Loop backward of the Swin variant (T = 2, fp32 kernels): the chain rule + per-step recompute around the Swin VJP, incl.
+    dLoss/dcond accumulated over the steps at the condition map's own size, vs torch autograd of the CPU port."""
+    from oracle import torch_cpu_port as P
+    c = cases["denoise_bwd_swin"]
+    be = U.backend_for(c)
+    sd = P.to_torch_sd(synth.make_state_dict(c["wseed"], "swin"))
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], tuple(c["cond_hw"]))
+    ge = np.random.RandomState(6).standard_normal(inp["x_T"].shape).astype(np.float32)
+    x0, rgx, rgc, rgrads = P.ddim_loop_vjp(sd, inp["x_T"], inp["cond"], ge, T=2, variant="swin")
+    be.zero_grad()
+    gx, gc = be.denoise_backward(U.cu(inp["x_T"]), U.cu(inp["cond"]), U.cu(ge), 2, "fp32", need_grad_xT=True)
+    errs = {"grad_xT": _rel(gx.cpu().numpy(), rgx.numpy()), "grad_cond": _rel(gc.cpu().numpy(), rgc.numpy())}
+    for name, ref in rgrads.items():
+        errs[name] = _rel(be.grad(name).cpu().numpy(), ref.numpy())
+    U.record("loop_bwd_swin", **{k.replace("model.", ""): v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if v > 5e-3}       # ReLU-tie sensitivity over chained steps, see the Res loop test
+    assert not bad, bad
