@@ -1,0 +1,539 @@
+// dd_dcn.hip -- NLSPN spatial propagation and the DCNv2 operator under it (include/ddepth_dcn.h).
+//
+// Reference: the vendored DCNv2 CUDA extension (src/model/deformconv/src/cuda/modulated_deform_im2col_cuda.cuh,
+// modulated_deform_conv_cuda.cu) and its one caller, NLSPN (src/model/nlspnmodel.py:22-207).  The reference materialises a
+// column buffer (C*kh*kw x B*Ho*Wo floats) with one kernel and contracts it with cuBLAS; NLSPN then calls that pair 18 + 8 times
+// per image on a ONE-channel map with an all-ones 3x3 "weight".  None of that is a GEMM worth a matrix core: it is a gather.
+// Here sampling and contraction are one kernel, nothing but the operands and the result touches HBM, and the two NLSPN stages
+// have their own fused kernels:
+//   nlspn_affinity_kernel   the whole of _get_offset_affinity after its convolution (24 planes in, 27 out, 8 confidence gathers)
+//   nlspn_prop_kernel       one propagation iteration: 18 offset + 9 affinity planes streamed with 16-B loads (4 pixels per lane),
+//                           36 bilinear corner gathers per pixel served by L2 / the vector L1 (the depth map is 1.7 MB at KITTI
+//                           size), one 16-B store.  112 B of HBM traffic per pixel per iteration: the HBM roofline bounds it.
+// All kernels are fp32 (the reference's arithmetic) and follow the reference's evaluation order inside a sample.
+#include "../../include/ddepth.h"
+#include "../../include/ddepth_dcn.h"
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+namespace {
+
+thread_local std::string g_dcn_err;
+
+int dcn_fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_dcn_err = buf;
+  return code;
+}
+
+#define DCN_HIP(expr)                                                                            \
+  do {                                                                                           \
+    hipError_t _e = (expr);                                                                      \
+    if (_e != hipSuccess) return dcn_fail(DD_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e));   \
+  } while (0)
+
+// ---- bilinear cell of one sampling position (mdmcn_im2col_bilinear, ...cuh:23-54, and the kernel's range test, ...cuh:179) ----
+struct Tap {
+  float h, w;      // sampling position
+  float lh, lw;    // fractional parts
+  int hl, wl;      // floor cell
+  bool inside;     // h > -1 && w > -1 && h < H && w < W: outside this the sample (and every gradient through it) is zero
+};
+
+__device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
+  Tap t;
+  t.h = h;
+  t.w = w;
+  t.inside = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
+  const float fh = floorf(h), fw = floorf(w);
+  t.hl = (int)fh;
+  t.wl = (int)fw;
+  t.lh = h - fh;
+  t.lw = w - fw;
+  return t;
+}
+
+// the four corner values, zero where a corner lies outside the image (...cuh:36-47)
+__device__ __forceinline__ void corner_vals(const float* __restrict__ im, int H, int W, const Tap& t, float& v1, float& v2,
+                                            float& v3, float& v4) {
+  const bool y0 = t.inside && t.hl >= 0, y1 = t.inside && t.hl + 1 <= H - 1;
+  const bool x0 = t.wl >= 0, x1 = t.wl + 1 <= W - 1;
+  const float* r = im + (long long)t.hl * W + t.wl;
+  v1 = (y0 && x0) ? r[0] : 0.f;
+  v2 = (y0 && x1) ? r[1] : 0.f;
+  v3 = (y1 && x0) ? r[W] : 0.f;
+  v4 = (y1 && x1) ? r[W + 1] : 0.f;
+}
+
+__device__ __forceinline__ float bilerp(const Tap& t, float v1, float v2, float v3, float v4) {
+  const float hh = 1.f - t.lh, hw = 1.f - t.lw;                        // ...cuh:33-34
+  const float w1 = hh * hw, w2 = hh * t.lw, w3 = t.lh * hw, w4 = t.lh * t.lw;   // ...cuh:50
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;                        // ...cuh:52
+}
+
+__device__ __forceinline__ float sample_plane(const float* __restrict__ im, int H, int W, float h, float w) {
+  const Tap t = make_tap(h, w, H, W);
+  float v1, v2, v3, v4;
+  corner_vals(im, H, W, t, v1, v2, v3, v4);
+  return bilerp(t, v1, v2, v3, v4);
+}
+
+template <int VEC> struct VecLoad;
+template <> struct VecLoad<1> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <> struct VecLoad<4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// One propagation iteration of NLSPN (nlspnmodel.py:165-171 via ...cuh:126-194 with C = 1 and the 1 x K "GEMM" of
+// modulated_deform_conv_cuda.cu:107-115):  out = b + sum_k w_k * aff_k * bilinear(fin, pixel + tap_k + offset_k).
+// Block = 64 x 4 lanes, a lane owns VEC consecutive pixels of a row: the 27 operand planes are read as 16-B row segments, the
+// result is one 16-B store; `blend` (preserve_input) additionally receives the NEXT iteration's input
+// (1 - mask_fix) * out + mask_fix * feat_fix (nlspnmodel.py:199-201), so that the next launch gathers from one array.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int KF, int VEC>
+__global__ void __launch_bounds__(256) nlspn_prop_kernel(const float* __restrict__ fin, const float* __restrict__ offset,
+                                                         const float* __restrict__ aff, const float* __restrict__ wk,
+                                                         const float* __restrict__ bk, float* __restrict__ out,
+                                                         const float* __restrict__ fix, float* __restrict__ blend, int H, int W) {
+  constexpr int K = KF * KF, PAD = (KF - 1) / 2;
+  const int b = blockIdx.z;
+  const int h = blockIdx.y * 4 + threadIdx.y;
+  const int w0 = (blockIdx.x * 64 + threadIdx.x) * VEC;
+  if (h >= H || w0 >= W) return;
+  const size_t HW = (size_t)H * W;
+  const size_t pix = (size_t)h * W + w0;
+  const float* im = fin + (size_t)b * HW;
+  const float* ob = offset + (size_t)b * 2 * K * HW + pix;
+  const float* ab = aff + (size_t)b * K * HW + pix;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+  // one kernel row (KF taps x VEC pixels = 4*KF*VEC gathers) in flight per lane at a time: ~100 VGPRs, 4-5 waves per SIMD, so that
+  // the waves' load -> gather -> store phases overlap (fully unrolled the compiler takes 256 VGPRs = 1 wave per SIMD)
+#pragma unroll 1
+  for (int i = 0; i < KF; ++i) {
+#pragma unroll
+    for (int j = 0; j < KF; ++j) {
+      const int k = i * KF + j;
+      float oh[VEC], ow[VEC], a[VEC];
+      VecLoad<VEC>::ld(ob + (size_t)(2 * k) * HW, oh);
+      VecLoad<VEC>::ld(ob + (size_t)(2 * k + 1) * HW, ow);
+      VecLoad<VEC>::ld(ab + (size_t)k * HW, a);
+      const float wgt = wk[k];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float hs = (float)(h - PAD + i) + oh[v];             // ...cuh:177: h_in + i * dilation_h + offset_h
+        const float ws = (float)(w0 + v - PAD + j) + ow[v];
+        acc[v] += (sample_plane(im, H, W, hs, ws) * a[v]) * wgt;   // col = val * mask (...cuh:189), then . w
+      }
+    }
+  }
+  const float bias = bk[0];
+  float res[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) res[v] = bias + acc[v];
+  VecLoad<VEC>::st(out + (size_t)b * HW + pix, res);
+  if (blend != nullptr) {
+    float fx[VEC];
+    VecLoad<VEC>::ld(fix + (size_t)b * HW + pix, fx);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) fx[v] = fx[v] > 0.f ? fx[v] : res[v];
+    VecLoad<VEC>::st(blend + (size_t)b * HW + pix, fx);
+  }
+}
+
+// dst = (1 - mask_fix) * src + mask_fix * fix with mask_fix = fix > 0 (the blend before the FIRST iteration)
+__global__ void __launch_bounds__(256) nlspn_blend_kernel(const float* __restrict__ src, const float* __restrict__ fix,
+                                                          float* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float f = fix[i];
+    dst[i] = f > 0.f ? f : src[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// NLSPN._get_offset_affinity after conv_offset_aff (nlspnmodel.py:90-163), one lane per pixel.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int KF>
+__global__ void __launch_bounds__(256) nlspn_affinity_kernel(const float* __restrict__ raw, const float* __restrict__ conf,
+                                                             const float* __restrict__ gamma_p, const float* __restrict__ wconf_p,
+                                                             const float* __restrict__ bconf_p, float* __restrict__ offset,
+                                                             float* __restrict__ aff, int H, int W, int mode, int legacy) {
+  constexpr int K = KF * KF, NUM = K - 1, REF = NUM / 2;
+  constexpr float CEN = (float)((KF - 1) / 2);
+  const int b = blockIdx.z;
+  const int h = blockIdx.y * 4 + threadIdx.y;
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (h >= H || w >= W) return;
+  const size_t HW = (size_t)H * W;
+  const size_t pix = (size_t)h * W + w;
+  const float* r = raw + (size_t)b * 3 * NUM * HW + pix;
+  float* o = offset + (size_t)b * 2 * K * HW + pix;
+  float* ao = aff + (size_t)b * K * HW + pix;
+  const float gamma = gamma_p[0];
+  const float* cim = conf ? conf + (size_t)b * HW : nullptr;
+  const float wconf = conf ? wconf_p[0] : 0.f, bconf = conf ? bconf_p[0] : 0.f;
+  float a[NUM];
+  float sabs = 0.f;
+#pragma unroll
+  for (int n = 0; n < NUM; ++n) {
+    const int m = n < REF ? n : n + 1;           // position of neighbour n once the zero reference offset is inserted (:96-99)
+    // torch.cat((o1, o2), 1).view(B, num, 2, H, W): neighbour n owns channels 2n (rows) and 2n+1 (columns) of the first 2*num (:92-95)
+    float oh = r[(size_t)(2 * n) * HW], ow = r[(size_t)(2 * n + 1) * HW];
+    if (conf && legacy) {                        // :126-134, in place on a view of `offset`: the returned offsets carry the shift
+      oh = (oh + (float)(m / KF)) - CEN;
+      ow = (ow + (float)(m % KF)) - CEN;
+    }
+    o[(size_t)(2 * m) * HW] = oh;
+    o[(size_t)(2 * m + 1) * HW] = ow;
+    float v = r[(size_t)(2 * NUM + n) * HW];
+    if (mode == DD_AFF_TC) v = tanhf(v) / gamma;                        // :103-104
+    else if (mode == DD_AFF_TGASS) v = tanhf(v) / (gamma + 1e-8f);      // :105-106
+    if (conf) {
+      // 1x1 modulated deformable conv of the confidence with a mask of ones, padding 0 (:136-141): bilinear sample at pixel + offset
+      const float c = bconf + (sample_plane(cim, H, W, (float)h + oh, (float)w + ow) * 1.0f) * wconf;
+      v *= c;                                                           // :143-144
+    }
+    a[n] = v;
+    sabs += fabsf(v);
+  }
+  o[(size_t)(2 * REF) * HW] = 0.f;
+  o[(size_t)(2 * REF + 1) * HW] = 0.f;
+  float s = sabs + 1e-4f;                                               // :147-148
+  if (mode == DD_AFF_ASS || mode == DD_AFF_TGASS) s = s < 1.f ? 1.f : s;   // :150-151
+  float sum = 0.f;
+#pragma unroll
+  for (int n = 0; n < NUM; ++n) {
+    if (mode != DD_AFF_TC) a[n] = a[n] / s;                             // :153-154
+    sum += a[n];
+    ao[(size_t)(n < REF ? n : n + 1) * HW] = a[n];
+  }
+  ao[(size_t)REF * HW] = 1.f - sum;                                     // :156-161
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// General DCNv2 (any C, groups, deformable groups, stride, dilation).  No model in the reference tree uses it beyond C = 1, so
+// these are plain one-lane-per-output kernels: correct for every shape the extension accepts, tuned for none.
+// ------------------------------------------------------------------------------------------------------------------------
+struct DcnShape {
+  int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, group, dg;
+};
+
+__global__ void __launch_bounds__(256) dcn_fwd_kernel(DcnShape s, const float* __restrict__ in, const float* __restrict__ wgt,
+                                                      const float* __restrict__ bias, const float* __restrict__ off,
+                                                      const float* __restrict__ msk, float* __restrict__ out, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int wo = (int)(idx % s.Wo), ho = (int)((idx / s.Wo) % s.Ho);
+  const int co = (int)((idx / ((size_t)s.Wo * s.Ho)) % s.Co), b = (int)(idx / ((size_t)s.Wo * s.Ho * s.Co));
+  const int Cog = s.Co / s.group, Ck = s.C / s.group, cpdg = s.C / s.dg, K = s.kh * s.kw;
+  const int g = co / Cog;
+  const size_t HoWo = (size_t)s.Ho * s.Wo, HW = (size_t)s.H * s.W, po = (size_t)ho * s.Wo + wo;
+  float acc = 0.f;
+  for (int cl = 0; cl < Ck; ++cl) {
+    const int ci = g * Ck + cl, d = ci / cpdg;
+    const float* im = in + ((size_t)b * s.C + ci) * HW;
+    const float* op = off + ((size_t)(b * s.dg + d) * 2 * K) * HoWo + po;
+    const float* mp = msk + ((size_t)(b * s.dg + d) * K) * HoWo + po;
+    const float* wp = wgt + ((size_t)co * Ck + cl) * K;
+    for (int i = 0; i < s.kh; ++i)
+      for (int j = 0; j < s.kw; ++j) {
+        const int k = i * s.kw + j;
+        const float hs = (float)(ho * s.sh - s.ph + i * s.dh) + op[(size_t)(2 * k) * HoWo];
+        const float ws = (float)(wo * s.sw - s.pw + j * s.dw) + op[(size_t)(2 * k + 1) * HoWo];
+        acc += (sample_plane(im, s.H, s.W, hs, ws) * mp[(size_t)k * HoWo]) * wp[k];
+      }
+  }
+  out[idx] = bias[co] + acc;
+}
+
+// gradients w.r.t. offset, mask (modulated_deformable_col2im_coord_gpu_kernel, ...cuh:256-328) and input
+// (modulated_deformable_col2im_gpu_kernel, ...cuh:196-254) in one pass: one lane per (b, deformable group, tap, ho, wo); the
+// column gradient W^T . grad_out (modulated_deform_conv_cuda.cu:218-223) is formed on the fly.
+__global__ void __launch_bounds__(256) dcn_bwd_data_kernel(DcnShape s, const float* __restrict__ in, const float* __restrict__ wgt,
+                                                           const float* __restrict__ off, const float* __restrict__ msk,
+                                                           const float* __restrict__ go, float* __restrict__ gin,
+                                                           float* __restrict__ goff, float* __restrict__ gmsk, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int K = s.kh * s.kw;
+  const int wo = (int)(idx % s.Wo), ho = (int)((idx / s.Wo) % s.Ho);
+  const int k = (int)((idx / ((size_t)s.Wo * s.Ho)) % K);
+  const int d = (int)((idx / ((size_t)s.Wo * s.Ho * K)) % s.dg), b = (int)(idx / ((size_t)s.Wo * s.Ho * K * s.dg));
+  const int i = k / s.kw, j = k % s.kw;
+  const int Cog = s.Co / s.group, Ck = s.C / s.group, cpdg = s.C / s.dg;
+  const size_t HoWo = (size_t)s.Ho * s.Wo, HW = (size_t)s.H * s.W, po = (size_t)ho * s.Wo + wo;
+  const float oh = off[((size_t)(b * s.dg + d) * 2 * K + 2 * k) * HoWo + po];
+  const float ow = off[((size_t)(b * s.dg + d) * 2 * K + 2 * k + 1) * HoWo + po];
+  const float m = msk[((size_t)(b * s.dg + d) * K + k) * HoWo + po];
+  const float hs = (float)(ho * s.sh - s.ph + i * s.dh) + oh;
+  const Tap t = make_tap(hs, (float)(wo * s.sw - s.pw + j * s.dw) + ow, s.H, s.W);
+  // the reference's col2im launcher passes pad_h for pad_w (...cuh:372): the input gradient lands where THAT position falls
+  const Tap ti = (s.ph == s.pw) ? t : make_tap(hs, (float)(wo * s.sw - s.ph + j * s.dw) + ow, s.H, s.W);
+  float g_oh = 0.f, g_ow = 0.f, g_m = 0.f;
+  for (int ci = d * cpdg; ci < (d + 1) * cpdg; ++ci) {
+    const int g = ci / Ck, cl = ci - g * Ck;
+    float gc = 0.f;
+    for (int c2 = 0; c2 < Cog; ++c2) {
+      const int co = g * Cog + c2;
+      gc += wgt[((size_t)co * Ck + cl) * K + k] * go[((size_t)b * s.Co + co) * HoWo + po];
+    }
+    const float* im = in + ((size_t)b * s.C + ci) * HW;
+    if (t.inside) {
+      float v1, v2, v3, v4;
+      corner_vals(im, s.H, s.W, t, v1, v2, v3, v4);
+      g_m += gc * bilerp(t, v1, v2, v3, v4);                               // ...cuh:307
+      // mdmcn_get_coordinate_weight (...cuh:83-125)
+      const float a_w = (float)(t.wl + 1) - t.w, b_w = t.w - (float)t.wl;
+      const float a_h = (float)(t.hl + 1) - t.h, b_h = t.h - (float)t.hl;
+      const float dh = -a_w * v1 - b_w * v2 + a_w * v3 + b_w * v4;         // bp_dir == 0
+      const float dw = -a_h * v1 + a_h * v2 - b_h * v3 + b_h * v4;         // bp_dir == 1
+      g_oh += dh * gc * m;                                                 // ...cuh:312
+      g_ow += dw * gc * m;
+    }
+    if (gin != nullptr && ti.inside) {
+      const float top = gc * m;                                            // ...cuh:232
+      float* gp = gin + ((size_t)b * s.C + ci) * HW;
+      const int h0 = ti.hl, w0 = ti.wl, h1 = h0 + 1, w1 = w0 + 1;
+      // mdmcn_get_gradient_weight (...cuh:56-81) for the in-image corners
+      const float wh0 = (float)(h0 + 1) - ti.h, wh1 = (ti.h + 1.f) - (float)h1;
+      const float ww0 = (float)(w0 + 1) - ti.w, ww1 = (ti.w + 1.f) - (float)w1;
+      if (h0 >= 0 && w0 >= 0) atomicAdd(gp + (size_t)h0 * s.W + w0, wh0 * ww0 * top);
+      if (h0 >= 0 && w1 <= s.W - 1) atomicAdd(gp + (size_t)h0 * s.W + w1, wh0 * ww1 * top);
+      if (h1 <= s.H - 1 && w0 >= 0) atomicAdd(gp + (size_t)h1 * s.W + w0, wh1 * ww0 * top);
+      if (h1 <= s.H - 1 && w1 <= s.W - 1) atomicAdd(gp + (size_t)h1 * s.W + w1, wh1 * ww1 * top);
+    }
+  }
+  if (goff != nullptr) {
+    goff[((size_t)(b * s.dg + d) * 2 * K + 2 * k) * HoWo + po] = g_oh;
+    goff[((size_t)(b * s.dg + d) * 2 * K + 2 * k + 1) * HoWo + po] = g_ow;
+  }
+  if (gmsk != nullptr) gmsk[((size_t)(b * s.dg + d) * K + k) * HoWo + po] = g_m;
+}
+
+__device__ __forceinline__ float block_sum_256(float v) {
+  __shared__ float part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return part[0] + part[1] + part[2] + part[3];
+}
+
+// grad_weight[co][cl][k] = sum over (b, ho, wo) of grad_out * column (modulated_deform_conv_cuda.cu:249-272); blockIdx.x = weight
+// element, blockIdx.y = slab of the B*Ho*Wo positions; partial sums meet in one fp32 atomic per block.
+__global__ void __launch_bounds__(256) dcn_bwd_weight_kernel(DcnShape s, const float* __restrict__ in, const float* __restrict__ off,
+                                                             const float* __restrict__ msk, const float* __restrict__ go,
+                                                             float* __restrict__ gw, size_t npos, size_t slab) {
+  const int K = s.kh * s.kw, Cog = s.Co / s.group, Ck = s.C / s.group, cpdg = s.C / s.dg;
+  const int k = blockIdx.x % K, cl = (blockIdx.x / K) % Ck, co = blockIdx.x / (K * Ck);
+  const int g = co / Cog, ci = g * Ck + cl, d = ci / cpdg;
+  const int i = k / s.kw, j = k % s.kw;
+  const size_t HoWo = (size_t)s.Ho * s.Wo, HW = (size_t)s.H * s.W;
+  const size_t n0 = (size_t)blockIdx.y * slab, n1 = n0 + slab < npos ? n0 + slab : npos;
+  float acc = 0.f;
+  for (size_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    const int b = (int)(n / HoWo);
+    const size_t po = n - (size_t)b * HoWo;
+    const int ho = (int)(po / s.Wo), wo = (int)(po - (size_t)ho * s.Wo);
+    const float oh = off[((size_t)(b * s.dg + d) * 2 * K + 2 * k) * HoWo + po];
+    const float ow = off[((size_t)(b * s.dg + d) * 2 * K + 2 * k + 1) * HoWo + po];
+    const float m = msk[((size_t)(b * s.dg + d) * K + k) * HoWo + po];
+    const float val = sample_plane(in + ((size_t)b * s.C + ci) * HW, s.H, s.W, (float)(ho * s.sh - s.ph + i * s.dh) + oh,
+                                   (float)(wo * s.sw - s.pw + j * s.dw) + ow);
+    acc += go[((size_t)b * s.Co + co) * HoWo + po] * (val * m);
+  }
+  acc = block_sum_256(acc);
+  if (threadIdx.x == 0) atomicAdd(gw + blockIdx.x, acc);
+}
+
+// grad_bias[co] = sum over (b, ho, wo) of grad_out (at::addmv with ones, modulated_deform_conv_cuda.cu:273)
+__global__ void __launch_bounds__(256) dcn_bwd_bias_kernel(DcnShape s, const float* __restrict__ go, float* __restrict__ gb,
+                                                           size_t npos, size_t slab) {
+  const int co = blockIdx.x;
+  const size_t HoWo = (size_t)s.Ho * s.Wo;
+  const size_t n0 = (size_t)blockIdx.y * slab, n1 = n0 + slab < npos ? n0 + slab : npos;
+  float acc = 0.f;
+  for (size_t n = n0 + threadIdx.x; n < n1; n += 256) {
+    const size_t b = n / HoWo, po = n - b * HoWo;
+    acc += go[(b * s.Co + co) * HoWo + po];
+  }
+  acc = block_sum_256(acc);
+  if (threadIdx.x == 0) atomicAdd(gb + co, acc);
+}
+
+int check_dcn_args(DcnShape& s, int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                   int group, int dg, int im2col_step) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || ph < 0 ||
+      pw < 0 || group <= 0 || dg <= 0 || im2col_step <= 0)
+    return dcn_fail(DD_ERR_INVALID_ARG, "sizes, strides, dilations, groups and im2col_step must be positive (paddings non-negative)");
+  const int step = B < im2col_step ? B : im2col_step;
+  if (B % step != 0)                                           // modulated_deform_conv_cuda.cu:58
+    return dcn_fail(DD_ERR_INVALID_ARG, "batch(%d) must divide im2col_step(%d)", B, step);
+  if (C % group != 0 || Cout % group != 0)                     // :60-61
+    return dcn_fail(DD_ERR_INVALID_ARG, "channels(%d) and channels_out(%d) must divide group(%d)", C, Cout, group);
+  if (C % dg != 0) return dcn_fail(DD_ERR_INVALID_ARG, "channels(%d) must divide deformable_group(%d)", C, dg);
+  const int Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) / sh + 1, Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) / sw + 1;   // :75-76
+  if (Ho <= 0 || Wo <= 0 || H + 2 * ph < dh * (kh - 1) + 1 || W + 2 * pw < dw * (kw - 1) + 1)
+    return dcn_fail(DD_ERR_INVALID_ARG, "empty output (%d x %d)", Ho, Wo);
+  s = DcnShape{B, C, H, W, Cout, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, group, dg};
+  return DD_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int KF>
+int launch_prop(const float* fin, const float* offset, const float* aff, const float* w, const float* b, float* out, const float* fix,
+                float* blend, int B, int H, int W, hipStream_t st) {
+  // 4 pixels per lane only for the 3x3 kernel: 5x5 / 7x7 rows would need 200+ VGPRs per lane at VEC = 4
+  const bool vec4 = KF == 3 && (W % 4 == 0) && aligned16(fin) && aligned16(offset) && aligned16(aff) && aligned16(out) &&
+                    (blend == nullptr || (aligned16(fix) && aligned16(blend)));
+  const int lanes_x = vec4 ? W / 4 : W;
+  const dim3 grid((lanes_x + 63) / 64, (H + 3) / 4, B), block(64, 4);
+  if constexpr (KF == 3) {
+    if (vec4) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 4>), grid, block, 0, st, fin, offset, aff, w, b, out, fix, blend, H, W);
+  }
+  if (!vec4) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 1>), grid, block, 0, st, fin, offset, aff, w, b, out, fix, blend, H, W);
+  DCN_HIP(hipGetLastError());
+  return DD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dd_dcn_last_error(void) { return g_dcn_err.c_str(); }
+
+int dd_dcn_forward(const float* input, const float* weight, const float* bias, const float* offset, const float* mask, float* output,
+                   int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group, int dg,
+                   int im2col_step, void* stream) {
+  if (!input || !weight || !bias || !offset || !mask || !output) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
+  DcnShape s;
+  if (int rc = check_dcn_args(s, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, im2col_step)) return rc;
+  const size_t total = (size_t)B * Cout * s.Ho * s.Wo;
+  if (total > (size_t)INT_MAX * 256) return dcn_fail(DD_ERR_INVALID_ARG, "output too large");
+  hipLaunchKernelGGL(dcn_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, input, weight, bias,
+                     offset, mask, output, total);
+  DCN_HIP(hipGetLastError());
+  return DD_OK;
+}
+
+int dd_dcn_backward(const float* input, const float* weight, const float* bias, const float* offset, const float* mask,
+                    const float* grad_output, float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight,
+                    float* grad_bias, int B, int C, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                    int group, int dg, int im2col_step, void* stream) {
+  (void)bias;
+  if (!input || !weight || !offset || !mask || !grad_output) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
+  DcnShape s;
+  if (int rc = check_dcn_args(s, B, C, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, im2col_step)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int K = kh * kw;
+  const size_t npos = (size_t)B * s.Ho * s.Wo;
+  if (grad_input) DCN_HIP(hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), st));
+  if (grad_input || grad_offset || grad_mask) {
+    const size_t total = npos * K * dg;
+    if (total > (size_t)INT_MAX * 256) return dcn_fail(DD_ERR_INVALID_ARG, "problem too large");
+    hipLaunchKernelGGL(dcn_bwd_data_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, input, weight, offset, mask,
+                       grad_output, grad_input, grad_offset, grad_mask, total);
+    DCN_HIP(hipGetLastError());
+  }
+  // slabs of positions so that a one-channel NLSPN-sized problem (9 weight elements) still fills the chip
+  size_t nslab = (npos + 8191) / 8192;
+  if (nslab > 1024) nslab = 1024;
+  const size_t slab = (npos + nslab - 1) / nslab;
+  if (grad_weight) {
+    const size_t nw = (size_t)Cout * (C / group) * K;
+    DCN_HIP(hipMemsetAsync(grad_weight, 0, nw * sizeof(float), st));
+    hipLaunchKernelGGL(dcn_bwd_weight_kernel, dim3((unsigned)nw, (unsigned)nslab), dim3(256), 0, st, s, input, offset, mask, grad_output,
+                       grad_weight, npos, slab);
+    DCN_HIP(hipGetLastError());
+  }
+  if (grad_bias) {
+    DCN_HIP(hipMemsetAsync(grad_bias, 0, (size_t)Cout * sizeof(float), st));
+    hipLaunchKernelGGL(dcn_bwd_bias_kernel, dim3((unsigned)Cout, (unsigned)nslab), dim3(256), 0, st, s, grad_output, grad_bias, npos, slab);
+    DCN_HIP(hipGetLastError());
+  }
+  return DD_OK;
+}
+
+int dd_nlspn_offset_affinity(const float* offset_aff, const float* confidence, const float* aff_scale_const, const float* w_conf,
+                             const float* b_conf, float* offset, float* aff, int B, int H, int W, int k_f, int affinity, int conf_prop,
+                             int legacy, void* stream) {
+  if (!offset_aff || !aff_scale_const || !offset || !aff) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
+  if (B <= 0 || H <= 0 || W <= 0) return dcn_fail(DD_ERR_INVALID_ARG, "B, H, W must be positive");
+  if (affinity < DD_AFF_AS || affinity > DD_AFF_TGASS) return dcn_fail(DD_ERR_INVALID_ARG, "unknown affinity mode %d", affinity);
+  if (conf_prop && (!confidence || !w_conf || !b_conf))                     // `assert confidence is not None`, nlspnmodel.py:180
+    return dcn_fail(DD_ERR_INVALID_ARG, "conf_prop needs confidence, w_conf and b_conf");
+  const float* conf = conf_prop ? confidence : nullptr;
+  const dim3 grid((W + 63) / 64, (H + 3) / 4, B), block(64, 4);
+  hipStream_t st = (hipStream_t)stream;
+  switch (k_f) {
+    case 3: hipLaunchKernelGGL(nlspn_affinity_kernel<3>, grid, block, 0, st, offset_aff, conf, aff_scale_const, w_conf, b_conf, offset, aff, H, W, affinity, legacy); break;
+    case 5: hipLaunchKernelGGL(nlspn_affinity_kernel<5>, grid, block, 0, st, offset_aff, conf, aff_scale_const, w_conf, b_conf, offset, aff, H, W, affinity, legacy); break;
+    case 7: hipLaunchKernelGGL(nlspn_affinity_kernel<7>, grid, block, 0, st, offset_aff, conf, aff_scale_const, w_conf, b_conf, offset, aff, H, W, affinity, legacy); break;
+    default: return dcn_fail(DD_ERR_UNSUPPORTED, "prop_kernel %d: this build has 3, 5 and 7 (the reference asserts an odd size, nlspnmodel.py:35)", k_f);
+  }
+  DCN_HIP(hipGetLastError());
+  return DD_OK;
+}
+
+int dd_nlspn_workspace_bytes(int B, int H, int W, int preserve_input, int64_t* bytes) {
+  if (!bytes || B <= 0 || H <= 0 || W <= 0) return dcn_fail(DD_ERR_INVALID_ARG, "bad arguments");
+  *bytes = preserve_input ? (int64_t)2 * B * H * W * (int64_t)sizeof(float) : 0;
+  return DD_OK;
+}
+
+int dd_nlspn_propagate(const float* feat_init, const float* offset, const float* aff, const float* feat_fix, const float* w,
+                       const float* b, float* feat_list, void* workspace, int B, int H, int W, int k_f, int prop_time,
+                       int preserve_input, void* stream) {
+  if (!feat_init || !offset || !aff || !w || !b || !feat_list) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || prop_time <= 0) return dcn_fail(DD_ERR_INVALID_ARG, "B, H, W, prop_time must be positive");
+  if (preserve_input && (!feat_fix || !workspace))                          // `assert feat_init.shape == feat_fix.shape`, nlspnmodel.py:188
+    return dcn_fail(DD_ERR_INVALID_ARG, "preserve_input needs feat_fix and a workspace of dd_nlspn_workspace_bytes()");
+  if (k_f != 3 && k_f != 5 && k_f != 7)
+    return dcn_fail(DD_ERR_UNSUPPORTED, "prop_kernel %d: this build has 3, 5 and 7", k_f);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)B * H * W;
+  float* ws[2] = {nullptr, nullptr};
+  if (preserve_input) {
+    ws[0] = static_cast<float*>(workspace);
+    ws[1] = ws[0] + n;
+    hipLaunchKernelGGL(nlspn_blend_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, feat_init, feat_fix, ws[0], n);
+    DCN_HIP(hipGetLastError());
+  }
+  for (int it = 0; it < prop_time; ++it) {
+    const float* fin = preserve_input ? ws[it & 1] : (it == 0 ? feat_init : feat_list + (size_t)(it - 1) * n);
+    float* out = feat_list + (size_t)it * n;
+    float* blend = (preserve_input && it + 1 < prop_time) ? ws[(it + 1) & 1] : nullptr;
+    int rc;
+    switch (k_f) {
+      case 3: rc = launch_prop<3>(fin, offset, aff, w, b, out, feat_fix, blend, B, H, W, st); break;
+      case 5: rc = launch_prop<5>(fin, offset, aff, w, b, out, feat_fix, blend, B, H, W, st); break;
+      default: rc = launch_prop<7>(fin, offset, aff, w, b, out, feat_fix, blend, B, H, W, st); break;
+    }
+    if (rc) return rc;
+  }
+  return DD_OK;
+}
+
+}  // extern "C"
