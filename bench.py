@@ -41,6 +41,64 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "naive_fp32": 157.3
 DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "naive_fp32": "f32"}
 
 
+def nlspn_extra(dev, B, H, W, T=18):
+    """Times NLSPN.forward of diffusiondepth_amd.nlspn (fused HIP path) at B and at 1 map, and the reference's own DCN device code on
+    the host (oracle/_ref, kind "reference") for ONE propagation iteration of one map as the CPU figure beside it."""
+    import types
+    from diffusiondepth_amd import dcn
+    from diffusiondepth_amd.nlspn import NLSPN
+    a = types.SimpleNamespace(prop_time=T, affinity="TGASS", affinity_gamma=0.5, conf_prop=True, preserve_input=False, legacy=False)
+    m = NLSPN(a, 8, 1, 3, 3).to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(7240)
+    with torch.no_grad():
+        m.conv_offset_aff.weight.copy_(0.1 * torch.randn(m.conv_offset_aff.weight.shape, device=dev, generator=gen))
+        m.conv_offset_aff.bias.copy_(0.3 * torch.randn(24, device=dev, generator=gen))
+        m.conv_offset_aff.bias[16:] += 0.6
+    feat = 10 * torch.rand(B, 1, H, W, device=dev, generator=gen)
+    guide = 2 * torch.randn(B, 8, H, W, device=dev, generator=gen)
+    conf = torch.rand(B, 1, H, W, device=dev, generator=gen)
+
+    def timed(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / n
+
+    with torch.no_grad():
+        offset, aff = dcn.nlspn_offset_affinity(m.conv_offset_aff(guide), conf, m.aff_scale_const, m.w_conf, m.b, 3, "TGASS", True, False)
+        t_prop = timed(lambda: dcn.nlspn_propagate(feat, offset, aff, None, m.w, m.b, 3, T, False))
+        t_mod = timed(lambda: m(feat, guide, conf))
+        t_mod1 = timed(lambda: m(feat[:1], guide[:1], conf[:1])) if B != 1 else t_mod
+        y = m(feat[:1], guide[:1], conf[:1])[1][0]                  # result of the first iteration, for the spot check below
+    by = 112.0 * B * H * W * T
+    out = {"what": f"NLSPN refinement (prop_time {T}, 3x3, TGASS, conf_prop) at {H}x{W}, fp32, fused HIP path", "batch": B,
+           "module_forward_ms": round(t_mod, 4), "maps_per_s": round(B / t_mod * 1e3, 1), "latency_b1_ms": round(t_mod1, 4),
+           "roofline": {"bound": "hbm", "kernel": "nlspn_prop_lds_kernel<3,16> (one propagation iteration)", "achieved": round(by / (t_prop * 1e-3) / 1e9, 1),
+                        "peak": 8000.0, "unit": "GB/s", "frac": round(by / (t_prop * 1e-3) / 8e12, 4), "traffic": None,
+                        "avg_launch_us": round(t_prop / T * 1e3, 2), "algorithmic_bytes_per_launch": 112 * B * H * W}}
+    try:
+        from oracle import dcn_ref
+        if dcn_ref.available():
+            f1, o1, a1 = (t[:1].cpu().numpy() for t in (feat, offset, aff))
+            w1, b1 = np.ones((1, 1, 3, 3), np.float32), np.zeros(1, np.float32)
+            c0 = time.perf_counter()
+            y_ref = dcn_ref.forward(f1, w1, b1, o1, a1, pad=(1, 1))
+            cs = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": round(1.0 / (cs * T), 4), "unit": "maps/s", "cores": 1, "kind": "reference",
+                                   "sample": f"ONE propagation iteration of one {H}x{W} map through the reference's own DCN device code "
+                                             f"compiled for the host (oracle/_ref/libref_dcn.so) + fp32 GEMV: {cs * 1e3:.1f} ms; x{T} iterations",
+                                   "gpu_vs_reference_maxrel_iter1": float(np.abs(y.cpu().numpy() - y_ref).max() / np.abs(y_ref).max())}
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +114,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-latency-b1", action="store_true", help="skip the B=1 latency extra (keeps a profile to one launch shape)")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the training-step timing (loop forward + backward, batch 1)")
+    ap.add_argument("--no-nlspn-extra", action="store_true", help="skip the NLSPN refinement timing (SURVEY.md 8f rank 4)")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
     ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
     ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
@@ -230,6 +289,16 @@ def main():
         train = {"what": f"{T}-step loop forward + backward (per-step recompute), batch 1, {args.precision}", "ms": round(tms, 3),
                  "tflops_fwd_recompute_dgrad_wgrad": round(4.0 * T * h * w * FPS / tms / 1e9, 1)}
 
+    # ---- NLSPN refinement extra (BASELINE config 5 "+ NLSPN refine"): the 18-iteration spatial propagation at
+    # image resolution, fused HIP path (dd_nlspn_offset_affinity + dd_nlspn_propagate).  HBM-bound: 112 algorithmic bytes per pixel per
+    # iteration (18 offset + 9 affinity planes read, 1 written; the gathered map stays in L2 / LDS).  Never allowed to break the main line.
+    nlspn = None
+    if rank == 0 and world == 1 and not args.no_nlspn_extra:
+        try:
+            nlspn = nlspn_extra(dev, B, H, W)
+        except Exception as e:  # noqa: BLE001
+            nlspn = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         maps = B * args.steps * world
         out = {
@@ -241,7 +310,7 @@ def main():
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant},
-            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train,
+            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train, "nlspn_refine": nlspn,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -19,6 +19,7 @@
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 namespace {
@@ -87,6 +88,22 @@ __device__ __forceinline__ float sample_plane(const float* __restrict__ im, int 
   return bilerp(t, v1, v2, v3, v4);
 }
 
+// The same sample with two UNCONDITIONAL 8-byte loads (global_load_dwordx2 at a 4-byte-aligned address) instead of four predicated
+// dword loads: row / column indices are clamped into the image, out-of-image corners are zeroed by selects.  Needs W >= 2.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ float sample_pair(const float* __restrict__ im, int H, int W, float h, float w) {
+  const Tap t = make_tap(h, w, H, W);
+  const int c0 = min(max(t.wl, 0), W - 2);
+  const int r0 = min(max(t.hl, 0), H - 1), r1 = min(max(t.hl + 1, 0), H - 1);
+  const f2u p = *reinterpret_cast<const f2u*>(im + (size_t)r0 * W + c0);
+  const f2u q = *reinterpret_cast<const f2u*>(im + (size_t)r1 * W + c0);
+  const int d = t.wl - c0;                  // inside the range test: -1 (left column out), 0, +1 (right column out)
+  const bool y0 = t.inside && t.hl >= 0, y1 = t.inside && t.hl + 1 <= H - 1;
+  const float pl = d == 0 ? p.x : (d == 1 ? p.y : 0.f), pr = d == 0 ? p.y : (d == -1 ? p.x : 0.f);
+  const float ql = d == 0 ? q.x : (d == 1 ? q.y : 0.f), qr = d == 0 ? q.y : (d == -1 ? q.x : 0.f);
+  return bilerp(t, y0 ? pl : 0.f, y0 ? pr : 0.f, y1 ? ql : 0.f, y1 ? qr : 0.f);
+}
+
 template <int VEC> struct VecLoad;
 template <> struct VecLoad<1> {
   static __device__ __forceinline__ void ld(const float* p, float (&v)[1]) { v[0] = *p; }
@@ -109,7 +126,7 @@ template <> struct VecLoad<4> {
 // result is one 16-B store; `blend` (preserve_input) additionally receives the NEXT iteration's input
 // (1 - mask_fix) * out + mask_fix * feat_fix (nlspnmodel.py:199-201), so that the next launch gathers from one array.
 // ------------------------------------------------------------------------------------------------------------------------
-template <int KF, int VEC>
+template <int KF, int VEC, bool PAIR>
 __global__ void __launch_bounds__(256) nlspn_prop_kernel(const float* __restrict__ fin, const float* __restrict__ offset,
                                                          const float* __restrict__ aff, const float* __restrict__ wk,
                                                          const float* __restrict__ bk, float* __restrict__ out,
@@ -143,7 +160,8 @@ __global__ void __launch_bounds__(256) nlspn_prop_kernel(const float* __restrict
       for (int v = 0; v < VEC; ++v) {
         const float hs = (float)(h - PAD + i) + oh[v];             // ...cuh:177: h_in + i * dilation_h + offset_h
         const float ws = (float)(w0 + v - PAD + j) + ow[v];
-        acc[v] += (sample_plane(im, H, W, hs, ws) * a[v]) * wgt;   // col = val * mask (...cuh:189), then . w
+        const float val = PAIR ? sample_pair(im, H, W, hs, ws) : sample_plane(im, H, W, hs, ws);
+        acc[v] += (val * a[v]) * wgt;                              // col = val * mask (...cuh:189), then . w
       }
     }
   }
@@ -158,6 +176,183 @@ __global__ void __launch_bounds__(256) nlspn_prop_kernel(const float* __restrict
 #pragma unroll
     for (int v = 0; v < VEC; ++v) fx[v] = fx[v] > 0.f ? fx[v] : res[v];
     VecLoad<VEC>::st(blend + (size_t)b * HW + pix, fx);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same iteration with the gathered map staged through LDS.  A block owns a TH x 64 pixel tile and first copies the tile plus an
+// R-pixel halo of `fin` into LDS, ZERO-filled outside the image -- which is exactly the reference's corner rule (...cuh:36-47), so
+// samples whose 2x2 cell lies in the staged window need no validity logic at all: two ds_read2_b32 and the four weights.  Samples
+// that leave the window (|offset| beyond ~R pixels) fall back to the global-memory sampler.  A lane owns ONE pixel per row
+// (consecutive lanes = consecutive columns: at small offsets the LDS reads are conflict-free; row stride 81 dwords) and walks TH / 4 rows.
+// The 27 operand planes are streamed with coalesced dword loads (256 B per wave instruction).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int KF, int TH, bool PAIR>
+__global__ void __launch_bounds__(256) nlspn_prop_lds_kernel(const float* __restrict__ fin, const float* __restrict__ offset,
+                                                             const float* __restrict__ aff, const float* __restrict__ wk,
+                                                             const float* __restrict__ bk, float* __restrict__ out,
+                                                             const float* __restrict__ fix, float* __restrict__ blend, int H, int W) {
+  constexpr int K = KF * KF, PAD = (KF - 1) / 2, R = 8, TW = 64, LW = TW + 2 * R, LH = TH + 2 * R, LS = LW + 1;
+  __shared__ float tile[LH * LS];
+  const int b = blockIdx.z;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const size_t HW = (size_t)H * W;
+  const float* im = fin + (size_t)b * HW;
+  const int tid = threadIdx.x;
+  {
+    constexpr int NFILL = (LH * LW + 255) / 256;      // all window loads in flight before the first LDS store
+    float tv[NFILL];
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / LW, c = idx - r * LW;
+      const int gy = y0 - R + r, gx = x0 - R + c;
+      tv[it] = im[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];      // clamped: always a valid address
+    }
+    // pin the loads above the selects below (otherwise LLVM sinks each load into its "in the image" branch, one latency after another)
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) asm volatile("" : "+v"(tv[it]));
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / LW, c = idx - r * LW;
+      const int gy = y0 - R + r, gx = x0 - R + c;
+      if (idx < LH * LW) tile[r * LS + c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? tv[it] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;
+  const int w = x0 + tx;
+  if (w >= W) return;
+  const float bias = bk[0];
+  for (int rr = ty; rr < TH; rr += 4) {
+    const int h = y0 + rr;
+    if (h >= H) break;
+    const size_t pix = (size_t)h * W + w;
+    const float* ob = offset + (size_t)b * 2 * K * HW + pix;
+    const float* ab = aff + (size_t)b * K * HW + pix;
+    float acc = 0.f;
+    // RA kernel rows at a time: first ALL their operand loads (3 * RA * KF independent dword loads in flight), then the LDS gathers
+    // (unconditional, indices clamped into the window), then -- rarely -- the global fallback for samples outside the window
+    constexpr int RA = KF == 3 ? 3 : 1;
+#pragma unroll 1
+    for (int i0 = 0; i0 < KF; i0 += RA) {
+      float oh[RA * KF], ow[RA * KF], a[RA * KF];
+#pragma unroll
+      for (int q = 0; q < RA * KF; ++q) {
+        const int k = i0 * KF + q;
+        oh[q] = ob[(size_t)(2 * k) * HW];
+        ow[q] = ob[(size_t)(2 * k + 1) * HW];
+        a[q] = ab[(size_t)k * HW];
+      }
+#pragma unroll
+      for (int q = 0; q < RA * KF; ++q) {
+        const int i = i0 + q / KF, j = q % KF;
+        const float hs = (float)(h - PAD + i) + oh[q];
+        const float ws = (float)(w - PAD + j) + ow[q];
+        const float fh = floorf(hs), fw = floorf(ws);
+        const int ly = (int)fh - (y0 - R), lx = (int)fw - (x0 - R);
+        const bool in_win = (unsigned)ly < (unsigned)(LH - 1) && (unsigned)lx < (unsigned)(LW - 1);
+        const float* p = tile + min(max(ly, 0), LH - 2) * LS + min(max(lx, 0), LW - 2);
+        const float lh = hs - fh, lw = ws - fw, hh = 1.f - lh, hw = 1.f - lw;
+        float val = (hh * hw) * p[0] + (hh * lw) * p[1] + (lh * hw) * p[LS] + (lh * lw) * p[LS + 1];
+        if (!in_win) val = PAIR ? sample_pair(im, H, W, hs, ws) : sample_plane(im, H, W, hs, ws);
+        acc += (val * a[q]) * wk[i * KF + j];
+      }
+    }
+    const float res = bias + acc;
+    out[(size_t)b * HW + pix] = res;
+    if (blend != nullptr) {
+      const float fx = fix[(size_t)b * HW + pix];
+      blend[(size_t)b * HW + pix] = fx > 0.f ? fx : res;
+    }
+  }
+}
+
+// 3x3 specialisation of the LDS kernel with the operand stream software-pipelined across the TH / 4 rows a lane walks: the 27 operand
+// loads of the first row are issued BEFORE the window fill and the barrier (HBM latency overlaps the L2 fill), and each row's loads
+// are issued before the previous row is evaluated (two register sets).
+template <int TH, bool PAIR>
+__global__ void __launch_bounds__(256) nlspn_prop_lds3_kernel(const float* __restrict__ fin, const float* __restrict__ offset,
+                                                              const float* __restrict__ aff, const float* __restrict__ wk,
+                                                              const float* __restrict__ bk, float* __restrict__ out,
+                                                              const float* __restrict__ fix, float* __restrict__ blend, int H, int W) {
+  constexpr int KF = 3, K = 9, PAD = 1, R = 8, TW = 64, LW = TW + 2 * R, LH = TH + 2 * R, LS = LW + 1, NR = TH / 4;
+  __shared__ float tile[LH * LS];
+  const int b = blockIdx.z;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const size_t HW = (size_t)H * W;
+  const float* im = fin + (size_t)b * HW;
+  const int tid = threadIdx.x;
+  const int tx = tid & 63, ty = tid >> 6;
+  const int w = x0 + tx;
+  const int wc = min(w, W - 1);                       // clamped: lanes past the right edge load (and discard) valid addresses
+  const float* ob = offset + (size_t)b * 2 * K * HW;
+  const float* ab = aff + (size_t)b * K * HW;
+  float ops[2][3 * K];                                // [set][oh(9), ow(9), a(9)]
+  auto load_ops = [&](int n, float (&o)[3 * K]) {
+    const size_t pix = (size_t)min(y0 + ty + 4 * n, H - 1) * W + wc;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      o[k] = ob[(size_t)(2 * k) * HW + pix];
+      o[K + k] = ob[(size_t)(2 * k + 1) * HW + pix];
+      o[2 * K + k] = ab[(size_t)k * HW + pix];
+    }
+  };
+  load_ops(0, ops[0]);
+  {
+    constexpr int NFILL = (LH * LW + 255) / 256;
+    float tv[NFILL];
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / LW, c = idx - r * LW;
+      tv[it] = im[(size_t)min(max(y0 - R + r, 0), H - 1) * W + min(max(x0 - R + c, 0), W - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) asm volatile("" : "+v"(tv[it]));      // keep the loads above the selects (see the generic kernel)
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) {
+      const int idx = tid + it * 256;
+      const int r = idx / LW, c = idx - r * LW;
+      const int gy = y0 - R + r, gx = x0 - R + c;
+      if (idx < LH * LW) tile[r * LS + c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? tv[it] : 0.f;
+    }
+  }
+  __syncthreads();
+  const float bias = bk[0];
+  float wt[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) wt[k] = wk[k];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    if (n + 1 < NR) load_ops(n + 1, ops[(n + 1) & 1]);
+    const float(&o)[3 * K] = ops[n & 1];
+    const int h = y0 + ty + 4 * n;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int i = k / KF, j = k % KF;
+      const float hs = (float)(h - PAD + i) + o[k];
+      const float ws = (float)(w - PAD + j) + o[K + k];
+      const float fh = floorf(hs), fw = floorf(ws);
+      const int ly = (int)fh - (y0 - R), lx = (int)fw - (x0 - R);
+      const bool in_win = (unsigned)ly < (unsigned)(LH - 1) && (unsigned)lx < (unsigned)(LW - 1);
+      const float* p = tile + min(max(ly, 0), LH - 2) * LS + min(max(lx, 0), LW - 2);
+      const float lh = hs - fh, lw = ws - fw, hh = 1.f - lh, hw = 1.f - lw;
+      float val = (hh * hw) * p[0] + (hh * lw) * p[1] + (lh * hw) * p[LS] + (lh * lw) * p[LS + 1];
+      if (!in_win) val = PAIR ? sample_pair(im, H, W, hs, ws) : sample_plane(im, H, W, hs, ws);
+      acc += (val * o[2 * K + k]) * wt[k];
+    }
+    if (h < H && w < W) {
+      const size_t pix = (size_t)b * HW + (size_t)h * W + w;
+      const float res = bias + acc;
+      out[pix] = res;
+      if (blend != nullptr) {
+        const float fx = fix[pix];
+        blend[pix] = fx > 0.f ? fx : res;
+      }
+    }
   }
 }
 
@@ -402,18 +597,61 @@ int check_dcn_args(DcnShape& s, int B, int C, int H, int W, int Cout, int kh, in
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Kernel choice for one propagation iteration.  DD_NLSPN_KERNEL (experiments; read per call) overrides the default: g4 | g1 = global
+// gathers with 4 / 1 pixels per lane, l8 | l16 | l32 = LDS window with that many tile rows; suffix p = pair-load sampler (fallback),
+// suffix q = the software-pipelined 3x3 LDS kernel.
+struct PropChoice { int lds_th; int vec; bool pair; bool pipelined; };
+
 template <int KF>
 int launch_prop(const float* fin, const float* offset, const float* aff, const float* w, const float* b, float* out, const float* fix,
                 float* blend, int B, int H, int W, hipStream_t st) {
   // 4 pixels per lane only for the 3x3 kernel: 5x5 / 7x7 rows would need 200+ VGPRs per lane at VEC = 4
-  const bool vec4 = KF == 3 && (W % 4 == 0) && aligned16(fin) && aligned16(offset) && aligned16(aff) && aligned16(out) &&
-                    (blend == nullptr || (aligned16(fix) && aligned16(blend)));
-  const int lanes_x = vec4 ? W / 4 : W;
-  const dim3 grid((lanes_x + 63) / 64, (H + 3) / 4, B), block(64, 4);
-  if constexpr (KF == 3) {
-    if (vec4) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 4>), grid, block, 0, st, fin, offset, aff, w, b, out, fix, blend, H, W);
+  const bool can_vec4 = KF == 3 && (W % 4 == 0) && aligned16(fin) && aligned16(offset) && aligned16(aff) && aligned16(out) &&
+                        (blend == nullptr || (aligned16(fix) && aligned16(blend)));
+  const bool can_pair = W >= 2;
+  // default (measured on MI355X, profiles/r01_run35_nlspn.md): LDS window, 16-row tiles, pair-load fallback
+  PropChoice c{16, 1, can_pair, false};
+  if (const char* e = getenv("DD_NLSPN_KERNEL")) {
+    const std::string m(e);
+    if (!m.empty() && m[0] == 'g') { c.lds_th = 0; c.vec = (m.size() > 1 && m[1] == '4' && can_vec4) ? 4 : 1; }
+    if (!m.empty() && m[0] == 'l') { c.lds_th = atoi(m.c_str() + 1); if (c.lds_th != 8 && c.lds_th != 16 && c.lds_th != 32) c.lds_th = 16; }
+    c.pair = can_pair && m.find('p') != std::string::npos;
+    c.pipelined = m.find('q') != std::string::npos;
   }
-  if (!vec4) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 1>), grid, block, 0, st, fin, offset, aff, w, b, out, fix, blend, H, W);
+#define DD_PROP_ARGS fin, offset, aff, w, b, out, fix, blend, H, W
+  if (c.lds_th && c.pipelined && KF == 3) {
+    const dim3 grid((W + 63) / 64, (H + c.lds_th - 1) / c.lds_th, B), block(256);
+    if (c.pair) {
+      if (c.lds_th == 8) hipLaunchKernelGGL((nlspn_prop_lds3_kernel<8, true>), grid, block, 0, st, DD_PROP_ARGS);
+      else if (c.lds_th == 16) hipLaunchKernelGGL((nlspn_prop_lds3_kernel<16, true>), grid, block, 0, st, DD_PROP_ARGS);
+      else hipLaunchKernelGGL((nlspn_prop_lds3_kernel<32, true>), grid, block, 0, st, DD_PROP_ARGS);
+    } else {
+      if (c.lds_th == 8) hipLaunchKernelGGL((nlspn_prop_lds3_kernel<8, false>), grid, block, 0, st, DD_PROP_ARGS);
+      else if (c.lds_th == 16) hipLaunchKernelGGL((nlspn_prop_lds3_kernel<16, false>), grid, block, 0, st, DD_PROP_ARGS);
+      else hipLaunchKernelGGL((nlspn_prop_lds3_kernel<32, false>), grid, block, 0, st, DD_PROP_ARGS);
+    }
+  } else if (c.lds_th) {
+    const dim3 grid((W + 63) / 64, (H + c.lds_th - 1) / c.lds_th, B), block(256);
+    if (c.pair) {
+      if (c.lds_th == 8) hipLaunchKernelGGL((nlspn_prop_lds_kernel<KF, 8, true>), grid, block, 0, st, DD_PROP_ARGS);
+      else if (c.lds_th == 16) hipLaunchKernelGGL((nlspn_prop_lds_kernel<KF, 16, true>), grid, block, 0, st, DD_PROP_ARGS);
+      else hipLaunchKernelGGL((nlspn_prop_lds_kernel<KF, 32, true>), grid, block, 0, st, DD_PROP_ARGS);
+    } else {
+      if (c.lds_th == 8) hipLaunchKernelGGL((nlspn_prop_lds_kernel<KF, 8, false>), grid, block, 0, st, DD_PROP_ARGS);
+      else if (c.lds_th == 16) hipLaunchKernelGGL((nlspn_prop_lds_kernel<KF, 16, false>), grid, block, 0, st, DD_PROP_ARGS);
+      else hipLaunchKernelGGL((nlspn_prop_lds_kernel<KF, 32, false>), grid, block, 0, st, DD_PROP_ARGS);
+    }
+  } else {
+    const int lanes_x = c.vec == 4 ? W / 4 : W;
+    const dim3 grid((lanes_x + 63) / 64, (H + 3) / 4, B), block(64, 4);
+    if constexpr (KF == 3) {
+      if (c.vec == 4 && c.pair) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 4, true>), grid, block, 0, st, DD_PROP_ARGS);
+      if (c.vec == 4 && !c.pair) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 4, false>), grid, block, 0, st, DD_PROP_ARGS);
+    }
+    if (c.vec != 4 && c.pair) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 1, true>), grid, block, 0, st, DD_PROP_ARGS);
+    if (c.vec != 4 && !c.pair) hipLaunchKernelGGL((nlspn_prop_kernel<KF, 1, false>), grid, block, 0, st, DD_PROP_ARGS);
+  }
+#undef DD_PROP_ARGS
   DCN_HIP(hipGetLastError());
   return DD_OK;
 }

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--height", type=int, default=352)
     ap.add_argument("--width", type=int, default=1216)
+    ap.add_argument("--variants", default="", help="comma-separated DD_NLSPN_KERNEL values to time (g4,g1,g4p,g1p,l8,l16,l32,l8p,...)")
     a = ap.parse_args()
     B, H, W, T = a.batch, a.height, a.width, 18
     args = types.SimpleNamespace(prop_time=T, affinity="TGASS", affinity_gamma=0.5, conf_prop=True, preserve_input=False, legacy=False)
@@ -66,6 +67,16 @@ def main():
         t_perop = timed(per_op, max(2, a.iters // 4))
         y_f = m(feat, guide, conf)[0]
         y_p = per_op()
+    variants = {}
+    if a.variants:
+        for mode in a.variants.split(","):
+            os.environ["DD_NLSPN_KERNEL"] = mode
+            with torch.no_grad():
+                t = timed(lambda: dcn.nlspn_propagate(feat, offset, aff, None, m.w, m.b, 3, T, False), a.iters)
+                y_v = dcn.nlspn_propagate(feat, offset, aff, None, m.w, m.b, 3, T, False)[-1]
+            variants[mode] = {"us_per_iter": 1e3 * t / T, "GBps": 112 * B * H * W * T / (t * 1e-3) / 1e9,
+                              "maxrel_vs_default": float((y_v - y_f).abs().max() / y_f.abs().max())}
+        os.environ.pop("DD_NLSPN_KERNEL", None)
     px = B * H * W
     bytes_iter = 112 * px
     out = {"B": B, "H": H, "W": W, "prop_time": T, "conv_offset_aff_ms": t_conv, "affinity_ms": t_aff, "propagate_ms": t_prop,
@@ -73,7 +84,7 @@ def main():
            "propagate_frac_hbm_peak": bytes_iter * T / (t_prop * 1e-3) / 8e12,
            "affinity_GBps": (24 + 1 + 27) * 4 * px / (t_aff * 1e-3) / 1e9,
            "module_forward_ms": t_mod, "per_op_formulation_ms": t_perop, "maps_per_s": B / (t_mod * 1e-3),
-           "fused_vs_per_op_maxrel": float((y_f - y_p).abs().max() / y_p.abs().max())}
+           "fused_vs_per_op_maxrel": float((y_f - y_p).abs().max() / y_p.abs().max()), "variants": variants}
     print(json.dumps(out))
 
 
