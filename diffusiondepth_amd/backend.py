@@ -18,7 +18,7 @@ VARIANTS = {"res": 0, "swin": 1}
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_commit_weights",
-    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
+    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_trace", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
     "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch",
 ]
 
@@ -59,6 +59,7 @@ def load_library():
         "dd_set_schedule": (c_int, [c_vp, c_vp, c_int]),
         "dd_condition": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_vp, c_int, c_vp]),
         "dd_denoise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+        "dd_denoise_trace": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_backward": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -255,6 +256,26 @@ class HipDenoiser:
                                           cond.shape[2], cond.shape[3], int(num_inference_steps),
                                           precision_id(precision), _stream_ptr(self.device)), "dd_denoise")
         return out
+
+    def denoise_trace(self, x_T, cond, num_inference_steps: int, precision="fp32"):
+        """The loop of the reference's *Vis heads: (T,B,16,h,w) tensor of the sample after every step; the last entry is what
+        denoise() returns."""
+        torch = _torch()
+        x_T = _check_tensor(x_T, "x_T", dtype=torch.float32)
+        cond_in = cond
+        cond = _check_tensor(cond, "cond", dtype=torch.float32)
+        if cond is not cond_in:
+            self._cond_token = None
+        B, C, h, w = x_T.shape
+        if C != 16 or cond.dim() != 4 or cond.shape[0] != B or cond.shape[1] != 256:
+            raise ValueError(f"x_T must be (B,16,h,w) and cond (B,256,ch,cw); got {tuple(x_T.shape)}, {tuple(cond.shape)}")
+        T = int(num_inference_steps)
+        states = torch.empty((max(T, 1), B, 16, h, w), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            self._ck(self._lib.dd_denoise_trace(self._h, x_T.data_ptr(), self._cond_arg(cond, precision), states.data_ptr(), B, h, w,
+                                                cond.shape[2], cond.shape[3], T, precision_id(precision), _stream_ptr(self.device)),
+                     "dd_denoise_trace")
+        return states
 
     def denoise_once(self, x_t, t, cond, precision="fp32"):
         torch = _torch()

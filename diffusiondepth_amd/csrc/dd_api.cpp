@@ -1069,6 +1069,55 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   return DD_OK;
 }
 
+int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* states, int B, int lat_h, int lat_w,
+                     int cond_h, int cond_w, int T, int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  if (rc) return rc;
+  if (!x_T || !states) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: null tensor pointer");
+  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: num_inference_steps must be in [1, num_train_timesteps]");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: unknown precision");
+  if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  Plan* pl = nullptr;
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version, 0}, &pl);
+  if (rc) return rc;
+  const bool naive = precision == DD_PREC_NAIVE_FP32;
+  const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
+  // X[k] = state entering step k (the stash of the loop backward); X[T] only on the unfused path
+  if (pl->xstash.bytes < (size_t)(T + 1) * n16 * 4) DD_HIP(pl->xstash.alloc((size_t)(T + 1) * n16 * 4));
+  float* X = pl->xstash.as<float>();
+  const long long* ts = pl->tsteps.as<long long>();
+  DD_HIP(launch_nchw_to_nhwc(x_T, X, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  if (rc) return rc;
+  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  for (int k = 0; k < T; ++k) {
+    if (naive) {
+      rc = enqueue_naive_eps(h, pl, k, X + (size_t)k * n16, ts, k, 0, s);
+      if (rc) return rc;
+      DD_HIP(launch_naive_axpby(X + (size_t)k * n16, pl->eps.as<float>(), pl->c1c2.as<float>(), k, X + (size_t)(k + 1) * n16, (long long)n16, s));
+    } else {
+      // conv1 of step k applies the update of step k-1 (reads X[k-1] and y4 of step k-1) and leaves x_k in X[k]
+      rc = enqueue_fused_step(h, pl, k, (k == 0) ? X : X + (size_t)(k - 1) * n16, X + (size_t)k * n16, k > 0, ts, k, 0, s);
+      if (rc) return rc;
+    }
+  }
+  h->n_eager_loops++;
+  // states[j] = sample after step j: X[j+1] for j < T-1; the last one is the final update (launch_final, as in dd_denoise)
+  for (int j = 0; j + 1 < T; ++j)
+    DD_HIP(launch_nhwc_to_nchw_f32(X + (size_t)(j + 1) * n16, EK_F32, states + (size_t)j * n16, B, LATENT_C, lat_h, lat_w, 0, s));
+  if (naive) {
+    DD_HIP(launch_nhwc_to_nchw_f32(X + (size_t)T * n16, EK_F32, states + (size_t)(T - 1) * n16, B, LATENT_C, lat_h, lat_w, 0, s));
+  } else {
+    DD_HIP(launch_final(X + (size_t)(T - 1) * n16, pl->y4.as<float>(), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
+                        h->L[3].beta.as<float>(), pl->c1c2.as<float>(), T - 1, 0, states + (size_t)(T - 1) * n16, B, lat_h, lat_w, s));
+  }
+  if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+
 int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, float* eps, int B, int lat_h,
                     int lat_w, int cond_h, int cond_w, int precision, void* stream) {
   int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);

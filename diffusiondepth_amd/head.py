@@ -14,7 +14,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .modules import CNNDDIMPipiline, DeepDepthTransformWithUpsampling, HipBound, ScheduledCNNRefine
+from .modules import CNNDDIMPipiline, CNNDDIMPipilineVis, DeepDepthTransformWithUpsampling, HipBound, ScheduledCNNRefine
+from .necks import HAHIHeteroNeck
 from .scheduler import DDIMScheduler
 
 HEADS = {}          # name -> class; stands in for the mmdet3d HEADS registry (…res.py:14)
@@ -34,6 +35,9 @@ def build_head(cfg: dict):
 class DDIMDepthEstimate_Res(nn.Module):
     _IN_CHANNELS = [64, 128, 256, 512]       # the reference overrides the constructor argument with these (…res.py:31)
     _VARIANT = "res"
+    _HAHI = False                            # HAHIHeteroNeck in front of the FPN (…swin_addHAHI.py:54-56,110)
+    _VIS = False                             # *Vis heads: pipeline returns every intermediate sample (…res_vis.py:124,141-143)
+    _HIP_FPN_WIDTHS = True                   # dd_condition is specialised for the ResNet / Swin-L pyramid widths
 
     def __init__(self, in_channels=(64, 128, 256, 512), up_scale_factor=1, inference_steps=20, num_train_timesteps=1000,
                  return_indices=None, depth_transform_cfg=None, depth_feature_dim=16, detach_fp=False, loss_cfgs=(),
@@ -57,9 +61,14 @@ class DDIMDepthEstimate_Res(nn.Module):
                                         variant=self._VARIANT)
         self.diffusion_inference_steps = inference_steps
         self.scheduler = DDIMScheduler(num_train_timesteps=num_train_timesteps, clip_sample=False)
-        self.pipeline = CNNDDIMPipiline(self.model, self.scheduler)
-        # present in the reference state_dict although unused in forward (…res.py:42-52)
-        self.convup_fp = nn.Sequential(nn.ConvTranspose2d(fpn_dim, fpn_dim, 2, 2, bias=False), nn.BatchNorm2d(fpn_dim), nn.ReLU(True))
+        self.pipeline = (CNNDDIMPipilineVis if self._VIS else CNNDDIMPipiline)(self.model, self.scheduler)
+        if self._HAHI:
+            self.hahineck = HAHIHeteroNeck(in_channels=list(in_channels), out_channels=list(in_channels), embedding_dim=512,
+                                           positional_encoding=dict(type="SinePositionalEncoding", num_feats=256),
+                                           scales=[1, 1, 1, 1], cross_att=False, self_att=False, num_points=8)
+        else:
+            # present in the reference state_dict although unused in forward (…res.py:42-52); the HAHI heads do not have it
+            self.convup_fp = nn.Sequential(nn.ConvTranspose2d(fpn_dim, fpn_dim, 2, 2, bias=False), nn.BatchNorm2d(fpn_dim), nn.ReLU(True))
         self.conv_lateral = nn.ModuleList()
         self.conv_up = nn.ModuleList()
         for i, c in enumerate(in_channels):
@@ -69,7 +78,7 @@ class DDIMDepthEstimate_Res(nn.Module):
                                                   nn.ReLU(True)))
         if condition_backend not in ("hip", "torch"):
             raise ValueError("condition_backend must be 'hip' or 'torch'")
-        self._hip_fpn = condition_backend == "hip"
+        self._hip_fpn = condition_backend == "hip" and self._HIP_FPN_WIDTHS
         if self._hip_fpn:
             bound.register("conv_lateral.", self.conv_lateral)
             bound.register("conv_up.", self.conv_up)
@@ -99,15 +108,20 @@ class DDIMDepthEstimate_Res(nn.Module):
             else:
                 fp = [it.detach() for it in fp]
         gt_map_t = self.depth_transform.t(gt_depth_map)                         # …res.py:102  (HIP encoder)
+        if self._HAHI:
+            fp = self.hahineck(fp)                                              # …swin_addHAHI.py:110
         x = self.aggregate_condition(fp)                                        # …res.py:108-118
-        refined_depth_t, = self.pipeline(batch_size=x.shape[0], device=x.device, dtype=x.dtype, shape=gt_map_t.shape[-3:],
-                                         input_args=(x, None, None, None),
-                                         num_inference_steps=self.diffusion_inference_steps, return_dict=False)   # :124-138
+        res = self.pipeline(batch_size=x.shape[0], device=x.device, dtype=x.dtype, shape=gt_map_t.shape[-3:],
+                            input_args=(x, None, None, None),
+                            num_inference_steps=self.diffusion_inference_steps, return_dict=False)                # :124-138
+        refined_depth_t = res[0]
         refined_depth = self.depth_transform.inv_t(refined_depth_t)             # :140  (HIP decoder)
+        # *Vis heads: every intermediate sample decoded (…res_vis.py:141-143)
+        processes_vis = [self.depth_transform.inv_t(m) for m in res[1]] if self._VIS else None
         ddim_loss = self.ddim_loss(pred_depth=refined_depth, gt_depth=gt_map_t, refine_module_inputs=(x, None, None, None),
                                    blur_depth_t=refined_depth_t, weight=1.0)    # :159-169
         return {"pred": refined_depth, "pred_init": gt_map_t, "blur_depth_t": gt_map_t, "ddim_loss": ddim_loss,
-                "gt_map_t": gt_map_t, "pred_uncertainty": None, "pred_inter": None, "weight_map": None, "guidance": None,
+                "gt_map_t": gt_map_t, "pred_uncertainty": None, "pred_inter": processes_vis, "weight_map": None, "guidance": None,
                 "offset": None, "aff": None, "gamma": None, "confidence": None}
 
     def ddim_loss(self, gt_depth, refine_module_inputs, blur_depth_t, weight, **kwargs):
@@ -131,3 +145,31 @@ class DDIMDepthEstimate_Swin_ADD(DDIMDepthEstimate_Res):
     to the latent size inside the library (once per call: up(feat + E[t]) = up(feat) + E[t])."""
     _IN_CHANNELS = [192, 384, 768, 1536]
     _VARIANT = "swin"
+
+
+@register_head
+class DDIMDepthEstimate_Swin_ADDHAHI(DDIMDepthEstimate_Swin_ADD):
+    """The head of the reference's headline Swin-L configuration (README.md:215,257; src/model/head/ddim_depth_estimate_res_swin_addHAHI.py:
+    15-241): Swin_ADD with the HAHIHeteroNeck (attention off) in front of the condition FPN and without the unused ``convup_fp``."""
+    _HAHI = True
+
+
+@register_head
+class DDIMDepthEstimate_MPVIT_ADDHAHI(DDIMDepthEstimate_Swin_ADDHAHI):
+    """MPViT-small pyramid [128, 216, 288, 288] (src/model/head/ddim_depth_estimate_res_mpvit_HAHI.py:32,51).  Same UpSample_add
+    denoiser; its FPN widths are not among dd_condition's two compiled pyramids, so the (once-per-image) FPN runs in PyTorch-ROCm
+    and hands the library an explicit condition map."""
+    _IN_CHANNELS = [128, 216, 288, 288]
+    _HIP_FPN_WIDTHS = False
+
+
+@register_head
+class DDIMDepthEstimate_ResVis(DDIMDepthEstimate_Res):
+    """src/model/head/ddim_depth_estimate_res_vis.py: 'pred_inter' = every intermediate sample of the loop, decoded."""
+    _VIS = True
+
+
+@register_head
+class DDIMDepthEstimate_Swin_ADDHAHIVis(DDIMDepthEstimate_Swin_ADDHAHI):
+    """src/model/head/ddim_depth_estimate_res_swin_addHAHI_vis.py."""
+    _VIS = True

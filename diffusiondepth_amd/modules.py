@@ -219,6 +219,32 @@ class CNNDDIMPipiline:
         return {"images": image}
 
 
+class CNNDDIMPipilineVis(CNNDDIMPipiline):
+    """Pipeline of the reference's *Vis heads (src/model/head/ddim_depth_estimate_res_vis.py:238-301): additionally returns
+    ``image_list``, the sample after every step.  eta == 0, no autograd: one dd_denoise_trace call."""
+
+    def __call__(self, batch_size, device, dtype, shape, input_args, generator=None, eta: float = 0.0,
+                 num_inference_steps: int = 50, return_dict: bool = True, x_T=None, **kwargs):
+        image_shape = (batch_size, *shape)
+        image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
+        self.scheduler.set_timesteps(num_inference_steps)
+        if self.scheduler.hip_supported(eta) is None and not _wants_grad(self.model, image, input_args[0]):
+            be = self.model.bound.ensure(image.device, self.scheduler)
+            states = be.denoise_trace(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
+            image_list = list(states.unbind(0))
+            image = image_list[-1]
+        else:
+            image_list = []
+            for t in self.scheduler.timesteps:
+                model_output = self.model(image, t.to(device), *input_args)
+                image = self.scheduler.step(model_output, t, image, eta=eta, use_clipped_model_output=True,
+                                            generator=generator)["prev_sample"]
+                image_list.append(image)
+        if not return_dict:
+            return (image, image_list)
+        return {"images": image, "image_list": image_list}
+
+
 def _conv_bn_relu(ch_in, ch_out, kernel, stride=1, padding=0, bn=True, relu=True):
     layers = [nn.Conv2d(ch_in, ch_out, kernel, stride, padding, bias=not bn)]
     if bn:

@@ -171,3 +171,40 @@ def make_backbone_features(seed: int, B: int, H: int, W: int, in_channels=(64, 1
         h, w = (h + 1) // 2, (w + 1) // 2
         feats.append(np.abs(rs.standard_normal((B, c, h, w))).astype(np.float32))
     return feats
+
+
+def make_hahi_state_dict(seed: int = 7242, in_channels=(192, 384, 768, 1536), embedding_dim: int = 512, num_points: int = 8,
+                         prefix: str = "hahineck.") -> dict:
+    """Weights of HAHIHeteroNeck as the heads build it (reference src/model/necks/hahi.py:56-118; in_channels == out_channels,
+    src/model/head/ddim_depth_estimate_res_swin_addHAHI.py:54-56): ConvModule = conv (no bias) + bn, plus the never-executed
+    attention / reference-point / level-embedding parameters."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def conv_module(name, cin, cout, k):
+        w, _ = _conv(rs, cout, cin, k, bias=False, gain=1.7)       # a little above the default scale: ReLU halves the variance
+        sd[prefix + name + ".conv.weight"] = w
+        g, b, m, v = _bn(rs, cout)
+        sd[prefix + name + ".bn.weight"], sd[prefix + name + ".bn.bias"] = g, b
+        sd[prefix + name + ".bn.running_mean"], sd[prefix + name + ".bn.running_var"] = m, v
+
+    def linear(name, cin, cout):
+        sd[prefix + name + ".weight"] = _uniform(rs, (cout, cin), 1.0 / np.sqrt(cin))
+        sd[prefix + name + ".bias"] = _uniform(rs, (cout,), 1.0 / np.sqrt(cin))
+
+    for i, c in enumerate(in_channels):
+        conv_module(f"lateral_convs.{i}", c, c, 1)
+    for i, c in enumerate(in_channels[1:]):
+        conv_module(f"trans_proj.{i}", c, embedding_dim, 1)
+    for i, c in enumerate(in_channels[1:]):
+        conv_module(f"trans_fusion.{i}", c + embedding_dim, c, 3)
+    conv_module("conv_proj.0", in_channels[0], embedding_dim, 1)
+    conv_module("conv_fusion.0", in_channels[0] + embedding_dim, in_channels[0], 3)
+    linear("reference_points", embedding_dim, 2)
+    sd[prefix + "level_embed"] = rs.standard_normal((4, embedding_dim)).astype(np.float32)
+    for att in ("multi_att", "self_attn"):
+        linear(att + ".sampling_offsets", embedding_dim, 8 * 4 * num_points * 2)
+        linear(att + ".attention_weights", embedding_dim, 8 * 4 * num_points)
+        linear(att + ".value_proj", embedding_dim, embedding_dim)
+        linear(att + ".output_proj", embedding_dim, embedding_dim)
+    return sd

@@ -119,6 +119,14 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
                int B, int lat_h, int lat_w, int cond_h, int cond_w,
                int num_inference_steps, int precision, void* stream);
 
+/* Replaces: CNNDDIMPipiline.__call__ of the *Vis heads (src/model/head/ddim_depth_estimate_res_vis.py:284-301,
+ * ..._swin_addHAHI_vis.py:289-306), which additionally returns image_list = the sample after EVERY step (decoded into the
+ * 'pred_inter' output, ...res_vis.py:141-143,177).  Same arguments as dd_denoise, but
+ *   states (T,B,16,h,w): states[j] = sample after step j; states[T-1] is the x_0 that dd_denoise returns.
+ * Runs the T steps as individual launches (no hipGraph: every intermediate state is kept, T x 6.8 MB per KITTI image). */
+int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* states, int B, int lat_h, int lat_w,
+                     int cond_h, int cond_w, int num_inference_steps, int precision, void* stream);
+
 /* Replaces: one ScheduledCNNRefine.forward(noisy_image, t, feat, None, None, None)
  * (…res.py:324-344) with per-sample timesteps t[B] (device int64), as called by ddim_loss
  * (…res.py:211).  eps (B,16,h,w) >= 0 (final GroupNorm+ReLU). */

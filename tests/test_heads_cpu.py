@@ -1,0 +1,61 @@
+"""CPU: the head variants beyond Res / Swin_ADD (six registered heads) and the HAHI neck in front of them.
+The neck is PyTorch on both sides, so its arithmetic is checked here against the golden minted from the reference class
+(tests/golden/make_golden_hahi.py); the full heads need the HIP library (tests/test_zz_gpu_heads.py)."""
+import numpy as np
+import pytest
+import torch
+
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import synth
+
+
+def test_registry_holds_every_head_the_reference_registers():
+    # src/model/head/__init__.py:2-7
+    want = {"DDIMDepthEstimate_Swin_ADD", "DDIMDepthEstimate_Swin_ADDHAHI", "DDIMDepthEstimate_Swin_ADDHAHIVis",
+            "DDIMDepthEstimate_MPVIT_ADDHAHI", "DDIMDepthEstimate_Res", "DDIMDepthEstimate_ResVis"}
+    assert want == set(dda.head.HEADS)
+    m = dda.head.build_head(dict(type="DDIMDepthEstimate_MPVIT_ADDHAHI", in_channels=[1, 2, 3, 4], inference_steps=5, num_train_timesteps=1000,
+                                 depth_feature_dim=16, loss_cfgs=[], init_cfg=None))
+    assert [l[0].in_channels for l in m.conv_lateral] == [128, 216, 288, 288]          # ..._mpvit_HAHI.py:32 overrides the argument
+    assert [c.conv.in_channels for c in m.hahineck.lateral_convs] == [128, 216, 288, 288]
+
+
+def test_hahi_head_state_dict_matches_reference_keys_and_shapes(golden, cases):
+    g, c = golden("head_swin_hahi"), cases["head_swin_hahi"]
+    head = dda.DDIMDepthEstimate_Swin_ADDHAHI(in_channels=[192, 384, 768, 1536], inference_steps=20)
+    own = {k: v for k, v in head.state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert sorted(own) == [str(k) for k in g["state_keys"]]
+    chans = (192, 384, 768, 1536)
+    sd = synth.make_state_dict(c["wseed"], "swin")
+    sd.update({k: v for k, v in synth.make_fpn_state_dict(c["fseed"], in_channels=chans).items() if not k.startswith("convup_fp")})
+    sd.update(synth.make_hahi_state_dict(c["hseed"], chans))
+    assert set(sd) == set(own)
+    for k, v in sd.items():
+        assert tuple(own[k].shape) == v.shape, k
+
+
+def test_hahi_neck_matches_reference_golden(golden, cases):
+    g, c = golden("head_swin_hahi"), cases["head_swin_hahi"]
+    chans = [192, 384, 768, 1536]
+    neck = dda.HAHIHeteroNeck(in_channels=chans, out_channels=chans, embedding_dim=512,
+                              positional_encoding=dict(type="SinePositionalEncoding", num_feats=256), scales=[1, 1, 1, 1],
+                              cross_att=False, self_att=False, num_points=8).eval()
+    sd = {k[len("hahineck."):]: torch.from_numpy(v) for k, v in synth.make_hahi_state_dict(c["hseed"], tuple(chans)).items()}
+    missing, unexpected = neck.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(c["iseed"], c["B"], c["H"] // 2, c["W"] // 2, in_channels=tuple(chans))]
+    with torch.no_grad():
+        outs = neck(fp)
+    assert [tuple(o.shape) for o in outs] == [tuple(f.shape) for f in fp]
+    for i, o in enumerate(outs):
+        assert np.abs(o[:, :2].numpy() - g[f"neck{i}_ch0_2"]).max() < 2e-5, i
+        assert abs(float(o.double().sum()) - g[f"neck{i}_sum"][0]) < 1e-4 * abs(g[f"neck{i}_sum"][0]) + 1e-2, i
+        assert abs(float(o.abs().max()) - g[f"neck{i}_sum"][1]) < 2e-5, i
+
+
+def test_hahi_attention_is_refused_like_the_reference_cannot_run_it():
+    with pytest.raises(NotImplementedError, match="not runnable in the reference"):
+        dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, cross_att=True, self_att=False)
+    n = dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, cross_att=False, self_att=False)
+    with pytest.raises(NotImplementedError):
+        n.multi_att(torch.zeros(1, 4, 16))

@@ -1,0 +1,91 @@
+"""GPU (`-m gpu`): the head variants added on top of Res / Swin_ADD, whole forward() against goldens minted from the reference's own
+head classes (tests/golden/make_golden_hahi.py):
+  DDIMDepthEstimate_Swin_ADDHAHI  (README.md:215 headline configuration): HAHI neck (PyTorch-ROCm) -> dd_condition (Swin-L widths) ->
+                                  dd_denoise (UpSample_add denoiser, 20 steps) -> dd_decode -> ddim_loss
+  DDIMDepthEstimate_ResVis        'pred_inter' through dd_denoise_trace
+Tolerance: north-star 1e-3 abs on predicted depth (fp32 mode)."""
+import numpy as np
+import pytest
+import torch
+
+from diffusiondepth_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def U():
+    if not torch.cuda.is_available():
+        pytest.fail("`-m gpu` tests need a HIP device: the product has no CPU fallback")
+    import gpu_util
+    return gpu_util
+
+
+def _run(head, fp, gt, inp, U):
+    draws = [U.cu(inp["x_T"]), torch.from_numpy(inp["noise"])]
+    real_randn, real_randint = torch.randn, torch.randint
+    torch.randn = lambda *a, **k: draws.pop(0)
+    torch.randint = lambda *a, **k: U.cu(inp["timesteps"])
+    try:
+        with torch.no_grad():
+            return head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+    finally:
+        torch.randn, torch.randint = real_randn, real_randint
+
+
+def _load(head, sd):
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    return head.cuda()
+
+
+def test_swin_hahi_head_forward_matches_reference_golden(U, golden, cases):
+    import diffusiondepth_amd as dda
+    c, g = cases["head_swin_hahi"], golden("head_swin_hahi")
+    chans = (192, 384, 768, 1536)
+    sd = synth.make_state_dict(c["wseed"], "swin", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update({k: v for k, v in synth.make_fpn_state_dict(c["fseed"], in_channels=chans).items() if not k.startswith("convup_fp")})
+    sd.update(synth.make_hahi_state_dict(c["hseed"], chans))
+    head = _load(dda.DDIMDepthEstimate_Swin_ADDHAHI(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000,
+                                                    depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval(), sd)
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H // 2, W // 2, in_channels=chans)]
+    gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w, (fp[0].shape[2], fp[0].shape[3]))
+    out = _run(head, fp, gt, inp, U)
+    assert set(out) == set(cases["head_res"]["output_keys"]) and out["pred_inter"] is None
+    e_pred = U.maxabs(out["pred"].cpu().numpy(), g["pred"])
+    e_init = U.maxabs(out["pred_init"].cpu().numpy(), g["pred_init"])
+    e_loss = abs(float(out["ddim_loss"]) - float(g["ddim_loss"][0]))
+    U.record("head_swin_hahi", pred_maxabs=e_pred, pred_init_maxabs=e_init, ddim_loss_abs=e_loss, pred_max=float(g["pred"].max()))
+    assert e_init < 2e-5 and e_pred < 1e-3 and e_loss < 1e-4 * max(1.0, float(g["ddim_loss"][0]))
+    assert head._bound.backend.counter("graph_launches") >= 1          # the loop ran in the library, as one hipGraph
+
+
+def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):
+    import diffusiondepth_amd as dda
+    c, g = cases["head_res_vis"], golden("head_res_vis")
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    head = _load(dda.DDIMDepthEstimate_ResVis(in_channels=[64, 128, 256, 512], inference_steps=c["T"], num_train_timesteps=1000,
+                                              depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval(), sd)
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+    out = _run(head, fp, gt, inp, U)
+    assert isinstance(out["pred_inter"], list) and len(out["pred_inter"]) == c["T"]
+    inter = torch.stack(out["pred_inter"]).cpu().numpy()
+    e_inter, e_pred = U.maxabs(inter, g["pred_inter"]), U.maxabs(out["pred"].cpu().numpy(), g["pred"])
+    U.record("head_res_vis", pred_inter_maxabs=e_inter, pred_maxabs=e_pred, ddim_loss_abs=abs(float(out["ddim_loss"]) - float(g["ddim_loss"][0])))
+    assert e_inter < 1e-3 and e_pred < 1e-3
+    assert torch.equal(out["pred_inter"][-1], out["pred"])
+    # dd_denoise_trace's last state is dd_denoise's result (graph replay vs eager launches of the same kernels), all precisions
+    be = head._bound.backend
+    x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+    for prec in ("fp32", "bf16", "naive_fp32"):
+        tr = be.denoise_trace(x, cond, 7, prec)
+        assert tuple(tr.shape) == (7,) + tuple(x.shape)
+        assert torch.equal(tr[-1], be.denoise(x, cond, 7, prec)), prec
