@@ -3,6 +3,7 @@
 
   head_swin_hahi.npz   DDIMDepthEstimate_Swin_ADDHAHI.forward -- the head of the reference's headline configuration (README.md:215):
                        HAHIHeteroNeck (attention off, src/model/necks/hahi.py) -> condition FPN -> 20-step loop -> decoder -> ddim_loss
+  head_mpvit_hahi.npz  DDIMDepthEstimate_MPVIT_ADDHAHI.forward (pyramid widths 128/216/288/288, odd-sized maps: both adaptive_avg_pool2d fixes active)
   head_res_vis.npz     DDIMDepthEstimate_ResVis.forward -- 'pred_inter' = every intermediate sample of the loop, decoded
                        (src/model/head/ddim_depth_estimate_res_vis.py:124,141-143,177)
 
@@ -100,7 +101,8 @@ def load_hahi_reference():
     hahi = _load_as("model.necks.hahi", "model/necks/hahi.py")
     head = _load_as("model.head.ddim_depth_estimate_res_swin_addHAHI", "model/head/ddim_depth_estimate_res_swin_addHAHI.py")
     vis = _load_as("model.head.ddim_depth_estimate_res_vis", "model/head/ddim_depth_estimate_res_vis.py")
-    return ns, hahi.HAHIHeteroNeck, head.DDIMDepthEstimate_Swin_ADDHAHI, vis.DDIMDepthEstimate_ResVis
+    mpvit = _load_as("model.head.ddim_depth_estimate_res_mpvit_HAHI", "model/head/ddim_depth_estimate_res_mpvit_HAHI.py")
+    return ns, mpvit.DDIMDepthEstimate_MPVIT_ADDHAHI, head.DDIMDepthEstimate_Swin_ADDHAHI, vis.DDIMDepthEstimate_ResVis
 
 
 def _load(head, *sds):
@@ -115,9 +117,8 @@ def _load(head, *sds):
     head.load_state_dict(full, strict=True)
 
 
-def gen_head_swin_hahi(HeadCls):
-    c = CASES["head_swin_hahi"]
-    chans = (192, 384, 768, 1536)
+def gen_head_swin_hahi(HeadCls, case="head_swin_hahi", chans=(192, 384, 768, 1536)):
+    c = CASES[case]
     head = HeadCls(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16, loss_cfgs=[]).eval()
     fsd = {k: v for k, v in synth.make_fpn_state_dict(c["fseed"], in_channels=chans).items() if not k.startswith("convup_fp")}
     _load(head, synth.make_state_dict(c["wseed"], "swin", c["decoder_gain"], c["decoder_log_scale"]), fsd,
@@ -137,7 +138,7 @@ def gen_head_swin_hahi(HeadCls):
     for i, n in enumerate(neck):
         out[f"neck{i}_ch0_2"] = t2n(n)[:, :2]
         out[f"neck{i}_sum"] = np.array([float(n.double().sum()), float(n.double().abs().max())])
-    print("head_swin_hahi: pred range", float(o["pred"].min()), float(o["pred"].max()), "ddim_loss", float(o["ddim_loss"]),
+    print(case + ": pred range", float(o["pred"].min()), float(o["pred"].max()), "ddim_loss", float(o["ddim_loss"]),
           "neck max", [float(n.abs().max()) for n in neck])
     return out
 
@@ -159,8 +160,9 @@ def gen_head_res_vis(VisCls):
 
 
 def main():
-    _, _, HeadCls, VisCls = load_hahi_reference()
+    _, MpvitCls, HeadCls, VisCls = load_hahi_reference()
     np.savez_compressed(os.path.join(HERE, "head_swin_hahi.npz"), **gen_head_swin_hahi(HeadCls))
+    np.savez_compressed(os.path.join(HERE, "head_mpvit_hahi.npz"), **gen_head_swin_hahi(MpvitCls, "head_mpvit_hahi", (128, 216, 288, 288)))
     np.savez_compressed(os.path.join(HERE, "head_res_vis.npz"), **gen_head_res_vis(VisCls))
 
 

@@ -39,15 +39,18 @@ def _load(head, sd):
     return head.cuda()
 
 
-def test_swin_hahi_head_forward_matches_reference_golden(U, golden, cases):
+@pytest.mark.parametrize("case,cls,chans", [("head_swin_hahi", "DDIMDepthEstimate_Swin_ADDHAHI", (192, 384, 768, 1536)),
+                                            ("head_mpvit_hahi", "DDIMDepthEstimate_MPVIT_ADDHAHI", (128, 216, 288, 288))], ids=["swin", "mpvit"])
+def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls, chans):
+    """mpvit: odd-sized pyramid (both adaptive_avg_pool2d size fixes active), FPN in PyTorch-ROCm (widths outside dd_condition's two
+    pyramids), explicit condition map handed to dd_denoise."""
     import diffusiondepth_amd as dda
-    c, g = cases["head_swin_hahi"], golden("head_swin_hahi")
-    chans = (192, 384, 768, 1536)
+    c, g = cases[case], golden(case)
     sd = synth.make_state_dict(c["wseed"], "swin", c["decoder_gain"], c["decoder_log_scale"])
     sd.update({k: v for k, v in synth.make_fpn_state_dict(c["fseed"], in_channels=chans).items() if not k.startswith("convup_fp")})
     sd.update(synth.make_hahi_state_dict(c["hseed"], chans))
-    head = _load(dda.DDIMDepthEstimate_Swin_ADDHAHI(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000,
-                                                    depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval(), sd)
+    head = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000,
+                                   depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval(), sd)
     B, H, W = c["B"], c["H"], c["W"]
     fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H // 2, W // 2, in_channels=chans)]
     gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
@@ -58,9 +61,16 @@ def test_swin_hahi_head_forward_matches_reference_golden(U, golden, cases):
     e_pred = U.maxabs(out["pred"].cpu().numpy(), g["pred"])
     e_init = U.maxabs(out["pred_init"].cpu().numpy(), g["pred_init"])
     e_loss = abs(float(out["ddim_loss"]) - float(g["ddim_loss"][0]))
-    U.record("head_swin_hahi", pred_maxabs=e_pred, pred_init_maxabs=e_init, ddim_loss_abs=e_loss, pred_max=float(g["pred"].max()))
+    U.record(case, pred_maxabs=e_pred, pred_init_maxabs=e_init, ddim_loss_abs=e_loss, pred_max=float(g["pred"].max()))
     assert e_init < 2e-5 and e_pred < 1e-3 and e_loss < 1e-4 * max(1.0, float(g["ddim_loss"][0]))
     assert head._bound.backend.counter("graph_launches") >= 1          # the loop ran in the library, as one hipGraph
+    if case == "head_swin_hahi":
+        # the Vis variant of the same head: same prediction, plus every intermediate sample decoded
+        vis = _load(dda.DDIMDepthEstimate_Swin_ADDHAHIVis(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000,
+                                                          depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval(), sd)
+        ov = _run(vis, fp, gt, inp, U)
+        assert len(ov["pred_inter"]) == c["T"] and torch.equal(ov["pred_inter"][-1], ov["pred"])
+        assert U.maxabs(ov["pred"].cpu().numpy(), g["pred"]) < 1e-3
 
 
 def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):
