@@ -99,6 +99,39 @@ def nlspn_extra(dev, B, H, W, T=18):
     return out
 
 
+def head_extra(dev, B, H, W, precision, T):
+    """Whole DDIMDepthEstimate_Res.forward (encoder, HIP condition FPN on synthetic backbone maps, T-step loop, decoder, ddim_loss) in
+    the reference's eval behaviour and with the two documented switches (head.py: loss_noise_device, eval_ddim_loss)."""
+    import diffusiondepth_amd as dda
+    from diffusiondepth_amd import synth
+    sd = synth.make_state_dict(7240)
+    sd.update(synth.make_fpn_state_dict(7241))
+    head = dda.DDIMDepthEstimate_Res(precision=precision, condition_backend="hip", inference_steps=T).eval()
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    head = head.to(dev)
+    fp = [torch.from_numpy(f).to(dev) for f in synth.make_backbone_features(1, B, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(2, B, H, W)).to(dev)
+
+    def timed(n=5):
+        with torch.no_grad():
+            for _ in range(2):
+                head(fp, gt, gt > 0, gt_depth_map=gt)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                head(fp, gt, gt > 0, gt_depth_map=gt)
+            torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n * 1e3
+    t_ref = timed()
+    head.loss_noise_device = "device"
+    t_dev = timed()
+    head.eval_ddim_loss = False
+    t_inf = timed()
+    return {"what": f"DDIMDepthEstimate_Res.forward at {H}x{W}, {precision}, batch {B}: encoder + HIP FPN + {T}-step loop + decoder (+ ddim_loss)",
+            "reference_eval_behaviour_ms": round(t_ref, 3), "loss_noise_on_device_ms": round(t_dev, 3), "inference_only_ms": round(t_inf, 3),
+            "inference_only_maps_per_s": round(B / t_inf * 1e3, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +147,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-latency-b1", action="store_true", help="skip the B=1 latency extra (keeps a profile to one launch shape)")
     ap.add_argument("--no-train-extra", action="store_true", help="skip the training-step timing (loop forward + backward, batch 1)")
+    ap.add_argument("--no-head-extra", action="store_true", help="skip the whole-head forward timing")
     ap.add_argument("--no-nlspn-extra", action="store_true", help="skip the NLSPN refinement timing (SURVEY.md 8f rank 4)")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
     ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
@@ -299,6 +333,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             nlspn = {"error": f"{type(e).__name__}: {e}"}
 
+    headx = None
+    if rank == 0 and world == 1 and args.variant == "res" and args.precision != "naive_fp32" and not args.no_head_extra:
+        try:
+            headx = head_extra(dev, B, H, W, args.precision, T)
+        except Exception as e:  # noqa: BLE001
+            headx = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         maps = B * args.steps * world
         out = {
@@ -310,7 +351,7 @@ def main():
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant},
-            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train, "nlspn_refine": nlspn,
+            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

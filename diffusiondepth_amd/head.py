@@ -41,8 +41,21 @@ class DDIMDepthEstimate_Res(nn.Module):
 
     def __init__(self, in_channels=(64, 128, 256, 512), up_scale_factor=1, inference_steps=20, num_train_timesteps=1000,
                  return_indices=None, depth_transform_cfg=None, depth_feature_dim=16, detach_fp=False, loss_cfgs=(),
-                 init_cfg=None, precision=None, condition_backend="hip", **kwargs):
+                 init_cfg=None, precision=None, condition_backend="hip", eval_ddim_loss=True, loss_noise_device="cpu", **kwargs):
+        """Beyond the reference's keywords (src/model/diffusion_dcbase_model.py:77-91):
+        precision          operand mode of the HIP kernels ("fp32" parity / "bf16" / "f16"; None = the library default)
+        condition_backend  "hip" (dd_condition) or "torch" for the FPN
+        eval_ddim_loss     True = the reference's behaviour: the DDIM loss (one more denoiser call, fed by a CPU randn of the latent's
+                           size) is computed on EVERY forward, also in eval / test (…res.py:159-169).  False skips it
+                           outside .train() and returns a zero scalar under 'ddim_loss' (inference-only deployments).
+        loss_noise_device  "cpu" = draw the loss noise on the host and copy it over, as the reference does (…res.py:203, quirk q3: same
+                           RNG stream as the reference); "device" = draw it on the GPU (same distribution, different stream; saves the
+                           6.8 MB-per-KITTI-map host RNG + H2D copy per forward)."""
         super().__init__()
+        if loss_noise_device not in ("cpu", "device"):
+            raise ValueError("loss_noise_device must be 'cpu' or 'device'")
+        self.eval_ddim_loss = bool(eval_ddim_loss)
+        self.loss_noise_device = loss_noise_device
         if depth_transform_cfg is not None and depth_transform_cfg.get("type", "DeepDepthTransformWithUpsampling") != \
                 "DeepDepthTransformWithUpsampling":
             raise NotImplementedError("only DeepDepthTransformWithUpsampling is used by the reference heads (…res.py:23)")
@@ -118,15 +131,21 @@ class DDIMDepthEstimate_Res(nn.Module):
         refined_depth = self.depth_transform.inv_t(refined_depth_t)             # :140  (HIP decoder)
         # *Vis heads: every intermediate sample decoded (…res_vis.py:141-143)
         processes_vis = [self.depth_transform.inv_t(m) for m in res[1]] if self._VIS else None
-        ddim_loss = self.ddim_loss(pred_depth=refined_depth, gt_depth=gt_map_t, refine_module_inputs=(x, None, None, None),
-                                   blur_depth_t=refined_depth_t, weight=1.0)    # :159-169
+        if self.training or self.eval_ddim_loss:
+            ddim_loss = self.ddim_loss(pred_depth=refined_depth, gt_depth=gt_map_t, refine_module_inputs=(x, None, None, None),
+                                       blur_depth_t=refined_depth_t, weight=1.0)    # :159-169
+        else:
+            ddim_loss = refined_depth.new_zeros(())
         return {"pred": refined_depth, "pred_init": gt_map_t, "blur_depth_t": gt_map_t, "ddim_loss": ddim_loss,
                 "gt_map_t": gt_map_t, "pred_uncertainty": None, "pred_inter": processes_vis, "weight_map": None, "guidance": None,
                 "offset": None, "aff": None, "gamma": None, "confidence": None}
 
     def ddim_loss(self, gt_depth, refine_module_inputs, blur_depth_t, weight, **kwargs):
         """…res.py:201-217: same RNG draw order (CPU randn for the noise, device randint for t)."""
-        noise = torch.randn(blur_depth_t.shape).to(blur_depth_t.device)
+        if self.loss_noise_device == "cpu":
+            noise = torch.randn(blur_depth_t.shape).to(blur_depth_t.device)
+        else:
+            noise = torch.randn(blur_depth_t.shape, device=blur_depth_t.device)
         bs = blur_depth_t.shape[0]
         timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bs,), device=gt_depth.device).long()
         be = self._bound.ensure(blur_depth_t.device, self.scheduler)

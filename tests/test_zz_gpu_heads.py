@@ -99,3 +99,40 @@ def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):
         tr = be.denoise_trace(x, cond, 7, prec)
         assert tuple(tr.shape) == (7,) + tuple(x.shape)
         assert torch.equal(tr[-1], be.denoise(x, cond, 7, prec)), prec
+
+
+def test_head_inference_switches(U, cases):
+    """eval_ddim_loss=False skips the (reference-mandated) eval-time DDIM loss without touching the prediction; loss_noise_device='device'
+    keeps a finite loss of the same magnitude; .train() always computes it."""
+    import diffusiondepth_amd as dda
+    c = cases["head_res"]
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+    outs = {}
+    for name, kw in (("ref", {}), ("inf", dict(eval_ddim_loss=False)), ("dev", dict(loss_noise_device="device"))):
+        head = _load(dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=5, num_train_timesteps=1000,
+                                               depth_feature_dim=16, loss_cfgs=[], precision="fp32", **kw).eval(), sd)
+        x_T = U.cu(inp["x_T"])
+        real = torch.randn
+        first = [True]
+
+        def randn(*a, **k):              # x_T injected (first draw), the loss noise drawn for real
+            if first[0]:
+                first[0] = False
+                return x_T
+            return real(*a, **k)
+        torch.randn = randn
+        try:
+            with torch.no_grad():
+                outs[name] = head(fp, gt, gt > 0, gt_depth_map=gt)
+        finally:
+            torch.randn = real
+    assert torch.equal(outs["inf"]["pred"], outs["ref"]["pred"]) and torch.equal(outs["dev"]["pred"], outs["ref"]["pred"])
+    assert float(outs["inf"]["ddim_loss"]) == 0.0 and outs["inf"]["ddim_loss"].is_cuda
+    lr, ld = float(outs["ref"]["ddim_loss"]), float(outs["dev"]["ddim_loss"])
+    assert np.isfinite(ld) and 0.5 * lr < ld < 2.0 * lr

@@ -36,6 +36,11 @@ with torch.no_grad():
     be = head_hip._bound.backend
     t_fpn_hip_noexp = timeit(lambda: be.condition(fp, prec, export=False))
     t_head_hip = timeit(lambda: head_hip(fp, gt, gt > 0, gt_depth_map=gt))
+    head_hip.loss_noise_device = "device"
+    t_head_dev = timeit(lambda: head_hip(fp, gt, gt > 0, gt_depth_map=gt))
+    head_hip.eval_ddim_loss = False
+    t_head_inf = timeit(lambda: head_hip(fp, gt, gt > 0, gt_depth_map=gt))
+    head_hip.eval_ddim_loss, head_hip.loss_noise_device = True, "cpu"
     be.set_option("layer_timing", 1)
     for _ in range(5): be.condition(fp, prec, export=False)
     torch.cuda.synchronize()
@@ -43,4 +48,5 @@ with torch.no_grad():
     be.set_option("layer_timing", 0)
 print(f"B={B} {prec}: FPN torch fp32 {t_fpn:.3f} ms | channels_last {t_fpn_cl:.3f} ms | autocast bf16 {t_fpn_bf16:.3f} ms | whole head.forward {t_head:.3f} ms")
 print(f"B={B} {prec}: FPN HIP {t_fpn_hip:.3f} ms (no export {t_fpn_hip_noexp:.3f} ms) | whole head.forward with HIP FPN {t_head_hip:.3f} ms")
+print(f"B={B} {prec}: whole head.forward, loss noise drawn on the device {t_head_dev:.3f} ms | eval_ddim_loss=False (inference only) {t_head_inf:.3f} ms = {B / t_head_inf * 1e3:.1f} maps/s")
 print("   FPN conv kernels avg us:", {l: round(1e3 * ms / max(n, 1), 1) for l, (ms, n) in lay.items()}, "launches", {l: n for l, (ms, n) in lay.items()})
