@@ -54,6 +54,7 @@ class DDIMDepthEstimate_Res(nn.Module):
         super().__init__()
         if loss_noise_device not in ("cpu", "device"):
             raise ValueError("loss_noise_device must be 'cpu' or 'device'")
+        self.neck_autocast = bool(kwargs.pop("neck_autocast", True))      # HAHI heads only: see forward()
         self.eval_ddim_loss = bool(eval_ddim_loss)
         self.loss_noise_device = loss_noise_device
         if depth_transform_cfg is not None and depth_transform_cfg.get("type", "DeepDepthTransformWithUpsampling") != \
@@ -122,7 +123,14 @@ class DDIMDepthEstimate_Res(nn.Module):
                 fp = [it.detach() for it in fp]
         gt_map_t = self.depth_transform.t(gt_depth_map)                         # …res.py:102  (HIP encoder)
         if self._HAHI:
-            fp = self.hahineck(fp)                                              # …swin_addHAHI.py:110
+            # the neck is PyTorch-ROCm (≈170 GFLOP per KITTI image at Swin-L widths); with 16-bit kernel operands selected for the hot
+            # path it runs under autocast in the same element type (fp32 precision modes keep the reference's fp32 arithmetic)
+            ac = {"bf16": torch.bfloat16, "f16": torch.float16}.get(self.model.precision) if (self.neck_autocast and fp[0].is_cuda and not self.training) else None
+            if ac is not None:
+                with torch.autocast("cuda", dtype=ac):
+                    fp = [f.float() for f in self.hahineck(fp)]
+            else:
+                fp = self.hahineck(fp)                                          # …swin_addHAHI.py:110
         x = self.aggregate_condition(fp)                                        # …res.py:108-118
         res = self.pipeline(batch_size=x.shape[0], device=x.device, dtype=x.dtype, shape=gt_map_t.shape[-3:],
                             input_args=(x, None, None, None),

@@ -71,6 +71,15 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
         ov = _run(vis, fp, gt, inp, U)
         assert len(ov["pred_inter"]) == c["T"] and torch.equal(ov["pred_inter"][-1], ov["pred"])
         assert U.maxabs(ov["pred"].cpu().numpy(), g["pred"]) < 1e-3
+        # bf16 operand mode: the PyTorch-ROCm neck runs under bf16 autocast, the rest on the bf16 kernels; error recorded and bounded
+        # (16-bit modes are judged on depth RMSE); neck_autocast=False keeps the neck in fp32
+        errs = {}
+        for ac in (True, False):
+            hb = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
+                                         loss_cfgs=[], precision="bf16", neck_autocast=ac).eval(), sd)
+            errs[ac] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
+        U.record(case + "_bf16", depth_rmse_neck_autocast=errs[True], depth_rmse_neck_fp32=errs[False], pred_max=float(g["pred"].max()))
+        assert errs[True] < 0.1 and errs[False] < 0.1
 
 
 def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):
