@@ -427,6 +427,105 @@ __global__ void __launch_bounds__(256) nlspn_affinity_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The same stage INCLUDING its convolution  offset_aff = conv_offset_aff(guidance)  (nlspnmodel.py:90: Conv2d(ch_g, 3*num, 3, padding 1,
+// bias)) for the shipped geometry ch_g = 8, k_g = 3, k_f = 3 (NLSPNModel, nlspnmodel.py:215,287-288): the 24-plane intermediate
+// (192 B per pixel written and re-read) never exists.  A block owns an 8 x 64 pixel tile; the 8-channel guidance tile + 1-pixel zero
+// halo (the conv's zero padding) is staged in LDS; a lane holds its pixel's 72-value patch in registers and walks the 24 output
+// channels with the weights as SCALAR operands (OIHW: the 72 weights of one output channel are contiguous -> s_load_dwordx8).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int CG>
+__global__ void __launch_bounds__(256) nlspn_guide_affinity_kernel(const float* __restrict__ guide, const float* __restrict__ cw,
+                                                                   const float* __restrict__ cb, const float* __restrict__ conf,
+                                                                   const float* __restrict__ gamma_p, const float* __restrict__ wconf_p,
+                                                                   const float* __restrict__ bconf_p, float* __restrict__ offset,
+                                                                   float* __restrict__ aff, int H, int W, int mode, int legacy) {
+  constexpr int KF = 3, K = 9, NUM = 8, REF = 4, TH = 8, TW = 64, LW = TW + 2, LH = TH + 2, LS = LW + 1;
+  __shared__ float tile[CG * LH * LS];
+  const int b = blockIdx.z;
+  const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+  const size_t HW = (size_t)H * W;
+  const int tid = threadIdx.x;
+  {
+    constexpr int NFILL = (CG * LH * LW + 255) / 256;
+    float tv[NFILL];
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) {
+      const int idx = tid + it * 256;
+      const int c = min(idx / (LH * LW), CG - 1), rem = idx % (LH * LW);
+      const int r = rem / LW, col = rem - r * LW;
+      tv[it] = guide[((size_t)b * CG + c) * HW + (size_t)min(max(y0 - 1 + r, 0), H - 1) * W + min(max(x0 - 1 + col, 0), W - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) asm volatile("" : "+v"(tv[it]));      // loads stay above the selects (see nlspn_prop_lds_kernel)
+#pragma unroll
+    for (int it = 0; it < NFILL; ++it) {
+      const int idx = tid + it * 256;
+      const int c = idx / (LH * LW), rem = idx % (LH * LW);
+      const int r = rem / LW, col = rem - r * LW;
+      const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+      if (idx < CG * LH * LW) tile[(c * LH + r) * LS + col] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? tv[it] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;
+  const int w = x0 + tx;
+  if (w >= W) return;
+  const float gamma = gamma_p[0];
+  const float* cim = conf ? conf + (size_t)b * HW : nullptr;
+  const float wconf = conf ? wconf_p[0] : 0.f, bconf = conf ? bconf_p[0] : 0.f;
+  for (int rr = ty; rr < TH; rr += 4) {
+    const int h = y0 + rr;
+    if (h >= H) break;
+    float g[CG * K];
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+#pragma unroll
+      for (int t = 0; t < K; ++t) g[c * K + t] = tile[(c * LH + rr + t / KF) * LS + tx + t % KF];
+    auto conv_out = [&](int co) {                       // one output channel of conv_offset_aff at this pixel; weights are scalar operands
+      float acc = cb[co];
+#pragma unroll
+      for (int q = 0; q < CG * K; ++q) acc += cw[co * CG * K + q] * g[q];
+      return acc;
+    };
+    // ---- from here on: nlspn_affinity_kernel<3> (nlspnmodel.py:92-161), neighbour by neighbour so that only a[] stays live ----
+    const size_t pix = (size_t)h * W + w;
+    float* o = offset + (size_t)b * 2 * K * HW + pix;
+    float* ao = aff + (size_t)b * K * HW + pix;
+    float a[NUM];
+    float sabs = 0.f;
+#pragma unroll
+    for (int n = 0; n < NUM; ++n) {
+      const int m = n < REF ? n : n + 1;
+      float oh = conv_out(2 * n), ow = conv_out(2 * n + 1);
+      if (conf && legacy) {
+        oh = (oh + (float)(m / KF)) - 1.f;
+        ow = (ow + (float)(m % KF)) - 1.f;
+      }
+      o[(size_t)(2 * m) * HW] = oh;
+      o[(size_t)(2 * m + 1) * HW] = ow;
+      float v = conv_out(2 * NUM + n);
+      if (mode == DD_AFF_TC) v = tanhf(v) / gamma;
+      else if (mode == DD_AFF_TGASS) v = tanhf(v) / (gamma + 1e-8f);
+      if (conf) v *= bconf + (sample_plane(cim, H, W, (float)h + oh, (float)w + ow) * 1.0f) * wconf;
+      a[n] = v;
+      sabs += fabsf(v);
+    }
+    o[(size_t)(2 * REF) * HW] = 0.f;
+    o[(size_t)(2 * REF + 1) * HW] = 0.f;
+    float s_ = sabs + 1e-4f;
+    if (mode == DD_AFF_ASS || mode == DD_AFF_TGASS) s_ = s_ < 1.f ? 1.f : s_;
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < NUM; ++n) {
+      if (mode != DD_AFF_TC) a[n] = a[n] / s_;
+      sum += a[n];
+      ao[(size_t)(n < REF ? n : n + 1) * HW] = a[n];
+    }
+    ao[(size_t)REF * HW] = 1.f - sum;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // General DCNv2 (any C, groups, deformable groups, stride, dilation).  No model in the reference tree uses it beyond C = 1, so
 // these are plain one-lane-per-output kernels: correct for every shape the extension accepts, tuned for none.
 // ------------------------------------------------------------------------------------------------------------------------
@@ -731,6 +830,23 @@ int dd_nlspn_offset_affinity(const float* offset_aff, const float* confidence, c
     case 7: hipLaunchKernelGGL(nlspn_affinity_kernel<7>, grid, block, 0, st, offset_aff, conf, aff_scale_const, w_conf, b_conf, offset, aff, H, W, affinity, legacy); break;
     default: return dcn_fail(DD_ERR_UNSUPPORTED, "prop_kernel %d: this build has 3, 5 and 7 (the reference asserts an odd size, nlspnmodel.py:35)", k_f);
   }
+  DCN_HIP(hipGetLastError());
+  return DD_OK;
+}
+
+int dd_nlspn_guided_offset_affinity(const float* guidance, const float* conv_weight, const float* conv_bias, const float* confidence,
+                                    const float* aff_scale_const, const float* w_conf, const float* b_conf, float* offset, float* aff,
+                                    int B, int ch_g, int H, int W, int k_g, int k_f, int affinity, int conf_prop, int legacy, void* stream) {
+  if (!guidance || !conv_weight || !conv_bias || !aff_scale_const || !offset || !aff) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
+  if (B <= 0 || H <= 0 || W <= 0) return dcn_fail(DD_ERR_INVALID_ARG, "B, H, W must be positive");
+  if (affinity < DD_AFF_AS || affinity > DD_AFF_TGASS) return dcn_fail(DD_ERR_INVALID_ARG, "unknown affinity mode %d", affinity);
+  if (conf_prop && (!confidence || !w_conf || !b_conf)) return dcn_fail(DD_ERR_INVALID_ARG, "conf_prop needs confidence, w_conf and b_conf");
+  if (ch_g != 8 || k_g != 3 || k_f != 3)
+    return dcn_fail(DD_ERR_UNSUPPORTED, "fused guidance convolution is built for ch_g 8, k_g 3, k_f 3 (NLSPNModel's geometry); got %d, %d, %d: "
+                                        "run the convolution separately and call dd_nlspn_offset_affinity", ch_g, k_g, k_f);
+  const dim3 grid((W + 63) / 64, (H + 7) / 8, B), block(256);
+  hipLaunchKernelGGL(nlspn_guide_affinity_kernel<8>, grid, block, 0, (hipStream_t)stream, guidance, conv_weight, conv_bias,
+                     conf_prop ? confidence : nullptr, aff_scale_const, w_conf, b_conf, offset, aff, H, W, affinity, legacy);
   DCN_HIP(hipGetLastError());
   return DD_OK;
 }

@@ -19,7 +19,8 @@ from torch.nn.modules.utils import _pair
 from . import backend
 
 # every symbol include/ddepth_dcn.h declares (checked by tests/test_abi.py)
-ABI_SYMBOLS = ["dd_dcn_last_error", "dd_dcn_forward", "dd_dcn_backward", "dd_nlspn_offset_affinity", "dd_nlspn_workspace_bytes",
+ABI_SYMBOLS = ["dd_dcn_last_error", "dd_dcn_forward", "dd_dcn_backward", "dd_nlspn_offset_affinity", "dd_nlspn_guided_offset_affinity",
+               "dd_nlspn_workspace_bytes",
                "dd_nlspn_propagate"]
 
 _bound = None
@@ -34,6 +35,7 @@ def _lib():
         lib.dd_dcn_forward.restype, lib.dd_dcn_forward.argtypes = c_int, [c_vp] * 6 + [c_int] * 16 + [c_vp]
         lib.dd_dcn_backward.restype, lib.dd_dcn_backward.argtypes = c_int, [c_vp] * 11 + [c_int] * 16 + [c_vp]
         lib.dd_nlspn_offset_affinity.restype, lib.dd_nlspn_offset_affinity.argtypes = c_int, [c_vp] * 7 + [c_int] * 7 + [c_vp]
+        lib.dd_nlspn_guided_offset_affinity.restype, lib.dd_nlspn_guided_offset_affinity.argtypes = c_int, [c_vp] * 9 + [c_int] * 10 + [c_vp]
         lib.dd_nlspn_workspace_bytes.restype = c_int
         lib.dd_nlspn_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)]
         lib.dd_nlspn_propagate.restype, lib.dd_nlspn_propagate.argtypes = c_int, [c_vp] * 8 + [c_int] * 6 + [c_vp]
@@ -173,6 +175,36 @@ def nlspn_offset_affinity(offset_aff, confidence, aff_scale_const, w_conf, b_con
         _ck(_lib().dd_nlspn_offset_affinity(offset_aff.data_ptr(), confidence.data_ptr() if conf_prop else None, dp(aff_scale_const),
                                             dp(w_conf), dp(b_conf), offset.data_ptr(), aff.data_ptr(), B, H, W, k_f, AFFINITY_ID[affinity],
                                             int(bool(conf_prop)), int(bool(legacy)), _stream(offset_aff)), "dd_nlspn_offset_affinity")
+    return offset, aff
+
+
+def guided_supported(ch_g, k_g, k_f):
+    """Geometry dd_nlspn_guided_offset_affinity is built for (NLSPNModel's: src/model/nlspnmodel.py:215,287-288)."""
+    return ch_g == 8 and k_g == 3 and k_f == 3
+
+
+def nlspn_guided_offset_affinity(guidance, conv_weight, conv_bias, confidence, aff_scale_const, w_conf, b_conf, k_g, k_f, affinity,
+                                 conf_prop, legacy):
+    """dd_nlspn_guided_offset_affinity: conv_offset_aff + the whole of _get_offset_affinity (src/model/nlspnmodel.py:87-163) in one kernel."""
+    guidance = _dev_f32(guidance.contiguous(), "guidance")
+    B, ch_g, H, W = guidance.shape
+    num = k_f * k_f - 1
+    if tuple(conv_weight.shape) != (3 * num, ch_g, k_g, k_g):
+        raise RuntimeError(f"conv_offset_aff.weight must be {(3 * num, ch_g, k_g, k_g)}, got {tuple(conv_weight.shape)}")
+    if conf_prop:
+        if confidence is None:
+            raise AssertionError("conf_prop needs a confidence map")          # nlspnmodel.py:180
+        confidence = _dev_f32(confidence.contiguous(), "confidence")
+        if tuple(confidence.shape) != (B, 1, H, W):
+            raise RuntimeError(f"confidence must be {(B, 1, H, W)}, got {tuple(confidence.shape)}")
+    offset = torch.empty((B, 2 * (num + 1), H, W), device=guidance.device, dtype=torch.float32)
+    aff = torch.empty((B, num + 1, H, W), device=guidance.device, dtype=torch.float32)
+    dp = lambda t: _dev_f32(t.detach().contiguous(), "parameter").data_ptr()
+    with torch.cuda.device(guidance.device):
+        _ck(_lib().dd_nlspn_guided_offset_affinity(guidance.data_ptr(), dp(conv_weight), dp(conv_bias),
+                                                   confidence.data_ptr() if conf_prop else None, dp(aff_scale_const), dp(w_conf), dp(b_conf),
+                                                   offset.data_ptr(), aff.data_ptr(), B, ch_g, H, W, k_g, k_f, AFFINITY_ID[affinity],
+                                                   int(bool(conf_prop)), int(bool(legacy)), _stream(guidance)), "dd_nlspn_guided_offset_affinity")
     return offset, aff
 
 

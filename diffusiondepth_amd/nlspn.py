@@ -7,8 +7,9 @@ libddepth_hip.so:
   * autograd needed (training): the reference's own formulation -- torch ops plus ``ModulatedDeformConvFunction`` once per
     confidence neighbour and once per iteration -- with the HIP DCNv2 forward / backward of diffusiondepth_amd.dcn under it.
 
-``conv_offset_aff`` (ch_g -> 3*num, 3x3) stays a torch convolution (MIOpen): the encoder-decoder producing guidance / confidence /
-initial depth is PyTorch-ROCm too (north star: "NLSPN-style refinement stay in PyTorch-ROCm" apart from this hot stage).
+``conv_offset_aff`` (ch_g -> 3*num, 3x3) is evaluated inside the affinity kernel for NLSPNModel's geometry (ch_g 8, 3x3, 3x3:
+dd_nlspn_guided_offset_affinity) and is a torch convolution (MIOpen) otherwise and in training; the encoder-decoder producing guidance /
+confidence / initial depth is PyTorch-ROCm (north star: "NLSPN-style refinement stay in PyTorch-ROCm" apart from this hot stage).
 """
 from __future__ import annotations
 
@@ -60,6 +61,7 @@ class NLSPN(nn.Module):
         self.groups = self.ch_f
         self.deformable_groups = 1
         self.im2col_step = 64
+        self.fuse_guidance_conv = True      # inference path: dd_nlspn_guided_offset_affinity where its geometry applies (A/B switch)
 
     # -- the reference's formulation (autograd path) ---------------------------------------------------------------------
     def _get_offset_affinity(self, guidance, confidence=None, rgb=None):
@@ -129,9 +131,16 @@ class NLSPN(nn.Module):
         if self.args.preserve_input:
             assert feat_init.shape == feat_fix.shape
         if not self._needs_autograd(feat_init, guidance, confidence):
-            offset_aff = self.conv_offset_aff(guidance)
-            offset, aff = dcn.nlspn_offset_affinity(offset_aff, confidence if self.args.conf_prop else None, self.aff_scale_const,
-                                                    self.w_conf, self.b, self.k_f, self.affinity, self.args.conf_prop, self.args.legacy)
+            conf = confidence if self.args.conf_prop else None
+            if self.fuse_guidance_conv and dcn.guided_supported(self.ch_g, self.k_g, self.k_f):
+                # conv_offset_aff evaluated inside the affinity kernel (NLSPNModel's geometry): no 24-plane intermediate
+                offset, aff = dcn.nlspn_guided_offset_affinity(guidance, self.conv_offset_aff.weight, self.conv_offset_aff.bias, conf,
+                                                               self.aff_scale_const, self.w_conf, self.b, self.k_g, self.k_f, self.affinity,
+                                                               self.args.conf_prop, self.args.legacy)
+            else:
+                offset_aff = self.conv_offset_aff(guidance)          # torch / MIOpen
+                offset, aff = dcn.nlspn_offset_affinity(offset_aff, conf, self.aff_scale_const, self.w_conf, self.b, self.k_f,
+                                                        self.affinity, self.args.conf_prop, self.args.legacy)
             feats = dcn.nlspn_propagate(feat_init, offset, aff, feat_fix if self.args.preserve_input else None, self.w, self.b,
                                         self.k_f, self.prop_time, self.args.preserve_input)
             list_feat = list(feats.unbind(0))

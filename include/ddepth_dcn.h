@@ -79,6 +79,15 @@ int dd_nlspn_offset_affinity(const float* offset_aff, const float* confidence, c
                              const float* b_conf, float* offset, float* aff, int B, int H, int W, int k_f, int affinity, int conf_prop,
                              int legacy, void* stream);
 
+/* The same stage INCLUDING the convolution in front of it: offset_aff = self.conv_offset_aff(guidance) (nlspnmodel.py:90,
+ * nn.Conv2d(ch_g, 3*num, k_g, padding (k_g-1)/2, bias), :50-53) is evaluated inside the kernel and the 3*num-plane intermediate never
+ * reaches HBM.  Built for the geometry NLSPNModel uses (ch_g = 8, k_g = 3, k_f = 3; nlspnmodel.py:215,287-288); anything else is
+ * DD_ERR_UNSUPPORTED (run the convolution separately and call dd_nlspn_offset_affinity).
+ *   guidance (B, ch_g, H, W)   conv_weight (3*num, ch_g, k_g, k_g)   conv_bias (3*num)   -- device pointers; the rest as above. */
+int dd_nlspn_guided_offset_affinity(const float* guidance, const float* conv_weight, const float* conv_bias, const float* confidence,
+                                    const float* aff_scale_const, const float* w_conf, const float* b_conf, float* offset, float* aff,
+                                    int B, int ch_g, int H, int W, int k_g, int k_f, int affinity, int conf_prop, int legacy, void* stream);
+
 /* Bytes of scratch dd_nlspn_propagate needs (0 unless preserve_input). */
 int dd_nlspn_workspace_bytes(int B, int H, int W, int preserve_input, int64_t* bytes);
 

@@ -203,6 +203,24 @@ def test_nlspn_full_size_properties(U):
     err = float((lhs - rhs).abs().max() / rhs.abs().max())
     U.record("nlspn_full_size_linearity", err=err)
     assert err < 1e-5
+    # (f) the guidance convolution evaluated inside the affinity kernel (dd_nlspn_guided_offset_affinity) == torch conv + dd_nlspn_offset_affinity
+    m2 = NLSPN(_args(), 8, 1, 3, 3).cuda().eval()
+    with torch.no_grad():
+        m2.conv_offset_aff.weight.copy_(0.1 * torch.randn(24, 8, 3, 3, device="cuda", generator=gen))
+        m2.conv_offset_aff.bias.copy_(0.3 * torch.randn(24, device="cuda", generator=gen))
+        guide, conf = 2 * torch.randn(B, 8, H, W, device="cuda", generator=gen), torch.rand(B, 1, H, W, device="cuda", generator=gen)
+        for legacy in (False, True):
+            m2.args.legacy = legacy
+            m2.fuse_guidance_conv = True
+            _, _, o_f, a_f, _ = m2(feat, guide, conf)
+            m2.fuse_guidance_conv = False
+            _, _, o_u, a_u, _ = m2(feat, guide, conf)
+            eo, ea = float((o_f - o_u).abs().max()), float((a_f - a_u).abs().max())
+            U.record("nlspn_guided_vs_unfused", legacy=int(legacy), offset_abs=eo, aff_abs=ea, offset_max=float(o_u.abs().max()))
+            assert eo < 2e-5 and ea < 1e-5, (legacy, eo, ea)
+    with pytest.raises(RuntimeError, match="built for ch_g 8"):
+        dcn.nlspn_guided_offset_affinity(torch.zeros(1, 4, 8, 8, device="cuda"), torch.zeros(24, 4, 3, 3, device="cuda"), torch.zeros(24, device="cuda"),
+                                         None, m.aff_scale_const, m.w_conf, m.b, 3, 3, "TGASS", False, False)
     # (e) an odd width takes the one-pixel-per-lane kernel: same numbers as the 4-pixel kernel on the common columns' interior
     Wc = W - 3
     crop = lambda t: t[..., :Wc].contiguous()

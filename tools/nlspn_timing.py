@@ -57,6 +57,11 @@ def main():
         t_aff = timed(lambda: dcn.nlspn_offset_affinity(offset_aff, conf, m.aff_scale_const, m.w_conf, m.b, 3, "TGASS", True, False), a.iters)
         t_prop = timed(lambda: dcn.nlspn_propagate(feat, offset, aff, None, m.w, m.b, 3, T, False), a.iters)
         t_mod = timed(lambda: m(feat, guide, conf), a.iters)
+        t_guided = timed(lambda: dcn.nlspn_guided_offset_affinity(guide, m.conv_offset_aff.weight, m.conv_offset_aff.bias, conf, m.aff_scale_const,
+                                                                  m.w_conf, m.b, 3, 3, "TGASS", True, False), a.iters)
+        m.fuse_guidance_conv = False
+        t_mod_unfused = timed(lambda: m(feat, guide, conf), a.iters)
+        m.fuse_guidance_conv = True
 
         def per_op():
             o, af = m._get_offset_affinity(guide, conf)
@@ -79,7 +84,7 @@ def main():
         os.environ.pop("DD_NLSPN_KERNEL", None)
     px = B * H * W
     bytes_iter = 112 * px
-    out = {"B": B, "H": H, "W": W, "prop_time": T, "conv_offset_aff_ms": t_conv, "affinity_ms": t_aff, "propagate_ms": t_prop,
+    out = {"B": B, "H": H, "W": W, "prop_time": T, "conv_offset_aff_ms": t_conv, "affinity_ms": t_aff, "guided_conv_affinity_ms": t_guided, "module_forward_unfused_conv_ms": t_mod_unfused, "propagate_ms": t_prop,
            "propagate_us_per_iter": 1e3 * t_prop / T, "propagate_GBps": bytes_iter * T / (t_prop * 1e-3) / 1e9,
            "propagate_frac_hbm_peak": bytes_iter * T / (t_prop * 1e-3) / 8e12,
            "affinity_GBps": (24 + 1 + 27) * 4 * px / (t_aff * 1e-3) / 1e9,
