@@ -35,7 +35,7 @@ def _lib():
         lib.dd_dcn_forward.restype, lib.dd_dcn_forward.argtypes = c_int, [c_vp] * 6 + [c_int] * 16 + [c_vp]
         lib.dd_dcn_backward.restype, lib.dd_dcn_backward.argtypes = c_int, [c_vp] * 11 + [c_int] * 16 + [c_vp]
         lib.dd_nlspn_offset_affinity.restype, lib.dd_nlspn_offset_affinity.argtypes = c_int, [c_vp] * 7 + [c_int] * 7 + [c_vp]
-        lib.dd_nlspn_guided_offset_affinity.restype, lib.dd_nlspn_guided_offset_affinity.argtypes = c_int, [c_vp] * 9 + [c_int] * 10 + [c_vp]
+        lib.dd_nlspn_guided_offset_affinity.restype, lib.dd_nlspn_guided_offset_affinity.argtypes = c_int, [c_vp] * 9 + [c_int] * 9 + [c_vp]
         lib.dd_nlspn_workspace_bytes.restype = c_int
         lib.dd_nlspn_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)]
         lib.dd_nlspn_propagate.restype, lib.dd_nlspn_propagate.argtypes = c_int, [c_vp] * 8 + [c_int] * 6 + [c_vp]

@@ -125,6 +125,25 @@ def test_library_exports_every_dcn_symbol():
     assert lib.dd_dcn_last_error() == b""
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Arity of every bound function == the parameter count of its prototype in include/*.h (a wrong argtypes list only shows on the GPU
+    box otherwise), and argument validation answers before any HIP call (NULL pointers -> DD_ERR_INVALID_ARG + message, no GPU needed)."""
+    import diffusiondepth_amd as dda
+    from diffusiondepth_amd import dcn
+    lib = dcn._lib()
+    dda.load_library()
+    for hdr in ("ddepth.h", "ddepth_dcn.h"):
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", hdr)).read(), flags=re.S)
+        for name, params in re.findall(r"(?:int|const char\*)\s+(dd_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+            n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+            fn = getattr(lib, name)
+            assert fn.argtypes is not None and len(fn.argtypes) == n, (name, n, len(fn.argtypes or ()))
+    assert lib.dd_nlspn_guided_offset_affinity(*([None] * 9), 1, 8, 4, 4, 3, 3, 3, 1, 0, None) == 1
+    assert b"null tensor pointer" in lib.dd_dcn_last_error()
+    assert lib.dd_dcn_forward(*([None] * 6), *([1] * 16), None) == 1 and lib.dd_dcn_backward(*([None] * 11), *([1] * 16), None) == 1
+    assert lib.dd_nlspn_propagate(*([None] * 8), 1, 4, 4, 3, 18, 0, None) == 1 and lib.dd_nlspn_offset_affinity(*([None] * 7), 1, 4, 4, 3, 3, 1, 0, None) == 1
+
+
 def _args(**kw):
     d = dict(prop_time=18, affinity="TGASS", affinity_gamma=0.5, conf_prop=True, preserve_input=False, legacy=False)
     d.update(kw)
