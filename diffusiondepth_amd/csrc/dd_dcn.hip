@@ -441,6 +441,7 @@ __global__ void __launch_bounds__(256) nlspn_guide_affinity_kernel(const float* 
                                                                    float* __restrict__ aff, int H, int W, int mode, int legacy) {
   constexpr int KF = 3, K = 9, NUM = 8, REF = 4, TH = 8, TW = 64, LW = TW + 2, LH = TH + 2, LS = LW + 1;
   __shared__ float tile[CG * LH * LS];
+  __shared__ float asave[NUM * 256];
   const int b = blockIdx.z;
   const int y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
   const size_t HW = (size_t)H * W;
@@ -482,18 +483,25 @@ __global__ void __launch_bounds__(256) nlspn_guide_affinity_kernel(const float* 
 #pragma unroll
       for (int t = 0; t < K; ++t) g[c * K + t] = tile[(c * LH + rr + t / KF) * LS + tx + t % KF];
     auto conv_out = [&](int co) {                       // one output channel of conv_offset_aff at this pixel; weights are scalar operands
-      float acc = cb[co];
+      asm volatile("" ::: "memory");                    // keep this channel's 72 scalar weight loads behind the previous channel's (SGPR budget)
+      float p0 = cb[co], p1 = 0.f, p2 = 0.f, p3 = 0.f;  // four independent chains: a single 72-long FMA chain is latency-bound
 #pragma unroll
-      for (int q = 0; q < CG * K; ++q) acc += cw[co * CG * K + q] * g[q];
-      return acc;
+      for (int q = 0; q < CG * K; q += 4) {
+        p0 += cw[co * CG * K + q] * g[q];
+        p1 += cw[co * CG * K + q + 1] * g[q + 1];
+        p2 += cw[co * CG * K + q + 2] * g[q + 2];
+        p3 += cw[co * CG * K + q + 3] * g[q + 3];
+      }
+      return (p0 + p1) + (p2 + p3);
     };
     // ---- from here on: nlspn_affinity_kernel<3> (nlspnmodel.py:92-161), neighbour by neighbour so that only a[] stays live ----
     const size_t pix = (size_t)h * W + w;
     float* o = offset + (size_t)b * 2 * K * HW + pix;
     float* ao = aff + (size_t)b * K * HW + pix;
-    float a[NUM];
+    // the neighbour loop is NOT unrolled: unrolled, the 1728 scalar weight loads are hoisted together and spill (1000+ SGPRs); the
+    // eight affinities wait for the normalisation in a per-lane LDS slot instead of a dynamically indexed register array
     float sabs = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int n = 0; n < NUM; ++n) {
       const int m = n < REF ? n : n + 1;
       float oh = conv_out(2 * n), ow = conv_out(2 * n + 1);
@@ -507,7 +515,7 @@ __global__ void __launch_bounds__(256) nlspn_guide_affinity_kernel(const float* 
       if (mode == DD_AFF_TC) v = tanhf(v) / gamma;
       else if (mode == DD_AFF_TGASS) v = tanhf(v) / (gamma + 1e-8f);
       if (conf) v *= bconf + (sample_plane(cim, H, W, (float)h + oh, (float)w + ow) * 1.0f) * wconf;
-      a[n] = v;
+      asave[n * 256 + tid] = v;
       sabs += fabsf(v);
     }
     o[(size_t)(2 * REF) * HW] = 0.f;
@@ -517,9 +525,10 @@ __global__ void __launch_bounds__(256) nlspn_guide_affinity_kernel(const float* 
     float sum = 0.f;
 #pragma unroll
     for (int n = 0; n < NUM; ++n) {
-      if (mode != DD_AFF_TC) a[n] = a[n] / s_;
-      sum += a[n];
-      ao[(size_t)(n < REF ? n : n + 1) * HW] = a[n];
+      float an = asave[n * 256 + tid];                  // written by this lane only: no barrier needed
+      if (mode != DD_AFF_TC) an = an / s_;
+      sum += an;
+      ao[(size_t)(n < REF ? n : n + 1) * HW] = an;
     }
     ao[(size_t)REF * HW] = 1.f - sum;
   }

@@ -215,9 +215,17 @@ def test_nlspn_full_size_properties(U):
             _, _, o_f, a_f, _ = m2(feat, guide, conf)
             m2.fuse_guidance_conv = False
             _, _, o_u, a_u, _ = m2(feat, guide, conf)
-            eo, ea = float((o_f - o_u).abs().max()), float((a_f - a_u).abs().max())
-            U.record("nlspn_guided_vs_unfused", legacy=int(legacy), offset_abs=eo, aff_abs=ea, offset_max=float(o_u.abs().max()))
-            assert eo < 2e-5 and ea < 1e-5, (legacy, eo, ea)
+            # reference point for the convolution: fp64 on the host (MIOpen picks a Winograd fp32 kernel for the unfused path, which is
+            # the LESS accurate of the two: its distance is recorded, the fused kernel is held to the tight bound)
+            oa64 = torch.nn.functional.conv2d(guide[:1].double().cpu(), m2.conv_offset_aff.weight.double().cpu(),
+                                              m2.conv_offset_aff.bias.double().cpu(), padding=1).float().cuda()
+            o_r, a_r = dcn.nlspn_offset_affinity(oa64, conf[:1], m2.aff_scale_const, m2.w_conf, m2.b, 3, "TGASS", True, legacy)
+            eo, ea = float((o_f[:1] - o_r).abs().max()), float((a_f[:1] - a_r).abs().max())
+            eo_m, ea_m = float((o_u[:1] - o_r).abs().max()), float((a_u[:1] - a_r).abs().max())
+            U.record("nlspn_guided_conv", legacy=int(legacy), fused_offset_abs=eo, fused_aff_abs=ea, miopen_offset_abs=eo_m, miopen_aff_abs=ea_m,
+                     offset_max=float(o_r.abs().max()))
+            assert eo < 4e-6 and ea < 1e-5, (legacy, eo, ea)
+            assert float((o_f - o_u).abs().max()) < 5e-5 and float((a_f - a_u).abs().max()) < 2e-4       # fused vs MIOpen-based path, whole batch
     with pytest.raises(RuntimeError, match="built for ch_g 8"):
         dcn.nlspn_guided_offset_affinity(torch.zeros(1, 4, 8, 8, device="cuda"), torch.zeros(24, 4, 3, 3, device="cuda"), torch.zeros(24, device="cuda"),
                                          None, m.aff_scale_const, m.w_conf, m.b, 3, 3, "TGASS", False, False)
