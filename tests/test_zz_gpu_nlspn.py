@@ -224,7 +224,10 @@ def test_nlspn_full_size_properties(U):
             eo_m, ea_m = float((o_u[:1] - o_r).abs().max()), float((a_u[:1] - a_r).abs().max())
             U.record("nlspn_guided_conv", legacy=int(legacy), fused_offset_abs=eo, fused_aff_abs=ea, miopen_offset_abs=eo_m, miopen_aff_abs=ea_m,
                      offset_max=float(o_r.abs().max()))
-            assert eo < 4e-6 and ea < 1e-5, (legacy, eo, ea)
+            # offsets: fp32 round-off of values up to ~11.  Affinities: the confidence is sampled at (float)w + offset with w up to 1215,
+            # i.e. on a 1.2e-4 grid (fp32 ulp at 1024..2048) -- in the reference too (modulated_deform_im2col_cuda.cuh:177-178) -- so a
+            # 1e-6 difference in an offset can move a sample by one grid step: |d aff| <= 1.2e-4 * |grad conf| * 0.25 per neighbour
+            assert eo < 4e-6 and ea < 2e-4, (legacy, eo, ea)
             assert float((o_f - o_u).abs().max()) < 5e-5 and float((a_f - a_u).abs().max()) < 2e-4       # fused vs MIOpen-based path, whole batch
     with pytest.raises(RuntimeError, match="built for ch_g 8"):
         dcn.nlspn_guided_offset_affinity(torch.zeros(1, 4, 8, 8, device="cuda"), torch.zeros(24, 4, 3, 3, device="cuda"), torch.zeros(24, device="cuda"),
