@@ -4,8 +4,8 @@ libddepth_hip.so:
 
   * no autograd needed (inference; the BASELINE config "… + NLSPN refine" eval): two fused kernels, dd_nlspn_offset_affinity +
     dd_nlspn_propagate (prop_time launches), instead of the reference's 8 + 18 im2col/GEMM pairs;
-  * autograd needed (training): the reference's own formulation -- torch ops plus ``ModulatedDeformConvFunction`` once per
-    confidence neighbour and once per iteration -- with the HIP DCNv2 forward / backward of diffusiondepth_amd.dcn under it.
+  * autograd needed (training): torch tensor ops plus ``ModulatedDeformConvFunction`` (the HIP DCNv2 forward / backward of
+    diffusiondepth_amd.dcn) once per confidence neighbour and once per iteration, as the reference's autograd graph has it.
 
 ``conv_offset_aff`` (ch_g -> 3*num, 3x3) is evaluated inside the affinity kernel for NLSPNModel's geometry (ch_g 8, 3x3, 3x3:
 dd_nlspn_guided_offset_affinity) and is a torch convolution (MIOpen) otherwise and in training; the encoder-decoder producing guidance /
@@ -63,52 +63,42 @@ class NLSPN(nn.Module):
         self.im2col_step = 64
         self.fuse_guidance_conv = True      # inference path: dd_nlspn_guided_offset_affinity where its geometry applies (A/B switch)
 
-    # -- the reference's formulation (autograd path) ---------------------------------------------------------------------
+    # -- autograd path: same arithmetic as nlspnmodel.py:87-171, written on whole tensors ------------------------------------------
+    def _neighbour_shift(self, like):
+        """--legacy (nlspnmodel.py:126-134): neighbour m = (hh, ww) gets (hh - c, ww - c) added to its offsets, in place on the tensor
+        that is later returned and propagated with; as a constant (2*(num+1),) vector here."""
+        c = (self.k_f - 1) / 2
+        sh = [(m // self.k_f - c, m % self.k_f - c) if m != self.idx_ref else (0.0, 0.0) for m in range(self.num + 1)]
+        return torch.tensor(sh, dtype=like.dtype, device=like.device).view(1, -1, 1, 1)
+
     def _get_offset_affinity(self, guidance, confidence=None, rgb=None):
         B, _, H, W = guidance.shape
-        offset_aff = self.conv_offset_aff(guidance)
-        o1, o2, aff = torch.chunk(offset_aff, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1).view(B, self.num, 2, H, W)
-        list_offset = list(torch.chunk(offset, self.num, dim=1))
-        list_offset.insert(self.idx_ref, torch.zeros((B, 1, 2, H, W)).type_as(offset))
-        offset = torch.cat(list_offset, dim=1).view(B, -1, H, W)
-        if self.affinity in ['AS', 'ASS']:
-            pass
-        elif self.affinity == 'TC':
-            aff = torch.tanh(aff) / self.aff_scale_const
+        num, ref = self.num, self.idx_ref
+        raw = self.conv_offset_aff(guidance)                                   # (B, 3*num, H, W)
+        # the first 2*num channels, pairwise, are the (row, column) offsets of the num neighbours (:91-95); the reference pixel gets (0, 0)
+        pairs = raw[:, :2 * num].reshape(B, num, 2, H, W)
+        offset = torch.cat([pairs[:, :ref], pairs.new_zeros(B, 1, 2, H, W), pairs[:, ref:]], dim=1).reshape(B, 2 * (num + 1), H, W)
+        aff = raw[:, 2 * num:]
+        if self.affinity == 'TC':
+            aff = torch.tanh(aff) / self.aff_scale_const                       # :103-104
         elif self.affinity == 'TGASS':
-            aff = torch.tanh(aff) / (self.aff_scale_const + 1e-8)
+            aff = torch.tanh(aff) / (self.aff_scale_const + 1e-8)              # :105-106
         if self.args.conf_prop:
-            list_conf = []
-            offset_each = torch.chunk(offset, self.num + 1, dim=1)
-            modulation_dummy = torch.ones((B, 1, H, W)).type_as(offset).detach()
-            for idx_off in range(0, self.num + 1):
-                ww = idx_off % self.k_f
-                hh = idx_off // self.k_f
-                if ww == (self.k_f - 1) / 2 and hh == (self.k_f - 1) / 2:
-                    continue
-                offset_tmp = offset_each[idx_off].detach()
-                if self.args.legacy:            # in place on a view of `offset`, as in the reference (:126-134)
-                    offset_tmp[:, 0, :, :] = offset_tmp[:, 0, :, :] + hh - (self.k_f - 1) / 2
-                    offset_tmp[:, 1, :, :] = offset_tmp[:, 1, :, :] + ww - (self.k_f - 1) / 2
-                conf_tmp = ModulatedDeformConvFunction.apply(confidence, offset_tmp.contiguous(), modulation_dummy, self.w_conf, self.b,
-                                                             self.stride, 0, self.dilation, self.groups, self.deformable_groups,
-                                                             self.im2col_step)
-                list_conf.append(conf_tmp)
-            conf_aff = torch.cat(list_conf, dim=1)
-            aff = aff * conf_aff.contiguous()
-        aff_abs = torch.abs(aff)
-        aff_abs_sum = torch.sum(aff_abs, dim=1, keepdim=True) + 1e-4
-        if self.affinity in ['ASS', 'TGASS']:
-            aff_abs_sum[aff_abs_sum < 1.0] = 1.0
-        if self.affinity in ['AS', 'ASS', 'TGASS']:
-            aff = aff / aff_abs_sum
-        aff_sum = torch.sum(aff, dim=1, keepdim=True)
-        aff_ref = 1.0 - aff_sum
-        list_aff = list(torch.chunk(aff, self.num, dim=1))
-        list_aff.insert(self.idx_ref, aff_ref)
-        aff = torch.cat(list_aff, dim=1)
-        return offset, aff
+            if self.args.legacy:
+                offset = offset + self._neighbour_shift(offset)
+            where = offset.detach()                                            # no gradient reaches the offsets through the confidence (:122)
+            ones = where.new_ones(B, 1, H, W)
+            sampled = [ModulatedDeformConvFunction.apply(confidence, where[:, 2 * m:2 * m + 2].contiguous(), ones, self.w_conf, self.b,
+                                                         self.stride, 0, self.dilation, self.groups, self.deformable_groups, self.im2col_step)
+                       for m in range(num + 1) if m != ref]                     # 1x1 sampling of the confidence at pixel + offset (:136-141)
+            aff = aff * torch.cat(sampled, dim=1)                               # :143-144
+        total = aff.abs().sum(dim=1, keepdim=True) + 1e-4                       # :147-148
+        if self.affinity in ('ASS', 'TGASS'):
+            total = total.clamp_min(1.0)                                        # :150-151 (values below 1 become the constant 1)
+        if self.affinity in ('AS', 'ASS', 'TGASS'):
+            aff = aff / total                                                   # :153-154
+        centre = 1.0 - aff.sum(dim=1, keepdim=True)                             # :156-157
+        return offset, torch.cat([aff[:, :ref], centre, aff[:, ref:]], dim=1)   # :159-161
 
     def _propagate_once(self, feat, offset, aff):
         return ModulatedDeformConvFunction.apply(feat.contiguous(), offset.contiguous(), aff.contiguous(), self.w, self.b, self.stride,
@@ -145,16 +135,13 @@ class NLSPN(nn.Module):
                                         self.k_f, self.prop_time, self.args.preserve_input)
             list_feat = list(feats.unbind(0))
             return list_feat[-1], list_feat, offset, aff, self.aff_scale_const.data
-        # training: the reference's loop (:176-207) on the HIP DCNv2 operator
+        # training: one DCNv2 operator call per neighbour / per iteration, differentiable end to end (nlspnmodel.py:176-207)
         offset, aff = self._get_offset_affinity(guidance, confidence if self.args.conf_prop else None, rgb)
-        if self.args.preserve_input:
-            mask_fix = torch.sum(feat_fix > 0.0, dim=1, keepdim=True).detach()
-            mask_fix = (mask_fix > 0.0).type_as(feat_fix)
-        feat_result = feat_init
-        list_feat = []
-        for k in range(1, self.prop_time + 1):
-            if self.args.preserve_input:
-                feat_result = (1.0 - mask_fix) * feat_result + mask_fix * feat_fix
-            feat_result = self._propagate_once(feat_result, offset, aff)
-            list_feat.append(feat_result)
-        return feat_result, list_feat, offset, aff, self.aff_scale_const.data
+        keep = (feat_fix > 0.0).any(dim=1, keepdim=True) if self.args.preserve_input else None      # mask_fix (:189-191)
+        feat, list_feat = feat_init, []
+        for _ in range(self.prop_time):
+            if keep is not None:
+                feat = torch.where(keep, feat_fix, feat)                       # (1 - mask_fix) * feat + mask_fix * feat_fix (:199-201)
+            feat = self._propagate_once(feat, offset, aff)
+            list_feat.append(feat)
+        return feat, list_feat, offset, aff, self.aff_scale_const.data

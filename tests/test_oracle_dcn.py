@@ -172,3 +172,35 @@ def test_nlspn_mirror_contract():
         with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
             dcn.modulated_deform_conv_forward(torch.zeros(1, 1, 4, 4), torch.ones(1, 1, 3, 3), torch.zeros(1), torch.zeros(1, 18, 4, 4),
                                               torch.ones(1, 9, 4, 4), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 64)
+
+
+@pytest.mark.parametrize("name", NLSPN_CASES)
+def test_nlspn_mirror_tensor_formulation_matches_reference_goldens(golden, name, monkeypatch):
+    """Host logic of diffusiondepth_amd.nlspn.NLSPN's autograd path (channel regrouping, --legacy shift, tanh / gamma, confidence
+    weighting, normalisation, preserve_input blend) with the DCNv2 operator replaced by the oracle: no GPU involved."""
+    import diffusiondepth_amd.nlspn as N
+
+    class OracleFn:
+        @staticmethod
+        def apply(inp, off, mask, w, b, stride, pad, dil, groups, dg, step):
+            y = O.mdcn_forward(inp.detach().numpy(), w.detach().numpy(), b.detach().numpy(), off.detach().numpy(), mask.detach().numpy(),
+                               pad=(pad, pad))
+            return torch.from_numpy(y.astype(np.float32))
+
+    monkeypatch.setattr(N, "ModulatedDeformConvFunction", OracleFn)
+    g = golden("nlspn_" + name)
+    B, H, W, ch_g, k_f, T, cp, pi, lg = [int(v) for v in g["meta"]]
+    m = N.NLSPN(_args(prop_time=T, affinity=str(g["affinity"]), conf_prop=bool(cp), preserve_input=bool(pi), legacy=bool(lg)), ch_g, 1, 3, k_f)
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        m.conv_offset_aff.weight.copy_(t("conv_weight"))
+        m.conv_offset_aff.bias.copy_(t("conv_bias"))
+        off, aff = m._get_offset_affinity(t("guidance"), t("confidence") if cp else None)
+        keep = (t("feat_fix") > 0).any(1, keepdim=True) if pi else None
+        feat = t("feat_init")
+        for _ in range(T):
+            if keep is not None:
+                feat = torch.where(keep, t("feat_fix"), feat)
+            feat = m._propagate_once(feat, off, aff)
+    assert float((off - t("offset")).abs().max()) < 1e-6 and float((aff - t("aff")).abs().max()) < 1e-6
+    assert float((feat - t("y")).abs().max()) < TOL * np.abs(g["y"]).max()
