@@ -22,45 +22,34 @@ from .dcn import ModulatedDeformConvFunction
 
 class NLSPN(nn.Module):
     def __init__(self, args, ch_g, ch_f, k_g, k_f):
+        """Same signature, attributes and parameter tree as the reference module (nlspnmodel.py:23-85): ``args`` carries prop_time,
+        affinity, affinity_gamma, conf_prop, preserve_input, legacy (src/config.py:78-112)."""
         super().__init__()
-        assert ch_f == 1, 'only tested with ch_f == 1 but {}'.format(ch_f)                # nlspnmodel.py:30
-        assert (k_g % 2) == 1, 'only odd kernel is supported but k_g = {}'.format(k_g)    # :32-33
-        pad_g = int((k_g - 1) / 2)
-        assert (k_f % 2) == 1, 'only odd kernel is supported but k_f = {}'.format(k_f)    # :35-36
-        pad_f = int((k_f - 1) / 2)
+        if ch_f != 1:
+            raise AssertionError('only tested with ch_f == 1 but {}'.format(ch_f))            # the reference's assert (:30)
+        for name, k in (("k_g", k_g), ("k_f", k_f)):
+            if k % 2 != 1:
+                raise AssertionError('only odd kernel is supported but {} = {}'.format(name, k))   # (:32-36)
+        if args.affinity not in ('AS', 'ASS', 'TC', 'TGASS'):
+            raise NotImplementedError(args.affinity)                                           # (:69-70)
         self.args = args
-        self.prop_time = self.args.prop_time
-        self.affinity = self.args.affinity
+        self.prop_time, self.affinity = args.prop_time, args.affinity
         self.ch_g, self.ch_f, self.k_g, self.k_f = ch_g, ch_f, k_g, k_f
-        self.num = self.k_f * self.k_f - 1          # zero offset for the centre pixel (:46-48)
+        self.num = k_f * k_f - 1                 # neighbours; the centre pixel has a fixed zero offset (:46-48)
         self.idx_ref = self.num // 2
-        if self.affinity in ['AS', 'ASS', 'TC', 'TGASS']:
-            self.conv_offset_aff = nn.Conv2d(self.ch_g, 3 * self.num, kernel_size=self.k_g, stride=1, padding=pad_g, bias=True)
-            self.conv_offset_aff.weight.data.zero_()                                      # :55-56
-            self.conv_offset_aff.bias.data.zero_()
-            if self.affinity == 'TC':
-                self.aff_scale_const = nn.Parameter(self.num * torch.ones(1))
-                self.aff_scale_const.requires_grad = False
-            elif self.affinity == 'TGASS':
-                self.aff_scale_const = nn.Parameter(self.args.affinity_gamma * self.num * torch.ones(1))
-            else:
-                self.aff_scale_const = nn.Parameter(torch.ones(1))
-                self.aff_scale_const.requires_grad = False
-        else:
-            raise NotImplementedError
-        # "dummy parameters for gathering" (:73-80)
-        self.w = nn.Parameter(torch.ones((self.ch_f, 1, self.k_f, self.k_f)))
-        self.b = nn.Parameter(torch.zeros(self.ch_f))
-        self.w.requires_grad = False
-        self.b.requires_grad = False
-        self.w_conf = nn.Parameter(torch.ones((1, 1, 1, 1)))
-        self.w_conf.requires_grad = False
-        self.stride = 1
-        self.padding = pad_f
-        self.dilation = 1
-        self.groups = self.ch_f
-        self.deformable_groups = 1
-        self.im2col_step = 64
+        # guidance -> (2 offsets + 1 affinity) per neighbour; zero-initialised like the reference (:50-56)
+        self.conv_offset_aff = nn.Conv2d(ch_g, 3 * self.num, kernel_size=k_g, stride=1, padding=(k_g - 1) // 2, bias=True)
+        nn.init.zeros_(self.conv_offset_aff.weight)
+        nn.init.zeros_(self.conv_offset_aff.bias)
+        # affinity scale: num (TC, frozen), affinity_gamma * num (TGASS, trainable), 1 (AS / ASS, frozen)   (:58-68)
+        scale = self.num if self.affinity == 'TC' else (args.affinity_gamma * self.num if self.affinity == 'TGASS' else 1.0)
+        self.aff_scale_const = nn.Parameter(torch.full((1,), float(scale)), requires_grad=self.affinity == 'TGASS')
+        # frozen all-ones "weight" / zero "bias" of the gathering operator, and the 1x1 weight of the confidence sampling (:73-80)
+        self.w = nn.Parameter(torch.ones(ch_f, 1, k_f, k_f), requires_grad=False)
+        self.b = nn.Parameter(torch.zeros(ch_f), requires_grad=False)
+        self.w_conf = nn.Parameter(torch.ones(1, 1, 1, 1), requires_grad=False)
+        self.stride, self.padding, self.dilation = 1, (k_f - 1) // 2, 1
+        self.groups, self.deformable_groups, self.im2col_step = ch_f, 1, 64
         self.fuse_guidance_conv = True      # inference path: dd_nlspn_guided_offset_affinity where its geometry applies (A/B switch)
 
     # -- autograd path: same arithmetic as nlspnmodel.py:87-171, written on whole tensors ------------------------------------------
