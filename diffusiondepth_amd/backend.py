@@ -215,10 +215,11 @@ class HipDenoiser:
             raise ValueError("condition() expects the 4 pyramid levels of the ResNet backbone")
         fp = [_check_tensor(f, f"fp[{i}]", dtype=torch.float32) for i, f in enumerate(fp)]
         B = fp[0].shape[0]
-        c0 = 192 if self.variant == "swin" else 64
-        for i, f in enumerate(fp):
-            if f.dim() != 4 or f.shape[0] != B or f.shape[1] != c0 << i:
-                raise ValueError(f"fp[{i}] must be (B,{c0 << i},h,w), got {tuple(f.shape)}")
+        # pyramids dd_condition is built for: ResNet (res variant); Swin-L or MPViT-small (swin variant: same UpSample_add denoiser)
+        allowed = [(192, 384, 768, 1536), (128, 216, 288, 288)] if self.variant == "swin" else [(64, 128, 256, 512)]
+        widths = tuple(int(f.shape[1]) if f.dim() == 4 else -1 for f in fp)
+        if widths not in allowed or any(f.dim() != 4 or f.shape[0] != B for f in fp):
+            raise ValueError(f"fp must be 4 maps (B,C_i,h_i,w_i) with C in {allowed}, got {[tuple(f.shape) for f in fp]}")
         ptrs = (ctypes.c_void_p * 4)(*[f.data_ptr() for f in fp])
         hs = (ctypes.c_int * 4)(*[f.shape[2] for f in fp])
         ws = (ctypes.c_int * 4)(*[f.shape[3] for f in fp])

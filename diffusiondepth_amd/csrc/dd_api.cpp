@@ -63,8 +63,20 @@ inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
 constexpr int FPN_LEVELS = 4;
 constexpr int FPN_CIN_RES[FPN_LEVELS] = {64, 128, 256, 512};       // ResNet pyramid widths (reference ...res.py:31 in_channels)
 constexpr int FPN_CIN_SWIN[FPN_LEVELS] = {192, 384, 768, 1536};   // Swin-L pyramid widths (reference ...res_swin_add.py:31)
-inline const int* fpn_cin(int variant) { return variant == DD_VARIANT_SWIN ? FPN_CIN_SWIN : FPN_CIN_RES; }
-inline int fpn_lat_layer(int variant, int level) { return (variant == DD_VARIANT_SWIN ? 15 : 10) + level; }   // kernel layer id
+// MPViT-small pyramid of DDIMDepthEstimate_MPVIT_ADDHAHI (reference src/model/head/ddim_depth_estimate_res_mpvit_HAHI.py:32); same
+// UpSample_add denoiser as the Swin heads (DD_VARIANT_SWIN).  216 is not a multiple of the 32-channel activation block: level 1 is
+// carried with 224 channels (8 zero channels, zero weights).  The pyramid is recognised from the lateral weights' sizes (dd_set_weight).
+constexpr int FPN_CIN_MPVIT[FPN_LEVELS] = {128, 216, 288, 288};
+constexpr int FPN_CIN_MPVIT_PAD[FPN_LEVELS] = {128, 224, 288, 288};
+constexpr int FPN_LAYER_MPVIT[FPN_LEVELS] = {24, 25, 26, 26};
+enum { PYR_DEFAULT = 0, PYR_MPVIT = 1 };
+inline const int* fpn_cin(int variant, int pyr) {
+  return pyr == PYR_MPVIT ? FPN_CIN_MPVIT : (variant == DD_VARIANT_SWIN ? FPN_CIN_SWIN : FPN_CIN_RES);
+}
+inline const int* fpn_cin_pad(int variant, int pyr) { return pyr == PYR_MPVIT ? FPN_CIN_MPVIT_PAD : fpn_cin(variant, pyr); }
+inline int fpn_lat_layer(int variant, int pyr, int level) {      // kernel layer id
+  return pyr == PYR_MPVIT ? FPN_LAYER_MPVIT[level] : (variant == DD_VARIANT_SWIN ? 15 : 10) + level;
+}
 
 struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   int cin = 0, cout = 0;
@@ -113,7 +125,7 @@ struct Plan {
 
 // workspace of dd_condition for one pyramid shape / element kind
 struct FpnWork {
-  int B = 0, ek = -1, hs[FPN_LEVELS] = {0}, ws[FPN_LEVELS] = {0};
+  int B = 0, ek = -1, pyr = 0, hs[FPN_LEVELS] = {0}, ws[FPN_LEVELS] = {0};
   DevBuf fin[FPN_LEVELS];        // backbone features, activation layout
   DevBuf lat[FPN_LEVELS];        // levels 1..3: x_i = relu(bn(conv(f_i))) [+ top-down term]
   DevBuf up[FPN_LEVELS - 1];     // conv_up[j](x_{j+1}) at 2h x 2w of level j+1
@@ -154,6 +166,7 @@ struct dd_handle_s {
   std::map<std::tuple<int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
   bool fpn_committed = false;
+  int fpn_pyramid = PYR_DEFAULT;  // PYR_MPVIT once MPViT-sized lateral weights were set (DD_VARIANT_SWIN only)
   DevBuf fpn_lat_w[FPN_LEVELS][NUM_EK], fpn_lat_b[FPN_LEVELS];
   DevBuf fpn_up_w[FPN_LEVELS - 1][NUM_EK], fpn_up_b[FPN_LEVELS - 1];
   std::unique_ptr<FpnWork> fpn_work;
@@ -166,8 +179,9 @@ struct dd_handle_s {
   bool ev_valid = false;
   hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
   int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
-  double layer_ms[16] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3, 10..14 condition FPN)
-  int64_t layer_cnt[16] = {0};
+  static constexpr int N_LAYER_SLOTS = 32;   // kernel layer ids run up to 27 (see dd_igemm2_cfg.h)
+  double layer_ms[N_LAYER_SLOTS] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3, 10..18 / 24..26 condition FPN, 20..23 dgrad)
+  int64_t layer_cnt[N_LAYER_SLOTS] = {0};
   std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
 
   int fail(int code, const std::string& m) { err = m; return code; }
@@ -195,7 +209,7 @@ int weight_group(const std::string& name) {
   return 2;
 }
 
-std::vector<WeightSpec> required_weights(int variant) {
+std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
   std::vector<WeightSpec> v = {
       {"model.noise_embedding.0.weight", 64 * 16 * 9}, {"model.noise_embedding.0.bias", 64},
       {"model.noise_embedding.1.weight", 64}, {"model.noise_embedding.1.bias", 64},
@@ -229,7 +243,7 @@ std::vector<WeightSpec> required_weights(int variant) {
     const char* bn[4] = {"weight", "bias", "running_mean", "running_var"};
     for (int i = 0; i < FPN_LEVELS; ++i) {
       const std::string pre = "conv_lateral." + std::to_string(i);
-      v.push_back({pre + ".0.weight", (int64_t)COND_C * fpn_cin(variant)[i] * 9});
+      v.push_back({pre + ".0.weight", (int64_t)COND_C * fpn_cin(variant, pyr)[i] * 9});
       for (const char* b : bn) v.push_back({pre + ".1." + b, COND_C});
     }
     for (int j = 0; j < FPN_LEVELS - 1; ++j) {
@@ -532,8 +546,11 @@ void drain_layer_events(dd_handle_t h) {
   for (auto& t : h->pending_ev) {
     float ms = 0.f;
     if (hipEventSynchronize(std::get<2>(t)) == hipSuccess && hipEventElapsedTime(&ms, std::get<1>(t), std::get<2>(t)) == hipSuccess) {
-      h->layer_ms[std::get<0>(t)] += ms;
-      h->layer_cnt[std::get<0>(t)] += 1;
+      const int slot = std::get<0>(t);
+      if (slot >= 0 && slot < dd_handle_s::N_LAYER_SLOTS) {
+        h->layer_ms[slot] += ms;
+        h->layer_cnt[slot] += 1;
+      }
     }
     (void)hipEventDestroy(std::get<1>(t));
     (void)hipEventDestroy(std::get<2>(t));
@@ -587,7 +604,20 @@ int dd_destroy(dd_handle_t h) {
 int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel) {
   if (!h) return DD_ERR_INVALID_ARG;
   if (!name || !data || numel <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_set_weight: null name/data or non-positive numel");
-  for (const auto& ws : required_weights(h->variant)) {
+  if (h->variant == DD_VARIANT_SWIN) {
+    // the Swin-L and the MPViT-small heads share this variant's denoiser; which pyramid the FPN has shows in the lateral weights
+    const std::string nm(name);
+    for (int i = 0; i < FPN_LEVELS; ++i)
+      if (nm == "conv_lateral." + std::to_string(i) + ".0.weight") {
+        const int pyr = numel == (int64_t)COND_C * FPN_CIN_MPVIT[i] * 9 ? PYR_MPVIT : PYR_DEFAULT;
+        if (pyr != h->fpn_pyramid) {
+          for (int j = 0; j < FPN_LEVELS; ++j) h->host_w.erase("conv_lateral." + std::to_string(j) + ".0.weight");   // other pyramid's
+          h->fpn_pyramid = pyr;
+          h->fpn_committed = false;
+        }
+      }
+  }
+  for (const auto& ws : required_weights(h->variant, h->fpn_pyramid)) {
     if (ws.name == name) {
       if (ws.numel != numel)
         return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight: ") + name + " expects " + std::to_string(ws.numel) +
@@ -610,7 +640,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   // one must be complete.
   int have[3] = {0, 0, 0}, need[3] = {0, 0, 0};
   std::string first_missing[3];
-  for (const auto& ws : required_weights(h->variant)) {
+  for (const auto& ws : required_weights(h->variant, h->fpn_pyramid)) {
     const int grp = weight_group(ws.name);
     need[grp]++;
     if (h->host_w.count(ws.name)) have[grp]++;
@@ -725,13 +755,15 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     for (int i = 0; i < FPN_LEVELS; ++i) {
       const std::string pre = "conv_lateral." + std::to_string(i);
       fold(pre + ".1", sc, sh);
-      std::vector<float> w = h->host_w[pre + ".0.weight"];            // [256][cin][3][3]
-      const size_t per = (size_t)fpn_cin(h->variant)[i] * 9;
+      const std::vector<float>& w0 = h->host_w[pre + ".0.weight"];    // [256][cin][3][3]
+      const size_t per = (size_t)fpn_cin(h->variant, h->fpn_pyramid)[i] * 9;
+      const size_t per_pad = (size_t)fpn_cin_pad(h->variant, h->fpn_pyramid)[i] * 9;      // zero weights for the padding channels
+      std::vector<float> w((size_t)COND_C * per_pad, 0.f);
       for (int co = 0; co < COND_C; ++co)
-        for (size_t k = 0; k < per; ++k) w[co * per + k] = (float)((double)w[co * per + k] * sc[co]);
+        for (size_t k = 0; k < per; ++k) w[co * per_pad + k] = (float)((double)w0[co * per + k] * sc[co]);
       for (int ek = 0; ek < NUM_EK; ++ek) {
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(fpn_lat_layer(h->variant, i), ek), ek, true, packed);
+        pack_conv_weights(w.data(), conv_pack_geom2(fpn_lat_layer(h->variant, h->fpn_pyramid, i), ek), ek, true, packed);
         int rc = upload(h, h->fpn_lat_w[i][ek], packed.data(), packed.size(), s); if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
@@ -856,7 +888,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
-    for (int i = 0; i < 16; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
+    for (int i = 0; i < dd_handle_s::N_LAYER_SLOTS; ++i) { h->layer_ms[i] = 0; h->layer_cnt[i] = 0; }
   } else return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: unknown key '" + k + "'");
   return DD_OK;
 }
@@ -873,7 +905,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
 }
 
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches) {
-  if (!h || layer < 1 || layer > 14 || !total_ms || !launches) return DD_ERR_INVALID_ARG;
+  if (!h || layer < 1 || layer > dd_handle_s::N_LAYER_SLOTS || !total_ms || !launches) return DD_ERR_INVALID_ARG;
   drain_layer_events(h);
   *total_ms = h->layer_ms[layer - 1];
   *launches = h->layer_cnt[layer - 1];
@@ -898,7 +930,7 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
   for (int i = 0; i < FPN_LEVELS; ++i) {
     if (!feats[i] || feat_h[i] <= 0 || feat_w[i] <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: null feature pointer or non-positive size");
-    if ((long long)B * feat_h[i] * feat_w[i] * fpn_cin(h->variant)[i] >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
+    if ((long long)B * feat_h[i] * feat_w[i] * fpn_cin_pad(h->variant, h->fpn_pyramid)[i] >= (1LL << 31) * 4) return h->fail(DD_ERR_INVALID_ARG, "tensor too large");
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
@@ -906,17 +938,17 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   const size_t es = ek_size(ek);
   // workspace for this pyramid shape
   FpnWork* fw = h->fpn_work.get();
-  bool same = fw && fw->B == B && fw->ek == ek;
+  bool same = fw && fw->B == B && fw->ek == ek && fw->pyr == h->fpn_pyramid;
   for (int i = 0; same && i < FPN_LEVELS; ++i) same = fw->hs[i] == feat_h[i] && fw->ws[i] == feat_w[i];
   if (!same) {
     DD_HIP(hipDeviceSynchronize());
     h->fpn_work.reset(new FpnWork());
     fw = h->fpn_work.get();
-    fw->B = B; fw->ek = ek;
+    fw->B = B; fw->ek = ek; fw->pyr = h->fpn_pyramid;
     for (int i = 0; i < FPN_LEVELS; ++i) {
       fw->hs[i] = feat_h[i]; fw->ws[i] = feat_w[i];
       const size_t px = (size_t)B * feat_h[i] * feat_w[i];
-      DD_HIP(fw->fin[i].alloc(px * fpn_cin(h->variant)[i] * es));
+      DD_HIP(fw->fin[i].alloc(px * fpn_cin_pad(h->variant, h->fpn_pyramid)[i] * es));
       if (i > 0) {
         DD_HIP(fw->lat[i].alloc(px * COND_C * es));
         DD_HIP(fw->up[i - 1].alloc(px * 4 * COND_C * es));
@@ -953,8 +985,9 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   // top-down pass (reference ...res.py:108-118): x_3 = lat_3(f_3);  x_i = lat_i(f_i) + pool(up_i(x_{i+1}))
   for (int i = FPN_LEVELS - 1; i >= 0; --i) {
     const int hh = feat_h[i], ww = feat_w[i];
-    DD_HIP(launch_nchw_to_nhwc(feats[i], fw->fin[i].p, ek, B, fpn_cin(h->variant)[i], hh, ww, 1, s));
-    const int lat_layer = fpn_lat_layer(h->variant, i);
+    DD_HIP(launch_nchw_to_nhwc_padded(feats[i], fw->fin[i].p, ek, B, fpn_cin(h->variant, h->fpn_pyramid)[i],
+                                      fpn_cin_pad(h->variant, h->fpn_pyramid)[i], hh, ww, 1, s));
+    const int lat_layer = fpn_lat_layer(h->variant, h->fpn_pyramid, i);
     ConvParams p{};
     p.B = B; p.h = hh; p.w = ww;
     p.tiles_x = (ww + 31) / 32;

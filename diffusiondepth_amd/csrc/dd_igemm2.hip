@@ -713,6 +713,9 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 21: return launch_one2<EK, 21>(p, s);
     case 22: return launch_one2<EK, 22>(p, s);
     case 23: return launch_one2<EK, 23>(p, s);
+    case 24: return launch_one2<EK, 24>(p, s);
+    case 25: return launch_one2<EK, 25>(p, s);
+    case 26: return launch_one2<EK, 26>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -752,6 +755,9 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 20: return geom2_of<EK, 20>();
     case 21: return geom2_of<EK, 21>();
     case 22: return geom2_of<EK, 22>();
+    case 24: return geom2_of<EK, 24>();
+    case 25: return geom2_of<EK, 25>();
+    case 26: return geom2_of<EK, 26>();
     default: return geom2_of<EK, 23>();
   }
 }

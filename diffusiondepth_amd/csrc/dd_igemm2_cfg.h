@@ -45,13 +45,15 @@ template <int EK_, int LAYER_> struct Cfg2 {
   //   15..18 = the same lateral convs for the Swin-L pyramid (192|384|768|1536 -> 256; reference ...res_swin_add.py:31,57-84)
   // Backward: 20..23 = data gradients of conv4, conv3, conv2, conv1 -- the same implicit GEMM with
   //   W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] on the raw GroupNorm-backward result: 16->64, 64->256, 256->64, 64->16
-  static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18);
+  //   24..26 = lateral convs of the MPViT-small pyramid (reference ...res_mpvit_HAHI.py:32: 128 | 216 | 288 | 288 -> 256; 216 is carried
+  //            as 224 = 7 blocks of 32 with zero channels / zero weights; levels 2 and 3 share layer 26)
+  static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18) || (LAYER >= 24 && LAYER <= 26);
   static constexpr bool IS_DGRAD = (LAYER >= 20 && LAYER <= 23);
   static constexpr bool IS_UP = (LAYER == 14);
   static constexpr int KS = IS_UP ? 1 : 3;                       // kernel size
   static constexpr int HALO = KS / 2;
   static constexpr int NTAPS = KS * KS;
-  static constexpr int CIN = (LAYER == 1 || LAYER == 20) ? LATENT_C : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? HID_C : IS_LAT ? (LAYER >= 15 ? (192 << (LAYER - 15)) : (64 << (LAYER - 10))) : COND_C;
+  static constexpr int CIN = (LAYER == 1 || LAYER == 20) ? LATENT_C : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? HID_C : IS_LAT ? (LAYER >= 24 ? (LAYER == 24 ? 128 : LAYER == 25 ? 224 : 288) : LAYER >= 15 ? (192 << (LAYER - 15)) : (64 << (LAYER - 10))) : COND_C;
   static constexpr int COUT = IS_UP ? 4 * COND_C : IS_LAT ? COND_C
                             : (LAYER == 21) ? COND_C : (LAYER == 23) ? LATENT_C
                             : (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;

@@ -82,6 +82,9 @@ hipError_t launch_conv_igemm2ws(int layer, int ek, const ConvParams& p, hipStrea
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
 // dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h
 hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s);
+// same, into a destination with Cd >= C channels (zero-filled beyond C; Cd a multiple of 16): pyramid widths that are not a
+// multiple of the 32-channel activation block (MPViT-small's 216 -> 224)
+hipError_t launch_nchw_to_nhwc_padded(const float* src, void* dst, int ek, int B, int C, int Cd, int h, int w, int blocked, hipStream_t s);
 // Swin variant: bilinear (align_corners=True) upsample of the NCHW fp32 condition map (B,C,ch,cw) to (h,w), written in the
 // channel-blocked activation layout (reference ...swin_addHAHI.py:332: F.interpolate(..., mode='bilinear', align_corners=True))
 hipError_t launch_upsample_to_blocked(const float* src, void* dst, int ek, int B, int C, int ch, int cw, int h, int w, hipStream_t s);

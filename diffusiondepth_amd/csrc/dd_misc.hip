@@ -25,7 +25,9 @@ __device__ __forceinline__ float ld_elem(const void* base, size_t idx, int ek) {
 // ------------------------------------------------------------------------------------------------
 template <int EK>
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ src, void* __restrict__ dst,
-                                                           int C, long long HW, int blocked) {
+                                                           int C, int Cd, long long HW, int blocked) {
+  // C = channels of the NCHW source, Cd >= C = channels of the destination (zero-filled beyond C: pyramid widths that are not a
+  // multiple of the 32-channel block, e.g. MPViT's 216 -> 224)
   __shared__ float tile[64][65];
   const int b = blockIdx.z;
   const long long p0 = (long long)blockIdx.x * 64;
@@ -44,10 +46,10 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   const int opx = tid >> 2, part = tid & 3;           // 4 threads per pixel, 16 channels each
   if (p0 + opx >= HW) return;
   const int cbase = c0 + part * 16;
-  if (cbase >= C) return;                              // C is a multiple of 16 for every tensor we convert
-  // destination offset in the activation layout of dd_elem.h (channel-blocked when C >= 32); h*w is all that matters
-  const size_t o = (C < ACT_CB || !blocked) ? ((size_t)b * HW + p0 + opx) * C + cbase
-                                : (((size_t)b * (C / ACT_CB) + cbase / ACT_CB) * HW + p0 + opx) * ACT_CB + (cbase % ACT_CB);
+  if (cbase >= Cd) return;                             // Cd is a multiple of 16 for every tensor we convert
+  // destination offset in the activation layout of dd_elem.h (channel-blocked when Cd >= 32); h*w is all that matters
+  const size_t o = (Cd < ACT_CB || !blocked) ? ((size_t)b * HW + p0 + opx) * Cd + cbase
+                                : (((size_t)b * (Cd / ACT_CB) + cbase / ACT_CB) * HW + p0 + opx) * ACT_CB + (cbase % ACT_CB);
   if constexpr (EK == EK_F32) {
     float4* d = reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + o);
 #pragma unroll
@@ -67,14 +69,17 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   }
 }
 
-hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s) {
-  if (C % 16 != 0) return hipErrorInvalidValue;
+hipError_t launch_nchw_to_nhwc_padded(const float* src, void* dst, int ek, int B, int C, int Cd, int h, int w, int blocked, hipStream_t s) {
+  if (Cd % 16 != 0 || Cd < C || C <= 0) return hipErrorInvalidValue;
   const long long HW = (long long)h * w;
-  dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
-  if (ek == EK_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, HW, blocked);
-  else if (ek == EK_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, HW, blocked);
-  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, HW, blocked);
+  dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((Cd + 63) / 64), (unsigned)B);
+  if (ek == EK_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F32>, grid, dim3(256), 0, s, src, dst, C, Cd, HW, blocked);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_BF16>, grid, dim3(256), 0, s, src, dst, C, Cd, HW, blocked);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<EK_F16>, grid, dim3(256), 0, s, src, dst, C, Cd, HW, blocked);
   return hipGetLastError();
+}
+hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s) {
+  return launch_nchw_to_nhwc_padded(src, dst, ek, B, C, C, h, w, blocked, s);
 }
 
 // ------------------------------------------------------------------------------------------------

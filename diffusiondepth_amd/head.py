@@ -184,10 +184,8 @@ class DDIMDepthEstimate_Swin_ADDHAHI(DDIMDepthEstimate_Swin_ADD):
 @register_head
 class DDIMDepthEstimate_MPVIT_ADDHAHI(DDIMDepthEstimate_Swin_ADDHAHI):
     """MPViT-small pyramid [128, 216, 288, 288] (src/model/head/ddim_depth_estimate_res_mpvit_HAHI.py:32,51).  Same UpSample_add
-    denoiser; its FPN widths are not among dd_condition's two compiled pyramids, so the (once-per-image) FPN runs in PyTorch-ROCm
-    and hands the library an explicit condition map."""
+    denoiser; dd_condition carries the 216-channel level as 224 (zero channels / zero weights)."""
     _IN_CHANNELS = [128, 216, 288, 288]
-    _HIP_FPN_WIDTHS = False
 
 
 @register_head

@@ -42,8 +42,7 @@ def _load(head, sd):
 @pytest.mark.parametrize("case,cls,chans", [("head_swin_hahi", "DDIMDepthEstimate_Swin_ADDHAHI", (192, 384, 768, 1536)),
                                             ("head_mpvit_hahi", "DDIMDepthEstimate_MPVIT_ADDHAHI", (128, 216, 288, 288))], ids=["swin", "mpvit"])
 def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls, chans):
-    """mpvit: odd-sized pyramid (both adaptive_avg_pool2d size fixes active), FPN in PyTorch-ROCm (widths outside dd_condition's two
-    pyramids), explicit condition map handed to dd_denoise."""
+    """mpvit: odd-sized pyramid (both adaptive_avg_pool2d size fixes active), pyramid widths 128 / 216 / 288 / 288 through dd_condition."""
     import diffusiondepth_amd as dda
     c, g = cases[case], golden(case)
     sd = synth.make_state_dict(c["wseed"], "swin", c["decoder_gain"], c["decoder_log_scale"])
@@ -64,6 +63,18 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
     U.record(case, pred_maxabs=e_pred, pred_init_maxabs=e_init, ddim_loss_abs=e_loss, pred_max=float(g["pred"].max()))
     assert e_init < 2e-5 and e_pred < 1e-3 and e_loss < 1e-4 * max(1.0, float(g["ddim_loss"][0]))
     assert head._bound.backend.counter("graph_launches") >= 1          # the loop ran in the library, as one hipGraph
+    if case == "head_mpvit_hahi":
+        # the MPViT pyramid (128 / 216 -> 224 / 288 / 288) through dd_condition == the same modules in PyTorch-ROCm
+        assert head._hip_fpn
+        with torch.no_grad():
+            nf = head.hahineck(fp)
+            c_hip = head.aggregate_condition(nf)
+            head._hip_fpn = False
+            c_torch = head.aggregate_condition(nf)
+            head._hip_fpn = True
+        e_c = float((c_hip - c_torch).abs().max())
+        U.record("mpvit_fpn_hip_vs_torch", cond_maxabs=e_c, cond_max=float(c_torch.abs().max()))
+        assert e_c < 1e-4 * max(1.0, float(c_torch.abs().max()))
     if case == "head_swin_hahi":
         # the Vis variant of the same head: same prediction, plus every intermediate sample decoded
         vis = _load(dda.DDIMDepthEstimate_Swin_ADDHAHIVis(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000,
