@@ -78,8 +78,8 @@ const char* dd_version(void);
  * the reference's own layout (OIHW conv weights, (in,out,kh,kw) for the ConvTranspose).
  * The condition FPN's parameters "conv_lateral.{0..3}.{0.weight,1.weight,1.bias,1.running_mean,1.running_var}" and
  * "conv_up.{0..2}.{...}" (src/model/head/ddim_depth_estimate_res.py:56-84, ..._res_swin_add.py:57-84) form a third,
- * optional group (needed by dd_condition only); lateral input widths are 64/128/256/512 for DD_VARIANT_RES and
- * 192/384/768/1536 for DD_VARIANT_SWIN.
+ * optional group (needed by dd_condition only); lateral input widths are 64/128/256/512 for DD_VARIANT_RES and, for
+ * DD_VARIANT_SWIN, 192/384/768/1536 (Swin-L) or 128/216/288/288 (MPViT-small, ..._res_mpvit_HAHI.py:32) -- recognised from numel.
  * Call dd_commit_weights after the last dd_set_weight (and again whenever weights changed, e.g.
  * after an optimizer step): it validates completeness and repacks into the kernels' layouts. */
 int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel);
@@ -96,7 +96,7 @@ int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_ti
  * with conv_lateral = Conv3x3(bias=False)+BN+ReLU, conv_up = ConvTranspose2d(k2,s2,bias=False)+BN+ReLU, BatchNorm in
  * eval mode (running statistics, folded into the convolutions at dd_commit_weights).
  *   feats[i]  (B, C_i, feat_h[i], feat_w[i])  device fp32 NCHW backbone features, i = 0 finest; n_levels = 4;
- *             C = {64,128,256,512} (DD_VARIANT_RES) or {192,384,768,1536} (DD_VARIANT_SWIN)
+ *             C = {64,128,256,512} (DD_VARIANT_RES); {192,384,768,1536} or {128,216,288,288} (DD_VARIANT_SWIN, per the weights set)
  *   cond_out  (B, 256, feat_h[0], feat_w[0]) device fp32 NCHW, or NULL
  * The result also stays inside the handle in the kernels' own layout: a following dd_denoise / dd_denoise_once with
  * cond == NULL, the same B and precision and cond_h == feat_h[0], cond_w == feat_w[0] (== lat_h, lat_w for
@@ -189,7 +189,7 @@ int dd_last_loop_ms(dd_handle_t h, float* ms);
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`
- * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant; 9 = conv3 with the hoisted condition term; 10..13 = conv_lateral[0..3], 14 = conv_up of dd_condition) since the option was set (used by bench.py for the per-kernel roofline figure). */
+ * (1..4 = conv1..conv4 of the Res denoiser; 5,6,7 = convA, convB, pred.0 of the Swin variant; 9 = conv3 with the hoisted condition term; 10..13 = conv_lateral[0..3], 14 = conv_up of dd_condition; 15..18 / 24..26 = the laterals of the Swin-L / MPViT pyramids; 20..23 = data-gradient convs) since the option was set (used by bench.py for the per-kernel roofline figure). */
 int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launches);
 
 /* Copies an internal intermediate of the last dd_denoise_once call to a caller DEVICE buffer as
