@@ -111,3 +111,138 @@ def depth_metric_sums(pred: torch.Tensor, gt: torch.Tensor, t_valid: float = 1e-
 def finalize_metrics(sums: torch.Tensor) -> Dict[str, float]:
     n = max(float(sums[3]), 1.0)
     return {"rmse": float((sums[0] / n).sqrt()), "mae": float(sums[1] / n), "rel": float(sums[2] / n), "n": n}
+
+
+class OverlappedGradReducer:
+    """Gradient averaging of data-parallel training OVERLAPPED with the backward pass (what apex DDP does for the reference,
+    src/main.py:106-114,148; SURVEY.md 8e: the one exchange step per iteration).
+
+    Parameters are cut into flat buckets of ~bucket_bytes in REVERSE registration order -- the order in which autograd finishes
+    them: the depth head (whose gradients come out of dd_denoise_backward in one piece) is reduced while the backbone's backward is
+    still running.  A bucket's all-reduce is issued asynchronously from the post-accumulate-grad hook of its last parameter, on the
+    collective's own stream (RCCL) -- so it overlaps the remaining backward kernels -- and ``finish()`` waits, averages and writes the
+    results back into ``.grad``.  Buckets are sized for xGMI (point-to-point links, per-link bandwidth bound): few and large.
+
+        reducer = OverlappedGradReducer(model.parameters())
+        loss.backward()            # collectives start as buckets fill
+        reducer.finish()           # before optimizer.step()
+
+    Parameters that received no gradient in this iteration (unused branches, e.g. the never-executed attention parameters of the
+    HAHI neck) are reduced as zeros so that every rank issues the same collectives in the same order.  Buckets launch strictly in
+    order, so a never-ready parameter would hold back every bucket behind it until finish(): the first finish() therefore learns
+    (and agrees across ranks on) the set of parameters no rank produced a gradient for, and later iterations treat them as ready
+    from the start; if one of them does receive a gradient later, finish() raises instead of silently dropping it
+    (``relearn_unused()`` starts over).  Not distributed (world size 1): every method is a no-op."""
+
+    def __init__(self, params, bucket_bytes: int = 64 << 20, average: bool = True):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.buckets: List[List[int]] = []
+        cur, nbytes = [], 0
+        for i in reversed(range(len(self.params))):
+            n = self.params[i].numel() * 4
+            if cur and nbytes + n > bucket_bytes:
+                self.buckets.append(cur)
+                cur, nbytes = [], 0
+            cur.append(i)
+            nbytes += n
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {i: b for b, idx in enumerate(self.buckets) for i in idx}
+        self._pending = [len(idx) for idx in self.buckets]
+        self._ready = [False] * len(self.params)
+        self._work = [None] * len(self.buckets)
+        self._flat = [None] * len(self.buckets)
+        self._unused = None                # indices no rank had a gradient for in the first iteration (None = not learned yet)
+        self._violation = None
+        self._next = 0                     # buckets are launched strictly in order (identical collective sequence on all ranks)
+        self.launched_in_backward = 0      # statistics: buckets whose all-reduce started from a hook (i.e. overlapped)
+        self._handles = []
+        if self.active:
+            for i, p in enumerate(self.params):
+                self._handles.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if self._unused is not None and i in self._unused:
+                self._violation = i        # declared unused after the first iteration, yet it has a gradient now: finish() raises
+                return
+            if self._ready[i]:
+                return                     # gradient accumulation over several backward passes: only the first call counts
+            self._ready[i] = True
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            self._launch_ready(from_hook=True)
+        return hook
+
+    def _launch(self, b):
+        group = [self.params[i] for i in self.buckets[b]]
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in group])
+        self._flat[b] = flat
+        self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _launch_ready(self, from_hook):
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self.launched_in_backward += int(from_hook)
+            self._next += 1
+
+    def finish(self) -> int:
+        """Waits for every bucket (launching, with zeros for missing gradients, those that never filled), writes the averaged
+        gradients back and re-arms the reducer for the next iteration.  Returns the number of collectives of this iteration."""
+        if not self.active:
+            return 0
+        if self._violation is not None:
+            i, self._violation = self._violation, None
+            raise RuntimeError(f"OverlappedGradReducer: parameter #{i} (shape {tuple(self.params[i].shape)}) had no gradient on any rank in "
+                               "the first iteration but received one now; its bucket was already reduced without it -- call "
+                               "relearn_unused() when the set of trained parameters changes")
+        while self._next < len(self.buckets):
+            self._launch(self._next)
+            self._next += 1
+        world = dist.get_world_size()
+        if self._unused is None:           # agree on the parameters nobody produced a gradient for (MAX over ranks of "was ready")
+            used = torch.tensor([1.0 if r else 0.0 for r in self._ready])
+            dev = self.params[0].device if self.params else torch.device("cpu")
+            used = used.to(dev)
+            dist.all_reduce(used, op=dist.ReduceOp.MAX)
+            self._unused = {i for i, u in enumerate(used.tolist()) if u == 0.0}
+        for b, idx in enumerate(self.buckets):
+            self._work[b].wait()
+            flat = self._flat[b]
+            if self.average:
+                flat /= world
+            off = 0
+            for i in idx:
+                p = self.params[i]
+                g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+        n = len(self.buckets)
+        self._rearm()
+        return n
+
+    def _rearm(self):
+        n = len(self.buckets)
+        self._pending = [len(idx) for idx in self.buckets]
+        self._ready = [False] * len(self.params)
+        for i in (self._unused or ()):     # known-unused parameters never hold a bucket back
+            self._ready[i] = True
+            self._pending[self._bucket_of[i]] -= 1
+        self._work = [None] * n
+        self._flat = [None] * n
+        self._next = 0
+
+    def relearn_unused(self):
+        """Forget which parameters are unused (call on every rank when the trained parameter set changes, e.g. after unfreezing)."""
+        self._unused, self._violation = None, None
+        self._rearm()
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -95,3 +95,63 @@ def test_two_rank_gloo_gradient_allreduce(tmp_path):
     for k, g in enumerate(r["g"]):
         want = 1.5 * (k + 1) if k < 4 else 2.5
         assert torch.allclose(g, torch.full_like(g, want)), k
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    ddist.init_from_env("gloo")
+    torch.manual_seed(0)                                     # same initial weights on both ranks
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 1, 3, padding=1))
+    unused = torch.nn.Parameter(torch.ones(5))               # a parameter no loss term touches (e.g. the HAHI attention parameters)
+    params = list(net.parameters()) + [unused]
+    red = ddist.OverlappedGradReducer(params, bucket_bytes=1024)      # tiny buckets -> several collectives, launched during backward
+    res = {}
+    for it in range(2):                                       # two iterations: the reducer re-arms itself
+        for p in params:
+            p.grad = None
+        x = torch.from_numpy(np.random.RandomState(10 * it + rank).standard_normal((2, 3, 12, 12)).astype(np.float32))
+        net(x).square().mean().backward()
+        res[f"launched_in_backward_{it}"] = red.launched_in_backward
+        res[f"n_{it}"] = red.finish()
+        res[f"g_{it}"] = [p.grad.clone() for p in params]
+    red.close()
+    if rank == 0:
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_overlapped_gradient_reducer(tmp_path):
+    """OverlappedGradReducer: buckets are all-reduced from autograd hooks while backward is still running; the result equals the
+    average of the two ranks' gradients computed in one process; unused parameters are reduced as zeros; the reducer re-arms."""
+    out = str(tmp_path / "o.pt")
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 1, 3, padding=1))
+    for it in range(2):
+        want = [torch.zeros_like(p) for p in net.parameters()]
+        for rank in range(2):
+            net.zero_grad()
+            x = torch.from_numpy(np.random.RandomState(10 * it + rank).standard_normal((2, 3, 12, 12)).astype(np.float32))
+            net(x).square().mean().backward()
+            for w, p in zip(want, net.parameters()):
+                w += p.grad / 2
+        got = r[f"g_{it}"]
+        assert r[f"n_{it}"] >= 3
+        for k, (g, w) in enumerate(zip(got[:-1], want)):
+            assert torch.allclose(g, w, rtol=1e-5, atol=1e-7), (it, k)
+        assert torch.equal(got[-1], torch.zeros(5))                       # the unused parameter: zeros averaged
+    # iteration 0: the unused parameter sits in the first bucket and holds the in-order launches back until finish(); finish() learns
+    # (across ranks) that nobody has a gradient for it, so in iteration 1 EVERY bucket starts its all-reduce from a hook inside backward
+    assert r["launched_in_backward_0"] == 0
+    assert r["launched_in_backward_1"] - r["launched_in_backward_0"] == r["n_1"]
+
+
+def test_overlapped_reducer_is_a_noop_without_a_process_group():
+    p = torch.nn.Parameter(torch.ones(3))
+    red = ddist.OverlappedGradReducer([p])
+    p.sum().backward()
+    assert red.finish() == 0 and torch.equal(p.grad, torch.ones(3))
