@@ -1,6 +1,8 @@
 // mfma_power.hip -- what does the matrix pipe sustain under the socket power cap with non-trivial operand data?
 //   mode 0: MFMA only (operands stay in registers)            mode 1: + one ds_read_b128 per MFMA (fresh operands from LDS)
 //   mode 2: as 1 plus ~6 VALU per MFMA (the mix of the conv kernels)
+//   mode 3: the mix a Winograd F(2x2,3x3) inner loop would have: 1 ds_read_b128 and ~20 VALU per MFMA,
+//           one ds_write_b128 per 2 MFMAs (the transformed input written to LDS)
 // usage: mfma_power <mode> <seconds> <zero-data 0|1> <waves per workgroup: 4|8>
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -35,6 +37,11 @@ __global__ void __launch_bounds__(512) k(float* out, int iters, unsigned seed, i
         v0 = fmaf(v0, 1.0001f, v1); v1 = fmaxf(v1 * 0.999f, v2); v2 = v2 + v0 * 1e-9f;
         v0 = fminf(v0, 3.f); v1 = fmaf(v1, 0.5f, 0.25f); v2 = fminf(v2, 5.f);
       }
+      if (MODE >= 3) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r) { v0 = v0 + v1; v1 = v1 - v2; }          // 14 more adds: the transform's additions
+        if (u & 1) lds[(idx + 2048) & 4095] = make_uint4(__float_as_uint(v0), __float_as_uint(v1), a[0].z, b[0].w);
+      }
       acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[u & 1]), __builtin_bit_cast(bf16x8_t, b[u >> 1]), acc[u], 0, 0, 0);
     }
     if ((it & 63) == 63) for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] *= 1e-30f;   // keep values finite
@@ -54,7 +61,8 @@ int main(int argc, char** argv) {
   auto launch = [&]() {
     if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(waves * 64), 0, 0, out, iters, 1234u, zero);
     else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(waves * 64), 0, 0, out, iters, 1234u, zero);
-    else hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(waves * 64), 0, 0, out, iters, 1234u, zero);
+    else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(waves * 64), 0, 0, out, iters, 1234u, zero);
+    else hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(waves * 64), 0, 0, out, iters, 1234u, zero);
   };
   launch(); hipDeviceSynchronize();
   auto t0 = std::chrono::steady_clock::now();
