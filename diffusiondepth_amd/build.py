@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddepth_hip.so")
-SOURCES = ["dd_api.cpp", "dd_igemm.hip", "dd_igemm2.hip", "dd_igemm2ws.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_dcn.hip"]
+SOURCES = ["dd_api.cpp", "dd_igemm.hip", "dd_igemm2.hip", "dd_igemm2ws.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_dcn.hip", "dd_wino.hip"]
 HEADERS = ["dd_kernels.h", "dd_elem.h", "dd_igemm2_cfg.h", os.path.join("..", "..", "include", "ddepth.h"),
            os.path.join("..", "..", "include", "ddepth_dcn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",

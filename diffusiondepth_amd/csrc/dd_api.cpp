@@ -86,6 +86,7 @@ struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   DevBuf w_oihw;                    // naive path
   DevBuf wpackT[NUM_EK];            // fused backward: W' packed for the dgrad layer (23 - conv index) of dd_igemm2.hip
   DevBuf wT_oihw;                   // naive backward: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (dgrad as a forward conv)
+  DevBuf wino[NUM_EK];              // convB only: Winograd-transformed weights (dd_wino.hip), 16-bit element kinds
   DevBuf gamma, beta;               // GroupNorm affine [cout]
 };
 
@@ -146,6 +147,7 @@ struct dd_handle_s {
   DevBuf emb;
   DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
   DevBuf zero_bias;          // 256 zeros
+  bool winograd = false;     // EXPERIMENTAL (dd_wino.hip): Swin convB in Winograd F(2x2,3x3) form in the 16-bit modes; off by default
   bool hoist_cond = false;   // Res variant, v2 kernels: conv3(cond) once per image instead of re-adding cond every step.
                              // Correct (tested) but measured slower on MI355X (conv3 174 -> 183..195 us at B=4), so off by default.
   DevBuf codec_buf;          // all folded codec weights in one allocation
@@ -413,6 +415,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       const int th = ws ? 8 : (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
       q.tiles_y = (k.h + th - 1) / th;
       if (ws) return launch_conv_igemm2ws(layer, ek, q, s);
+      if (layer == 6 && h->winograd && ek != EK_F32 && !h->ablate) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s); }
       return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
@@ -714,6 +717,14 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
       int rc = upload(h, L.bias, b.data(), b.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
+      if (i == 1) {                 // convB: Winograd image for the experimental kernel (bf16 / f16)
+        std::vector<uint16_t> u(wino_pack_bytes(COND_C, COND_C) / 2);
+        for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
+          wino_pack_u(w.data(), COND_C, COND_C, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
+          rc = upload(h, L.wino[ek], u.data(), u.size() * 2, s); if (rc) return rc;
+          DD_HIP(hipStreamSynchronize(s));
+        }
+      }
       // backward: data gradient of a 256->256 conv = the convB kernel (layer 6: raw input, no norm) on W^T flipped
       std::vector<float> wt(w.size());
       for (int co = 0; co < COND_C; ++co)
@@ -876,6 +887,10 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->ablate = (int)value;
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
+  else if (k == "winograd") {
+    if (h->winograd != (value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
+    h->winograd = value != 0;
+  }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
   else if (k == "wave_spec") {
     if (h->wave_spec != (int)(value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
@@ -1507,6 +1522,15 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
   int rc = ensure_codec_tmp(h, (size_t)B * (2 * lat_h) * (2 * lat_w) * LATENT_C * 4);
   if (rc) return rc;
   DD_HIP(launch_decode(h->codec, latent, h->codec_tmp.as<float>(), depth, B, lat_h, lat_w, reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+int dd_debug_wino_pack(const float* w_oihw, int cout, int cin, int precision, uint16_t* out, int64_t out_elems) {
+  // host-only: the Winograd weight image dd_commit_weights uploads for the experimental kernel (tests check the layout on the CPU)
+  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cout % 64 || cin % 16) return DD_ERR_INVALID_ARG;
+  if (precision != DD_PREC_BF16 && precision != DD_PREC_F16) return DD_ERR_INVALID_ARG;
+  if (out_elems != (int64_t)(wino_pack_bytes(cout, cin) / 2)) return DD_ERR_INVALID_ARG;
+  wino_pack_u(w_oihw, cout, cin, precision == DD_PREC_BF16 ? host_f32_to_bf16 : host_f32_to_f16, out);
   return DD_OK;
 }
 

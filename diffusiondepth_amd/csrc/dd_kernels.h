@@ -79,6 +79,12 @@ PackGeom conv_pack_geom2(int layer, int ek);
 bool conv_igemm2ws_supports(int layer);
 hipError_t launch_conv_igemm2ws(int layer, int ek, const ConvParams& p, hipStream_t s);
 
+// ---- Winograd F(2x2,3x3) form of the raw-input 256->256 convolution (dd_wino.hip; experimental, option "winograd") -------------
+// p.in / p.out: channel-blocked 16-bit activations (256 ch), p.wpack: wino_pack_u image, p.bias: [256] fp32; p.B / p.h / p.w set
+hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s);
+size_t wino_pack_bytes(int cout, int cin);
+void wino_pack_u(const float* w_oihw, int cout, int cin, uint16_t (*cvt)(float), uint16_t* out);
+
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
 // dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h
 hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s);

@@ -1,0 +1,268 @@
+// dd_wino.hip -- Winograd F(2x2,3x3) form of a raw-input 256->256 3x3 convolution (the Swin denoiser's upsample_fuse.convB, kernel
+// layer 6 of dd_igemm2.hip: no normalisation in front, no GroupNorm behind; reference src/model/head/ddim_depth_estimate_res_swin_addHAHI.py:
+// 328-333), 16-bit operand modes only.  EXPERIMENTAL, OFF BY DEFAULT (dd_set_option("winograd", 1)): written in round 1 without GPU time left
+// to run it -- DESIGN.md section 7 item 0 has the motivation (the direct kernels sit at the socket power cap; 16 instead of 36 multiplies per
+// 2x2 output tile), the measured instruction-mix ceiling (tools/micro/mfma_power.hip mode 3) and the numerics (tools/winograd_numerics.py).
+// This first version is written for being right, not fast: single-buffered LDS, three barriers per 16-channel chunk, plain global->LDS copies.
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        d = 4x4 input tile (stride 2), Y = 2x2 output tile
+//
+// Workgroup: 512 threads = 8 waves, 8x32 output pixels = 4x16 tiles = 64 tiles, 64 output channels (4 cout splits).  Per 16-channel chunk
+//   (a) the 10x34-pixel raw patch (16 ch) and the chunk's pre-transformed weights U[16 pos][64 co][16 ch] go to LDS,
+//   (b) lane (tile, channel pair) forms V = B^T d B in fp32 and writes V[16 pos][64 tiles][16 ch] (rounded to the operand type),
+//   (c) wave q multiplies positions 2q and 2q+1:  M_pos[co][tile] += U_pos[co][ch] . V_pos[ch][tile]  -- 2x2 blocks of v_mfma_f32_32x32x16,
+//       weights as the A operand, tiles as the B operand (dd_elem.h mma_step), 128 accumulator registers per lane.
+// Epilogue: the 16 position accumulators meet in LDS (fp32, one 32 co x 32 tile block at a time) and 128 lanes apply A^T M A, add the bias
+// and store 4 pixels x 8 couts (two 8-byte stores per pixel into the channel-blocked activation layout).
+#include "dd_elem.h"
+
+namespace dd {
+
+namespace {
+
+constexpr int W_TH = 8, W_TW = 32;                 // output pixels per workgroup
+constexpr int W_TY = W_TH / 2, W_TX = W_TW / 2;    // 4 x 16 Winograd tiles
+constexpr int W_TILES = W_TY * W_TX;               // 64
+constexpr int W_PH = W_TH + 2, W_PW = W_TW + 2;    // 10 x 34 input patch
+constexpr int W_CK = 16;                           // channels per chunk = one MFMA k-step
+constexpr int W_NT = 64;                           // output channels per workgroup
+constexpr int W_THREADS = 512;
+constexpr int W_RAW_BYTES = W_PH * W_PW * W_CK * 2;        // 10880
+constexpr int W_V_BYTES = 16 * W_TILES * W_CK * 2;         // 32768
+constexpr int W_U_BYTES = 16 * W_NT * W_CK * 2;            // 32768
+constexpr int W_V_OFF = 10944;                             // RAW region padded to a multiple of 64 B
+constexpr int W_U_OFF = W_V_OFF + W_V_BYTES;
+constexpr int W_SMEM = W_U_OFF + W_U_BYTES;                // 76480 B; the epilogue's 64 KB fp32 block reuses [0, 65536)
+static_assert(W_RAW_BYTES <= W_V_OFF && 16 * 32 * 32 * 4 <= W_SMEM, "LDS carve");
+
+template <int EK> __device__ __forceinline__ float ld16(uint32_t half) {
+  return (EK == EK_BF16) ? bf16_to_f32(half & 0xFFFFu) : f16_to_f32(half & 0xFFFFu);
+}
+
+}  // namespace
+
+template <int EK>
+__global__ void __launch_bounds__(W_THREADS) conv_wino_raw_kernel(ConvParams p) {
+  static_assert(EK == EK_BF16 || EK == EK_F16, "16-bit operand modes only");
+  constexpr int CIN = COND_C, COUT = COND_C, NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_raw = smem;
+  char* s_v = smem + W_V_OFF;
+  char* s_u = smem + W_U_OFF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, g = lane >> 5;
+  const int h = p.h, w = p.w;
+  const int wgid = blockIdx.x;
+  const int nsplit = wgid % NSPLIT;
+  const int tile_id = wgid / NSPLIT;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int b = tile_id / tiles_per_img;
+  const int trem = tile_id - b * tiles_per_img;
+  const int y0 = (trem / p.tiles_x) * W_TH, x0 = (trem % p.tiles_x) * W_TW;
+  const size_t HW = (size_t)h * w;
+  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * HW * CIN * 2;
+  const char* u_g = reinterpret_cast<const char*>(p.wpack) + (size_t)nsplit * NCHUNK * W_U_BYTES;
+
+  f32x16_t acc[2][2][2];          // [position of this wave][cout block][tile block]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
+
+  // transform role of this lane: tile tt, channels 2*cp and 2*cp+1 of the chunk
+  const int cp = tid & 7, tt = tid >> 3;
+  const int tty = tt / W_TX, ttx = tt - tty * W_TX;
+
+#pragma unroll 1
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    // ---- (a) raw patch + weights of this chunk -> LDS ----------------------------------------------------------------
+    // activation layout [B][C/32][h][w][32]: the chunk's 16 channels are 32 contiguous bytes per pixel
+    const size_t cbase = ((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + it * W_THREADS;                   // (patch pixel, 16-byte half)
+      if (item < W_PH * W_PW * 2) {
+        const int pp = item >> 1, hf = item & 1;
+        const int pr = pp / W_PW, pc = pp - pr * W_PW;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);                  // zero padding of the convolution
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w)
+          v = *reinterpret_cast<const uint4*>(in_b + (cbase + ((size_t)gy * w + gx) * ACT_CB) * 2 + hf * 16);
+        *reinterpret_cast<uint4*>(s_raw + pp * (W_CK * 2) + hf * 16) = v;
+      }
+    }
+    {
+      const char* src = u_g + (size_t)chunk * W_U_BYTES;
+#pragma unroll
+      for (int it = 0; it < W_U_BYTES / 16 / W_THREADS; ++it) {
+        const int piece = tid + it * W_THREADS;
+        *reinterpret_cast<uint4*>(s_u + piece * 16) = *reinterpret_cast<const uint4*>(src + (size_t)piece * 16);
+      }
+    }
+    __syncthreads();
+    // ---- (b) input transform V = B^T d B of tile tt, channel pair cp (fp32, rounded once on the way out) ----------------
+    {
+      float d[2][4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t pk = *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + 2 * ttx + j) * (W_CK * 2) + cp * 4);
+          d[0][i][j] = ld16<EK>(pk);
+          d[1][i][j] = ld16<EK>(pk >> 16);
+        }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float t[4][4];                                          // t = B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t[0][j] = d[c][0][j] - d[c][2][j];
+          t[1][j] = d[c][1][j] + d[c][2][j];
+          t[2][j] = d[c][2][j] - d[c][1][j];
+          t[3][j] = d[c][1][j] - d[c][3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                           // V = t B : columns likewise
+          d[c][i][0] = t[i][0] - t[i][2];
+          d[c][i][1] = t[i][1] + t[i][2];
+          d[c][i][2] = t[i][2] - t[i][1];
+          d[c][i][3] = t[i][1] - t[i][3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + cp * 2) * 2) = pack2<EK>(d[0][i][j], d[1][i][j]);
+    }
+    __syncthreads();
+    // ---- (c) positions 2*wave, 2*wave+1:  M[co][tile] += U[co][ch] . V[ch][tile] ----------------------------------------
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int pos = 2 * wave + a;
+      uint4 wf[2], vf[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const uint4*>(s_u + ((pos * W_NT + m * 32 + li) * W_CK + g * 8) * 2);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) vf[n] = *reinterpret_cast<const uint4*>(s_v + ((pos * W_TILES + n * 32 + li) * W_CK + g * 8) * 2);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) mma_step<EK>(acc[a][m][n], wf[m], vf[n]);
+    }
+    __syncthreads();                                            // everybody is done with RAW / U / V of this chunk
+  }
+
+  // ---- epilogue: Y = A^T M A per (cout, tile), one 32 co x 32 tile block at a time through LDS ----------------------------
+  float* s_m = reinterpret_cast<float*>(smem);                  // [16 pos][32 tiles][32 co] fp32 = 64 KB
+  char* out_b = reinterpret_cast<char*>(p.out) + (size_t)b * HW * COUT * 2;
+#pragma unroll 1
+  for (int blk = 0; blk < 4; ++blk) {
+    const int m = blk >> 1, n = blk & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int pos = 2 * wave + a;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // accumulator register r = 4q+i of lane (li, g): cout 8q + 4g + i of the block, tile li (dd_igemm2.hip epilogue convention)
+        float4 v;
+        if (m == 0 && n == 0) v = make_float4(acc[a][0][0][q * 4], acc[a][0][0][q * 4 + 1], acc[a][0][0][q * 4 + 2], acc[a][0][0][q * 4 + 3]);
+        else if (m == 0) v = make_float4(acc[a][0][1][q * 4], acc[a][0][1][q * 4 + 1], acc[a][0][1][q * 4 + 2], acc[a][0][1][q * 4 + 3]);
+        else if (n == 0) v = make_float4(acc[a][1][0][q * 4], acc[a][1][0][q * 4 + 1], acc[a][1][0][q * 4 + 2], acc[a][1][0][q * 4 + 3]);
+        else v = make_float4(acc[a][1][1][q * 4], acc[a][1][1][q * 4 + 1], acc[a][1][1][q * 4 + 2], acc[a][1][1][q * 4 + 3]);
+        *reinterpret_cast<float4*>(s_m + ((pos * 32 + li) * 32 + 8 * q + 4 * g)) = v;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int tj = tid >> 2, cg = tid & 3;                    // tile tj of the block, couts 8*cg .. 8*cg+7
+      const int T = n * 32 + tj;
+      const int ty = T / W_TX, tx = T - ty * W_TX;
+      const int co = nsplit * W_NT + m * 32 + cg * 8;
+#pragma unroll
+      for (int c8 = 0; c8 < 2; ++c8) {                          // four couts at a time keeps the transform at ~50 live registers
+        float t0[4][4], t1[4][4];                               // A^T M, accumulated row by row: rows (m0+m1+m2, m1-m2-m3); [col][cout]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 v4 = *reinterpret_cast<const float4*>(s_m + (((i * 4 + j) * 32 + tj) * 32 + cg * 8 + c8 * 4));
+            const float mv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (i == 0) { t0[j][c] = mv[c]; }
+              else if (i == 1) { t0[j][c] += mv[c]; t1[j][c] = mv[c]; }
+              else if (i == 2) { t0[j][c] += mv[c]; t1[j][c] -= mv[c]; }
+              else { t1[j][c] -= mv[c]; }
+            }
+          }
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co + c8 * 4);
+        const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int gy = y0 + 2 * ty + dy, gx = x0 + 2 * tx + dx;
+            if (gy < h && gx < w) {
+              float v[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float* tr = dy == 0 ? &t0[0][0] : &t1[0][0];
+                // (A^T M) A : columns (c0+c1+c2, c1-c2-c3)
+                v[c] = (dx == 0 ? (tr[0 * 4 + c] + tr[1 * 4 + c] + tr[2 * 4 + c]) : (tr[1 * 4 + c] - tr[2 * 4 + c] - tr[3 * 4 + c])) + bias[c];
+              }
+              *reinterpret_cast<uint2*>(out_b + act_offset(COUT, h, w, 0, co + c8 * 4, gy, gx) * 2) = make_uint2(pack2<EK>(v[0], v[1]), pack2<EK>(v[2], v[3]));
+            }
+          }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s) {
+  if (ek != EK_BF16 && ek != EK_F16) return hipErrorInvalidValue;
+  ConvParams q = p;
+  q.tiles_x = (p.w + W_TW - 1) / W_TW;
+  q.tiles_y = (p.h + W_TH - 1) / W_TH;
+  static bool attr_set[2] = {false, false};
+  const void* fn = ek == EK_BF16 ? reinterpret_cast<const void*>(&conv_wino_raw_kernel<EK_BF16>)
+                                 : reinterpret_cast<const void*>(&conv_wino_raw_kernel<EK_F16>);
+  if (!attr_set[ek == EK_F16]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM);
+    if (e != hipSuccess) return e;
+    attr_set[ek == EK_F16] = true;
+  }
+  const unsigned n_wg = (unsigned)(q.tiles_x * q.tiles_y * q.B * (COND_C / W_NT));
+  if (ek == EK_BF16) hipLaunchKernelGGL(conv_wino_raw_kernel<EK_BF16>, dim3(n_wg), dim3(W_THREADS), W_SMEM, s, q);
+  else hipLaunchKernelGGL(conv_wino_raw_kernel<EK_F16>, dim3(n_wg), dim3(W_THREADS), W_SMEM, s, q);
+  return hipGetLastError();
+}
+
+// Packed weights the kernel streams: [cout split (COUT / 64)][chunk (CIN / 16)][position 4*xi + nu][co 64][ch 16] of U = G g G^T
+// (computed in double, rounded once to the operand type by the caller-supplied converter).
+size_t wino_pack_bytes(int cout, int cin) { return (size_t)cout * cin * 16 * 2; }
+void wino_pack_u(const float* w_oihw, int cout, int cin, uint16_t (*cvt)(float), uint16_t* out) {
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  const int nsplit = cout / W_NT, nchunk = cin / W_CK;
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci) {
+      const float* g = w_oihw + ((size_t)co * cin + ci) * 9;
+      double t[4][3];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+          const int sp = co / W_NT, cl = co % W_NT, ch = ci / W_CK, ck = ci % W_CK;
+          out[((((size_t)sp * nchunk + ch) * 16 + (i * 4 + j)) * W_NT + cl) * W_CK + ck] = cvt((float)u);
+        }
+    }
+  (void)nsplit;
+}
+
+}  // namespace dd

@@ -181,7 +181,7 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * after every launch), "kernel_version" (2 = pipelined kernels [default], 1 = first-generation kernels),
  * "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
  * condition map is re-added in conv3's prologue every step - measured faster), "wave_spec" (1 = wave-specialised
- * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "layer_timing", "ablate" (timing experiments), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
+ * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "winograd" (1 = EXPERIMENTAL Winograd F(2x2,3x3) kernel for the Swin variant's convB in the bf16 / f16 modes, dd_wino.hip; 0 [default]), "layer_timing", "ablate" (timing experiments), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
@@ -196,6 +196,11 @@ int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launche
  * fp32 NCHW: name in {"y1","y2","y3","y4"} = raw conv outputs before GroupNorm (B,C,h,w).
  * Test hook for locating a failing layer. */
 int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, void* stream);
+
+/* Host-only test hook: writes the Winograd F(2x2,3x3) weight image of a (cout, cin, 3, 3) fp32 OIHW filter as the experimental kernel
+ * of option "winograd" streams it -- [cout/64][cin/16][16 positions][64][16] 16-bit elements of G g G^T, rounded once from double;
+ * precision bf16 or f16; out_elems must be cout*cin*16.  No device is touched. */
+int dd_debug_wino_pack(const float* w_oihw, int cout, int cin, int precision, uint16_t* out, int64_t out_elems);
 
 #ifdef __cplusplus
 }

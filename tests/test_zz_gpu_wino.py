@@ -1,0 +1,44 @@
+"""GPU, OPT-IN (`DD_TEST_WINOGRAD=1 pytest -m gpu tests/test_zz_gpu_wino.py`): the experimental Winograd F(2x2,3x3) kernel for the Swin
+denoiser's convB (csrc/dd_wino.hip, option "winograd").  Written at the end of round 1 with no GPU time left: its index math is pinned on
+the CPU (tests/test_wino_kernel_emulation.py), its numerics by tools/winograd_numerics.py; this file is what the first GPU run of round 2
+should execute.  Skipped by default so that an unvalidated kernel cannot fail the round-end suite."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from diffusiondepth_amd import synth
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("DD_TEST_WINOGRAD") != "1", reason="experimental kernel: set DD_TEST_WINOGRAD=1")]
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 16, 24), (2, 13, 21), (1, 44, 152)], ids=["small", "ragged_b2", "kitti_quarter"])
+def test_winograd_convB_matches_the_direct_kernel(prec, shape):
+    import diffusiondepth_amd as dda
+    import gpu_util as U
+    B, h, w = shape
+    be = dda.HipDenoiser(variant="swin")
+    be.load_state_dict(synth.make_state_dict(7240, "swin"))
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    inp = synth.make_inputs(5, B, h, w, ((h + 1) // 2, (w + 1) // 2))
+    x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+    t = U.cu(inp["timesteps"])
+    ref = be.denoise_once(x, t, cond, "fp32").cpu().numpy()
+    be.set_option("winograd", 0)
+    direct = be.denoise_once(x, t, cond, prec).cpu().numpy()
+    be.set_option("winograd", 1)
+    wino = be.denoise_once(x, t, cond, prec).cpu().numpy()
+    e_d, e_w = U.rms(direct, ref), U.rms(wino, ref)
+    U.record(f"winograd_convB_{prec}_{h}x{w}", eps_rms_direct=e_d, eps_rms_winograd=e_w, eps_max=float(np.abs(ref).max()))
+    assert np.isfinite(wino).all()
+    assert e_w < 2.0 * e_d + 1e-4, (e_d, e_w)             # tools/winograd_numerics.py: ~1.2x the direct kernels' error
+    # the whole loop, graph replay included
+    T = 5
+    x0_d = be.denoise(x, cond, T, prec)
+    be.set_option("winograd", 0)
+    x0_ref = be.denoise(x, cond, T, "fp32")
+    x0_dir = be.denoise(x, cond, T, prec)
+    s = float(x0_ref.abs().max())
+    assert float((x0_d - x0_ref).abs().max()) < 2.0 * float((x0_dir - x0_ref).abs().max()) + 1e-4 * s
