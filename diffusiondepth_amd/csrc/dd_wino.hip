@@ -3,7 +3,8 @@
 // 328-333), 16-bit operand modes only.  EXPERIMENTAL, OFF BY DEFAULT (dd_set_option("winograd", 1)): written in round 1 without GPU time left
 // to run it -- DESIGN.md section 7 item 0 has the motivation (the direct kernels sit at the socket power cap; 16 instead of 36 multiplies per
 // 2x2 output tile), the measured instruction-mix ceiling (tools/micro/mfma_power.hip mode 3) and the numerics (tools/winograd_numerics.py).
-// This first version is written for being right, not fast: single-buffered LDS, three barriers per 16-channel chunk, plain global->LDS copies.
+// First GPU contact (run 40): parity as predicted (eps error 1.09x the direct kernel's), but 2.3x SLOWER than the direct convB: still written
+// for being right, not fast -- single-buffered LDS, three barriers per 16-channel chunk, the input transform repeated by the 4 cout splits.
 //
 //   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A        d = 4x4 input tile (stride 2), Y = 2x2 output tile
 //
@@ -77,33 +78,54 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_kernel(ConvParams p) 
   const int cp = tid & 7, tt = tid >> 3;
   const int tty = tt / W_TX, ttx = tt - tty * W_TX;
 
+  // raw patch and weights of a chunk travel global -> registers -> LDS, one chunk ahead: the loads of chunk c+1 are in flight while
+  // chunk c is transformed and multiplied (without this every chunk exposed a full global-load latency: 1214 us per KITTI B=4 launch)
+  static_assert(W_U_BYTES / 16 / W_THREADS == 4, "four weight pieces per lane");
+  uint4 r0, r1, u0, u1, u2, u3;      // named registers (an indexed array behind lambdas ended up in scratch memory)
+  // per-lane patch items (pixel, 16-byte half) do not depend on the chunk
+  const int item1 = tid + W_THREADS;
+  const bool have1 = item1 < W_PH * W_PW * 2;
+  auto item_geom = [&](int item, size_t& goff, bool& inside) {
+    const int pp = item >> 1, hf = item & 1;
+    const int pr = pp / W_PW, pc = pp - pr * W_PW;
+    const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+    inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
+    const int gyc = min(max(gy, 0), h - 1), gxc = min(max(gx, 0), w - 1);            // clamped: unconditional load, select afterwards
+    goff = ((size_t)gyc * w + gxc) * ACT_CB * 2 + hf * 16;
+  };
+  size_t goff0, goff1;
+  bool in0, in1;
+  item_geom(tid, goff0, in0);
+  item_geom(have1 ? item1 : 0, goff1, in1);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  auto gload = [&](int chunk) {
+    // activation layout [B][C/32][h][w][32]: the chunk's 16 channels are 32 contiguous bytes per pixel
+    const char* cb = in_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
+    const uint4 a0 = *reinterpret_cast<const uint4*>(cb + goff0);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(cb + goff1);
+    r0 = in0 ? a0 : zero4;                                     // zero padding of the convolution
+    r1 = in1 ? a1 : zero4;
+    const char* src = u_g + (size_t)chunk * W_U_BYTES + (size_t)tid * 16;
+    u0 = *reinterpret_cast<const uint4*>(src);
+    u1 = *reinterpret_cast<const uint4*>(src + (size_t)W_THREADS * 16);
+    u2 = *reinterpret_cast<const uint4*>(src + (size_t)2 * W_THREADS * 16);
+    u3 = *reinterpret_cast<const uint4*>(src + (size_t)3 * W_THREADS * 16);
+  };
+  auto lstore = [&]() {
+    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = r0;
+    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = r1;
+    *reinterpret_cast<uint4*>(s_u + tid * 16) = u0;
+    *reinterpret_cast<uint4*>(s_u + (tid + W_THREADS) * 16) = u1;
+    *reinterpret_cast<uint4*>(s_u + (tid + 2 * W_THREADS) * 16) = u2;
+    *reinterpret_cast<uint4*>(s_u + (tid + 3 * W_THREADS) * 16) = u3;
+  };
+  gload(0);
 #pragma unroll 1
   for (int chunk = 0; chunk < NCHUNK; ++chunk) {
-    // ---- (a) raw patch + weights of this chunk -> LDS ----------------------------------------------------------------
-    // activation layout [B][C/32][h][w][32]: the chunk's 16 channels are 32 contiguous bytes per pixel
-    const size_t cbase = ((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int item = tid + it * W_THREADS;                   // (patch pixel, 16-byte half)
-      if (item < W_PH * W_PW * 2) {
-        const int pp = item >> 1, hf = item & 1;
-        const int pr = pp / W_PW, pc = pp - pr * W_PW;
-        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);                  // zero padding of the convolution
-        if (gy >= 0 && gy < h && gx >= 0 && gx < w)
-          v = *reinterpret_cast<const uint4*>(in_b + (cbase + ((size_t)gy * w + gx) * ACT_CB) * 2 + hf * 16);
-        *reinterpret_cast<uint4*>(s_raw + pp * (W_CK * 2) + hf * 16) = v;
-      }
-    }
-    {
-      const char* src = u_g + (size_t)chunk * W_U_BYTES;
-#pragma unroll
-      for (int it = 0; it < W_U_BYTES / 16 / W_THREADS; ++it) {
-        const int piece = tid + it * W_THREADS;
-        *reinterpret_cast<uint4*>(s_u + piece * 16) = *reinterpret_cast<const uint4*>(src + (size_t)piece * 16);
-      }
-    }
+    // ---- (a) this chunk's raw patch + weights: registers -> LDS; next chunk's loads start ----------------------------------
+    lstore();
     __syncthreads();
+    if (chunk + 1 < NCHUNK) gload(chunk + 1);
     // ---- (b) input transform V = B^T d B of tile tt, channel pair cp (fp32, rounded once on the way out) ----------------
     {
       float d[2][4][4];
