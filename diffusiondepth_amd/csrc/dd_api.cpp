@@ -147,7 +147,7 @@ struct dd_handle_s {
   DevBuf emb;
   DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
   DevBuf zero_bias;          // 256 zeros
-  bool winograd = false;     // EXPERIMENTAL (dd_wino.hip): Swin convB in Winograd F(2x2,3x3) form in the 16-bit modes; off by default
+  int winograd = 0;          // EXPERIMENTAL (dd_wino.hip): Swin convB in Winograd F(2x2,3x3) form in the 16-bit modes; off by default
   bool hoist_cond = false;   // Res variant, v2 kernels: conv3(cond) once per image instead of re-adding cond every step.
                              // Correct (tested) but measured slower on MI355X (conv3 174 -> 183..195 us at B=4), so off by default.
   DevBuf codec_buf;          // all folded codec weights in one allocation
@@ -415,7 +415,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       const int th = ws ? 8 : (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
       q.tiles_y = (k.h + th - 1) / th;
       if (ws) return launch_conv_igemm2ws(layer, ek, q, s);
-      if (layer == 6 && h->winograd && ek != EK_F32 && !h->ablate) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s); }
+      if (layer == 6 && h->winograd && ek != EK_F32 && !h->ablate) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s, h->winograd); }
       return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
@@ -888,8 +888,9 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
   else if (k == "winograd") {
-    if (h->winograd != (value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
-    h->winograd = value != 0;
+    if (value < 0 || value > 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1 (validated, slow) or 2 (double-buffered, never run)");
+    if (h->winograd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
+    h->winograd = (int)value;
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
   else if (k == "wave_spec") {

@@ -81,7 +81,7 @@ hipError_t launch_conv_igemm2ws(int layer, int ek, const ConvParams& p, hipStrea
 
 // ---- Winograd F(2x2,3x3) form of the raw-input 256->256 convolution (dd_wino.hip; experimental, option "winograd") -------------
 // p.in / p.out: channel-blocked 16-bit activations (256 ch), p.wpack: wino_pack_u image, p.bias: [256] fp32; p.B / p.h / p.w set
-hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s);
+hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int version = 1);   // version 2: double-buffered, never run yet
 size_t wino_pack_bytes(int cout, int cin);
 void wino_pack_u(const float* w_oihw, int cout, int cin, uint16_t (*cvt)(float), uint16_t* out);
 

@@ -246,11 +246,250 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_kernel(ConvParams p) 
   }
 }
 
-hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s) {
+// ------------------------------------------------------------------------------------------------------------------------------------
+// v2 (option "winograd" = 2; NEVER RUN: written after the last GPU second of round 1): the same arithmetic and the same LDS images, but
+// double-buffered so that the two heavy phases overlap inside every wave: while the matrix pipe works on chunk c (fragments of U[c], V[c]
+// read, 8 MFMAs issued), the VALU transforms chunk c+1 (raw[c+1] -> V[c+1]); two barriers per chunk instead of three, none between the
+// MFMAs and the transform.  v1 measured 1131 us per KITTI B=4 launch against 494 us for the direct kernel: its three barrier-separated
+// phases (LDS fill, VALU transform, MFMA) never overlap and only one workgroup fits a CU.
+//   buffers of chunk k: raw[k & 1], U[k & 1], V[k & 1]
+//   iteration c:  registers(chunk c+1) -> raw / U [(c+1) & 1];  barrier A;  global loads of chunk c+2 -> registers;
+//                 MFMAs of chunk c;  transform raw[(c+1) & 1] -> V[(c+1) & 1];  barrier B
+//   (raw / U [(c+1)&1] were last read in iteration c-2 / c-1 before their barrier B; V[(c+1)&1] was last read by the MFMAs of c-1)
+// ------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int W2_RAW_STRIDE = W_V_OFF;                          // 10944
+constexpr int W2_V_OFF = 2 * W2_RAW_STRIDE;                     // 21888
+constexpr int W2_U_OFF = W2_V_OFF + 2 * W_V_BYTES;              // 87424
+constexpr int W2_SMEM = W2_U_OFF + 2 * W_U_BYTES;               // 152960 B of the CU's 160 KB
+static_assert(W2_SMEM <= 160 * 1024 && 16 * 32 * 32 * 4 <= W2_SMEM, "LDS carve (v2)");
+}  // namespace
+
+template <int EK>
+__global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams p) {
+  static_assert(EK == EK_BF16 || EK == EK_F16, "16-bit operand modes only");
+  constexpr int CIN = COND_C, COUT = COND_C, NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, g = lane >> 5;
+  const int h = p.h, w = p.w;
+  const int wgid = blockIdx.x;
+  const int nsplit = wgid % NSPLIT;
+  const int tile_id = wgid / NSPLIT;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int b = tile_id / tiles_per_img;
+  const int trem = tile_id - b * tiles_per_img;
+  const int y0 = (trem / p.tiles_x) * W_TH, x0 = (trem % p.tiles_x) * W_TW;
+  const size_t HW = (size_t)h * w;
+  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * HW * CIN * 2;
+  const char* u_g = reinterpret_cast<const char*>(p.wpack) + (size_t)nsplit * NCHUNK * W_U_BYTES;
+
+  f32x16_t acc[2][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][m][n][r] = 0.f;
+
+  const int cp = tid & 7, tt = tid >> 3;
+  const int tty = tt / W_TX, ttx = tt - tty * W_TX;
+
+  uint4 r0, r1, u0, u1, u2, u3;
+  const int item1 = tid + W_THREADS;
+  const bool have1 = item1 < W_PH * W_PW * 2;
+  auto item_geom = [&](int item, size_t& goff, bool& inside) {
+    const int pp = item >> 1, hf = item & 1;
+    const int pr = pp / W_PW, pc = pp - pr * W_PW;
+    const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+    inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
+    const int gyc = min(max(gy, 0), h - 1), gxc = min(max(gx, 0), w - 1);
+    goff = ((size_t)gyc * w + gxc) * ACT_CB * 2 + hf * 16;
+  };
+  size_t goff0, goff1;
+  bool in0, in1;
+  item_geom(tid, goff0, in0);
+  item_geom(have1 ? item1 : 0, goff1, in1);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  auto gload = [&](int chunk) {
+    const char* cb = in_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
+    const uint4 a0 = *reinterpret_cast<const uint4*>(cb + goff0);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(cb + goff1);
+    r0 = in0 ? a0 : zero4;
+    r1 = in1 ? a1 : zero4;
+    const char* src = u_g + (size_t)chunk * W_U_BYTES + (size_t)tid * 16;
+    u0 = *reinterpret_cast<const uint4*>(src);
+    u1 = *reinterpret_cast<const uint4*>(src + (size_t)W_THREADS * 16);
+    u2 = *reinterpret_cast<const uint4*>(src + (size_t)2 * W_THREADS * 16);
+    u3 = *reinterpret_cast<const uint4*>(src + (size_t)3 * W_THREADS * 16);
+  };
+  auto lstore = [&](int buf) {
+    char* s_raw = smem + buf * W2_RAW_STRIDE;
+    char* s_u = smem + W2_U_OFF + buf * W_U_BYTES;
+    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = r0;
+    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = r1;
+    *reinterpret_cast<uint4*>(s_u + tid * 16) = u0;
+    *reinterpret_cast<uint4*>(s_u + (tid + W_THREADS) * 16) = u1;
+    *reinterpret_cast<uint4*>(s_u + (tid + 2 * W_THREADS) * 16) = u2;
+    *reinterpret_cast<uint4*>(s_u + (tid + 3 * W_THREADS) * 16) = u3;
+  };
+  auto transform = [&](int buf) {                               // raw[buf] -> V[buf]: tile tt, channel pair cp
+    const char* s_raw = smem + buf * W2_RAW_STRIDE;
+    char* s_v = smem + W2_V_OFF + buf * W_V_BYTES;
+    float d[2][4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t pk = *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + 2 * ttx + j) * (W_CK * 2) + cp * 4);
+        d[0][i][j] = ld16<EK>(pk);
+        d[1][i][j] = ld16<EK>(pk >> 16);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      float t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[c][0][j] - d[c][2][j];
+        t[1][j] = d[c][1][j] + d[c][2][j];
+        t[2][j] = d[c][2][j] - d[c][1][j];
+        t[3][j] = d[c][1][j] - d[c][3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        d[c][i][0] = t[i][0] - t[i][2];
+        d[c][i][1] = t[i][1] + t[i][2];
+        d[c][i][2] = t[i][2] - t[i][1];
+        d[c][i][3] = t[i][1] - t[i][3];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + cp * 2) * 2) = pack2<EK>(d[0][i][j], d[1][i][j]);
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  gload(1);
+  transform(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int chunk = 0; chunk < NCHUNK; ++chunk) {
+    const int cur = chunk & 1, nxt = cur ^ 1;
+    const bool more = chunk + 1 < NCHUNK;
+    if (more) lstore(nxt);                                      // registers hold chunk + 1
+    __syncthreads();                                            // A: raw / U of chunk + 1 visible
+    if (chunk + 2 < NCHUNK) gload(chunk + 2);
+    {
+      const char* s_v = smem + W2_V_OFF + cur * W_V_BYTES;
+      const char* s_u = smem + W2_U_OFF + cur * W_U_BYTES;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int pos = 2 * wave + a;
+        uint4 wf[2], vf[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const uint4*>(s_u + ((pos * W_NT + m * 32 + li) * W_CK + g * 8) * 2);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) vf[n] = *reinterpret_cast<const uint4*>(s_v + ((pos * W_TILES + n * 32 + li) * W_CK + g * 8) * 2);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) mma_step<EK>(acc[a][m][n], wf[m], vf[n]);
+      }
+    }
+    if (more) transform(nxt);                                   // VALU + LDS while the matrix pipe drains the 8 MFMAs above
+    __syncthreads();                                            // B: V of chunk + 1 complete, fragment reads of this chunk done
+  }
+
+  // ---- epilogue: identical to v1 --------------------------------------------------------------------------------------------
+  float* s_m = reinterpret_cast<float*>(smem);
+  char* out_b = reinterpret_cast<char*>(p.out) + (size_t)b * HW * COUT * 2;
+#pragma unroll 1
+  for (int blk = 0; blk < 4; ++blk) {
+    const int m = blk >> 1, n = blk & 1;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int pos = 2 * wave + a;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float4 v;
+        if (m == 0 && n == 0) v = make_float4(acc[a][0][0][q * 4], acc[a][0][0][q * 4 + 1], acc[a][0][0][q * 4 + 2], acc[a][0][0][q * 4 + 3]);
+        else if (m == 0) v = make_float4(acc[a][0][1][q * 4], acc[a][0][1][q * 4 + 1], acc[a][0][1][q * 4 + 2], acc[a][0][1][q * 4 + 3]);
+        else if (n == 0) v = make_float4(acc[a][1][0][q * 4], acc[a][1][0][q * 4 + 1], acc[a][1][0][q * 4 + 2], acc[a][1][0][q * 4 + 3]);
+        else v = make_float4(acc[a][1][1][q * 4], acc[a][1][1][q * 4 + 1], acc[a][1][1][q * 4 + 2], acc[a][1][1][q * 4 + 3]);
+        *reinterpret_cast<float4*>(s_m + ((pos * 32 + li) * 32 + 8 * q + 4 * g)) = v;
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int tj = tid >> 2, cg = tid & 3;
+      const int T = n * 32 + tj;
+      const int ty = T / W_TX, tx = T - ty * W_TX;
+      const int co = nsplit * W_NT + m * 32 + cg * 8;
+#pragma unroll
+      for (int c8 = 0; c8 < 2; ++c8) {
+        float t0[4][4], t1[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 v4 = *reinterpret_cast<const float4*>(s_m + (((i * 4 + j) * 32 + tj) * 32 + cg * 8 + c8 * 4));
+            const float mv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              if (i == 0) { t0[j][c] = mv[c]; }
+              else if (i == 1) { t0[j][c] += mv[c]; t1[j][c] = mv[c]; }
+              else if (i == 2) { t0[j][c] += mv[c]; t1[j][c] -= mv[c]; }
+              else { t1[j][c] -= mv[c]; }
+            }
+          }
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co + c8 * 4);
+        const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int gy = y0 + 2 * ty + dy, gx = x0 + 2 * tx + dx;
+            if (gy < h && gx < w) {
+              float v[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const float* tr = dy == 0 ? &t0[0][0] : &t1[0][0];
+                v[c] = (dx == 0 ? (tr[0 * 4 + c] + tr[1 * 4 + c] + tr[2 * 4 + c]) : (tr[1 * 4 + c] - tr[2 * 4 + c] - tr[3 * 4 + c])) + bias[c];
+              }
+              *reinterpret_cast<uint2*>(out_b + act_offset(COUT, h, w, 0, co + c8 * 4, gy, gx) * 2) = make_uint2(pack2<EK>(v[0], v[1]), pack2<EK>(v[2], v[3]));
+            }
+          }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int version) {
   if (ek != EK_BF16 && ek != EK_F16) return hipErrorInvalidValue;
   ConvParams q = p;
   q.tiles_x = (p.w + W_TW - 1) / W_TW;
   q.tiles_y = (p.h + W_TH - 1) / W_TH;
+  if (version == 2) {
+    static bool attr2[2] = {false, false};
+    const void* fn2 = ek == EK_BF16 ? reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_BF16>)
+                                    : reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_F16>);
+    if (!attr2[ek == EK_F16]) {
+      hipError_t e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
+      if (e != hipSuccess) return e;
+      attr2[ek == EK_F16] = true;
+    }
+    const unsigned n2 = (unsigned)(q.tiles_x * q.tiles_y * q.B * (COND_C / W_NT));
+    if (ek == EK_BF16) hipLaunchKernelGGL(conv_wino_raw_v2_kernel<EK_BF16>, dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
+    else hipLaunchKernelGGL(conv_wino_raw_v2_kernel<EK_F16>, dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
+    return hipGetLastError();
+  }
   static bool attr_set[2] = {false, false};
   const void* fn = ek == EK_BF16 ? reinterpret_cast<const void*>(&conv_wino_raw_kernel<EK_BF16>)
                                  : reinterpret_cast<const void*>(&conv_wino_raw_kernel<EK_F16>);

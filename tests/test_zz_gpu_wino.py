@@ -1,7 +1,9 @@
 """GPU, OPT-IN (`DD_TEST_WINOGRAD=1 pytest -m gpu tests/test_zz_gpu_wino.py`): the experimental Winograd F(2x2,3x3) kernel for the Swin
 denoiser's convB (csrc/dd_wino.hip, option "winograd").  Written at the end of round 1 with no GPU time left: its index math is pinned on
 the CPU (tests/test_wino_kernel_emulation.py), its numerics by tools/winograd_numerics.py; this file is what the first GPU run of round 2
-should execute.  Skipped by default so that an unvalidated kernel cannot fail the round-end suite."""
+should execute.  Skipped by default so that an unvalidated kernel cannot fail the round-end suite.
+State at the end of round 1 (tools/gpu/wino_try.py, run 40): v1 ran once -- eps error 1.09x the direct kernel's in f16 and bf16, 1131 us per
+KITTI B=4 launch against 494 us direct; v2 (double-buffered, MFMAs overlapping the next chunk's transform) has never run."""
 import os
 
 import numpy as np
@@ -13,9 +15,10 @@ from diffusiondepth_amd import synth
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("DD_TEST_WINOGRAD") != "1", reason="experimental kernel: set DD_TEST_WINOGRAD=1")]
 
 
+@pytest.mark.parametrize("version", [1, 2], ids=["v1", "v2_double_buffered"])
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 16, 24), (2, 13, 21), (1, 44, 152)], ids=["small", "ragged_b2", "kitti_quarter"])
-def test_winograd_convB_matches_the_direct_kernel(prec, shape):
+def test_winograd_convB_matches_the_direct_kernel(prec, shape, version):
     import diffusiondepth_amd as dda
     import gpu_util as U
     B, h, w = shape
@@ -28,7 +31,7 @@ def test_winograd_convB_matches_the_direct_kernel(prec, shape):
     ref = be.denoise_once(x, t, cond, "fp32").cpu().numpy()
     be.set_option("winograd", 0)
     direct = be.denoise_once(x, t, cond, prec).cpu().numpy()
-    be.set_option("winograd", 1)
+    be.set_option("winograd", version)
     wino = be.denoise_once(x, t, cond, prec).cpu().numpy()
     e_d, e_w = U.rms(direct, ref), U.rms(wino, ref)
     U.record(f"winograd_convB_{prec}_{h}x{w}", eps_rms_direct=e_d, eps_rms_winograd=e_w, eps_max=float(np.abs(ref).max()))
