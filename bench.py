@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--no-nlspn-extra", action="store_true", help="skip the NLSPN refinement timing (SURVEY.md 8f rank 4)")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
     ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
+    ap.add_argument("--winograd", type=int, default=0, choices=[0, 1, 2],
+                    help="EXPERIMENTAL (Swin variant, bf16 / f16): Winograd F(2x2,3x3) kernel for convB (csrc/dd_wino.hip); 1 = validated but slow, "
+                         "2 = double-buffered, unvalidated.  Off in every quoted number.")
     ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
@@ -188,6 +191,8 @@ def main():
     be.set_option("kernel_version", args.kernel_version)
     be.set_option("hoist_cond", 1 if args.hoist else 0)
     be.set_option("wave_spec", 1 if args.wave_spec else 0)
+    if args.winograd:
+        be.set_option("winograd", args.winograd)
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if (args.hoist and args.kernel_version == 2) else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
@@ -350,7 +355,7 @@ def main():
             "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
-                       "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant},
+                       "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant, "winograd": args.winograd},
             "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
         }
         print(json.dumps(out), flush=True)
