@@ -888,7 +888,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
   else if (k == "winograd") {
-    if (value < 0 || value > 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1 (validated, slow) or 2 (double-buffered, never run)");
+    if (value < 0 || value > 3) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1 (validated, slow), 2 (double-buffered, never run) or 3 (2 + packed-f16 transform)");
     if (h->winograd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
     h->winograd = (int)value;
   }

@@ -265,9 +265,13 @@ constexpr int W2_SMEM = W2_U_OFF + 2 * W_U_BYTES;               // 152960 B of t
 static_assert(W2_SMEM <= 160 * 1024 && 16 * 32 * 32 * 4 <= W2_SMEM, "LDS carve (v2)");
 }  // namespace
 
-template <int EK>
+// PK (f16 only, option "winograd" = 3): the input transform's 64 additions run as 32 packed f16 adds on the channel PAIR (v_pk_add_f16),
+// without unpacking to fp32 and re-packing: ~60 instead of ~150 VALU instructions per lane and chunk.  Every add rounds to f16;
+// tools/winograd_numerics.py puts the cost at +4.5 % depth RMSE (2.63e-4 instead of 2.52e-4; direct f16 2.11e-4).
+template <int EK, bool PK>
 __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams p) {
   static_assert(EK == EK_BF16 || EK == EK_F16, "16-bit operand modes only");
+  static_assert(!PK || EK == EK_F16, "packed transform adds exist for f16 only");
   constexpr int CIN = COND_C, COUT = COND_C, NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,6 +342,34 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   auto transform = [&](int buf) {                               // raw[buf] -> V[buf]: tile tt, channel pair cp
     const char* s_raw = smem + buf * W2_RAW_STRIDE;
     char* s_v = smem + W2_V_OFF + buf * W_V_BYTES;
+    if constexpr (PK) {
+      f16x2_t e[4][4], t[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          e[i][j] = __builtin_bit_cast(f16x2_t, *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + 2 * ttx + j) * (W_CK * 2) + cp * 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = e[0][j] - e[2][j];
+        t[1][j] = e[1][j] + e[2][j];
+        t[2][j] = e[2][j] - e[1][j];
+        t[3][j] = e[1][j] - e[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        e[i][0] = t[i][0] - t[i][2];
+        e[i][1] = t[i][1] + t[i][2];
+        e[i][2] = t[i][2] - t[i][1];
+        e[i][3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + cp * 2) * 2) = __builtin_bit_cast(uint32_t, e[i][j]);
+      return;
+    }
     float d[2][4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -476,18 +508,21 @@ hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int 
   ConvParams q = p;
   q.tiles_x = (p.w + W_TW - 1) / W_TW;
   q.tiles_y = (p.h + W_TH - 1) / W_TH;
-  if (version == 2) {
-    static bool attr2[2] = {false, false};
-    const void* fn2 = ek == EK_BF16 ? reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_BF16>)
-                                    : reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_F16>);
-    if (!attr2[ek == EK_F16]) {
-      hipError_t e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
+  if (version >= 2) {
+    const int which = ek == EK_BF16 ? 0 : (version == 3 ? 2 : 1);      // version 3 = packed-f16 transform (f16 only; bf16 runs v2)
+    static bool attr2[3] = {false, false, false};
+    const void* fns[3] = {reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_BF16, false>),
+                          reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_F16, false>),
+                          reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_F16, true>)};
+    if (!attr2[which]) {
+      hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
       if (e != hipSuccess) return e;
-      attr2[ek == EK_F16] = true;
+      attr2[which] = true;
     }
     const unsigned n2 = (unsigned)(q.tiles_x * q.tiles_y * q.B * (COND_C / W_NT));
-    if (ek == EK_BF16) hipLaunchKernelGGL(conv_wino_raw_v2_kernel<EK_BF16>, dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
-    else hipLaunchKernelGGL(conv_wino_raw_v2_kernel<EK_F16>, dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
+    if (which == 0) hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK_BF16, false>), dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
+    else if (which == 1) hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK_F16, false>), dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
+    else hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK_F16, true>), dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
     return hipGetLastError();
   }
   static bool attr_set[2] = {false, false};

@@ -15,7 +15,7 @@ from diffusiondepth_amd import synth
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("DD_TEST_WINOGRAD") != "1", reason="experimental kernel: set DD_TEST_WINOGRAD=1")]
 
 
-@pytest.mark.parametrize("version", [1, 2], ids=["v1", "v2_double_buffered"])
+@pytest.mark.parametrize("version", [1, 2, 3], ids=["v1", "v2_double_buffered", "v3_packed_f16_transform"])
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(1, 16, 24), (2, 13, 21), (1, 44, 152)], ids=["small", "ragged_b2", "kitti_quarter"])
 def test_winograd_convB_matches_the_direct_kernel(prec, shape, version):

@@ -12,13 +12,13 @@ for (B, h, w) in ((1, 16, 24), (2, 13, 21)):
     for prec in ("f16", "bf16"):
         be.set_option("winograd", 0); d = be.denoise_once(x, t, cond, prec)
         rms = lambda a: float((a - ref).pow(2).mean().sqrt())
-        for ver in (1, 2):
+        for ver in (1, 2, 3):
             be.set_option("winograd", ver); wv = be.denoise_once(x, t, cond, prec); torch.cuda.synchronize()
             print(f"{B}x{h}x{w} {prec}: eps rms err direct {rms(d):.3e} winograd v{ver} {rms(wv):.3e} finite {bool(torch.isfinite(wv).all())}", flush=True)
 B, h, w = 4, 176, 608
 inp = synth.make_inputs(7, B, h, w, (88, 304))
 x, cond = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
-for wino in (0, 1, 2):
+for wino in (0, 1, 2, 3):
     be.set_option("winograd", wino); be.set_option("layer_timing", 1)
     for _ in range(2): be.denoise(x, cond, 5, "f16")
     torch.cuda.synchronize(); ms, n = be.layer_ms(6); print(f"KITTI B=4 f16 convB winograd={wino}: {1e3 * ms / max(n, 1):.1f} us per launch ({n} launches)", flush=True)

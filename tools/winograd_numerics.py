@@ -34,13 +34,28 @@ def conv_direct(a, w, b, dt):
     return F.conv2d(rnd(a, dt), rnd(w, dt), b, padding=1)
 
 
+NATIVE_ADDS = False       # True: the input transform's additions run in the 16-bit type itself (v_pk_add_f16: a rounding after EVERY add)
+
+
+def _bt_d_b_native(tiles, dt):
+    """B^T d B with every addition rounded to dt (what packed 16-bit VALU adds would do); tiles (...,4,4) already in dt."""
+    r = lambda x: rnd(x, dt)
+    d0, d1, d2, d3 = tiles[..., 0, :], tiles[..., 1, :], tiles[..., 2, :], tiles[..., 3, :]
+    t = torch.stack([r(d0 - d2), r(d1 + d2), r(d2 - d1), r(d1 - d3)], dim=-2)
+    c0, c1, c2, c3 = t[..., 0], t[..., 1], t[..., 2], t[..., 3]
+    return torch.stack([r(c0 - c2), r(c1 + c2), r(c2 - c1), r(c1 - c3)], dim=-1)
+
+
 def conv_winograd(a, w, b, dt):
     """F(2x2,3x3): a (B,C,H,W) fp32 (already the conv's input values), w (Co,C,3,3).  16-bit rounding is applied to V and U."""
     Bn, C, H, W = a.shape
     Hp, Wp = H + (H % 2), W + (W % 2)
     x = F.pad(a, (1, 1 + Wp - W, 1, 1 + Hp - H))                                  # zero padding of the conv + even size
     tiles = x.unfold(2, 4, 2).unfold(3, 4, 2)                                      # (B,C,Hp/2,Wp/2,4,4)
-    V = rnd(torch.einsum("ij,bchwjk,lk->bchwil", BT, rnd(tiles, dt), BT), dt)      # the MFMA operand is V rounded; d itself is 16-bit too
+    if NATIVE_ADDS and dt is not None:
+        V = _bt_d_b_native(rnd(tiles, dt), dt)
+    else:
+        V = rnd(torch.einsum("ij,bchwjk,lk->bchwil", BT, rnd(tiles, dt), BT), dt)  # the MFMA operand is V rounded; d itself is 16-bit too
     U = rnd(torch.einsum("ij,ocjk,lk->ocil", G, w, G), dt)                         # pre-transformed in fp32, then rounded
     M = torch.einsum("ocil,bchwil->bohwil", U, V)                                  # fp32 accumulation over channels
     Y = torch.einsum("ij,bohwjk,lk->bohwil", AT, M, AT)                            # (B,Co,Hp/2,Wp/2,2,2)
@@ -104,6 +119,11 @@ def main():
             for wino in (False, True):
                 d = P.decode(sd, loop(sd, inp["x_T"], inp["cond"], a.T, dt, wino))
                 rows.setdefault(f"{name} {'winograd conv2/conv3' if wino else 'direct'}", []).append(float((d - ref).pow(2).mean().sqrt()))
+        global NATIVE_ADDS
+        NATIVE_ADDS = True
+        d = P.decode(sd, loop(sd, inp["x_T"], inp["cond"], a.T, torch.float16, True))
+        rows.setdefault("f16 winograd, transform adds in f16", []).append(float((d - ref).pow(2).mean().sqrt()))
+        NATIVE_ADDS = False
         print(f"seed {s}: depth range {float(ref.min()):.2f}..{float(ref.max()):.2f}", flush=True)
     print(f"\nlatent {a.h}x{a.w}, T={a.T}: depth RMSE vs the fp32 reference loop (mean over {a.seeds} weight / input seeds)")
     for k, v in rows.items():
