@@ -151,9 +151,9 @@ def main():
     ap.add_argument("--no-nlspn-extra", action="store_true", help="skip the NLSPN refinement timing (SURVEY.md 8f rank 4)")
     ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
     ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
-    ap.add_argument("--winograd", type=int, default=0, choices=[0, 1, 2, 3],
-                    help="EXPERIMENTAL (Swin variant, bf16 / f16): Winograd F(2x2,3x3) kernel for convB (csrc/dd_wino.hip); 1 = validated but slow, "
-                         "2 = double-buffered, 3 = 2 + packed-f16 transform (both unvalidated).  Off in every quoted number.")
+    ap.add_argument("--winograd", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
+                    help="EXPERIMENTAL (bf16 / f16): Winograd F(2x2,3x3) kernels (csrc/dd_wino.hip); 1..3 = the Swin convB only: 1 = validated but slow, "
+                         "2 = double-buffered, 3 = 2 + packed-f16 transform; 4 / 5 = every large convolution of either variant (all unvalidated).  Off in every quoted number.")
     ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")

@@ -86,7 +86,7 @@ struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   DevBuf w_oihw;                    // naive path
   DevBuf wpackT[NUM_EK];            // fused backward: W' packed for the dgrad layer (23 - conv index) of dd_igemm2.hip
   DevBuf wT_oihw;                   // naive backward: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (dgrad as a forward conv)
-  DevBuf wino[NUM_EK];              // convB only: Winograd-transformed weights (dd_wino.hip), 16-bit element kinds
+  DevBuf wino[NUM_EK];              // conv2 / conv3 / convA / convB: Winograd-transformed weights (dd_wino.hip), 16-bit element kinds
   DevBuf gamma, beta;               // GroupNorm affine [cout]
 };
 
@@ -110,6 +110,7 @@ struct Plan {
   DevBuf xstash;           // loop backward: the T states entering each step + the running gradient, fp32 NHWC16
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
+  DevBuf wtab;             // experimental Winograd kernels: (a, b, e) prologue table [B][256][4] floats (wino_gn_table_kernel)
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
@@ -415,7 +416,22 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       const int th = ws ? 8 : (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
       q.tiles_y = (k.h + th - 1) / th;
       if (ws) return launch_conv_igemm2ws(layer, ek, q, s);
-      if (layer == 6 && h->winograd && ek != EK_F32 && !h->ablate) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s, h->winograd); }
+      if (h->winograd && ek != EK_F32 && !h->ablate && pl->key.kver == 2) {
+        // EXPERIMENTAL (dd_wino.hip).  1..3: the Swin convB only (1 = the validated-but-slow v1, 2 = double-buffered, 3 = 2 + packed-f16
+        // transform); 4 / 5: every large convolution of the denoiser on the double-buffered kernel (5: packed-f16 transform in f16 mode)
+        if (h->winograd <= 3 && layer == 6) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s, h->winograd); }
+        if (h->winograd >= 4 && conv_wino_supports(layer)) {
+          ConvLayer& WL = layer == 2 ? h->L[1] : layer == 5 ? h->LA : layer == 6 ? h->LB : h->L[2];
+          q.wpack = WL.wino[ek].p;
+          if (layer == 2 || layer == 3 || layer == 5) {       // GroupNorm (+ condition) prologue: table first, on the same stream
+            if (pl->wtab.bytes < (size_t)k.B * COND_C * 16) { hipError_t e = pl->wtab.alloc((size_t)k.B * COND_C * 16); if (e != hipSuccess) return e; }
+            hipError_t e = launch_wino_gn_table(q, layer == 2 ? HID_C : COND_C, pl->wtab.as<float>(), layer != 2, s);
+            if (e != hipSuccess) return e;
+            q.cadd = pl->wtab.as<float>();
+          }
+          return launch_conv_wino_layer(layer, ek, q, s, h->winograd == 5);
+        }
+      }
       return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
@@ -680,6 +696,14 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     std::copy(b.begin(), b.end(), bpad.begin());
     int rc = upload(h, L.bias, bpad.data(), bpad.size() * 4, s); if (rc) return rc;
     rc = upload(h, L.w_oihw, w.data(), w.size() * 4, s); if (rc) return rc;
+    if (l == 1 || l == 2) {          // conv2 / conv3 (Swin: pred.0): Winograd images for the experimental kernels (bf16 / f16)
+      std::vector<uint16_t> u(wino_pack_bytes(L.cout, L.cin) / 2);
+      for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
+        wino_pack_u(w.data(), L.cout, L.cin, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
+        rc = upload(h, L.wino[ek], u.data(), u.size() * 2, s); if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
+    }
     {
       std::vector<float> wt(w.size());
       for (int co = 0; co < L.cout; ++co)
@@ -717,7 +741,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
       int rc = upload(h, L.bias, b.data(), b.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
-      if (i == 1) {                 // convB: Winograd image for the experimental kernel (bf16 / f16)
+      {                             // convA / convB: Winograd images for the experimental kernels (bf16 / f16)
         std::vector<uint16_t> u(wino_pack_bytes(COND_C, COND_C) / 2);
         for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
           wino_pack_u(w.data(), COND_C, COND_C, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
@@ -888,7 +912,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
   else if (k == "winograd") {
-    if (value < 0 || value > 3) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1 (validated, slow), 2 (double-buffered, never run) or 3 (2 + packed-f16 transform)");
+    if (value < 0 || value > 5) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1..3 (Swin convB: validated-slow / double-buffered / + packed-f16 transform) or 4 / 5 (all large convolutions, never run)");
     if (h->winograd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
     h->winograd = (int)value;
   }

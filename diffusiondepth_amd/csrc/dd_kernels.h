@@ -82,6 +82,10 @@ hipError_t launch_conv_igemm2ws(int layer, int ek, const ConvParams& p, hipStrea
 // ---- Winograd F(2x2,3x3) form of the raw-input 256->256 convolution (dd_wino.hip; experimental, option "winograd") -------------
 // p.in / p.out: channel-blocked 16-bit activations (256 ch), p.wpack: wino_pack_u image, p.bias: [256] fp32; p.B / p.h / p.w set
 hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int version = 1);   // version 2: double-buffered, never run yet
+// generalised double-buffered kernel (never run): layers 2, 3 (Res conv2 / conv3), 5, 6, 7 (Swin convA / convB / pred.0)
+bool conv_wino_supports(int layer);
+hipError_t launch_conv_wino_layer(int layer, int ek, const ConvParams& p, hipStream_t s, bool packed_f16_transform);
+hipError_t launch_wino_gn_table(const ConvParams& p, int C, float* tab, bool with_emb, hipStream_t s);
 size_t wino_pack_bytes(int cout, int cin);
 void wino_pack_u(const float* w_oihw, int cout, int cin, uint16_t (*cvt)(float), uint16_t* out);
 

@@ -268,12 +268,21 @@ static_assert(W2_SMEM <= 160 * 1024 && 16 * 32 * 32 * 4 <= W2_SMEM, "LDS carve (
 // PK (f16 only, option "winograd" = 3): the input transform's 64 additions run as 32 packed f16 adds on the channel PAIR (v_pk_add_f16),
 // without unpacking to fp32 and re-packing: ~60 instead of ~150 VALU instructions per lane and chunk.  Every add rounds to f16;
 // tools/winograd_numerics.py puts the cost at +4.5 % depth RMSE (2.63e-4 instead of 2.52e-4; direct f16 2.11e-4).
-template <int EK, bool PK>
+// Generalised (option "winograd" = 4 / 5, NEVER RUN) to every large convolution of both denoisers:
+//   CIN, COUT  64->256 (conv2), 256->64 (conv3, Swin pred.0), 256->256 (Swin convA / convB)
+//   PRO        PRO_RAW: operands as stored | PRO_GN: relu(a*y + b) | PRO_GN_ADD: relu(a*y + b) + cond + e   -- applied when the prefetched
+//              registers go to LDS, from the per-(image, channel) table (a, b, e) that wino_gn_table_kernel derives from the producer's
+//              GroupNorm partial sums (p.cadd points at it: [B][CIN][4] floats); zero padding applies AFTER the normalisation
+//   STATS      Sigma / Sigma x^2 of this layer's fp32 outputs per GroupNorm group -> one fp64 atomic per group per workgroup (slot layout of
+//              dd_kernels.h, as dd_igemm2.hip's epilogue)
+template <int EK, bool PK, int CIN, int COUT, int PRO, bool STATS>
 __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams p) {
   static_assert(EK == EK_BF16 || EK == EK_F16, "16-bit operand modes only");
   static_assert(!PK || EK == EK_F16, "packed transform adds exist for f16 only");
-  constexpr int CIN = COND_C, COUT = COND_C, NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
+  static_assert(CIN % 32 == 0 && COUT % W_NT == 0 && (COUT == 64 || COUT == 256), "channel-blocked layouts, 64 couts per workgroup");
+  constexpr int NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_tab = reinterpret_cast<float*>(smem + W2_SMEM);        // [3][CIN]: a, b, e of the prologue (PRO != PRO_RAW)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, g = lane >> 5;
   const int h = p.h, w = p.w;
@@ -287,6 +296,13 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   const size_t HW = (size_t)h * w;
   const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * HW * CIN * 2;
   const char* u_g = reinterpret_cast<const char*>(p.wpack) + (size_t)nsplit * NCHUNK * W_U_BYTES;
+  const char* cond_b = (PRO == PRO_GN_ADD) ? reinterpret_cast<const char*>(p.cond) + (size_t)b * HW * CIN * 2 : nullptr;
+  if constexpr (PRO != PRO_RAW) {
+    if (tid < CIN) {
+      const float4 t4 = reinterpret_cast<const float4*>(p.cadd)[(size_t)b * CIN + tid];
+      s_tab[tid] = t4.x; s_tab[CIN + tid] = t4.y; s_tab[2 * CIN + tid] = t4.z;
+    }                                                           // visible after the first barrier below
+  }
 
   f32x16_t acc[2][2][2];
 #pragma unroll
@@ -302,6 +318,8 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   const int tty = tt / W_TX, ttx = tt - tty * W_TX;
 
   uint4 r0, r1, u0, u1, u2, u3;
+  uint4 c0 = make_uint4(0u, 0u, 0u, 0u), c1 = c0;                // PRO_GN_ADD: the condition map's pieces
+  int loaded_chunk = 0;                                         // chunk whose pieces the registers hold (prologue table index)
   const int item1 = tid + W_THREADS;
   const bool have1 = item1 < W_PH * W_PW * 2;
   auto item_geom = [&](int item, size_t& goff, bool& inside) {
@@ -323,17 +341,52 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     const uint4 a1 = *reinterpret_cast<const uint4*>(cb + goff1);
     r0 = in0 ? a0 : zero4;
     r1 = in1 ? a1 : zero4;
+    if constexpr (PRO == PRO_GN_ADD) {
+      const char* cc = cond_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
+      c0 = *reinterpret_cast<const uint4*>(cc + goff0);
+      c1 = *reinterpret_cast<const uint4*>(cc + goff1);
+    }
+    loaded_chunk = chunk;
     const char* src = u_g + (size_t)chunk * W_U_BYTES + (size_t)tid * 16;
     u0 = *reinterpret_cast<const uint4*>(src);
     u1 = *reinterpret_cast<const uint4*>(src + (size_t)W_THREADS * 16);
     u2 = *reinterpret_cast<const uint4*>(src + (size_t)2 * W_THREADS * 16);
     u3 = *reinterpret_cast<const uint4*>(src + (size_t)3 * W_THREADS * 16);
   };
+  // prologue of one 16-byte piece (8 channels starting at ch0 of one pixel): relu(a*y + b) [+ cond + e]; outside the image: zero
+  auto prologue = [&](const uint4& raw, const uint4& cnd, bool inside, int ch0) -> uint4 {
+    if constexpr (PRO == PRO_RAW) { (void)cnd; (void)inside; (void)ch0; return raw; }     // gload already zeroed the padding
+    float v[8], ta[8], tb[8];
+    Piece<EK>::unpack(raw, v);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float4 a4 = *reinterpret_cast<const float4*>(s_tab + ch0 + 4 * q);
+      const float4 b4 = *reinterpret_cast<const float4*>(s_tab + CIN + ch0 + 4 * q);
+      ta[4 * q] = a4.x; ta[4 * q + 1] = a4.y; ta[4 * q + 2] = a4.z; ta[4 * q + 3] = a4.w;
+      tb[4 * q] = b4.x; tb[4 * q + 1] = b4.y; tb[4 * q + 2] = b4.z; tb[4 * q + 3] = b4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaxf(fmaf(ta[i], v[i], tb[i]), 0.f);
+    if constexpr (PRO == PRO_GN_ADD) {
+      float cv[8], te[8];
+      Piece<EK>::unpack(cnd, cv);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 e4 = *reinterpret_cast<const float4*>(s_tab + 2 * CIN + ch0 + 4 * q);
+        te[4 * q] = e4.x; te[4 * q + 1] = e4.y; te[4 * q + 2] = e4.z; te[4 * q + 3] = e4.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = v[i] + (cv[i] + te[i]);        // same association as dd_igemm2.hip's transform_item
+    }
+    const uint4 o = Piece<EK>::pack(v);
+    return inside ? o : make_uint4(0u, 0u, 0u, 0u);
+  };
   auto lstore = [&](int buf) {
     char* s_raw = smem + buf * W2_RAW_STRIDE;
     char* s_u = smem + W2_U_OFF + buf * W_U_BYTES;
-    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = r0;
-    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = r1;
+    const int chb = loaded_chunk * W_CK;
+    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = prologue(r0, c0, in0, chb + (tid & 1) * 8);
+    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = prologue(r1, c1, in1, chb + (item1 & 1) * 8);
     *reinterpret_cast<uint4*>(s_u + tid * 16) = u0;
     *reinterpret_cast<uint4*>(s_u + (tid + W_THREADS) * 16) = u1;
     *reinterpret_cast<uint4*>(s_u + (tid + 2 * W_THREADS) * 16) = u2;
@@ -405,6 +458,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   };
 
   gload(0);
+  if constexpr (PRO != PRO_RAW) __syncthreads();                // the prologue table is in LDS
   lstore(0);
   __syncthreads();
   gload(1);
@@ -438,9 +492,12 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     __syncthreads();                                            // B: V of chunk + 1 complete, fragment reads of this chunk done
   }
 
-  // ---- epilogue: identical to v1 --------------------------------------------------------------------------------------------
+  // ---- epilogue: as v1, plus the GroupNorm partial sums of this layer's outputs (STATS) ------------------------------------------------
   float* s_m = reinterpret_cast<float*>(smem);
   char* out_b = reinterpret_cast<char*>(p.out) + (size_t)b * HW * COUT * 2;
+  // local statistics slots: COUT == 256: the workgroup's 64 couts are exactly GroupNorm group `nsplit` -> slot 0 only;
+  //                         COUT == 64: four groups of 16 couts -> slot = (32 m + 8 cg) / 16
+  float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int blk = 0; blk < 4; ++blk) {
     const int m = blk >> 1, n = blk & 1;
@@ -463,6 +520,8 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       const int T = n * 32 + tj;
       const int ty = T / W_TX, tx = T - ty * W_TX;
       const int co = nsplit * W_NT + m * 32 + cg * 8;
+      const int slot = (COUT == 256) ? 0 : ((m * 32 + cg * 8) >> 4);
+      float ssum = 0.f, ssq = 0.f;
 #pragma unroll
       for (int c8 = 0; c8 < 2; ++c8) {
         float t0[4][4], t1[4][4];
@@ -494,13 +553,113 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
                 const float* tr = dy == 0 ? &t0[0][0] : &t1[0][0];
                 v[c] = (dx == 0 ? (tr[0 * 4 + c] + tr[1 * 4 + c] + tr[2 * 4 + c]) : (tr[1 * 4 + c] - tr[2 * 4 + c] - tr[3 * 4 + c])) + bias[c];
               }
+              if constexpr (STATS) {                            // from the fp32 values, before the 16-bit rounding (as dd_igemm2.hip)
+                ssum += (v[0] + v[1]) + (v[2] + v[3]);
+                ssq += fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+              }
               *reinterpret_cast<uint2*>(out_b + act_offset(COUT, h, w, 0, co + c8 * 4, gy, gx) * 2) = make_uint2(pack2<EK>(v[0], v[1]), pack2<EK>(v[2], v[3]));
             }
           }
       }
+      if constexpr (STATS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == slot) { ls[k] += ssum; lq[k] += ssq; }
+      }
     }
     __syncthreads();
   }
+  if constexpr (STATS) {
+    // lanes 0..127 (waves 0 and 1) hold the partial sums: butterfly inside each wave (fp32), fp64 from there on
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ls[k] += __shfl_xor(ls[k], off, 64); lq[k] += __shfl_xor(lq[k], off, 64); }
+    double* s_red = reinterpret_cast<double*>(smem);            // every LDS image is dead behind the loop's last barrier
+    if (wave < 2 && lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s_red[wave * 8 + 2 * k] = (double)ls[k]; s_red[wave * 8 + 2 * k + 1] = (double)lq[k]; }
+    }
+    __syncthreads();
+    constexpr int NG_LOCAL = (COUT == 256) ? 1 : 4;
+    if (tid < 2 * NG_LOCAL) {
+      const double tot = s_red[tid] + s_red[8 + tid];
+      const int gbase = (COUT == 256) ? nsplit : 0;             // COUT == 256: this workgroup's couts are group `nsplit`
+      atomicAdd(p.stats_out + ((size_t)b * STAT_SLOTS + (wgid % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid, tot);
+    }
+  }
+}
+
+// (a, b, e) of the prologue for every (image, channel): a = gamma / sqrt(var + eps), b = beta - mean * a from the producing layer's
+// GroupNorm partial sums (32 slots x 4 groups x (Sigma, Sigma x^2), fp64), e = E[t][c] (PRO_GN_ADD) or 0.  One block per image.
+__global__ void __launch_bounds__(256) wino_gn_table_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ emb,
+                                                            const long long* __restrict__ tvec, int t_base, int t_bstride,
+                                                            float* __restrict__ tab, int C, double count_per_group) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  if (c >= C) return;
+  const int grp = c / (C / GN_GROUPS);
+  double sm = 0.0, sq = 0.0;
+  for (int sl = 0; sl < STAT_SLOTS; ++sl) {
+    const double* st = stats + ((size_t)b * STAT_SLOTS + sl) * STAT_STRIDE + grp * 2;
+    sm += st[0];
+    sq += st[1];
+  }
+  const double mean = sm / count_per_group;
+  double var = sq / count_per_group - mean * mean;              // biased, as torch
+  var = var > 0.0 ? var : 0.0;
+  const double a = (double)gamma[c] / sqrt(var + (double)GN_EPS);
+  float e = 0.f;
+  if (emb != nullptr) e = emb[(size_t)tvec[t_base + b * t_bstride] * COND_C + c];
+  reinterpret_cast<float4*>(tab)[(size_t)b * C + c] = make_float4((float)a, (float)((double)beta[c] - mean * a), e, 0.f);
+}
+
+hipError_t launch_wino_gn_table(const ConvParams& p, int C, float* tab, bool with_emb, hipStream_t s) {
+  hipLaunchKernelGGL(wino_gn_table_kernel, dim3((unsigned)p.B), dim3(256), 0, s, p.stats_in, p.gn_gamma, p.gn_beta,
+                     with_emb ? p.emb : nullptr, p.tvec, p.t_base, p.t_bstride, tab, C, (double)p.h * (double)p.w * (double)(C / GN_GROUPS));
+  return hipGetLastError();
+}
+
+namespace {
+template <int EK, bool PK, int CIN, int COUT, int PRO, bool STATS>
+hipError_t launch_wino_inst(const ConvParams& p, hipStream_t s) {
+  constexpr int SMEM = W2_SMEM + 3 * CIN * 4;                   // + the prologue table
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK, PK, CIN, COUT, PRO, STATS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  ConvParams q = p;
+  q.tiles_x = (p.w + W_TW - 1) / W_TW;
+  q.tiles_y = (p.h + W_TH - 1) / W_TH;
+  const unsigned n_wg = (unsigned)(q.tiles_x * q.tiles_y * q.B * (COUT / W_NT));
+  hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK, PK, CIN, COUT, PRO, STATS>), dim3(n_wg), dim3(W_THREADS), SMEM, s, q);
+  return hipGetLastError();
+}
+template <int EK, bool PK>
+hipError_t launch_wino_layer_ek(int layer, const ConvParams& p, hipStream_t s) {
+  switch (layer) {
+    case 2: return launch_wino_inst<EK, PK, HID_C, COND_C, PRO_GN, true>(p, s);          // conv2: relu(gn1(y1)) -> y2 (+ GN2 statistics)
+    case 3: return launch_wino_inst<EK, PK, COND_C, HID_C, PRO_GN_ADD, true>(p, s);      // conv3: relu(gn2(y2)) + cond + E[t] -> y3 (+ GN3)
+    case 5: return launch_wino_inst<EK, PK, COND_C, COND_C, PRO_GN_ADD, false>(p, s);    // Swin convA
+    case 6: return launch_wino_inst<EK, PK, COND_C, COND_C, PRO_RAW, false>(p, s);       // Swin convB
+    case 7: return launch_wino_inst<EK, PK, COND_C, HID_C, PRO_RAW, true>(p, s);         // Swin pred.0 (+ GN3 statistics)
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
+
+bool conv_wino_supports(int layer) { return layer == 2 || layer == 3 || layer == 5 || layer == 6 || layer == 7; }
+
+// p as dd_api.cpp fills it for the direct kernel of `layer`, except p.wpack = the layer's wino_pack_u image and (layers 2, 3, 5)
+// p.cadd = the [B][CIN][4] table written by launch_wino_gn_table on the same stream just before
+hipError_t launch_conv_wino_layer(int layer, int ek, const ConvParams& p, hipStream_t s, bool packed_f16_transform) {
+  if (ek == EK_BF16) return launch_wino_layer_ek<EK_BF16, false>(layer, p, s);
+  if (ek != EK_F16) return hipErrorInvalidValue;
+  return packed_f16_transform ? launch_wino_layer_ek<EK_F16, true>(layer, p, s) : launch_wino_layer_ek<EK_F16, false>(layer, p, s);
 }
 
 hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int version) {
@@ -509,21 +668,7 @@ hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int 
   q.tiles_x = (p.w + W_TW - 1) / W_TW;
   q.tiles_y = (p.h + W_TH - 1) / W_TH;
   if (version >= 2) {
-    const int which = ek == EK_BF16 ? 0 : (version == 3 ? 2 : 1);      // version 3 = packed-f16 transform (f16 only; bf16 runs v2)
-    static bool attr2[3] = {false, false, false};
-    const void* fns[3] = {reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_BF16, false>),
-                          reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_F16, false>),
-                          reinterpret_cast<const void*>(&conv_wino_raw_v2_kernel<EK_F16, true>)};
-    if (!attr2[which]) {
-      hipError_t e = hipFuncSetAttribute(fns[which], hipFuncAttributeMaxDynamicSharedMemorySize, W2_SMEM);
-      if (e != hipSuccess) return e;
-      attr2[which] = true;
-    }
-    const unsigned n2 = (unsigned)(q.tiles_x * q.tiles_y * q.B * (COND_C / W_NT));
-    if (which == 0) hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK_BF16, false>), dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
-    else if (which == 1) hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK_F16, false>), dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
-    else hipLaunchKernelGGL((conv_wino_raw_v2_kernel<EK_F16, true>), dim3(n2), dim3(W_THREADS), W2_SMEM, s, q);
-    return hipGetLastError();
+    return launch_conv_wino_layer(6, ek, p, s, version == 3);
   }
   static bool attr_set[2] = {false, false};
   const void* fn = ek == EK_BF16 ? reinterpret_cast<const void*>(&conv_wino_raw_kernel<EK_BF16>)

@@ -26,15 +26,18 @@ def _act_offset(Cc, h, w, b, c, y, x):                       # dd_elem.h act_off
     return ((((b * (Cc // 32) + c // 32) * h + y) * w + x) * 32) + c % 32
 
 
-def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_blocked):
-    """inp_blocked / out_blocked: flat f16 arrays in the activation layout [B][C/32][h][w][32]; upack: flat uint16 image."""
+def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_blocked, C=256, COUT=256, tab=None, cond_blocked=None):
+    """inp_blocked / out_blocked: flat f16 arrays in the activation layout [B][C/32][h][w][32]; upack: flat uint16 image.
+    tab (generalised kernel): [B][C][4] floats (a, b, e, -) of the GroupNorm (+ condition) prologue applied when a piece goes to LDS;
+    cond_blocked: the condition map in the input's layout.  Returns the workgroup's GroupNorm partial sums {slot: [sum, sumsq]}."""
     HW = h * w
     y0, x0 = ty0 * TH, tx0 * TW
     acc = np.zeros((8, 2, 2, 2, 64, 16), np.float32)          # [wave][a][m][n][lane][r]
     lane = np.arange(64)
     li, g = lane & 31, lane >> 5
+    stats = {}
     for chunk in range(C // CK):
-        # (a) raw patch and U chunk -> "LDS"
+        # (a) raw patch and U chunk -> "LDS" (the generalised kernel applies the prologue to each 8-channel piece on the way)
         s_raw = np.zeros((PH * PW, CK), np.float16)
         cbase = (chunk >> 1) * HW * 32 + (chunk & 1) * CK
         for pp in range(PH * PW):
@@ -42,7 +45,15 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
             gy, gx = y0 - 1 + pr, x0 - 1 + pc
             if 0 <= gy < h and 0 <= gx < w:
                 o = b * HW * C + cbase + (gy * w + gx) * 32
-                s_raw[pp] = inp_blocked[o:o + CK]
+                for hf in range(2):
+                    v = inp_blocked[o + hf * 8:o + hf * 8 + 8].astype(np.float32)
+                    if tab is not None:
+                        ch0 = chunk * CK + hf * 8
+                        t = tab[b, ch0:ch0 + 8]
+                        v = np.maximum(t[:, 0] * v + t[:, 1], np.float32(0))
+                        if cond_blocked is not None:
+                            v = v + (cond_blocked[o + hf * 8:o + hf * 8 + 8].astype(np.float32) + t[:, 2])
+                    s_raw[pp, hf * 8:hf * 8 + 8] = v.astype(np.float16)
         u0 = (nsplit * (C // CK) + chunk) * 16 * NT * CK
         s_u = upack[u0:u0 + 16 * NT * CK].view(np.float16).reshape(16, NT, CK)
         # (b) transform: thread tid -> tile tt = tid >> 3, channel pair cp = tid & 7
@@ -103,8 +114,13 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
                         if gy < h and gx < w:
                             v = (tr[0] + tr[1] + tr[2]) if dx == 0 else (tr[1] - tr[2] - tr[3])
                             v = v + bias[co + c8 * 4:co + c8 * 4 + 4]
-                            o = b * HW * C + _act_offset(C, h, w, 0, co + c8 * 4, gy, gx)
+                            o = b * HW * COUT + _act_offset(COUT, h, w, 0, co + c8 * 4, gy, gx)
                             out_blocked[o:o + 4] = v.astype(np.float16)
+                            slot = 0 if COUT == 256 else (m * 32 + cg * 8) >> 4            # local GroupNorm slot, as the kernel
+                            gslot = (nsplit if COUT == 256 else 0) + slot
+                            st = stats.setdefault(gslot, np.zeros(2, np.float64))
+                            st += [float(v.astype(np.float64).sum()), float((v.astype(np.float64) ** 2).sum())]
+    return stats
 
 
 def _to_blocked(x):                                          # (B,C,h,w) -> flat [B][C/32][h][w][32]
@@ -139,3 +155,33 @@ def test_winograd_workgroup_emulation_matches_conv2d():
         cs = slice(nsplit * NT, nsplit * NT + NT)
         err = np.abs(got[:, cs, ys, xs] - ref[:, cs, ys, xs]).max()
         assert err < 6e-3 * max(1.0, np.abs(ref).max()), (ty0, tx0, nsplit, err)       # f16 operands (V, U rounded) + f16 output
+
+
+def test_generalised_winograd_kernel_emulation_conv3_like():
+    """The generalised kernel as conv3 (256 -> 64, prologue relu(a*y + b) + cond + e from the table, GroupNorm partial sums out):
+    prologue channel indexing, the [B][C][4] table, output layout of a 64-channel tensor and the statistics slots."""
+    lib = dda.load_library()
+    rs = np.random.RandomState(1)
+    B, h, w, CIN, COUT = 2, 9, 35, 256, 64
+    y2 = _f16(rs.standard_normal((B, CIN, h, w)))
+    cond = _f16(np.abs(rs.standard_normal((B, CIN, h, w))))
+    tab = np.zeros((B, CIN, 4), np.float32)
+    tab[..., 0] = rs.uniform(0.5, 1.5, (B, CIN)); tab[..., 1] = rs.uniform(-0.3, 0.3, (B, CIN)); tab[..., 2] = rs.uniform(-0.5, 0.5, (B, CIN))
+    wgt = (rs.standard_normal((COUT, CIN, 3, 3)) / np.sqrt(CIN * 9)).astype(np.float32)
+    bias = rs.standard_normal(COUT).astype(np.float32)
+    up = np.zeros(COUT * CIN * 16, np.uint16)
+    assert lib.dd_debug_wino_pack(wgt.ctypes.data_as(ctypes.c_void_p), COUT, CIN, dda.precision_id("f16"), up.ctypes.data_as(ctypes.c_void_p), up.size) == 0
+    bi = 1
+    f = np.maximum(tab[bi, :, 0, None, None] * y2[bi].astype(np.float32) + tab[bi, :, 1, None, None], 0) + (cond[bi].astype(np.float32) + tab[bi, :, 2, None, None])
+    f = f.astype(np.float16).astype(np.float32)                                  # the operand the kernels see
+    ref = F.conv2d(torch.from_numpy(f[None]), torch.from_numpy(wgt), torch.from_numpy(bias), padding=1).numpy()[0]
+    out_b = np.zeros(B * COUT * h * w, np.float16)
+    ty0, tx0 = (h - 1) // TH, (w - 1) // TW                                      # the ragged corner tile
+    stats = _emulate_workgroup(_to_blocked(y2), up, bias, h, w, bi, ty0, tx0, 0, out_b, C=CIN, COUT=COUT, tab=tab, cond_blocked=_to_blocked(cond))
+    got = out_b.reshape(B, COUT // 32, h, w, 32).transpose(0, 1, 4, 2, 3).reshape(B, COUT, h, w).astype(np.float32)[bi]
+    ys, xs = slice(ty0 * TH, h), slice(tx0 * TW, w)
+    assert np.abs(got[:, ys, xs] - ref[:, ys, xs]).max() < 6e-3 * max(1.0, np.abs(ref).max())
+    assert np.abs(got[:, :ty0 * TH]).max() == 0.0                                # nothing written outside the tile
+    for grp in range(4):                                                        # GroupNorm groups of 16 couts
+        r = ref[grp * 16:(grp + 1) * 16, ys, xs].astype(np.float64)
+        assert abs(stats[grp][0] - r.sum()) < 2e-2 * max(1.0, abs(r.sum())) and abs(stats[grp][1] - (r ** 2).sum()) < 1e-2 * (r ** 2).sum()
