@@ -561,6 +561,29 @@ int enqueue_loop_body(dd_handle_t h, Plan* pl, hipStream_t s) {
   return DD_OK;
 }
 
+// Winograd weight images for the experimental kernels of dd_wino.hip (conv2, conv3 / Swin pred.0, Swin convA / convB; bf16 and f16).
+// Built only while option "winograd" is on -- the default path never executes this -- from the host copies dd_set_weight keeps.
+int pack_wino_weights(dd_handle_t h, hipStream_t s) {
+  struct Item { ConvLayer* L; const char* name; int cout, cin; };
+  std::vector<Item> items = {{&h->L[1], "model.noise_embedding.3.weight", COND_C, HID_C}, {&h->L[2], "model.pred.0.weight", HID_C, COND_C}};
+  if (h->variant == DD_VARIANT_SWIN) {
+    items.push_back({&h->LA, "model.upsample_fuse.convA.conv.weight", COND_C, COND_C});
+    items.push_back({&h->LB, "model.upsample_fuse.convB.conv.weight", COND_C, COND_C});
+  }
+  for (const Item& it : items) {
+    auto f = h->host_w.find(it.name);
+    if (f == h->host_w.end()) return h->fail(DD_ERR_STATE, std::string("winograd: parameter '") + it.name + "' was never set");
+    std::vector<uint16_t> u(wino_pack_bytes(it.cout, it.cin) / 2);
+    for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
+      wino_pack_u(f->second.data(), it.cout, it.cin, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
+      int rc = upload(h, it.L->wino[ek], u.data(), u.size() * 2, s);
+      if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));     // `u` is reused
+    }
+  }
+  return DD_OK;
+}
+
 void drain_layer_events(dd_handle_t h) {
   for (auto& t : h->pending_ev) {
     float ms = 0.f;
@@ -696,14 +719,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     std::copy(b.begin(), b.end(), bpad.begin());
     int rc = upload(h, L.bias, bpad.data(), bpad.size() * 4, s); if (rc) return rc;
     rc = upload(h, L.w_oihw, w.data(), w.size() * 4, s); if (rc) return rc;
-    if (l == 1 || l == 2) {          // conv2 / conv3 (Swin: pred.0): Winograd images for the experimental kernels (bf16 / f16)
-      std::vector<uint16_t> u(wino_pack_bytes(L.cout, L.cin) / 2);
-      for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
-        wino_pack_u(w.data(), L.cout, L.cin, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
-        rc = upload(h, L.wino[ek], u.data(), u.size() * 2, s); if (rc) return rc;
-        DD_HIP(hipStreamSynchronize(s));
-      }
-    }
+
     {
       std::vector<float> wt(w.size());
       for (int co = 0; co < L.cout; ++co)
@@ -741,14 +757,6 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
       int rc = upload(h, L.bias, b.data(), b.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
-      {                             // convA / convB: Winograd images for the experimental kernels (bf16 / f16)
-        std::vector<uint16_t> u(wino_pack_bytes(COND_C, COND_C) / 2);
-        for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
-          wino_pack_u(w.data(), COND_C, COND_C, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
-          rc = upload(h, L.wino[ek], u.data(), u.size() * 2, s); if (rc) return rc;
-          DD_HIP(hipStreamSynchronize(s));
-        }
-      }
       // backward: data gradient of a 256->256 conv = the convB kernel (layer 6: raw input, no norm) on W^T flipped
       std::vector<float> wt(w.size());
       for (int co = 0; co < COND_C; ++co)
@@ -773,6 +781,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     }
     DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
     DD_HIP(hipStreamSynchronize(s));
+    if (h->winograd) { int rc = pack_wino_weights(h, s); if (rc) return rc; }     // experimental kernels only; never in the default path
     h->committed = true;
   }
   if (do_fpn) {
@@ -914,7 +923,13 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "winograd") {
     if (value < 0 || value > 5) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1..3 (Swin convB: validated-slow / double-buffered / + packed-f16 transform) or 4 / 5 (all large convolutions, never run)");
     if (h->winograd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
+    const bool turn_on = h->winograd == 0 && value != 0;
     h->winograd = (int)value;
+    if (turn_on && h->committed) {            // weights are already on the device: build the Winograd images now (otherwise at commit)
+      DD_HIP(hipSetDevice(h->device));
+      int rc = pack_wino_weights(h, nullptr);
+      if (rc) { h->winograd = 0; return rc; }
+    }
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
   else if (k == "wave_spec") {
