@@ -515,51 +515,40 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       }
     }
     __syncthreads();
-    if (tid < 128) {
-      const int tj = tid >> 2, cg = tid & 3;
+    {
+      // all 512 lanes: lane -> (tile tj, cout quad cg*8 + c8*4 .. +3, output row dy); it reads the three M rows its output row needs
+      // (dy = 0: rows 0,1,2 of A^T M; dy = 1: rows 1,2,3), forms both output columns and stores 2 pixels x 4 couts
+      const int tj = tid >> 4, cg = (tid >> 2) & 3, c8 = (tid >> 1) & 1, dy = tid & 1;
       const int T = n * 32 + tj;
       const int ty = T / W_TX, tx = T - ty * W_TX;
-      const int co = nsplit * W_NT + m * 32 + cg * 8;
+      const int co = nsplit * W_NT + m * 32 + cg * 8 + c8 * 4;
       const int slot = (COUT == 256) ? 0 : ((m * 32 + cg * 8) >> 4);
+      float t[4][4];                                            // (A^T M)[dy][j][cout]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 r1 = *reinterpret_cast<const float4*>(s_m + (((1 * 4 + j) * 32 + tj) * 32 + cg * 8 + c8 * 4));
+        const float4 r2 = *reinterpret_cast<const float4*>(s_m + (((2 * 4 + j) * 32 + tj) * 32 + cg * 8 + c8 * 4));
+        const float4 re = *reinterpret_cast<const float4*>(s_m + ((((dy ? 3 : 0) * 4 + j) * 32 + tj) * 32 + cg * 8 + c8 * 4));
+        if (dy == 0) { t[j][0] = re.x + r1.x + r2.x; t[j][1] = re.y + r1.y + r2.y; t[j][2] = re.z + r1.z + r2.z; t[j][3] = re.w + r1.w + r2.w; }
+        else { t[j][0] = r1.x - r2.x - re.x; t[j][1] = r1.y - r2.y - re.y; t[j][2] = r1.z - r2.z - re.z; t[j][3] = r1.w - r2.w - re.w; }
+      }
+      const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co);
+      const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
       float ssum = 0.f, ssq = 0.f;
+      const int gy = y0 + 2 * ty + dy;
 #pragma unroll
-      for (int c8 = 0; c8 < 2; ++c8) {
-        float t0[4][4], t1[4][4];
+      for (int dx = 0; dx < 2; ++dx) {
+        const int gx = x0 + 2 * tx + dx;
+        if (gy < h && gx < w) {
+          float v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 v4 = *reinterpret_cast<const float4*>(s_m + (((i * 4 + j) * 32 + tj) * 32 + cg * 8 + c8 * 4));
-            const float mv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              if (i == 0) { t0[j][c] = mv[c]; }
-              else if (i == 1) { t0[j][c] += mv[c]; t1[j][c] = mv[c]; }
-              else if (i == 2) { t0[j][c] += mv[c]; t1[j][c] -= mv[c]; }
-              else { t1[j][c] -= mv[c]; }
-            }
+          for (int c = 0; c < 4; ++c) v[c] = (dx == 0 ? (t[0][c] + t[1][c] + t[2][c]) : (t[1][c] - t[2][c] - t[3][c])) + bias[c];
+          if constexpr (STATS) {                                // from the fp32 values, before the 16-bit rounding (as dd_igemm2.hip)
+            ssum += (v[0] + v[1]) + (v[2] + v[3]);
+            ssq += fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
           }
-        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + co + c8 * 4);
-        const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            const int gy = y0 + 2 * ty + dy, gx = x0 + 2 * tx + dx;
-            if (gy < h && gx < w) {
-              float v[4];
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const float* tr = dy == 0 ? &t0[0][0] : &t1[0][0];
-                v[c] = (dx == 0 ? (tr[0 * 4 + c] + tr[1 * 4 + c] + tr[2 * 4 + c]) : (tr[1 * 4 + c] - tr[2 * 4 + c] - tr[3 * 4 + c])) + bias[c];
-              }
-              if constexpr (STATS) {                            // from the fp32 values, before the 16-bit rounding (as dd_igemm2.hip)
-                ssum += (v[0] + v[1]) + (v[2] + v[3]);
-                ssq += fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
-              }
-              *reinterpret_cast<uint2*>(out_b + act_offset(COUT, h, w, 0, co + c8 * 4, gy, gx) * 2) = make_uint2(pack2<EK>(v[0], v[1]), pack2<EK>(v[2], v[3]));
-            }
-          }
+          *reinterpret_cast<uint2*>(out_b + act_offset(COUT, h, w, 0, co, gy, gx) * 2) = make_uint2(pack2<EK>(v[0], v[1]), pack2<EK>(v[2], v[3]));
+        }
       }
       if constexpr (STATS) {
 #pragma unroll
@@ -570,20 +559,22 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     __syncthreads();
   }
   if constexpr (STATS) {
-    // lanes 0..127 (waves 0 and 1) hold the partial sums: butterfly inside each wave (fp32), fp64 from there on
+    // every wave holds partial sums: butterfly inside each wave (fp32), fp64 from there on
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
       for (int k = 0; k < 4; ++k) { ls[k] += __shfl_xor(ls[k], off, 64); lq[k] += __shfl_xor(lq[k], off, 64); }
     double* s_red = reinterpret_cast<double*>(smem);            // every LDS image is dead behind the loop's last barrier
-    if (wave < 2 && lane == 0) {
+    if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) { s_red[wave * 8 + 2 * k] = (double)ls[k]; s_red[wave * 8 + 2 * k + 1] = (double)lq[k]; }
     }
     __syncthreads();
     constexpr int NG_LOCAL = (COUT == 256) ? 1 : 4;
     if (tid < 2 * NG_LOCAL) {
-      const double tot = s_red[tid] + s_red[8 + tid];
+      double tot = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < W_THREADS / 64; ++wv) tot += s_red[wv * 8 + tid];
       const int gbase = (COUT == 256) ? nsplit : 0;             // COUT == 256: this workgroup's couts are group `nsplit`
       atomicAdd(p.stats_out + ((size_t)b * STAT_SLOTS + (wgid % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid, tot);
     }

@@ -26,7 +26,8 @@ def _act_offset(Cc, h, w, b, c, y, x):                       # dd_elem.h act_off
     return ((((b * (Cc // 32) + c // 32) * h + y) * w + x) * 32) + c % 32
 
 
-def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_blocked, C=256, COUT=256, tab=None, cond_blocked=None):
+def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_blocked, C=256, COUT=256, tab=None, cond_blocked=None,
+                       v2_epilogue=False):
     """inp_blocked / out_blocked: flat f16 arrays in the activation layout [B][C/32][h][w][32]; upack: flat uint16 image.
     tab (generalised kernel): [B][C][4] floats (a, b, e, -) of the GroupNorm (+ condition) prologue applied when a piece goes to LDS;
     cond_blocked: the condition map in the input's layout.  Returns the workgroup's GroupNorm partial sums {slot: [sum, sumsq]}."""
@@ -98,6 +99,29 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
                 for q in range(4):
                     for l in range(64):
                         s_m[pos, li[l], 8 * q + 4 * g[l]:8 * q + 4 * g[l] + 4] = acc[wave, a, m, n, l, 4 * q:4 * q + 4]
+        if v2_epilogue:
+            # the double-buffered kernel: all 512 lanes, lane -> (tile, cout quad, output row dy)
+            for tid in range(512):
+                tj, cg, c8, dy = tid >> 4, (tid >> 2) & 3, (tid >> 1) & 1, tid & 1
+                T = n * 32 + tj
+                ty, tx = divmod(T, TX)
+                co = nsplit * NT + m * 32 + cg * 8 + c8 * 4
+                cs = slice(cg * 8 + c8 * 4, cg * 8 + c8 * 4 + 4)
+                t = np.zeros((4, 4), np.float32)
+                for j in range(4):
+                    r1, r2, re = s_m[1 * 4 + j, tj, cs], s_m[2 * 4 + j, tj, cs], s_m[(3 if dy else 0) * 4 + j, tj, cs]
+                    t[j] = (re + r1 + r2) if dy == 0 else (r1 - r2 - re)
+                gy = y0 + 2 * ty + dy
+                for dx in range(2):
+                    gx = x0 + 2 * tx + dx
+                    if gy < h and gx < w:
+                        v = ((t[0] + t[1] + t[2]) if dx == 0 else (t[1] - t[2] - t[3])) + bias[co:co + 4]
+                        o = b * HW * COUT + _act_offset(COUT, h, w, 0, co, gy, gx)
+                        out_blocked[o:o + 4] = v.astype(np.float16)
+                        slot = 0 if COUT == 256 else (m * 32 + cg * 8) >> 4
+                        st = stats.setdefault((nsplit if COUT == 256 else 0) + slot, np.zeros(2, np.float64))
+                        st += [float(v.astype(np.float64).sum()), float((v.astype(np.float64) ** 2).sum())]
+            continue
         for tid in range(128):
             tj, cg = tid >> 2, tid & 3
             T = n * 32 + tj
@@ -177,7 +201,8 @@ def test_generalised_winograd_kernel_emulation_conv3_like():
     ref = F.conv2d(torch.from_numpy(f[None]), torch.from_numpy(wgt), torch.from_numpy(bias), padding=1).numpy()[0]
     out_b = np.zeros(B * COUT * h * w, np.float16)
     ty0, tx0 = (h - 1) // TH, (w - 1) // TW                                      # the ragged corner tile
-    stats = _emulate_workgroup(_to_blocked(y2), up, bias, h, w, bi, ty0, tx0, 0, out_b, C=CIN, COUT=COUT, tab=tab, cond_blocked=_to_blocked(cond))
+    stats = _emulate_workgroup(_to_blocked(y2), up, bias, h, w, bi, ty0, tx0, 0, out_b, C=CIN, COUT=COUT, tab=tab, cond_blocked=_to_blocked(cond),
+                               v2_epilogue=True)
     got = out_b.reshape(B, COUT // 32, h, w, 32).transpose(0, 1, 4, 2, 3).reshape(B, COUT, h, w).astype(np.float32)[bi]
     ys, xs = slice(ty0 * TH, h), slice(tx0 * TW, w)
     assert np.abs(got[:, ys, xs] - ref[:, ys, xs]).max() < 6e-3 * max(1.0, np.abs(ref).max())
