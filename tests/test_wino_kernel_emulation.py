@@ -210,3 +210,29 @@ def test_generalised_winograd_kernel_emulation_conv3_like():
     for grp in range(4):                                                        # GroupNorm groups of 16 couts
         r = ref[grp * 16:(grp + 1) * 16, ys, xs].astype(np.float64)
         assert abs(stats[grp][0] - r.sum()) < 2e-2 * max(1.0, abs(r.sum())) and abs(stats[grp][1] - (r ** 2).sum()) < 1e-2 * (r ** 2).sum()
+
+
+def test_generalised_winograd_kernel_emulation_conv2_like():
+    """conv2 instance: 64 -> 256 (4 chunks, 4 cout splits), prologue relu(a*y + b) without a condition term, statistics of GroupNorm group
+    `nsplit` (the workgroup's 64 couts are exactly one of the 4 groups of 64)."""
+    lib = dda.load_library()
+    rs = np.random.RandomState(2)
+    B, h, w, CIN, COUT = 1, 8, 32, 64, 256
+    y1 = _f16(rs.standard_normal((B, CIN, h, w)))
+    tab = np.zeros((B, CIN, 4), np.float32)
+    tab[..., 0] = rs.uniform(0.5, 1.5, (B, CIN)); tab[..., 1] = rs.uniform(-0.3, 0.3, (B, CIN))
+    wgt = (rs.standard_normal((COUT, CIN, 3, 3)) / np.sqrt(CIN * 9)).astype(np.float32)
+    bias = rs.standard_normal(COUT).astype(np.float32)
+    up = np.zeros(COUT * CIN * 16, np.uint16)
+    assert lib.dd_debug_wino_pack(wgt.ctypes.data_as(ctypes.c_void_p), COUT, CIN, dda.precision_id("f16"), up.ctypes.data_as(ctypes.c_void_p), up.size) == 0
+    a1 = np.maximum(tab[0, :, 0, None, None] * y1[0].astype(np.float32) + tab[0, :, 1, None, None], 0).astype(np.float16).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(a1[None]), torch.from_numpy(wgt), torch.from_numpy(bias), padding=1).numpy()[0]
+    out_b = np.zeros(B * COUT * h * w, np.float16)
+    nsplit = 2
+    stats = _emulate_workgroup(_to_blocked(y1), up, bias, h, w, 0, 0, 0, nsplit, out_b, C=CIN, COUT=COUT, tab=tab, v2_epilogue=True)
+    got = out_b.reshape(B, COUT // 32, h, w, 32).transpose(0, 1, 4, 2, 3).reshape(B, COUT, h, w).astype(np.float32)[0]
+    cs = slice(nsplit * NT, nsplit * NT + NT)
+    assert np.abs(got[cs] - ref[cs]).max() < 6e-3 * max(1.0, np.abs(ref).max())
+    assert set(stats) == {nsplit}
+    r = ref[cs].astype(np.float64)
+    assert abs(stats[nsplit][0] - r.sum()) < 2e-2 * max(1.0, abs(r.sum())) and abs(stats[nsplit][1] - (r ** 2).sum()) < 1e-2 * (r ** 2).sum()
