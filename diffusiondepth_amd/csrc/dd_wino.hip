@@ -381,12 +381,22 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     const uint4 o = Piece<EK>::pack(v);
     return inside ? o : make_uint4(0u, 0u, 0u, 0u);
   };
+  // raw image in LDS: pixel (pr, pc) lives in slot pr * 34 + (pc ^ ((pc >> 2) & 1)).  With linear columns the transform's ds_read_b32 (banks
+  // = dword mod 32, lane groups of 32 = 4 tiles x 8 channel pairs, tiles 2 pixels = 16 dwords apart) hit every bank twice; swapping the
+  // column pairs (4,5) (6,7) of every 8 makes the four tiles' pixels differ mod 4 for every j (checked exhaustively: 2-way -> 1-way; the
+  // 16-byte stores below stay conflict-free)
+  auto raw_slot = [&](int item) {
+    const int pp = item >> 1;
+    const int pr = pp / W_PW, pc = pp - pr * W_PW;
+    return (pr * W_PW + (pc ^ ((pc >> 2) & 1))) * (W_CK * 2) + (item & 1) * 16;
+  };
+  const int slot0 = raw_slot(tid), slot1 = raw_slot(have1 ? item1 : 0);
   auto lstore = [&](int buf) {
     char* s_raw = smem + buf * W2_RAW_STRIDE;
     char* s_u = smem + W2_U_OFF + buf * W_U_BYTES;
     const int chb = loaded_chunk * W_CK;
-    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = prologue(r0, c0, in0, chb + (tid & 1) * 8);
-    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = prologue(r1, c1, in1, chb + (item1 & 1) * 8);
+    *reinterpret_cast<uint4*>(s_raw + slot0) = prologue(r0, c0, in0, chb + (tid & 1) * 8);
+    if (have1) *reinterpret_cast<uint4*>(s_raw + slot1) = prologue(r1, c1, in1, chb + (item1 & 1) * 8);
     *reinterpret_cast<uint4*>(s_u + tid * 16) = u0;
     *reinterpret_cast<uint4*>(s_u + (tid + W_THREADS) * 16) = u1;
     *reinterpret_cast<uint4*>(s_u + (tid + 2 * W_THREADS) * 16) = u2;
@@ -401,7 +411,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          e[i][j] = __builtin_bit_cast(f16x2_t, *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + 2 * ttx + j) * (W_CK * 2) + cp * 4));
+          e[i][j] = __builtin_bit_cast(f16x2_t, *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + ((2 * ttx + j) ^ (((2 * ttx + j) >> 2) & 1))) * (W_CK * 2) + cp * 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         t[0][j] = e[0][j] - e[2][j];
@@ -428,7 +438,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t pk = *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + 2 * ttx + j) * (W_CK * 2) + cp * 4);
+        const uint32_t pk = *reinterpret_cast<const uint32_t*>(s_raw + ((2 * tty + i) * W_PW + ((2 * ttx + j) ^ (((2 * ttx + j) >> 2) & 1))) * (W_CK * 2) + cp * 4);
         d[0][i][j] = ld16<EK>(pk);
         d[1][i][j] = ld16<EK>(pk >> 16);
       }

@@ -41,8 +41,10 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
         # (a) raw patch and U chunk -> "LDS" (the generalised kernel applies the prologue to each 8-channel piece on the way)
         s_raw = np.zeros((PH * PW, CK), np.float16)
         cbase = (chunk >> 1) * HW * 32 + (chunk & 1) * CK
-        for pp in range(PH * PW):
-            pr, pc = divmod(pp, PW)
+        swz = (lambda c: c ^ ((c >> 2) & 1)) if v2_epilogue else (lambda c: c)     # v2: bank-conflict-free column order of the raw image
+        for pp_lin in range(PH * PW):
+            pr, pc = divmod(pp_lin, PW)
+            pp = pr * PW + swz(pc)
             gy, gx = y0 - 1 + pr, x0 - 1 + pc
             if 0 <= gy < h and 0 <= gx < w:
                 o = b * HW * C + cbase + (gy * w + gx) * 32
@@ -65,7 +67,7 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
             d = np.zeros((2, 4, 4), np.float32)
             for i in range(4):
                 for j in range(4):
-                    pk = s_raw[(2 * tty + i) * PW + 2 * ttx + j, 2 * cp:2 * cp + 2].astype(np.float32)
+                    pk = s_raw[(2 * tty + i) * PW + swz(2 * ttx + j), 2 * cp:2 * cp + 2].astype(np.float32)
                     d[0, i, j], d[1, i, j] = pk[0], pk[1]
             for c in range(2):
                 t = np.stack([d[c, 0] - d[c, 2], d[c, 1] + d[c, 2], d[c, 2] - d[c, 1], d[c, 1] - d[c, 3]])
