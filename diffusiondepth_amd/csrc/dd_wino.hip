@@ -397,10 +397,13 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     const int chb = loaded_chunk * W_CK;
     *reinterpret_cast<uint4*>(s_raw + slot0) = prologue(r0, c0, in0, chb + (tid & 1) * 8);
     if (have1) *reinterpret_cast<uint4*>(s_raw + slot1) = prologue(r1, c1, in1, chb + (item1 & 1) * 8);
-    *reinterpret_cast<uint4*>(s_u + tid * 16) = u0;
-    *reinterpret_cast<uint4*>(s_u + (tid + W_THREADS) * 16) = u1;
-    *reinterpret_cast<uint4*>(s_u + (tid + 2 * W_THREADS) * 16) = u2;
-    *reinterpret_cast<uint4*>(s_u + (tid + 3 * W_THREADS) * 16) = u3;
+    // U / V images: row r (cout or tile, 0..63 inside a position) holds its two 16-byte k-halves swapped when bit 3 of r is set: the
+    // fragment ds_read_b128 (banks = dword mod 64, lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} ...) then touch every bank once per group
+    // (linear rows: twice; checked with the bank calculator).  Piece q of the packed image = (row = q >> 1, half = q & 1).
+    *reinterpret_cast<uint4*>(s_u + ((tid) ^ ((tid >> 4) & 1)) * 16) = u0;
+    *reinterpret_cast<uint4*>(s_u + ((tid + W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u1;
+    *reinterpret_cast<uint4*>(s_u + ((tid + 2 * W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u2;
+    *reinterpret_cast<uint4*>(s_u + ((tid + 3 * W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u3;
   };
   auto transform = [&](int buf) {                               // raw[buf] -> V[buf]: tile tt, channel pair cp
     const char* s_raw = smem + buf * W2_RAW_STRIDE;
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + cp * 2) * 2) = __builtin_bit_cast(uint32_t, e[i][j]);
+          *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + ((cp * 2) ^ (((tt >> 3) & 1) << 3))) * 2) = __builtin_bit_cast(uint32_t, e[i][j]);
       return;
     }
     float d[2][4][4];
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + cp * 2) * 2) = pack2<EK>(d[0][i][j], d[1][i][j]);
+        *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + ((cp * 2) ^ (((tt >> 3) & 1) << 3))) * 2) = pack2<EK>(d[0][i][j], d[1][i][j]);
   };
 
   gload(0);
@@ -489,9 +492,9 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
         const int pos = 2 * wave + a;
         uint4 wf[2], vf[2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const uint4*>(s_u + ((pos * W_NT + m * 32 + li) * W_CK + g * 8) * 2);
+        for (int m = 0; m < 2; ++m) wf[m] = *reinterpret_cast<const uint4*>(s_u + ((pos * W_NT + m * 32 + li) * W_CK + ((g ^ ((li >> 3) & 1)) * 8)) * 2);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) vf[n] = *reinterpret_cast<const uint4*>(s_v + ((pos * W_TILES + n * 32 + li) * W_CK + g * 8) * 2);
+        for (int n = 0; n < 2; ++n) vf[n] = *reinterpret_cast<const uint4*>(s_v + ((pos * W_TILES + n * 32 + li) * W_CK + ((g ^ ((li >> 3) & 1)) * 8)) * 2);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -59,6 +59,14 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
                     s_raw[pp, hf * 8:hf * 8 + 8] = v.astype(np.float16)
         u0 = (nsplit * (C // CK) + chunk) * 16 * NT * CK
         s_u = upack[u0:u0 + 16 * NT * CK].view(np.float16).reshape(16, NT, CK)
+        if v2_epilogue:
+            # v2 stores piece q = (row, half) of the packed image at q ^ ((row >> 3) & 1): rows with bit 3 set hold their k-halves swapped
+            phys = np.zeros_like(s_u)
+            for row in range(NT):
+                f = (row >> 3) & 1
+                phys[:, row, :8], phys[:, row, 8:] = (s_u[:, row, 8:], s_u[:, row, :8]) if f else (s_u[:, row, :8], s_u[:, row, 8:])
+            s_u = phys
+        hsel = (lambda l_i, g_: (g_ ^ ((l_i >> 3) & 1)) * 8) if v2_epilogue else (lambda l_i, g_: g_ * 8)   # where a lane finds its k-half
         # (b) transform: thread tid -> tile tt = tid >> 3, channel pair cp = tid & 7
         s_v = np.zeros((16, TILES, CK), np.float16)
         for tid in range(512):
@@ -74,7 +82,8 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
                 v = np.stack([t[:, 0] - t[:, 2], t[:, 1] + t[:, 2], t[:, 2] - t[:, 1], t[:, 1] - t[:, 3]], axis=1)
                 for i in range(4):
                     for j in range(4):
-                        s_v[i * 4 + j, tt, 2 * cp + c] = np.float16(v[i, j])
+                        chv = (2 * cp + c) ^ ((((tt >> 3) & 1) << 3) if v2_epilogue else 0)
+                        s_v[i * 4 + j, tt, chv] = np.float16(v[i, j])
         # (c) MFMA: wave q, positions 2q + a; fragments per the lane mapping
         for wave in range(8):
             for a in range(2):
@@ -82,11 +91,11 @@ def _emulate_workgroup(inp_blocked, upack, bias, h, w, b, ty0, tx0, nsplit, out_
                 for m in range(2):
                     A = np.zeros((32, 16), np.float32)
                     for l in range(64):
-                        A[li[l], g[l] * 8:g[l] * 8 + 8] = s_u[pos, m * 32 + li[l], g[l] * 8:g[l] * 8 + 8]
+                        A[li[l], g[l] * 8:g[l] * 8 + 8] = s_u[pos, m * 32 + li[l], hsel(li[l], g[l]):hsel(li[l], g[l]) + 8]
                     for n in range(2):
                         Bm = np.zeros((16, 32), np.float32)
                         for l in range(64):
-                            Bm[g[l] * 8:g[l] * 8 + 8, li[l]] = s_v[pos, n * 32 + li[l], g[l] * 8:g[l] * 8 + 8]
+                            Bm[g[l] * 8:g[l] * 8 + 8, li[l]] = s_v[pos, n * 32 + li[l], hsel(li[l], g[l]):hsel(li[l], g[l]) + 8]
                         D = A @ Bm                                  # 32 (cout) x 32 (tile)
                         for r in range(16):
                             rows = 8 * (r // 4) + 4 * g + r % 4
