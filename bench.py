@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--winograd", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
                     help="EXPERIMENTAL (bf16 / f16): Winograd F(2x2,3x3) kernels (csrc/dd_wino.hip); 1..3 = the Swin convB only: 1 = validated but slow, "
                          "2 = double-buffered, 3 = 2 + packed-f16 transform; 4 / 5 = every large convolution of either variant (all unvalidated).  Off in every quoted number.")
+    ap.add_argument("--winograd-dma", action="store_true", help="with --winograd >= 2: weight images by LDS-DMA (experimental)")
     ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
@@ -192,6 +193,7 @@ def main():
     be.set_option("hoist_cond", 1 if args.hoist else 0)
     be.set_option("wave_spec", 1 if args.wave_spec else 0)
     if args.winograd:
+        be.set_option("winograd_dma", 1 if args.winograd_dma else 0)
         be.set_option("winograd", args.winograd)
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if (args.hoist and args.kernel_version == 2) else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)

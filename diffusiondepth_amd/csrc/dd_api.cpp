@@ -148,6 +148,7 @@ struct dd_handle_s {
   DevBuf emb;
   DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
   DevBuf zero_bias;          // 256 zeros
+  bool wino_dma = false;     // EXPERIMENTAL, with winograd >= 2: weight images by LDS-DMA (option "winograd_dma")
   int winograd = 0;          // EXPERIMENTAL (dd_wino.hip): Swin convB in Winograd F(2x2,3x3) form in the 16-bit modes; off by default
   bool hoist_cond = false;   // Res variant, v2 kernels: conv3(cond) once per image instead of re-adding cond every step.
                              // Correct (tested) but measured slower on MI355X (conv3 174 -> 183..195 us at B=4), so off by default.
@@ -419,6 +420,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       if (h->winograd && ek != EK_F32 && !h->ablate && pl->key.kver == 2) {
         // EXPERIMENTAL (dd_wino.hip).  1..3: the Swin convB only (1 = the validated-but-slow v1, 2 = double-buffered, 3 = 2 + packed-f16
         // transform); 4 / 5: every large convolution of the denoiser on the double-buffered kernel (5: packed-f16 transform in f16 mode)
+        q.step = h->wino_dma ? 1 : 0;                          // dd_wino.hip reads bit 0 as "weights by LDS-DMA" (conv1's field otherwise)
         if (h->winograd <= 3 && layer == 6) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s, h->winograd); }
         if (h->winograd >= 4 && conv_wino_supports(layer)) {
           ConvLayer& WL = layer == 2 ? h->L[1] : layer == 5 ? h->LA : layer == 6 ? h->LB : h->L[2];
@@ -920,6 +922,10 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->ablate = (int)value;
   }
   else if (k == "hoist_cond") h->hoist_cond = value != 0;
+  else if (k == "winograd_dma") {
+    if (h->wino_dma != (value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
+    h->wino_dma = value != 0;
+  }
   else if (k == "winograd") {
     if (value < 0 || value > 5) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1..3 (Swin convB: validated-slow / double-buffered / + packed-f16 transform) or 4 / 5 (all large convolutions, never run)");
     if (h->winograd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs

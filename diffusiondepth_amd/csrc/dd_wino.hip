@@ -103,8 +103,8 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_kernel(ConvParams p) 
     const char* cb = in_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
     const uint4 a0 = *reinterpret_cast<const uint4*>(cb + goff0);
     const uint4 a1 = *reinterpret_cast<const uint4*>(cb + goff1);
-    r0 = in0 ? a0 : zero4;                                     // zero padding of the convolution
-    r1 = in1 ? a1 : zero4;
+    r0 = a0;                                                   // the zero-padding select waits for lstore(): selecting here would make
+    r1 = a1;                                                   // the wave wait for the loads at once and the prefetch would be none
     const char* src = u_g + (size_t)chunk * W_U_BYTES + (size_t)tid * 16;
     u0 = *reinterpret_cast<const uint4*>(src);
     u1 = *reinterpret_cast<const uint4*>(src + (size_t)W_THREADS * 16);
@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_kernel(ConvParams p) 
     u3 = *reinterpret_cast<const uint4*>(src + (size_t)3 * W_THREADS * 16);
   };
   auto lstore = [&]() {
-    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = r0;
-    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = r1;
+    *reinterpret_cast<uint4*>(s_raw + (tid >> 1) * (W_CK * 2) + (tid & 1) * 16) = in0 ? r0 : zero4;      // zero padding of the convolution
+    if (have1) *reinterpret_cast<uint4*>(s_raw + (item1 >> 1) * (W_CK * 2) + (item1 & 1) * 16) = in1 ? r1 : zero4;
     *reinterpret_cast<uint4*>(s_u + tid * 16) = u0;
     *reinterpret_cast<uint4*>(s_u + (tid + W_THREADS) * 16) = u1;
     *reinterpret_cast<uint4*>(s_u + (tid + 2 * W_THREADS) * 16) = u2;
@@ -283,10 +283,14 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   constexpr int NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_tab = reinterpret_cast<float*>(smem + W2_SMEM);        // [3][CIN]: a, b, e of the prologue (PRO != PRO_RAW)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, g = lane >> 5;
   const int h = p.h, w = p.w;
   const int wgid = blockIdx.x;
+  // p.step bit 0 (option "winograd_dma"; the field is conv1's otherwise): the weight images go global -> LDS by LDS-DMA instead of through
+  // registers and six ds_write_b128 per lane (13 LDS-path cycles each, MI355X_MICROARCH.md section LDS)
+  const bool use_dma = (p.step & 1) != 0;
+  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int nsplit = wgid % NSPLIT;
   const int tile_id = wgid / NSPLIT;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
@@ -339,23 +343,42 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     const char* cb = in_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
     const uint4 a0 = *reinterpret_cast<const uint4*>(cb + goff0);
     const uint4 a1 = *reinterpret_cast<const uint4*>(cb + goff1);
-    r0 = in0 ? a0 : zero4;
-    r1 = in1 ? a1 : zero4;
+    r0 = a0;                                                    // selects deferred to lstore() (a select here stalls on the load at once)
+    r1 = a1;
     if constexpr (PRO == PRO_GN_ADD) {
       const char* cc = cond_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
       c0 = *reinterpret_cast<const uint4*>(cc + goff0);
       c1 = *reinterpret_cast<const uint4*>(cc + goff1);
     }
     loaded_chunk = chunk;
-    const char* src = u_g + (size_t)chunk * W_U_BYTES + (size_t)tid * 16;
-    u0 = *reinterpret_cast<const uint4*>(src);
-    u1 = *reinterpret_cast<const uint4*>(src + (size_t)W_THREADS * 16);
-    u2 = *reinterpret_cast<const uint4*>(src + (size_t)2 * W_THREADS * 16);
-    u3 = *reinterpret_cast<const uint4*>(src + (size_t)3 * W_THREADS * 16);
+    if (!use_dma) {
+      const char* src = u_g + (size_t)chunk * W_U_BYTES + (size_t)tid * 16;
+      u0 = *reinterpret_cast<const uint4*>(src);
+      u1 = *reinterpret_cast<const uint4*>(src + (size_t)W_THREADS * 16);
+      u2 = *reinterpret_cast<const uint4*>(src + (size_t)2 * W_THREADS * 16);
+      u3 = *reinterpret_cast<const uint4*>(src + (size_t)3 * W_THREADS * 16);
+    }
+  };
+  // LDS-DMA of one chunk's weight image (32 KB = 32 KiB-pieces; wave q copies pieces q, q+8, q+16, q+24; lane l lands at M0 + 16 l).
+  // Issued through inline asm exactly as dd_igemm2.hip's weight ring (hipcc would drain vmcnt(0) behind the builtin); hipcc does not count
+  // these VMEM operations, so the wait for them is the explicit vmcnt(0) in front of the barrier that publishes them.  The k-half swizzle
+  // is applied on the SOURCE side: LDS piece P receives packed-image piece P ^ ((P >> 4) & 1).
+  auto dma_u = [&](int chunk, int buf) {
+    const char* src = u_g + (size_t)chunk * W_U_BYTES;
+#pragma unroll
+    for (int c = 0; c < W_U_BYTES / 1024 / (W_THREADS / 64); ++c) {
+      const int kc = c * (W_THREADS / 64) + wave;
+      const int P = kc * 64 + lane;
+      const char* gsrc = src + (size_t)(P ^ ((P >> 4) & 1)) * 16;
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(lds_base + W2_U_OFF + buf * W_U_BYTES + kc * 1024);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+    }
   };
   // prologue of one 16-byte piece (8 channels starting at ch0 of one pixel): relu(a*y + b) [+ cond + e]; outside the image: zero
   auto prologue = [&](const uint4& raw, const uint4& cnd, bool inside, int ch0) -> uint4 {
-    if constexpr (PRO == PRO_RAW) { (void)cnd; (void)inside; (void)ch0; return raw; }     // gload already zeroed the padding
+    if constexpr (PRO == PRO_RAW) { (void)cnd; (void)ch0; return inside ? raw : make_uint4(0u, 0u, 0u, 0u); }   // zero padding of the convolution
     float v[8], ta[8], tb[8];
     Piece<EK>::unpack(raw, v);
 #pragma unroll
@@ -400,10 +423,12 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     // U / V images: row r (cout or tile, 0..63 inside a position) holds its two 16-byte k-halves swapped when bit 3 of r is set: the
     // fragment ds_read_b128 (banks = dword mod 64, lane groups {0-3,12-15,20-27} {4-11,16-19,28-31} ...) then touch every bank once per group
     // (linear rows: twice; checked with the bank calculator).  Piece q of the packed image = (row = q >> 1, half = q & 1).
-    *reinterpret_cast<uint4*>(s_u + ((tid) ^ ((tid >> 4) & 1)) * 16) = u0;
-    *reinterpret_cast<uint4*>(s_u + ((tid + W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u1;
-    *reinterpret_cast<uint4*>(s_u + ((tid + 2 * W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u2;
-    *reinterpret_cast<uint4*>(s_u + ((tid + 3 * W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u3;
+    if (!use_dma) {
+      *reinterpret_cast<uint4*>(s_u + ((tid) ^ ((tid >> 4) & 1)) * 16) = u0;
+      *reinterpret_cast<uint4*>(s_u + ((tid + W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u1;
+      *reinterpret_cast<uint4*>(s_u + ((tid + 2 * W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u2;
+      *reinterpret_cast<uint4*>(s_u + ((tid + 3 * W_THREADS) ^ ((tid >> 4) & 1)) * 16) = u3;
+    }
   };
   auto transform = [&](int buf) {                               // raw[buf] -> V[buf]: tile tt, channel pair cp
     const char* s_raw = smem + buf * W2_RAW_STRIDE;
@@ -470,9 +495,11 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
         *reinterpret_cast<uint32_t*>(s_v + (((i * 4 + j) * W_TILES + tt) * W_CK + ((cp * 2) ^ (((tt >> 3) & 1) << 3))) * 2) = pack2<EK>(d[0][i][j], d[1][i][j]);
   };
 
+  if (use_dma) dma_u(0, 0);
   gload(0);
   if constexpr (PRO != PRO_RAW) __syncthreads();                // the prologue table is in LDS
   lstore(0);
+  if (use_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of U(0) have landed
   __syncthreads();
   gload(1);
   transform(0);
@@ -482,8 +509,12 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
     const int cur = chunk & 1, nxt = cur ^ 1;
     const bool more = chunk + 1 < NCHUNK;
     if (more) lstore(nxt);                                      // registers hold chunk + 1
-    __syncthreads();                                            // A: raw / U of chunk + 1 visible
+    __syncthreads();                                            // A: raw (and, without DMA, U) of chunk + 1 visible
     if (chunk + 2 < NCHUNK) gload(chunk + 2);
+    // The DMA goes BEHIND every point where hipcc waits for its own loads (lstore above, and the conservative vmcnt waits it puts behind
+    // the barrier): s_waitcnt counts ALL outstanding VMEM operations, so a compiler wait with uncounted DMAs in flight would wait for them.
+    // U[nxt] was last read by the MFMAs of chunk - 1, two barriers ago; the DMA has the MFMAs + the transform below to land.
+    if (more && use_dma) dma_u(chunk + 1, nxt);
     {
       const char* s_v = smem + W2_V_OFF + cur * W_V_BYTES;
       const char* s_u = smem + W2_U_OFF + cur * W_U_BYTES;
@@ -502,7 +533,8 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       }
     }
     if (more) transform(nxt);                                   // VALU + LDS while the matrix pipe drains the 8 MFMAs above
-    __syncthreads();                                            // B: V of chunk + 1 complete, fragment reads of this chunk done
+    if (use_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of U(chunk + 1) (and the register prefetch behind it) landed
+    __syncthreads();                                            // B: V (DMA: and U) of chunk + 1 complete, fragment reads of this chunk done
   }
 
   // ---- epilogue: as v1, plus the GroupNorm partial sums of this layer's outputs (STATS) ------------------------------------------------

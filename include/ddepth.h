@@ -181,7 +181,7 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * after every launch), "kernel_version" (2 = pipelined kernels [default], 1 = first-generation kernels),
  * "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
  * condition map is re-added in conv3's prologue every step - measured faster), "wave_spec" (1 = wave-specialised
- * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "winograd" (EXPERIMENTAL Winograd F(2x2,3x3) kernels of dd_wino.hip, bf16 / f16 modes: 0 [default] = off; 1 = Swin convB, first version (ran once: correct, slow); 2 / 3 = Swin convB double-buffered / + packed-f16 input transform; 4 / 5 = every large convolution of either variant -- 2..5 have never run), "layer_timing", "ablate" (timing experiments), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
+ * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "winograd" (EXPERIMENTAL Winograd F(2x2,3x3) kernels of dd_wino.hip, bf16 / f16 modes: 0 [default] = off; 1 = Swin convB, first version (ran once: correct, slow); 2 / 3 = Swin convB double-buffered / + packed-f16 input transform; 4 / 5 = every large convolution of either variant -- 2..5 have never run), "winograd_dma" (1 = with winograd >= 2 the weight images reach LDS by LDS-DMA; never run), "layer_timing", "ablate" (timing experiments), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);

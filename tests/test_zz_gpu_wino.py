@@ -47,9 +47,10 @@ def test_winograd_convB_matches_the_direct_kernel(prec, shape, version):
     assert float((x0_d - x0_ref).abs().max()) < 2.0 * float((x0_dir - x0_ref).abs().max()) + 1e-4 * s
 
 
+@pytest.mark.parametrize("dma", [0, 1], ids=["regs", "lds_dma"])
 @pytest.mark.parametrize("variant", ["res", "swin"])
 @pytest.mark.parametrize("prec,opt", [("f16", 4), ("f16", 5), ("bf16", 4)], ids=["f16", "f16_packed_transform", "bf16"])
-def test_winograd_all_large_convolutions(variant, prec, opt):
+def test_winograd_all_large_convolutions(variant, prec, opt, dma):
     """Option 4 / 5: conv2 + conv3 (Res) or conv2 + convA + convB + pred.0 (Swin) on the generalised double-buffered kernel, with the
     GroupNorm (+ condition) prologue from wino_gn_table_kernel and the GroupNorm partial sums in the epilogue.  NEVER RUN in round 1."""
     import diffusiondepth_amd as dda
@@ -62,10 +63,11 @@ def test_winograd_all_large_convolutions(variant, prec, opt):
     x, cond, t = U.cu(inp["x_T"]), U.cu(inp["cond"]), U.cu(inp["timesteps"])
     ref = be.denoise_once(x, t, cond, "fp32").cpu().numpy()
     direct = be.denoise_once(x, t, cond, prec).cpu().numpy()
+    be.set_option("winograd_dma", dma)
     be.set_option("winograd", opt)
     wino = be.denoise_once(x, t, cond, prec).cpu().numpy()
     e_d, e_w = U.rms(direct, ref), U.rms(wino, ref)
-    U.record(f"winograd_all_{variant}_{prec}_opt{opt}", eps_rms_direct=e_d, eps_rms_winograd=e_w)
+    U.record(f"winograd_all_{variant}_{prec}_opt{opt}_dma{dma}", eps_rms_direct=e_d, eps_rms_winograd=e_w)
     assert np.isfinite(wino).all() and e_w < 2.5 * e_d + 1e-4, (e_d, e_w)
     T = 5
     x0_w = be.denoise(x, cond, T, prec)

@@ -38,7 +38,7 @@ for variant in ("res", "swin"):
     B, h, w = 4, 176, 608
     inp = synth.make_inputs(7, B, h, w, (88, 304) if variant == "swin" else None)
     x, cond = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
-    for o in (0, 4, 5):
-        b2.set_option("winograd", o); b2.set_option("timing", 1)
+    for o, dma in ((0, 0), (4, 0), (5, 0), (4, 1), (5, 1)):
+        b2.set_option("winograd_dma", dma); b2.set_option("winograd", o); b2.set_option("timing", 1)
         for _ in range(3): b2.denoise(x, cond, 20, "f16")
-        torch.cuda.synchronize(); print(f"{variant} KITTI B=4 T=20 f16 winograd={o}: loop {b2.last_loop_ms():.2f} ms", flush=True)
+        torch.cuda.synchronize(); print(f"{variant} KITTI B=4 T=20 f16 winograd={o} dma={dma}: loop {b2.last_loop_ms():.2f} ms", flush=True)
