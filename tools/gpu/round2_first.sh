@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout 120 python tools/gpu/wino_try.py 2>&1 | tail -40
 DD_TEST_WINOGRAD=1 timeout 120 python -m pytest tests/test_zz_gpu_wino.py -m gpu -q -p no:cacheprovider 2>&1 | tail -6
-for wv in 0 2 3 4 5; do timeout 120 python bench.py --variant swin --precision f16 --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra --no-nlspn-extra --no-head-extra --no-latency-b1 --winograd $wv 2>&1 | tail -1 | python -c "
+for wv in 0 2 3 4 5; do timeout 120 python bench.py --variant swin --precision f16 --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra --no-nlspn-extra --no-head-extra --no-latency-b1 --winograd $wv $( [ "$wv" -ge 2 ] && echo --winograd-dma ) 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']
 print('winograd', d['config']['winograd'], d['value'], 'maps/s  loop_ms', r['loop_ms_graph'], 'per_layer_us', r['per_layer_avg_us'])"; done
