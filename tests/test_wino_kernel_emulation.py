@@ -247,3 +247,14 @@ def test_generalised_winograd_kernel_emulation_conv2_like():
     assert set(stats) == {nsplit}
     r = ref[cs].astype(np.float64)
     assert abs(stats[nsplit][0] - r.sum()) < 2e-2 * max(1.0, abs(r.sum())) and abs(stats[nsplit][1] - (r ** 2).sum()) < 1e-2 * (r ** 2).sum()
+
+
+def test_winograd_lds_layouts_are_bank_conflict_free():
+    """tools/lds_bank_check.py (rules of MI355X_MICROARCH.md section LDS): the swizzled LDS images of the double-buffered kernel have no
+    bank conflicts in any of its four access patterns; the linear layouts would be 2-way for the transform reads and the fragment reads."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import lds_bank_check as L
+    assert (L.transform_reads(True), L.v_writes(True), L.fragment_reads(True), L.raw_stores(True)) == (1, 1, 1, 1)
+    assert L.transform_reads(False) == 2 and L.fragment_reads(False) == 2
