@@ -420,7 +420,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       if (h->winograd && ek != EK_F32 && !h->ablate && pl->key.kver == 2) {
         // EXPERIMENTAL (dd_wino.hip).  1..3: the Swin convB only (1 = the validated-but-slow v1, 2 = double-buffered, 3 = 2 + packed-f16
         // transform); 4 / 5: every large convolution of the denoiser on the double-buffered kernel (5: packed-f16 transform in f16 mode)
-        q.step = h->wino_dma ? 1 : 0;                          // dd_wino.hip reads bit 0 as "weights by LDS-DMA" (conv1's field otherwise)
+        q.wino_flags = h->wino_dma ? 1 : 0;
         if (h->winograd <= 3 && layer == 6) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s, h->winograd); }
         if (h->winograd >= 4 && conv_wino_supports(layer)) {
           ConvLayer& WL = layer == 2 ? h->L[1] : layer == 5 ? h->LA : layer == 6 ? h->LB : h->L[2];
@@ -429,7 +429,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
             if (pl->wtab.bytes < (size_t)k.B * COND_C * 16) { hipError_t e = pl->wtab.alloc((size_t)k.B * COND_C * 16); if (e != hipSuccess) return e; }
             hipError_t e = launch_wino_gn_table(q, layer == 2 ? HID_C : COND_C, pl->wtab.as<float>(), layer != 2, s);
             if (e != hipSuccess) return e;
-            q.cadd = pl->wtab.as<float>();
+            q.wino_tab = pl->wtab.as<float>();
           }
           return launch_conv_wino_layer(layer, ek, q, s, h->winograd == 5);
         }

@@ -59,6 +59,8 @@ struct ConvParams {
   const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
   const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
+  const float* wino_tab;    // dd_wino.hip (experimental): [B][CIN][4] floats (a, b, e, -) of the GroupNorm (+ condition) prologue
+  int wino_flags;           // dd_wino.hip: bit 0 = weight images by LDS-DMA
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
                             // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
                             // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier

@@ -272,7 +272,7 @@ static_assert(W2_SMEM <= 160 * 1024 && 16 * 32 * 32 * 4 <= W2_SMEM, "LDS carve (
 //   CIN, COUT  64->256 (conv2), 256->64 (conv3, Swin pred.0), 256->256 (Swin convA / convB)
 //   PRO        PRO_RAW: operands as stored | PRO_GN: relu(a*y + b) | PRO_GN_ADD: relu(a*y + b) + cond + e   -- applied when the prefetched
 //              registers go to LDS, from the per-(image, channel) table (a, b, e) that wino_gn_table_kernel derives from the producer's
-//              GroupNorm partial sums (p.cadd points at it: [B][CIN][4] floats); zero padding applies AFTER the normalisation
+//              GroupNorm partial sums (p.wino_tab: [B][CIN][4] floats); zero padding applies AFTER the normalisation
 //   STATS      Sigma / Sigma x^2 of this layer's fp32 outputs per GroupNorm group -> one fp64 atomic per group per workgroup (slot layout of
 //              dd_kernels.h, as dd_igemm2.hip's epilogue)
 template <int EK, bool PK, int CIN, int COUT, int PRO, bool STATS>
@@ -287,9 +287,9 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   const int li = lane & 31, g = lane >> 5;
   const int h = p.h, w = p.w;
   const int wgid = blockIdx.x;
-  // p.step bit 0 (option "winograd_dma"; the field is conv1's otherwise): the weight images go global -> LDS by LDS-DMA instead of through
+  // p.wino_flags bit 0 (option "winograd_dma"): the weight images go global -> LDS by LDS-DMA instead of through
   // registers and six ds_write_b128 per lane (13 LDS-path cycles each, MI355X_MICROARCH.md section LDS)
-  const bool use_dma = (p.step & 1) != 0;
+  const bool use_dma = (p.wino_flags & 1) != 0;
   const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int nsplit = wgid % NSPLIT;
   const int tile_id = wgid / NSPLIT;
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   const char* cond_b = (PRO == PRO_GN_ADD) ? reinterpret_cast<const char*>(p.cond) + (size_t)b * HW * CIN * 2 : nullptr;
   if constexpr (PRO != PRO_RAW) {
     if (tid < CIN) {
-      const float4 t4 = reinterpret_cast<const float4*>(p.cadd)[(size_t)b * CIN + tid];
+      const float4 t4 = reinterpret_cast<const float4*>(p.wino_tab)[(size_t)b * CIN + tid];
       s_tab[tid] = t4.x; s_tab[CIN + tid] = t4.y; s_tab[2 * CIN + tid] = t4.z;
     }                                                           // visible after the first barrier below
   }
@@ -691,7 +691,7 @@ hipError_t launch_wino_layer_ek(int layer, const ConvParams& p, hipStream_t s) {
 bool conv_wino_supports(int layer) { return layer == 2 || layer == 3 || layer == 5 || layer == 6 || layer == 7; }
 
 // p as dd_api.cpp fills it for the direct kernel of `layer`, except p.wpack = the layer's wino_pack_u image and (layers 2, 3, 5)
-// p.cadd = the [B][CIN][4] table written by launch_wino_gn_table on the same stream just before
+// p.wino_tab = the [B][CIN][4] table written by launch_wino_gn_table on the same stream just before
 hipError_t launch_conv_wino_layer(int layer, int ek, const ConvParams& p, hipStream_t s, bool packed_f16_transform) {
   if (ek == EK_BF16) return launch_wino_layer_ek<EK_BF16, false>(layer, p, s);
   if (ek != EK_F16) return hipErrorInvalidValue;
