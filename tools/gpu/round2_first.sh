@@ -7,3 +7,5 @@ for wv in 0 2 3 4 5; do timeout 120 python bench.py --variant swin --precision f
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']
 print('winograd', d['config']['winograd'], d['value'], 'maps/s  loop_ms', r['loop_ms_graph'], 'per_layer_us', r['per_layer_avg_us'])"; done
+# PMC passes of the Winograd kernel afterwards (LDS bank conflicts, VALU / MFMA / LDS busy; ~2 GPU-minutes):
+#   BENCH_CFG="--precision f16 --batch 4 --size kitti --variant swin --winograd 2 --winograd-dma" bash tools/gpu/pmc.sh
