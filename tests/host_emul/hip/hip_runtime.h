@@ -1,0 +1,242 @@
+// tests/host_emul/hip/hip_runtime.h -- TEST INFRASTRUCTURE, never part of the product.
+//
+// A stand-in for <hip/hip_runtime.h> that lets a kernel translation unit of diffusiondepth_amd/csrc be compiled FOR THE HOST (clang++, x86) and
+// executed workgroup by workgroup, so that the index arithmetic, LDS images, barrier placement and buffer-reuse hazards of a kernel that has no
+// GPU time yet can be checked against a NumPy / torch reference on the CPU (tests/test_wino_host_emulation.py).
+//
+// Execution model: one workgroup at a time; every work-item is a fiber (ucontext) on ONE OS thread.  A fiber runs until it blocks (__syncthreads
+// or a wave-wide operation) or returns; the fibers of ONE WAVE are resumed round-robin until the whole wave waits at a workgroup barrier, then
+// the next wave runs.  So wave 0 always gets as far ahead of the others as the workgroup barriers permit (order 0; order 1 = the last wave
+// does): a missing barrier shows up as a wrong result deterministically, not as a race that may or may not fire.  LDS is one global array shared by the fibers of the workgroup (workgroups run one after the other).
+// Wave-wide operations (64 consecutive work-items): __shfl_xor and the 32x32 MFMAs exchange their operands through a per-wave scratch with two
+// wave-level rendezvous; the MFMA register layout is the one dd_elem.h / the CDNA4 ISA documents (A: row = lane % 32, k = 8 * (lane / 32) + e;
+// B: column = lane % 32, same k; D register r: row 8 * (r / 4) + 4 * (lane / 32) + r % 4, column lane % 32) -- the layout itself was confirmed
+// on the GPU by the kernels that already run there; the emulation only has to be consistent with it.
+// Not modelled: timing, bank conflicts, the asynchrony of global loads / LDS-DMA (copies complete at issue), occupancy.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <functional>
+#include <vector>
+
+#define __host__
+#define __device__
+#define __global__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+using std::max;
+using std::min;
+
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
+struct alignas(8) uint2 { uint32_t x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFailure = 719;
+typedef void* hipStream_t;
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+namespace hostemu {
+
+constexpr int WAVE = 64;
+constexpr size_t FIBER_STACK = 512 * 1024;
+
+struct Idx3 { unsigned x, y, z; };
+struct Fiber { ucontext_t ctx; char* stack; bool done; };
+struct Rendezvous { int count = 0; unsigned gen = 0; };
+
+struct State {
+  std::vector<Fiber> fibers;
+  ucontext_t sched;
+  int cur = -1, nthreads = 0;
+  const std::function<void()>* body = nullptr;
+  Rendezvous block;
+  std::vector<Rendezvous> wave;
+  std::vector<float> wave_a, wave_b, wave_v;      // per wave: MFMA operands [64][8] x 2, shuffle values [64]
+  unsigned long progress = 0;
+  int order = 0;                                  // 0: ascending work-item order, 1: descending
+  hipError_t last_error = hipSuccess;
+  unsigned long n_block_barriers = 0, n_wave_ops = 0;
+};
+inline State& st() { static State s; return s; }
+
+inline void yield() { State& s = st(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+inline void rendezvous(Rendezvous& r, int n) {
+  State& s = st();
+  const unsigned gen = r.gen;
+  if (++r.count == n) { r.count = 0; ++r.gen; ++s.progress; return; }
+  while (r.gen == gen) yield();
+}
+inline void fiber_entry() {
+  State& s = st();
+  (*s.body)();
+  s.fibers[s.cur].done = true;
+  ++s.progress;
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+
+}  // namespace hostemu
+
+// work-item / workgroup coordinates: plain globals, rewritten by the scheduler every time a fiber is resumed
+extern hostemu::Idx3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace hostemu {
+
+inline int lane_id() { return (int)(threadIdx.x % WAVE); }
+inline int wave_id() { return (int)(threadIdx.x / WAVE); }
+inline int wave_width() {                       // the last wave of a workgroup may be partial
+  State& s = st();
+  return std::min(WAVE, s.nthreads - wave_id() * WAVE);
+}
+inline void wave_sync() { State& s = st(); ++s.n_wave_ops; rendezvous(s.wave[wave_id()], wave_width()); }
+
+template <class Body>
+inline hipError_t launch(dim3 grid, dim3 block, Body&& body_) {
+  State& s = st();
+  const std::function<void()> body = body_;
+  const int n = (int)block.x;
+  s.nthreads = n;
+  s.body = &body;
+  blockDim = Idx3{block.x, 1, 1};
+  gridDim = Idx3{grid.x, 1, 1};
+  const int nw = (n + WAVE - 1) / WAVE;
+  s.wave.assign(nw, Rendezvous());
+  s.wave_a.assign((size_t)nw * WAVE * 8, 0.f);
+  s.wave_b.assign((size_t)nw * WAVE * 8, 0.f);
+  s.wave_v.assign((size_t)nw * WAVE, 0.f);
+  if ((int)s.fibers.size() < n) {
+    const size_t old = s.fibers.size();
+    s.fibers.resize(n);
+    for (size_t i = old; i < (size_t)n; ++i) s.fibers[i].stack = (char*)malloc(FIBER_STACK);
+  }
+  for (unsigned bx = 0; bx < grid.x; ++bx) {
+    blockIdx = Idx3{bx, 0, 0};
+    s.block = Rendezvous();
+    for (int w = 0; w < nw; ++w) s.wave[w] = Rendezvous();
+    for (int i = 0; i < n; ++i) {
+      Fiber& f = s.fibers[i];
+      f.done = false;
+      getcontext(&f.ctx);
+      f.ctx.uc_stack.ss_sp = f.stack;
+      f.ctx.uc_stack.ss_size = FIBER_STACK;
+      f.ctx.uc_link = nullptr;
+      makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    // A WAVE is the unit that runs ahead: its work-items are resumed round-robin until all of them wait at a workgroup barrier (or are done);
+    // only then does the next wave get the processor.  (Wave-wide operations make the lanes of one wave advance together anyway; scheduling
+    // all waves round-robin would also keep the WAVES in step from MFMA to MFMA and hide every missing workgroup barrier.)
+    int remaining = n;
+    while (remaining > 0) {
+      const unsigned long before = s.progress;
+      for (int wk = 0; wk < nw; ++wk) {
+        const int wv = s.order == 0 ? wk : nw - 1 - wk;
+        const int lo = wv * WAVE, hi = std::min(n, lo + WAVE);
+        unsigned long p0;
+        do {
+          p0 = s.progress;
+          for (int k = lo; k < hi; ++k) {
+            const int i = s.order == 0 ? k : hi - 1 - (k - lo);
+            if (s.fibers[i].done) continue;
+            s.cur = i;
+            threadIdx = Idx3{(unsigned)i, 0, 0};
+            swapcontext(&s.sched, &s.fibers[i].ctx);
+          }
+        } while (s.progress != p0);
+      }
+      remaining = 0;
+      for (int i = 0; i < n; ++i) remaining += s.fibers[i].done ? 0 : 1;
+      if (remaining > 0 && s.progress == before) {     // every live work-item waits and nothing was released: divergent barrier
+        fprintf(stderr, "hostemu: deadlock in workgroup %u (%d work-items blocked)\n", bx, remaining);
+        s.last_error = hipErrorLaunchFailure;
+        return s.last_error;
+      }
+    }
+  }
+  return hipSuccess;
+}
+
+// D = A (32 x K) . B (K x 32) + C with K = 16 (2-byte operands, 8 per lane) or K = 2 (fp32, 1 per lane)
+typedef __attribute__((ext_vector_type(16))) float v16f;
+inline v16f mfma_32x32(const float* a, const float* b, int per_lane, v16f c) {
+  State& s = st();
+  const int l = lane_id(), wv = wave_id();
+  float* wa = &s.wave_a[(size_t)wv * WAVE * 8];
+  float* wb = &s.wave_b[(size_t)wv * WAVE * 8];
+  for (int e = 0; e < per_lane; ++e) { wa[l * 8 + e] = a[e]; wb[l * 8 + e] = b[e]; }
+  wave_sync();
+  const int col = l % 32, half = l / 32;
+  for (int r = 0; r < 16; ++r) {
+    const int row = 8 * (r / 4) + 4 * half + r % 4;
+    float acc = 0.f;
+    for (int kh = 0; kh < 2; ++kh)
+      for (int e = 0; e < per_lane; ++e) acc += wa[(row + 32 * kh) * 8 + e] * wb[(col + 32 * kh) * 8 + e];
+    c[r] += acc;
+  }
+  wave_sync();
+  return c;
+}
+typedef __attribute__((ext_vector_type(8))) _Float16 v8h;
+typedef __attribute__((ext_vector_type(8))) __bf16 v8b;
+inline v16f mfma_f16(v8h a, v8h b, v16f c) {
+  float fa[8], fb[8];
+  for (int e = 0; e < 8; ++e) { fa[e] = (float)a[e]; fb[e] = (float)b[e]; }
+  return mfma_32x32(fa, fb, 8, c);
+}
+inline v16f mfma_bf16(v8b a, v8b b, v16f c) {
+  float fa[8], fb[8];
+  const uint4 ua = __builtin_bit_cast(uint4, a), ub = __builtin_bit_cast(uint4, b);
+  const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+  for (int e = 0; e < 4; ++e) {
+    fa[2 * e] = __builtin_bit_cast(float, wa[e] << 16); fa[2 * e + 1] = __builtin_bit_cast(float, wa[e] & 0xFFFF0000u);
+    fb[2 * e] = __builtin_bit_cast(float, wb[e] << 16); fb[2 * e + 1] = __builtin_bit_cast(float, wb[e] & 0xFFFF0000u);
+  }
+  return mfma_32x32(fa, fb, 8, c);
+}
+inline v16f mfma_f32(float a, float b, v16f c) { return mfma_32x32(&a, &b, 1, c); }
+
+inline float shfl_xor(float v, int mask) {
+  State& s = st();
+  float* wv = &s.wave_v[(size_t)wave_id() * WAVE];
+  wv[lane_id()] = v;
+  wave_sync();
+  const float r = wv[lane_id() ^ mask];
+  wave_sync();
+  return r;
+}
+
+}  // namespace hostemu
+
+static inline hipError_t hipGetLastError() { const hipError_t e = hostemu::st().last_error; hostemu::st().last_error = hipSuccess; return e; }
+static inline void __syncthreads() { hostemu::State& s = hostemu::st(); ++s.n_block_barriers; hostemu::rendezvous(s.block, s.nthreads); }
+static inline float __shfl_xor(float v, int mask, int /*width*/ = 64) { return hostemu::shfl_xor(v, mask); }
+static inline double atomicAdd(double* p, double v) { const double o = *p; *p = o + v; return o; }     // one OS thread
+static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
+
+// uniform-by-construction at every use in the kernels (wave index, LDS addresses): the identity is exact there
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hostemu::mfma_f16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hostemu::mfma_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hostemu::mfma_f32((a), (b), (c))
+
+#define hipLaunchKernelGGL(kernel, grid, block, smem_bytes, stream, ...) \
+  (hostemu::st().last_error = hostemu::launch((grid), (block), [=]() { (kernel)(__VA_ARGS__); }))
