@@ -1,0 +1,35 @@
+// dd_gcn.h -- the gfx950 constructs of the convolution kernels that have no C++ meaning (LDS-DMA, s_waitcnt, the LDS base address), behind
+// macros.  The device build gets exactly the instruction sequences the kernels carried inline before (the code objects are byte-identical);
+// tests/host_emul compiles the same kernel sources for the HOST with -DDD_HOST_EMULATION and maps the macros onto a model of the wave's VMEM
+// queue (tests/host_emul/hip/hip_runtime.h): s_waitcnt vmcnt(N) retires all but the newest N entries in issue order, an LDS-DMA lands either
+// at issue or only when a wait retires it -- the two extremes the hardware's timing lies between.
+#pragma once
+
+#ifdef DD_HOST_EMULATION
+
+#define DD_LDS_BASE(smem) 0u
+#define DD_LDS_DMA16(smem, gsrc, ldst) hostemu::lds_dma16((smem), (ldst), (gsrc))
+#define DD_WAIT_VM(n) hostemu::wait_vm(n)
+#define DD_WAIT_VM_LGKM0(n) hostemu::wait_vm(n)
+#define DD_WAIT_LGKM0() ((void)0)
+#define DD_VMEM_LOADS_ISSUED(n) hostemu::vmem_loads_issued(n)
+
+#else
+
+#define DD_LDS_BASE(smem) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem))
+// one wave-instruction: lane l copies 16 bytes from its global address gsrc to LDS address ldst (wave-uniform, via M0) + 16 * l.
+// Inline asm on purpose: with the __builtin form hipcc treats the DMA as an LDS write that may alias every later ds_read and drains
+// vmcnt(0) right behind it.  hipcc does not count asm VMEM operations: every wait for a DMA is one of the explicit macros below.
+#define DD_LDS_DMA16(smem, gsrc, ldst)                                                                                          \
+  do {                                                                                                                          \
+    unsigned keep_m0_;                                                                                                          \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"       \
+                 : "=&s"(keep_m0_) : "v"(gsrc), "s"(ldst) : "memory");                                                          \
+  } while (0)
+#define DD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#define DD_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
+#define DD_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// bookkeeping for the host model only: n ordinary global loads were just issued by this wave (they count in vmcnt)
+#define DD_VMEM_LOADS_ISSUED(n) ((void)0)
+
+#endif

@@ -23,6 +23,7 @@
 //   * bf16 / f16 outputs are stored 16 B per lane: `v_permlane32_swap` pairs the two half-waves'
 //     4-cout quads into 8 consecutive couts (cdna guide T21).
 #include "dd_igemm2_cfg.h"
+#include "dd_gcn.h"
 
 namespace dd {
 
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // `s_waitcnt vmcnt(0)` right after issuing it, which serialises DMA latency with the MFMAs.  hipcc does not count
   // asm VMEM ops, so every wait for the DMA below is explicit; VMEM loads retire in issue order, so hipcc's own
   // counted waits for the raw patch loads only become more conservative (cdna guide 5.7).
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds_base = DD_LDS_BASE(smem);
   auto issue_weights = [&](int s) {
     const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)nsplit * C::NSTAGE + s) * (size_t)C::W_BYTES + lane * 16;
     const unsigned dst = lds_base + C::W_OFF + (s & (C::NWB - 1)) * C::W_BYTES;
@@ -97,9 +98,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       if (kc < C::W_BYTES / 1024) {
         const char* gsrc = src + (size_t)kc * 1024;
         const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + kc * 1024);
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+        DD_LDS_DMA16(smem, gsrc, ldst);
       }
     }
   };
@@ -152,6 +151,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
       }
     }
+    DD_VMEM_LOADS_ISSUED(NIT * NLD * ((C::PRO == PRO_GN_ADD || (C::PRO == PRO_X && have_norm)) ? 2 : 1));   // host model only (dd_gcn.h)
   };
 
   float c1 = 1.f, c2 = 0.f;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }
   }
-  if (abl & 512) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
+  if (abl & 512) { DD_WAIT_VM(0); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
   if (have_norm && (first_tile || b != tab_img)) {
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     }
   }
   transform_write(0, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of weight stage 0 have landed
+  DD_WAIT_VM(0);   // this wave's DMA pieces of weight stage 0 have landed
   __syncthreads();                                    // patch 0 and weight stage 0 are in LDS for everybody
   if (abl & 1024) return;
   e_b = b; e_y0 = y0; e_x0 = x0; e_tile = tile;
@@ -433,13 +433,13 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     // this stage it is enough to wait until at most NRAW (= the raw loads) are outstanding: they keep flying for
     // two more stages (cdna guide T4: counted vmcnt).  Every wave issues exactly NRAW loads (clamped addresses).
     if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && (C::NTG > 1 || RD == 2) && !(abl & (2 | 128))) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
+      DD_WAIT_VM_LGKM0(NRAW);
     } else if (PF_HERE && s == C::NSTAGE - 2 && has_next) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");      // last weight stage landed, prefetch flies on
+      DD_WAIT_VM_LGKM0(NRAW);      // last weight stage landed, prefetch flies on
     } else if (C::PERSIST && s == C::NSTAGE - 1) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // no DMA pending: leave the prefetch alone
+      DD_WAIT_LGKM0();                          // no DMA pending: leave the prefetch alone
     } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      DD_WAIT_VM_LGKM0(0);
     }
     // raw s_barrier: __syncthreads() would make hipcc drain vmcnt(0) because an LDS-DMA may be pending
     if (!(abl & 64)) __builtin_amdgcn_s_barrier();
@@ -471,17 +471,17 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         asm volatile("" ::: "memory");
         issue_weights(chunk + 1);           // behind the transform: its compiler-counted vmcnt waits then do not cover the DMA
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DD_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (half == 1) {
         if (chunk + 2 < C::NCHUNK) load_raw(chunk + 2, 0);
         mfma_block(chunk, 0);
-        if (chunk + 2 < C::NCHUNK) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");   // DMA landed, raw loads fly on
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (chunk + 2 < C::NCHUNK) DD_WAIT_VM_LGKM0(NRAW);   // DMA landed, raw loads fly on
+        else DD_WAIT_VM_LGKM0(0);
       } else {
         if (more) transform_write(chunk + 1, nbuf, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        DD_WAIT_VM_LGKM0(0);
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

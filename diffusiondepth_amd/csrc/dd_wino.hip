@@ -16,15 +16,7 @@
 // Epilogue: the 16 position accumulators meet in LDS (fp32, one 32 co x 32 tile block at a time) and 128 lanes apply A^T M A, add the bias
 // and store 4 pixels x 8 couts (two 8-byte stores per pixel into the channel-blocked activation layout).
 #include "dd_elem.h"
-
-// tests/host_emul compiles this file for the host (work-items as fibers, LDS as an array: tests/test_wino_host_emulation.py) to check the
-// index arithmetic, the LDS images and the barrier / buffer-reuse scheme on the CPU.  Only the three constructs that have no host meaning
-// are switched: the LDS base address, the LDS-DMA (there: a copy that completes at issue) and the wait for it.
-#ifdef DD_HOST_EMULATION
-#define DD_WAIT_VMEM0() ((void)0)
-#else
-#define DD_WAIT_VMEM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
+#include "dd_gcn.h"     // LDS-DMA / s_waitcnt / LDS base address; tests/host_emul compiles this file for the host through the same macros
 
 namespace dd {
 
@@ -299,11 +291,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   // p.wino_flags bit 0 (option "winograd_dma"): the weight images go global -> LDS by LDS-DMA instead of through
   // registers and six ds_write_b128 per lane (13 LDS-path cycles each, MI355X_MICROARCH.md section LDS)
   const bool use_dma = (p.wino_flags & 1) != 0;
-#ifdef DD_HOST_EMULATION
-  const unsigned lds_base = 0;
-#else
-  const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-#endif
+  const unsigned lds_base = DD_LDS_BASE(smem);
   const int nsplit = wgid % NSPLIT;
   const int tile_id = wgid / NSPLIT;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
@@ -384,13 +372,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       const int P = kc * 64 + lane;
       const char* gsrc = src + (size_t)(P ^ ((P >> 4) & 1)) * 16;
       const unsigned ldst = __builtin_amdgcn_readfirstlane(lds_base + W2_U_OFF + buf * W_U_BYTES + kc * 1024);
-#ifdef DD_HOST_EMULATION
-      memcpy(smem + ldst + lane * 16, gsrc, 16);
-#else
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
-#endif
+      DD_LDS_DMA16(smem, gsrc, ldst);
     }
   };
   // prologue of one 16-byte piece (8 channels starting at ch0 of one pixel): relu(a*y + b) [+ cond + e]; outside the image: zero
@@ -516,7 +498,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   gload(0);
   if constexpr (PRO != PRO_RAW) __syncthreads();                // the prologue table is in LDS
   lstore(0);
-  if (use_dma) DD_WAIT_VMEM0();  // this wave's pieces of U(0) have landed
+  if (use_dma) DD_WAIT_VM(0);  // this wave's pieces of U(0) have landed
   __syncthreads();
   gload(1);
   transform(0);
@@ -550,7 +532,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
       }
     }
     if (more) transform(nxt);                                   // VALU + LDS while the matrix pipe drains the 8 MFMAs above
-    if (use_dma) DD_WAIT_VMEM0();  // the DMA of U(chunk + 1) (and the register prefetch behind it) landed
+    if (use_dma) DD_WAIT_VM(0);  // the DMA of U(chunk + 1) (and the register prefetch behind it) landed
     __syncthreads();                                            // B: V (DMA: and U) of chunk + 1 complete, fragment reads of this chunk done
   }
 

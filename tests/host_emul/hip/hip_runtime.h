@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <deque>
 #include <functional>
 #include <vector>
 
@@ -40,6 +41,8 @@ struct alignas(16) uint4 { uint32_t x, y, z, w; };
 struct alignas(8) uint2 { uint32_t x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
+struct alignas(16) double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
@@ -55,6 +58,9 @@ constexpr hipError_t hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFai
 typedef void* hipStream_t;
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }   // a 4-CU "device": persistent grids stay small
 
 namespace hostemu {
 
@@ -64,6 +70,9 @@ constexpr size_t FIBER_STACK = 512 * 1024;
 struct Idx3 { unsigned x, y, z; };
 struct Fiber { ucontext_t ctx; char* stack; bool done; };
 struct Rendezvous { int count = 0; unsigned gen = 0; };
+// one entry of a work-item's VMEM queue (s_waitcnt vmcnt counts them in issue order): an ordinary global load (dst == nullptr: the value was
+// taken at issue, only its slot in the queue matters) or a 16-byte LDS-DMA piece that lands when it is retired (dma_late) or landed at issue
+struct VmEntry { char* dst; const char* src; };
 
 struct State {
   std::vector<Fiber> fibers;
@@ -72,7 +81,10 @@ struct State {
   const std::function<void()>* body = nullptr;
   Rendezvous block;
   std::vector<Rendezvous> wave;
-  std::vector<float> wave_a, wave_b, wave_v;      // per wave: MFMA operands [64][8] x 2, shuffle values [64]
+  std::vector<float> wave_a, wave_b;              // per wave: MFMA operands [64][8] x 2
+  std::vector<uint64_t> wave_x;                   // per wave: shuffle / permlane values [64][2]
+  std::vector<std::deque<VmEntry>> vmq;           // per work-item
+  int dma_late = 0;                               // 0: an LDS-DMA lands at issue; 1: only when an s_waitcnt retires it
   unsigned long progress = 0;
   int order = 0;                                  // 0: ascending work-item order, 1: descending
   hipError_t last_error = hipSuccess;
@@ -123,7 +135,8 @@ inline hipError_t launch(dim3 grid, dim3 block, Body&& body_) {
   s.wave.assign(nw, Rendezvous());
   s.wave_a.assign((size_t)nw * WAVE * 8, 0.f);
   s.wave_b.assign((size_t)nw * WAVE * 8, 0.f);
-  s.wave_v.assign((size_t)nw * WAVE, 0.f);
+  s.wave_x.assign((size_t)nw * WAVE * 2, 0);
+  s.vmq.assign(n, std::deque<VmEntry>());
   if ((int)s.fibers.size() < n) {
     const size_t old = s.fibers.size();
     s.fibers.resize(n);
@@ -136,6 +149,7 @@ inline hipError_t launch(dim3 grid, dim3 block, Body&& body_) {
     for (int i = 0; i < n; ++i) {
       Fiber& f = s.fibers[i];
       f.done = false;
+      s.vmq[i].clear();
       getcontext(&f.ctx);
       f.ctx.uc_stack.ss_sp = f.stack;
       f.ctx.uc_stack.ss_size = FIBER_STACK;
@@ -214,14 +228,55 @@ inline v16f mfma_bf16(v8b a, v8b b, v16f c) {
 }
 inline v16f mfma_f32(float a, float b, v16f c) { return mfma_32x32(&a, &b, 1, c); }
 
-inline float shfl_xor(float v, int mask) {
+template <class T> inline T shfl_xor(T v, int mask) {
+  static_assert(sizeof(T) <= 8, "one 64-bit slot per lane");
   State& s = st();
-  float* wv = &s.wave_v[(size_t)wave_id() * WAVE];
-  wv[lane_id()] = v;
+  uint64_t* wx = &s.wave_x[(size_t)wave_id() * WAVE * 2];
+  uint64_t bits = 0;
+  memcpy(&bits, &v, sizeof(T));
+  wx[lane_id() * 2] = bits;
   wave_sync();
-  const float r = wv[lane_id() ^ mask];
+  const uint64_t rb = wx[(lane_id() ^ mask) * 2];
+  wave_sync();
+  T r;
+  memcpy(&r, &rb, sizeof(T));
+  return r;
+}
+// v_permlane32_swap_b32 vdst, src0: lanes 32..63 of vdst <-> lanes 0..31 of src0; returns {vdst', src0'}
+typedef __attribute__((ext_vector_type(2))) unsigned v2u;
+inline v2u permlane32_swap(unsigned vdst, unsigned src0) {
+  State& s = st();
+  uint64_t* wx = &s.wave_x[(size_t)wave_id() * WAVE * 2];
+  const int l = lane_id();
+  wx[l * 2] = vdst;
+  wx[l * 2 + 1] = src0;
+  wave_sync();
+  v2u r;
+  if (l < 32) { r[0] = vdst; r[1] = (unsigned)wx[(l + 32) * 2]; }
+  else { r[0] = (unsigned)wx[(l - 32) * 2 + 1]; r[1] = src0; }
   wave_sync();
   return r;
+}
+
+// ---- the wave's VMEM queue (dd_gcn.h) ------------------------------------------------------------------------------------------------------------
+inline void lds_dma16(char* smem, unsigned ldst, const char* gsrc) {
+  State& s = st();
+  char* dst = smem + ldst + lane_id() * 16;
+  if (s.dma_late) { s.vmq[s.cur].push_back(VmEntry{dst, gsrc}); return; }
+  memcpy(dst, gsrc, 16);
+  s.vmq[s.cur].push_back(VmEntry{nullptr, nullptr});
+}
+inline void vmem_loads_issued(int n) {
+  State& s = st();
+  for (int i = 0; i < n; ++i) s.vmq[s.cur].push_back(VmEntry{nullptr, nullptr});
+}
+inline void wait_vm(int n) {                    // s_waitcnt vmcnt(n): at most n operations outstanding, retired in issue order
+  std::deque<VmEntry>& q = st().vmq[st().cur];
+  while ((int)q.size() > n) {
+    const VmEntry e = q.front();
+    q.pop_front();
+    if (e.dst) memcpy(e.dst, e.src, 16);
+  }
 }
 
 }  // namespace hostemu
@@ -229,11 +284,15 @@ inline float shfl_xor(float v, int mask) {
 static inline hipError_t hipGetLastError() { const hipError_t e = hostemu::st().last_error; hostemu::st().last_error = hipSuccess; return e; }
 static inline void __syncthreads() { hostemu::State& s = hostemu::st(); ++s.n_block_barriers; hostemu::rendezvous(s.block, s.nthreads); }
 static inline float __shfl_xor(float v, int mask, int /*width*/ = 64) { return hostemu::shfl_xor(v, mask); }
+static inline double __shfl_xor(double v, int mask, int /*width*/ = 64) { return hostemu::shfl_xor(v, mask); }
 static inline double atomicAdd(double* p, double v) { const double o = *p; *p = o + v; return o; }     // one OS thread
 static inline float atomicAdd(float* p, float v) { const float o = *p; *p = o + v; return o; }
 
 // uniform-by-construction at every use in the kernels (wave index, LDS addresses): the identity is exact there
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_sched_group_barrier(mask, count, sync) ((void)0)
+#define __builtin_amdgcn_permlane32_swap(vdst, src0, fi, bc) hostemu::permlane32_swap((vdst), (src0))
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hostemu::mfma_f16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hostemu::mfma_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hostemu::mfma_f32((a), (b), (c))

@@ -20,6 +20,8 @@ extern "C" {
 
 // order: 0 = work-item 0 runs ahead, 1 = the last work-item runs ahead
 void emu_set_order(int order) { hostemu::st().order = order; }
+// 0: an LDS-DMA lands when it is issued; 1: only when an s_waitcnt retires it
+void emu_set_dma_late(int late) { hostemu::st().dma_late = late; }
 void emu_counters(unsigned long* block_barriers, unsigned long* wave_ops) {
   *block_barriers = hostemu::st().n_block_barriers;
   *wave_ops = hostemu::st().n_wave_ops;

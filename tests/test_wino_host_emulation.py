@@ -21,94 +21,15 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "diffusiondepth_amd", "csrc")
-EMU = os.path.join(ROOT, "tests", "host_emul")
-OUT = os.path.join(ROOT, "build", "host_emul")
-EK_BF16, EK_F16 = 1, 2
-STAT_SLOTS, STAT_STRIDE, GN_GROUPS = 32, 16, 4
-
-
-def _clangxx():
-    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
-        if c and os.path.exists(c):
-            return c
-    return None
-
-
-def _compile(cxx, csrc_dir, so):
-    cmd = [cxx, "-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-I", EMU, "-I", csrc_dir,
-           "-shared", "-fPIC", os.path.join(EMU, "wino_host.cpp"), "-o", so + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        pytest.fail("host build of dd_wino.hip failed:\n" + r.stderr[-4000:])
-    os.replace(so + ".tmp", so)
-
-
-def _bind(lib):
-    P = ctypes.c_void_p
-    lib.emu_wino_pack_bytes.restype = ctypes.c_longlong
-    lib.emu_wino_pack.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
-    lib.emu_wino_pack.restype = None
-    lib.emu_wino_table.argtypes = [P, P, P, P, P] + [ctypes.c_int] * 6 + [P]
-    lib.emu_wino_layer.argtypes = [ctypes.c_int] * 5 + [P] * 7 + [ctypes.c_int] * 3
-    lib.emu_set_order.argtypes = [ctypes.c_int]
-    return lib
-
-
-def _build():
-    cxx = _clangxx()
-    if cxx is None:
-        pytest.skip("no clang++ (the kernels use clang vector extensions; g++ cannot compile them)")
-    srcs = [os.path.join(EMU, "wino_host.cpp"), os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(CSRC, "dd_wino.hip"),
-            os.path.join(CSRC, "dd_elem.h"), os.path.join(CSRC, "dd_kernels.h")]
-    hsh = hashlib.sha1()
-    for s in srcs:
-        with open(s, "rb") as f:
-            hsh.update(f.read())
-    if os.environ.get("DD_EMU_LIB"):            # a hand-built variant (mutation experiments)
-        return ctypes.CDLL(os.environ["DD_EMU_LIB"])
-    os.makedirs(OUT, exist_ok=True)
-    so = os.path.join(OUT, "libwino_host_%s.so" % hsh.hexdigest()[:12])
-    if not os.path.exists(so):
-        _compile(cxx, CSRC, so)
-    return ctypes.CDLL(so)
+from hostemu_util import (CSRC, have_f16c, EK_BF16, EK_F16, GN_GROUPS, STAT_SLOTS, STAT_STRIDE, _bind, _build, _clangxx, _compile, blocked, from16, ptr,
+                          to16, unblocked)
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if not os.path.exists("/proc/cpuinfo") or "f16c" not in open("/proc/cpuinfo").read():
+    if not have_f16c():
         pytest.skip("host without F16C")
     return _bind(_build())
-
-
-# ---- 16-bit element kinds and the channel-blocked activation layout of dd_elem.h ([B][C/32][h][w][32]) ---------------------------------------
-def to16(x, ek):
-    x = np.ascontiguousarray(x, dtype=np.float32)
-    if ek == EK_F16:
-        return x.astype(np.float16).view(np.uint16)
-    u = x.view(np.uint32).astype(np.uint64)
-    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)        # round to nearest even
-
-
-def from16(u, ek):
-    if ek == EK_F16:
-        return u.view(np.float16).astype(np.float32)
-    return (u.astype(np.uint32) << 16).view(np.float32)
-
-
-def blocked(x_nchw16):
-    B, C, h, w = x_nchw16.shape
-    return np.ascontiguousarray(x_nchw16.reshape(B, C // 32, 32, h, w).transpose(0, 1, 3, 4, 2))
-
-
-def unblocked(x_blk, C):
-    B, nb, h, w, _ = x_blk.shape
-    return np.ascontiguousarray(x_blk.transpose(0, 1, 4, 2, 3).reshape(B, C, h, w))
-
-
-def ptr(a):
-    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
 LAYERS = {  # layer: (cin, cout, prologue, statistics)     dd_wino.hip launch_wino_layer_ek
@@ -222,11 +143,16 @@ def test_v2_packed_f16_transform(emu, layer):
     assert err < 2 * TOL[EK_F16][0] and worst < 2 * TOL[EK_F16][1], (err, worst)
 
 
-@pytest.mark.parametrize("layer,order", [(2, 0), (6, 1)])
-def test_v2_dma_weight_images(emu, layer, order):
-    """option "winograd_dma": same results as the register path bit for bit (the swizzle moves to the source side of the copy)"""
+@pytest.mark.parametrize("layer,order,late", [(2, 0, 0), (6, 1, 1), (3, 0, 1)])
+def test_v2_dma_weight_images(emu, layer, order, late):
+    """option "winograd_dma": same results as the register path bit for bit (the swizzle moves to the source side of the copy), whether the
+    DMA lands at issue or only at the s_waitcnt in front of barrier B (dd_gcn.h: the two extremes of the hardware's timing)"""
     e0 = run_case(emu, layer, EK_F16, dma=False, order=order)
-    e1 = run_case(emu, layer, EK_F16, dma=True, order=order)
+    emu.emu_set_dma_late(late)
+    try:
+        e1 = run_case(emu, layer, EK_F16, dma=True, order=order)
+    finally:
+        emu.emu_set_dma_late(0)
     assert e0 == e1
 
 
@@ -265,7 +191,7 @@ def test_emulation_catches_mutation(emu, name, tmp_path):
     assert src.count(old) >= 1, "mutation anchor not found: dd_wino.hip changed, update MUTATIONS"
     d = tmp_path / "csrc"
     d.mkdir()
-    for f in ("dd_elem.h", "dd_kernels.h"):
+    for f in ("dd_elem.h", "dd_kernels.h", "dd_gcn.h"):
         shutil.copy(os.path.join(CSRC, f), d / f)
     (d / "dd_wino.hip").write_text(src.replace(old, new))
     so = str(tmp_path / "libmut.so")
