@@ -16,6 +16,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "dd_gcn.h"
+
 #include <climits>
 #include <cstdarg>
 #include <cstdio>
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256) nlspn_prop_lds_kernel(const float* __rest
     }
     // pin the loads above the selects below (otherwise LLVM sinks each load into its "in the image" branch, one latency after another)
 #pragma unroll
-    for (int it = 0; it < NFILL; ++it) asm volatile("" : "+v"(tv[it]));
+    for (int it = 0; it < NFILL; ++it) DD_PIN_VGPR(tv[it]);
 #pragma unroll
     for (int it = 0; it < NFILL; ++it) {
       const int idx = tid + it * 256;
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(256) nlspn_prop_lds3_kernel(const float* __res
       tv[it] = im[(size_t)min(max(y0 - R + r, 0), H - 1) * W + min(max(x0 - R + c, 0), W - 1)];
     }
 #pragma unroll
-    for (int it = 0; it < NFILL; ++it) asm volatile("" : "+v"(tv[it]));      // keep the loads above the selects (see the generic kernel)
+    for (int it = 0; it < NFILL; ++it) DD_PIN_VGPR(tv[it]);      // keep the loads above the selects (see the generic kernel)
 #pragma unroll
     for (int it = 0; it < NFILL; ++it) {
       const int idx = tid + it * 256;
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(256) nlspn_guide_affinity_kernel(const float* 
       tv[it] = guide[((size_t)b * CG + c) * HW + (size_t)min(max(y0 - 1 + r, 0), H - 1) * W + min(max(x0 - 1 + col, 0), W - 1)];
     }
 #pragma unroll
-    for (int it = 0; it < NFILL; ++it) asm volatile("" : "+v"(tv[it]));      // loads stay above the selects (see nlspn_prop_lds_kernel)
+    for (int it = 0; it < NFILL; ++it) DD_PIN_VGPR(tv[it]);      // loads stay above the selects (see nlspn_prop_lds_kernel)
 #pragma unroll
     for (int it = 0; it < NFILL; ++it) {
       const int idx = tid + it * 256;

@@ -7,6 +7,8 @@
 
 #ifdef DD_HOST_EMULATION
 
+#define DD_DYN_SMEM(name) extern __attribute__((aligned(16))) char name[]          /* the harness defines dd::smem */
+#define DD_PIN_VGPR(x) ((void)(x))
 #define DD_LDS_BASE(smem) 0u
 #define DD_LDS_DMA16(smem, gsrc, ldst) hostemu::lds_dma16((smem), (ldst), (gsrc))
 #define DD_WAIT_VM(n) hostemu::wait_vm(n)
@@ -16,6 +18,10 @@
 
 #else
 
+// the workgroup's dynamic LDS (size given at launch)
+#define DD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+// "this value lives in a VGPR from here on": an empty asm the optimiser cannot look through (keeps loads above the selects that consume them)
+#define DD_PIN_VGPR(x) asm volatile("" : "+v"(x))
 #define DD_LDS_BASE(smem) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem))
 // one wave-instruction: lane l copies 16 bytes from its global address gsrc to LDS address ldst (wave-uniform, via M0) + 16 * l.
 // Inline asm on purpose: with the __builtin form hipcc treats the DMA as an LDS write that may alias every later ds_read and drains

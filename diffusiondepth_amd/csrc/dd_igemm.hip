@@ -22,6 +22,7 @@
 // conflict-free ds_read_b128).  In D a lane owns ONE pixel and 4 consecutive couts per register
 // quad, so the NHWC store and all per-pixel epilogue math are lane-local.
 #include "dd_elem.h"
+#include "dd_gcn.h"
 
 namespace dd {
 
@@ -68,7 +69,7 @@ template <class C>
 __global__ void __launch_bounds__(C::THREADS) conv_igemm_kernel(ConvParams p) {
   constexpr int EK = C::EK;
   constexpr int PW = C::PW, PSTR = C::PSTR, PPP = C::PPP, EPP = C::EPP, CK = C::CK;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DD_DYN_SMEM(smem);
   char* s_patch = smem;
   char* s_w = smem + C::PATCH_BYTES;
   float* s_tab = reinterpret_cast<float*>(smem + C::PATCH_BYTES + C::W_BYTES);

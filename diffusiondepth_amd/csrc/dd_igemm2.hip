@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   constexpr int EK = C::EK;
   constexpr int PW = C::PW, ROWB = C::ROWB, PPP = C::PPP, RPB = C::RPB, EPP = C::EPP, CK = C::CK;
   constexpr int NIT = C::NIT, NLD = C::NLD, IN_ESZ = C::IN_ESZ, NKQ = C::NKQ;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DD_DYN_SMEM(smem);
   float* s_tab = reinterpret_cast<float*>(smem + C::NPB * C::PATCH_BYTES + C::NWB * C::W_BYTES);
   float* tab_a = s_tab;
   float* tab_b = s_tab + C::CTAB;

@@ -11,6 +11,7 @@
 // last barrier); here that work runs on the SIMDs' VALU while the MFMA waves keep the matrix pipe busy.
 #define DD_FAT_CONV3 0      // the wave-specialised variant keeps the 8x32 / 3-taps-per-stage tiling
 #include "dd_igemm2_cfg.h"
+#include "dd_gcn.h"
 
 namespace dd {
 
@@ -23,7 +24,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
   constexpr int NIT = (C::ITEMS + STHREADS - 1) / STHREADS;
   static_assert(C::WAVES == 4 && C::NCHUNK > 1 && C::NPB == 2 && C::NWB == 2 && C::TG == 3, "layers this variant is written for");
   static_assert(C::PRO != PRO_X && NLD == 1, "PRO_GN / PRO_GN_ADD / PRO_RAW inputs");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DD_DYN_SMEM(smem);
   float* s_tab = reinterpret_cast<float*>(smem + C::NPB * C::PATCH_BYTES + C::NWB * C::W_BYTES);
   float* tab_a = s_tab;
   float* tab_b = s_tab + C::CTAB;
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
     const int stid = tid & (STHREADS - 1);
     const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * C::CIN * IN_ESZ;
     const char* cond_b = (C::PRO == PRO_GN_ADD) ? reinterpret_cast<const char*>(p.cond) + (size_t)b * h * w * C::CIN * IN_ESZ : nullptr;
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned lds_base = DD_LDS_BASE(smem);
     auto issue_weights = [&](int s) {
       const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)nsplit * C::NSTAGE + s) * (size_t)C::W_BYTES + lane * 16;
       const unsigned dst = lds_base + C::W_OFF + (s & 1) * C::W_BYTES;
@@ -72,9 +73,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
         if (kc < C::W_BYTES / 1024) {
           const char* gsrc = src + (size_t)kc * 1024;
           const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + kc * 1024);
-          unsigned keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+          DD_LDS_DMA16(smem, gsrc, ldst);
         }
       }
     };
@@ -105,6 +104,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
         raw[u] = *reinterpret_cast<const uint4*>(in_b + goff);
         if constexpr (C::PRO == PRO_GN_ADD) aux[u] = *reinterpret_cast<const uint4*>(cond_b + goff);
       }
+      DD_VMEM_LOADS_ISSUED(NIT * (C::PRO == PRO_GN_ADD ? 2 : 1));      // host model only (dd_gcn.h)
     };
     auto transform_write = [&](int chunk, int pbuf_off) {
       float ta[EPP], tb[EPP], te[EPP];
@@ -149,11 +149,11 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
 
     issue_weights(0);
     load_raw(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DD_WAIT_LGKM0();
     __builtin_amdgcn_s_barrier();                       // #1: GroupNorm table (built by the MFMA role) is visible
     asm volatile("" ::: "memory");
     transform_write(0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    DD_WAIT_VM_LGKM0(0);
     __builtin_amdgcn_s_barrier();                       // #2: patch 0 and weight stage 0 are in LDS
     asm volatile("" ::: "memory");
 #pragma unroll 1
@@ -167,8 +167,8 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
         if (tg == 0 && next) load_raw(chunk + 1);
         if (tg == 1 && next) transform_write(chunk + 1, ((chunk + 1) & 1) * C::PATCH_BYTES);
         // the DMA of stage s+1 must have landed before the barrier; raw loads issued in THIS stage may keep flying
-        if (tg == 0 && next) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NRAW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (tg == 0 && next) DD_WAIT_VM_LGKM0(NRAW);
+        else DD_WAIT_VM_LGKM0(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
     tab_b[tid] = (float)((double)my_beta - mean * a);
     if constexpr (C::PRO == PRO_GN_ADD) tab_e[tid] = my_emb;
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  DD_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();                         // #1
   asm volatile("" ::: "memory");
   if constexpr (C::ADD_C) {
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
   int wkt[NKQ];
 #pragma unroll
   for (int kq = 0; kq < NKQ; ++kq) wkt[kq] = C::W_OFF + li * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li));
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  DD_WAIT_VM_LGKM0(0);
   __builtin_amdgcn_s_barrier();                         // #2
   asm volatile("" ::: "memory");
 
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
             for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], wf[n], pf[m]);
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      DD_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }

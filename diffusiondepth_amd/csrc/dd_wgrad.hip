@@ -18,6 +18,7 @@
 // 3 ds_read_b128 per 3 MFMAs.  At the end every lane adds its 48 values to dW with fp32 atomics (slabs x 18 432 per type).
 // bf16 / f16 operands, fp32 accumulation.
 #include "dd_elem.h"
+#include "dd_gcn.h"
 
 namespace dd {
 
@@ -36,7 +37,7 @@ struct WgradParams {
 
 template <int EK>
 __global__ void __launch_bounds__(WG_THREADS, 3) wgrad_mfma_kernel(WgradParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DD_DYN_SMEM(smem);
   uint16_t* gT = reinterpret_cast<uint16_t*>(smem);
   uint16_t* aT = gT + 64 * GT_PITCH;
   const int tid = threadIdx.x;

@@ -47,7 +47,7 @@ template <int EK>
 __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_kernel(ConvParams p) {
   static_assert(EK == EK_BF16 || EK == EK_F16, "16-bit operand modes only");
   constexpr int CIN = COND_C, COUT = COND_C, NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DD_DYN_SMEM(smem);
   char* s_raw = smem;
   char* s_v = smem + W_V_OFF;
   char* s_u = smem + W_U_OFF;
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   static_assert(!PK || EK == EK_F16, "packed transform adds exist for f16 only");
   static_assert(CIN % 32 == 0 && COUT % W_NT == 0 && (COUT == 64 || COUT == 256), "channel-blocked layouts, 64 couts per workgroup");
   constexpr int NCHUNK = CIN / W_CK, NSPLIT = COUT / W_NT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  DD_DYN_SMEM(smem);
   float* s_tab = reinterpret_cast<float*>(smem + W2_SMEM);        // [3][CIN]: a, b, e of the prologue (PRO != PRO_RAW)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, g = lane >> 5;
