@@ -36,20 +36,11 @@ def library_path() -> str:
     return os.environ.get("DDEPTH_LIBRARY", os.path.join(_HERE, _LIB_NAME))
 
 
-def load_library():
-    """Loads libddepth_hip.so.  Fails loudly: there is no eager / CPU fallback for the hot path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = library_path()
-    if not os.path.exists(path):
-        raise RuntimeError(
-            f"{path} not found: build it with `python -m diffusiondepth_amd.build` (hipcc, gfx950). "
-            "diffusiondepth_amd has no fallback path for the DDIM hot loop.")
-    lib = ctypes.CDLL(path)
+def abi_signatures():
+    """ctypes (restype, argtypes) of every entry point of include/ddepth.h this module binds."""
     c_int, c_i64, c_vp, c_cp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_char_p
     fp = ctypes.POINTER(ctypes.c_float)
-    sig = {
+    return {
         "dd_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_int]),
         "dd_destroy": (c_int, [c_vp]),
         "dd_last_error": (c_cp, [c_vp]),
@@ -75,6 +66,20 @@ def load_library():
         "dd_debug_fetch": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
         "dd_debug_wino_pack": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_i64]),
     }
+
+
+def load_library():
+    """Loads libddepth_hip.so.  Fails loudly: there is no eager / CPU fallback for the hot path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -m diffusiondepth_amd.build` (hipcc, gfx950). "
+            "diffusiondepth_amd has no fallback path for the DDIM hot loop.")
+    lib = ctypes.CDLL(path)
+    sig = abi_signatures()
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args

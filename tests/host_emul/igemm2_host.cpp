@@ -1,20 +1,11 @@
-// tests/host_emul/igemm2_host.cpp -- TEST INFRASTRUCTURE: the production convolution kernels (diffusiondepth_amd/csrc/dd_igemm2.hip) compiled for
-// the host on top of the fiber shim in hip/hip_runtime.h, behind a small C interface for ctypes (tests/test_igemm2_host_emulation.py).  The
+// tests/host_emul/igemm2_host.cpp -- TEST INFRASTRUCTURE: a small C interface (ctypes, tests/test_igemm2_host_emulation.py) to the launchers of the
+// production convolution kernels (diffusiondepth_amd/csrc/dd_igemm2.hip) inside the host-emulated library (ddepth_host.cpp).  The
 // kernels have hundreds of green GPU parity tests; what the GPU cannot show is that they are free of RACES that the hardware's timing happens
 // not to trigger: here a wave runs ahead as far as the workgroup barriers allow, and an LDS-DMA lands either at issue or as late as the
 // s_waitcnt arithmetic permits (dd_gcn.h) -- the results must not depend on any of it.
-#include "dd_igemm2.hip"
-
-hostemu::Idx3 threadIdx, blockIdx, blockDim, gridDim;
-
-namespace dd {
-alignas(16) char smem[160 * 1024];
-}
+#include "dd_kernels.h"
 
 extern "C" {
-
-void emu_set_order(int order) { hostemu::st().order = order; }
-void emu_set_dma_late(int late) { hostemu::st().dma_late = late; }
 
 // cin, cout, cout_pad, ck, tg, nt, th, ks of (layer, element kind): the packed-weight geometry the host side packs with
 void emu_geom2(int layer, int ek, int* out8) {

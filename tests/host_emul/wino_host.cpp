@@ -1,15 +1,7 @@
-// tests/host_emul/wino_host.cpp -- TEST INFRASTRUCTURE: diffusiondepth_amd/csrc/dd_wino.hip compiled for the host on top of the fiber shim in
-// hip/hip_runtime.h, behind a small C interface for ctypes (tests/test_wino_host_emulation.py).  Built with
-//   clang++ -std=c++17 -O1 -mf16c -DDD_HOST_EMULATION -I tests/host_emul -I diffusiondepth_amd/csrc -shared -fPIC wino_host.cpp
-// The kernels, their launchers (launch_conv_wino_layer, launch_conv_wino_raw, launch_wino_gn_table) and the weight packer (wino_pack_u) are
-// the product's own source; nothing here restates them.
-#include "dd_wino.hip"
-
-hostemu::Idx3 threadIdx, blockIdx, blockDim, gridDim;
-
-namespace dd {
-alignas(16) char smem[160 * 1024];      // the workgroup's LDS (`extern __shared__ char smem[]` inside the kernels binds to this)
-}
+// tests/host_emul/wino_host.cpp -- TEST INFRASTRUCTURE: a small C interface (ctypes, tests/test_wino_host_emulation.py) to the Winograd kernels'
+// launchers (launch_conv_wino_layer, launch_conv_wino_raw, launch_wino_gn_table) and weight packer (wino_pack_u) of
+// diffusiondepth_amd/csrc/dd_wino.hip inside the host-emulated library (ddepth_host.cpp).  Nothing here restates the product's code.
+#include "dd_elem.h"
 
 namespace {
 uint16_t cvt_f16(float f) { return (uint16_t)dd::f32_to_f16(f); }
@@ -17,15 +9,6 @@ uint16_t cvt_bf16(float f) { return (uint16_t)dd::f32_to_bf16(f); }
 }  // namespace
 
 extern "C" {
-
-// order: 0 = work-item 0 runs ahead, 1 = the last work-item runs ahead
-void emu_set_order(int order) { hostemu::st().order = order; }
-// 0: an LDS-DMA lands when it is issued; 1: only when an s_waitcnt retires it
-void emu_set_dma_late(int late) { hostemu::st().dma_late = late; }
-void emu_counters(unsigned long* block_barriers, unsigned long* wave_ops) {
-  *block_barriers = hostemu::st().n_block_barriers;
-  *wave_ops = hostemu::st().n_wave_ops;
-}
 
 long long emu_wino_pack_bytes(int cout, int cin) { return (long long)dd::wino_pack_bytes(cout, cin); }
 void emu_wino_pack(const float* w_oihw, int cout, int cin, int ek, uint16_t* out) {

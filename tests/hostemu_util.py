@@ -30,47 +30,6 @@ def have_f16c():
     return os.path.exists("/proc/cpuinfo") and "f16c" in open("/proc/cpuinfo").read()
 
 
-def _compile(cxx, csrc_dir, so, unit="wino_host.cpp"):
-    cmd = [cxx, "-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-I", EMU, "-I", csrc_dir,
-           "-shared", "-fPIC", os.path.join(EMU, unit), "-o", so + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        pytest.fail("host build of %s failed:\n%s" % (unit, r.stderr[-4000:]))
-    os.replace(so + ".tmp", so)
-
-
-def _bind(lib):
-    P = ctypes.c_void_p
-    lib.emu_wino_pack_bytes.restype = ctypes.c_longlong
-    lib.emu_wino_pack.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
-    lib.emu_wino_pack.restype = None
-    lib.emu_wino_table.argtypes = [P, P, P, P, P] + [ctypes.c_int] * 6 + [P]
-    lib.emu_wino_layer.argtypes = [ctypes.c_int] * 5 + [P] * 7 + [ctypes.c_int] * 3
-    lib.emu_set_order.argtypes = [ctypes.c_int]
-    lib.emu_set_dma_late.argtypes = [ctypes.c_int]
-    return lib
-
-
-def _build(unit="wino_host.cpp", kernel_sources=("dd_wino.hip",), env_override="DD_EMU_LIB"):
-    """Compile tests/host_emul/<unit> (which #includes the kernel sources) into build/host_emul/, cached by the hash of everything it reads."""
-    cxx = _clangxx()
-    if cxx is None:
-        pytest.skip("no clang++ (the kernels use clang vector extensions; g++ cannot compile them)")
-    srcs = [os.path.join(EMU, unit), os.path.join(EMU, "hip", "hip_runtime.h")] + [os.path.join(CSRC, f) for f in kernel_sources] + \
-           [os.path.join(CSRC, f) for f in ("dd_elem.h", "dd_kernels.h", "dd_gcn.h", "dd_igemm2_cfg.h")]
-    hsh = hashlib.sha1()
-    for s in srcs:
-        with open(s, "rb") as f:
-            hsh.update(f.read())
-    if os.environ.get(env_override):            # a hand-built variant (mutation experiments)
-        return ctypes.CDLL(os.environ[env_override])
-    os.makedirs(OUT, exist_ok=True)
-    so = os.path.join(OUT, "lib%s_%s.so" % (unit.split(".")[0], hsh.hexdigest()[:12]))
-    if not os.path.exists(so):
-        _compile(cxx, CSRC, so, unit)
-    return ctypes.CDLL(so)
-
-
 # ---- 16-bit element kinds and the channel-blocked activation layout of dd_elem.h ([B][C/32][h][w][32]) ---------------------------------------
 def to16(x, ek):
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -100,3 +59,114 @@ def ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
+
+
+# ---- the whole library for the host: every csrc source + the harness units of tests/host_emul ------------------------------------------------------
+LIB_SOURCES = ("dd_api.cpp", "dd_igemm.hip", "dd_igemm2.hip", "dd_igemm2ws.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip",
+               "dd_dcn.hip", "dd_wino.hip")
+HARNESS_UNITS = ("ddepth_host.cpp", "igemm2_host.cpp", "wino_host.cpp")
+_FLAGS = ["-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-fPIC", "-c"]
+
+
+def _cc(cxx, src, obj, incs):
+    cmd = [cxx] + _FLAGS + [a for i in incs for a in ("-I", i)] + [src, "-o", obj]
+    return subprocess.run(cmd, capture_output=True, text=True)
+
+
+def _objects():
+    """Compile (in parallel, cached by the hash of every input) all translation units; -> (cxx, {unit: object path})."""
+    from concurrent.futures import ThreadPoolExecutor
+    cxx = _clangxx()
+    if cxx is None:
+        pytest.skip("no clang++ (the kernels use clang vector extensions; g++ cannot compile them)")
+    if not have_f16c():
+        pytest.skip("host without F16C")
+    hsh = hashlib.sha1()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    deps += [os.path.join(EMU, u) for u in HARNESS_UNITS] + [os.path.join(EMU, "hip", "hip_runtime.h"),
+                                                              os.path.join(ROOT, "include", "ddepth.h"), os.path.join(ROOT, "include", "ddepth_dcn.h")]
+    for s in deps:
+        with open(s, "rb") as f:
+            hsh.update(f.read())
+    objdir = os.path.join(OUT, "obj_" + hsh.hexdigest()[:12])
+    if not os.path.isdir(objdir) and os.path.isdir(OUT):          # a new source state: drop the builds of older ones
+        for d in os.listdir(OUT):
+            if d.startswith("obj_"):
+                shutil.rmtree(os.path.join(OUT, d), ignore_errors=True)
+    os.makedirs(objdir, exist_ok=True)
+    units = [os.path.join(CSRC, f) for f in LIB_SOURCES] + [os.path.join(EMU, u) for u in HARNESS_UNITS]
+    objs = {os.path.basename(u): os.path.join(objdir, os.path.basename(u).rsplit(".", 1)[0] + ".o") for u in units}
+    todo = [u for u in units if not os.path.exists(objs[os.path.basename(u)])]
+    if todo:
+        def cc(src):
+            tmp = objs[os.path.basename(src)] + ".tmp.o"
+            r = _cc(cxx, src, tmp, [EMU, CSRC])
+            if r.returncode == 0:
+                os.replace(tmp, objs[os.path.basename(src)])
+            return src, r
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+            for src, r in ex.map(cc, todo):
+                if r.returncode != 0:
+                    pytest.fail("host build of %s failed:\n%s" % (src, r.stderr[-4000:]))
+    return cxx, objs, objdir
+
+
+def _link(cxx, objs, so):
+    r = subprocess.run([cxx, "-shared", "-fPIC", "-o", so + ".tmp"] + list(objs), capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.fail("host link failed:\n" + r.stderr[-4000:])
+    os.replace(so + ".tmp", so)
+
+
+def build_library():
+    """build/host_emul/obj_<hash>/libddepth_hostemu.so: the complete C ABI (include/ddepth.h, include/ddepth_dcn.h) plus the harness entry points
+    (emu_*) executing on the CPU.  DD_EMU_LIB=<path> substitutes a hand-built variant."""
+    if os.environ.get("DD_EMU_LIB"):
+        return ctypes.CDLL(os.environ["DD_EMU_LIB"])
+    cxx, objs, objdir = _objects()
+    so = os.path.join(objdir, "libddepth_hostemu.so")
+    if not os.path.exists(so):
+        _link(cxx, objs.values(), so)
+    return ctypes.CDLL(so)
+
+
+def build_mutant(unit, old, new, tmp_path, count=None):
+    """The library with ONE source file textually changed (old -> new): only that unit is recompiled.  For the tests that check that the
+    emulation notices a broken kernel."""
+    cxx, objs, _ = _objects()
+    src = open(os.path.join(CSRC, unit)).read()
+    n = src.count(old)
+    assert n >= 1 and (count is None or n == count), "mutation anchor not found %d times in %s: the source changed, update the test" % (n, unit)
+    d = os.path.join(str(tmp_path), "csrc")
+    os.makedirs(d, exist_ok=True)
+    mut = os.path.join(d, unit)
+    with open(mut, "w") as f:
+        f.write(src.replace(old, new))
+    obj = os.path.join(str(tmp_path), "mut.o")
+    r = _cc(cxx, mut, obj, [EMU, CSRC])            # the unchanged headers come from the real csrc directory
+    if r.returncode != 0:
+        pytest.fail("host build of the mutated %s failed:\n%s" % (unit, r.stderr[-4000:]))
+    so = os.path.join(str(tmp_path), "libmut.so")
+    _link(cxx, [obj if k == unit else o for k, o in objs.items()], so)
+    return ctypes.CDLL(so)
+
+
+def bind_wino(lib):
+    P = ctypes.c_void_p
+    lib.emu_wino_pack_bytes.restype = ctypes.c_longlong
+    lib.emu_wino_pack.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
+    lib.emu_wino_pack.restype = None
+    lib.emu_wino_table.argtypes = [P, P, P, P, P] + [ctypes.c_int] * 6 + [P]
+    lib.emu_wino_layer.argtypes = [ctypes.c_int] * 5 + [P] * 7 + [ctypes.c_int] * 3
+    lib.emu_set_order.argtypes = [ctypes.c_int]
+    lib.emu_set_dma_late.argtypes = [ctypes.c_int]
+    return lib
+
+
+def bind_igemm2(lib):
+    P = ctypes.c_void_p
+    lib.emu_set_order.argtypes = [ctypes.c_int]
+    lib.emu_set_dma_late.argtypes = [ctypes.c_int]
+    lib.emu_geom2.argtypes = [ctypes.c_int, ctypes.c_int, P]
+    lib.emu_conv2.argtypes = [ctypes.c_int, ctypes.c_int] + [P] * 11 + [ctypes.c_int] * 2 + [P] * 3 + [ctypes.c_int] * 4 + [P] * 3
+    return lib

@@ -11,16 +11,13 @@ and the results must be the same in all four combinations.  Test infrastructure 
 from __future__ import annotations
 
 import ctypes
-import os
-import shutil
 
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from hostemu_util import (CSRC, EK_BF16, EK_F16, GN_GROUPS, STAT_SLOTS, STAT_STRIDE, _build, _clangxx, _compile, blocked, from16, have_f16c, ptr,
-                          to16, unblocked)
+from hostemu_util import EK_BF16, EK_F16, GN_GROUPS, STAT_SLOTS, STAT_STRIDE, bind_igemm2, blocked, build_library, build_mutant, from16, ptr, to16, unblocked
 
 EK_F32 = 0
 P = ctypes.c_void_p
@@ -28,17 +25,7 @@ P = ctypes.c_void_p
 
 @pytest.fixture(scope="module")
 def emu():
-    if not have_f16c():
-        pytest.skip("host without F16C")
-    return _bind_igemm2(_build("igemm2_host.cpp", ("dd_igemm2.hip",), env_override="DD_EMU_IGEMM2_LIB"))
-
-
-def _bind_igemm2(lib):
-    lib.emu_set_order.argtypes = [ctypes.c_int]
-    lib.emu_set_dma_late.argtypes = [ctypes.c_int]
-    lib.emu_geom2.argtypes = [ctypes.c_int, ctypes.c_int, P]
-    lib.emu_conv2.argtypes = [ctypes.c_int, ctypes.c_int] + [P] * 11 + [ctypes.c_int] * 2 + [P] * 3 + [ctypes.c_int] * 4 + [P] * 3
-    return lib
+    return bind_igemm2(build_library())
 
 
 def esz(ek):
@@ -273,16 +260,7 @@ def test_emulation_catches_a_lax_counted_wait(emu, tmp_path):
     `s_waitcnt vmcnt(NRAW)` leaves exactly the NRAW raw-patch loads in flight and so retires the weight DMA issued before them.  With
     NRAW + 1 the wave's last DMA piece may still be in flight at the barrier: only the late-landing model can see that, and it must."""
     old = "      DD_WAIT_VM_LGKM0(NRAW);\n    } else if (PF_HERE"
-    src = open(os.path.join(CSRC, "dd_igemm2.hip")).read()
-    assert src.count(old) == 1, "mutation anchor not found: dd_igemm2.hip changed, update this test"
-    d = tmp_path / "csrc"
-    d.mkdir()
-    for f in ("dd_elem.h", "dd_kernels.h", "dd_gcn.h", "dd_igemm2_cfg.h"):
-        shutil.copy(os.path.join(CSRC, f), d / f)
-    (d / "dd_igemm2.hip").write_text(src.replace(old, "      DD_WAIT_VM_LGKM0(NRAW + 1);\n    } else if (PF_HERE"))
-    so = str(tmp_path / "libmut.so")
-    _compile(_clangxx(), str(d), so, "igemm2_host.cpp")
-    mut = _bind_igemm2(ctypes.CDLL(so))
+    mut = bind_igemm2(build_mutant("dd_igemm2.hip", old, "      DD_WAIT_VM_LGKM0(NRAW + 1);\n    } else if (PF_HERE", tmp_path, count=1))
     run_layer(mut, 3, EK_F16, order=0, late=0)              # DMA lands at issue: the lax wait is invisible
     with pytest.raises(AssertionError):
         run_layer(mut, 3, EK_F16, order=0, late=1)          # DMA lands as late as the waits allow: stale weights

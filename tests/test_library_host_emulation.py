@@ -1,0 +1,316 @@
+"""The WHOLE library on the CPU: every source file of diffusiondepth_amd/csrc compiled for the host (tests/host_emul) and driven through the
+same C ABI the product binds (include/ddepth.h, include/ddepth_dcn.h), against the reference-minted golden vectors (tests/golden) and the
+fp64 oracle.  This is the product's own code -- dd_api.cpp's plans, graph capture (recorded and replayed), option plumbing, weight packing,
+every kernel -- executed work-item by work-item under the adversarial schedules of tests/host_emul/hip/hip_runtime.h.  It is
+how the parts that have had no GPU time yet (the Winograd options end to end) are exercised before their first GPU contact, and it keeps the
+kernels' logic under test in the CPU suite of every round; "device" memory is handed out filled with NaN patterns, so a read of anything the
+library did not write shows up.
+
+Default: a lean set (about one and a half minutes with the build).  DD_EMU_FULL=1 adds the fp32 runs of the larger golden cases (5-step loop with
+the 1e-3 depth gate, Swin single call, fused backward) and more option combinations (three more minutes).
+Test infrastructure only: the product never loads this build (diffusiondepth_amd/backend.py takes GPU tensors only)."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import synth
+from hostemu_driver import EmuDenoiser, _p, f32
+from hostemu_util import build_library
+from oracle import dcn_oracle as DO
+from oracle import ddim_oracle as O
+
+FULL = os.environ.get("DD_EMU_FULL") == "1"
+full_only = pytest.mark.skipif(not FULL, reason="larger emulation case: set DD_EMU_FULL=1")
+LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16": 1.5e-3, "bf16": 1e-2}        # x max|x_0|: the GPU parity tests' own bounds
+EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return build_library()
+
+
+_cache = {}
+
+
+def backend_for(lib, c):
+    key = (c["wseed"], c.get("variant", "res"), c.get("decoder_gain", 0.05), c.get("decoder_log_scale", 0.0))
+    if key not in _cache:
+        be = EmuDenoiser(lib, c.get("variant", "res"))
+        sd = synth.make_state_dict(c["wseed"], c.get("variant", "res"), c.get("decoder_gain", 0.05), c.get("decoder_log_scale", 0.0))
+        be.load_state_dict(sd)
+        be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+        _cache[key] = (be, sd)
+    be, sd = _cache[key]
+    for k in ("winograd", "winograd_dma", "wave_spec", "hoist_cond"):
+        be.set_option(k, 0)
+    be.set_option("kernel_version", 2)
+    be.timing(0, 0)
+    return be, sd
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+# ---- the denoiser against the reference's golden vectors ----------------------------------------------------------------------------------------
+def test_library_reports_itself_and_fails_loudly(lib, cases):
+    be, _ = backend_for(lib, cases["denoise_res"])
+    assert b"gfx950" in lib.dd_version()
+    with pytest.raises(RuntimeError):
+        be.set_option("no_such_option", 1)
+    fresh = EmuDenoiser(lib, "res")
+    with pytest.raises(RuntimeError, match="not committed"):
+        fresh.denoise(np.zeros((1, 16, 8, 8)), np.zeros((1, 256, 8, 8)), 2)
+    fresh.close()
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16"] + (["bf16", "naive_fp32"] if FULL else []))
+def test_single_denoiser_call_vs_reference_golden(lib, golden, cases, prec):
+    c, g = cases["denoise_res"], golden("denoise_res")
+    be, _ = backend_for(lib, c)
+    be.timing(order=1, dma_late=1)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    eps_b = be.denoise_once(inp["x_T"], inp["timesteps"], inp["cond"], prec)
+    assert eps_b.min() >= 0.0
+    assert maxabs(eps_b, g["eps_batch_t"]) < EPS_TOL[prec]
+    if FULL:
+        assert maxabs(be.denoise_once(inp["x_T"], c["t"], inp["cond"], prec), g["eps_scalar_t"]) < EPS_TOL[prec]
+
+
+def test_codec_and_add_noise_vs_reference_golden(lib, golden, cases):
+    c, g = cases["codec"], golden("codec")
+    be, _ = backend_for(lib, c)
+    for i, (B, H, W) in enumerate(c["sizes"]):
+        lat = be.encode(synth.make_gt_depth(c["iseed"] + i, B, H, W))
+        assert lat.shape == g[f"latent_{i}"].shape and maxabs(lat, g[f"latent_{i}"]) < 2e-5
+        h, w = synth.latent_hw(H, W)
+        z = np.random.RandomState(c["iseed"] + 100 + i).standard_normal((B, 16, h, w)).astype(np.float32) * c["latent_scale"]
+        d, dref = be.decode(z), g[f"depth_{i}"]
+        assert d.shape == dref.shape and float((np.abs(d - dref) / np.maximum(np.abs(dref), 1e-2)).max()) < 5e-5
+    cs, gs = cases["sched"], golden("sched")
+    rs = np.random.RandomState(cs["seed"])
+    rs.standard_normal(cs["shape"]); rs.standard_normal(cs["shape"])
+    B = len(cs["add_noise_t"])
+    x0 = rs.standard_normal((B,) + tuple(cs["shape"][1:])).astype(np.float32)
+    nz = rs.standard_normal((B,) + tuple(cs["shape"][1:])).astype(np.float32)
+    t = np.asarray(cs["add_noise_t"], np.int64)
+    out = np.full_like(x0, np.nan)
+    be.ck(lib.dd_add_noise(be.h, _p(x0), _p(nz), _p(t), _p(out), B, 16, x0.shape[2], x0.shape[3], None), "dd_add_noise")
+    assert maxabs(out, gs["add_noise"]) < 1e-6
+
+
+@pytest.mark.parametrize("prec", ["f16"] + (["fp32"] if FULL else []))
+def test_ddim_loop_vs_reference_golden(lib, golden, cases, prec):
+    c, g = cases["loop_res"], golden("loop_res")
+    be, _ = backend_for(lib, c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    x0 = be.denoise(inp["x_T"], inp["cond"], 5, prec)
+    ref = g["x0_T5"]
+    assert maxabs(x0, ref) < LATENT_TOL[prec] * np.abs(ref).max()
+    if prec == "fp32":
+        assert maxabs(be.decode(x0), g["depth_T5"]) < 1e-3                # the north-star tolerance on predicted depth
+
+
+# ---- the loop against the oracle, every kernel family and option ----------------------------------------------------------------------------------
+LOOP = dict(B=1, h=9, w=33, T=2)
+
+
+def _loop_case(lib, variant="res", cond_hw=None, **kw):
+    be, sd = backend_for(lib, {"wseed": 7244 if variant == "res" else 7245, "variant": variant})
+    p = dict(LOOP, **kw)
+    inp = synth.make_inputs(100 + p["h"], p["B"], p["h"], p["w"], cond_hw)
+    ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], p["T"], variant)
+    return be, inp, ref, p["T"]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "f16", "bf16"])
+def test_res_loop_vs_oracle_late_dma_last_wave_ahead(lib, prec):
+    be, inp, ref, T = _loop_case(lib, B=2 if (prec == "fp32" and FULL) else 1)
+    be.timing(order=1, dma_late=1)
+    x0 = be.denoise(inp["x_T"], inp["cond"], T, prec)
+    assert np.isfinite(x0).all() and maxabs(x0, ref) < LATENT_TOL[prec] * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("wino,dma,order", [(4, 0, 0), (5, 1, 1)])
+def test_res_loop_winograd_options_end_to_end(lib, wino, dma, order):
+    """options "winograd" 4 / 5 (conv2 + conv3 through dd_wino.hip: GroupNorm table kernel, prologue, statistics epilogue, weight packing,
+    all of dd_api.cpp's plumbing) have never run on a GPU: here they run end to end.  f16; the bound is the f16 loop bound."""
+    be, inp, ref, T = _loop_case(lib)
+    n0 = lib.emu_launch_count()
+    direct = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+    n_direct = lib.emu_launch_count() - n0
+    be.set_option("winograd", wino)
+    be.set_option("winograd_dma", dma)
+    be.timing(order=order, dma_late=dma)
+    n0 = lib.emu_launch_count()
+    x0 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+    assert lib.emu_launch_count() - n0 > n_direct, "the Winograd path adds its table kernels: it was not taken"
+    scale = np.abs(ref).max()
+    assert maxabs(x0, ref) < LATENT_TOL["f16"] * scale
+    assert maxabs(x0, direct) > 0.0                                   # and it is a different computation
+
+
+@pytest.mark.parametrize("opt", ["kernel_version_1", "wave_spec", "hoist_cond"])
+def test_res_loop_other_kernel_families(lib, opt):
+    """dd_igemm.hip (v1), the wave-specialised dd_igemm2ws.hip (its own LDS-DMA ring and counted waits: late landing) and the hoisted condition term"""
+    be, inp, ref, T = _loop_case(lib)
+    if opt == "kernel_version_1":
+        be.set_option("kernel_version", 1)
+    else:
+        be.set_option(opt, 1)
+    be.timing(order=1, dma_late=1)
+    x0 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+    assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("wino,dma", [(0, 0), (3, 1)] + ([(2, 0), (5, 1)] if FULL else []))
+def test_swin_loop_vs_oracle(lib, wino, dma):
+    be, inp, ref, T = _loop_case(lib, "swin", cond_hw=(3, 9), h=5, w=17, T=1)
+    be.set_option("winograd", wino)
+    be.set_option("winograd_dma", dma)
+    be.timing(order=dma, dma_late=dma)
+    x0 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+    assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
+
+
+@full_only
+def test_swin_single_call_vs_reference_golden(lib, golden, cases):
+    c, g = cases["denoise_swin"], golden("denoise_swin")
+    be, _ = backend_for(lib, c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], tuple(c["cond_hw"]))
+    assert maxabs(be.denoise_once(inp["x_T"], inp["timesteps"], inp["cond"], "fp32"), g["eps_batch_t"]) < EPS_TOL["fp32"]
+
+
+# ---- condition aggregation (FPN) ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32"] + (["f16"] if FULL else []))
+def test_fpn_condition_vs_oracle(lib, prec):
+    be, _ = backend_for(lib, {"wseed": 7240})
+    fsd = synth.make_fpn_state_dict(7241)
+    be.load_state_dict(fsd)
+    rs = np.random.RandomState(5)
+    H, W = 11, 19
+    fp = []
+    for i, cch in enumerate((64, 128, 256, 512)):
+        fp.append(rs.standard_normal((1, cch, (H + (1 << i) - 1) >> i, (W + (1 << i) - 1) >> i)).astype(np.float32))
+    ref = O.fpn_aggregate(fsd, fp)
+    be.timing(order=1, dma_late=1)
+    out = be.condition(fp, prec)
+    assert maxabs(out, ref) < (2e-5 if prec == "fp32" else 2e-2) * np.abs(ref).max()
+
+
+# ---- backward ----------------------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["naive_fp32"] + (["fp32"] if FULL else []))
+def test_backward_vs_reference_autograd_golden(lib, golden, cases, prec):
+    c, g = cases["denoise_bwd_res"], golden("denoise_bwd_res")
+    be, _ = backend_for(lib, c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    ge = np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32)
+    be.ck(lib.dd_zero_grad(be.h, None), "dd_zero_grad")
+    x, cond, t = f32(inp["x_T"]), f32(inp["cond"]), np.ascontiguousarray(inp["timesteps"], np.int64)
+    gx, gc = np.full_like(x, np.nan), np.full_like(cond, np.nan)
+    B, _, h, w = x.shape
+    be.timing(order=1, dma_late=1)
+    be.ck(lib.dd_denoise_once_backward(be.h, _p(x), _p(t), _p(cond), _p(ge), _p(gx), _p(gc), B, h, w, h, w, dda.backend.precision_id(prec), None),
+          "dd_denoise_once_backward")
+    assert maxabs(gx, g["grad_x"]) < 1e-4 * np.abs(g["grad_x"]).max()
+    assert maxabs(gc[:, :8], g["grad_cond_ch0_8"]) < 1e-4 * np.abs(g["grad_cond_ch0_8"]).max()
+    for name in ("model.pred.0.weight", "model.noise_embedding.1.weight"):
+        key = "grad." + name
+        if key in g:
+            out = np.full(g[key].shape, np.nan, np.float32)
+            be.ck(lib.dd_get_grad(be.h, name.encode(), _p(out), out.size, None), "dd_get_grad")
+            assert maxabs(out, g[key]) < 1e-4 * np.abs(g[key]).max(), name
+
+
+# ---- NLSPN refinement and the DCNv2 operator (include/ddepth_dcn.h) ------------------------------------------------------------------------------
+def _bind_dcn(lib):
+    c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+    lib.dd_dcn_last_error.restype = ctypes.c_char_p
+    lib.dd_dcn_forward.argtypes = [c_vp] * 6 + [c_int] * 16 + [c_vp]
+    lib.dd_dcn_backward.argtypes = [c_vp] * 11 + [c_int] * 16 + [c_vp]
+    lib.dd_nlspn_offset_affinity.argtypes = [c_vp] * 7 + [c_int] * 7 + [c_vp]
+    lib.dd_nlspn_guided_offset_affinity.argtypes = [c_vp] * 9 + [c_int] * 9 + [c_vp]
+    lib.dd_nlspn_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_int64)]
+    lib.dd_nlspn_propagate.argtypes = [c_vp] * 8 + [c_int] * 6 + [c_vp]
+    return lib
+
+
+@pytest.mark.parametrize("name", ["groups", "dg_stride", "k1"])
+def test_dcn_forward_backward_vs_reference_golden(lib, golden, name):
+    _bind_dcn(lib)
+    g = golden("dcn_" + name)
+    sh, sw, ph, pw, dh, dw, grp, dg, step = [int(v) for v in g["meta"]]
+    x, w, b, off, m, go = (f32(g[k]) for k in ("input", "weight", "bias", "offset", "mask", "grad_out"))
+    B, C, H, W = x.shape
+    Co, _, kh, kw = w.shape
+    y = np.full(g["out"].shape, np.nan, np.float32)
+    geo = (B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, grp, dg, step)
+    assert lib.dd_dcn_forward(_p(x), _p(w), _p(b), _p(off), _p(m), _p(y), *geo, None) == 0, lib.dd_dcn_last_error()
+    tol = 2e-5
+    assert maxabs(y, g["out"]) < tol * np.abs(g["out"]).max()
+    grads = [np.full(t.shape, np.nan, np.float32) for t in (x, off, m, w, b)]
+    assert lib.dd_dcn_backward(_p(x), _p(w), _p(b), _p(off), _p(m), _p(go), *[_p(t) for t in grads], *geo, None) == 0, lib.dd_dcn_last_error()
+    for k, v in zip(("g_input", "g_offset", "g_mask", "g_weight", "g_bias"), grads):
+        assert maxabs(v, g[k]) < tol * max(1e-6, np.abs(g[k]).max()), k
+
+
+AFFINITY_ID = {"AS": 0, "ASS": 1, "TC": 2, "TGASS": 3}
+
+
+@pytest.mark.parametrize("name", ["tgass", "preserve", "k5"] + (["as_noconf", "tc_legacy"] if FULL else []))
+def test_nlspn_refinement_vs_reference_golden(lib, golden, name):
+    """conv_offset_aff (fp64 on the host here) -> dd_nlspn_offset_affinity -> dd_nlspn_propagate, against the goldens minted by the reference's NLSPN"""
+    _bind_dcn(lib)
+    g = golden("nlspn_" + name)
+    B, H, W, ch_g, k_f, T, cp, pi, lg = [int(v) for v in g["meta"]]
+    affinity = str(g["affinity"]) if "affinity" in g else None
+    if affinity is None or affinity not in AFFINITY_ID:
+        affinity = {"tgass": "TGASS", "preserve": "TGASS", "k5": "TGASS", "as_noconf": "AS", "tc_legacy": "TC"}[name]
+    num = k_f * k_f - 1
+    oa = O.conv2d(g["guidance"].astype(np.float64), g["conv_weight"].astype(np.float64), g["conv_bias"].astype(np.float64)).astype(np.float32)
+    oa = np.ascontiguousarray(oa)
+    conf = f32(g["confidence"]) if cp else None
+    offset = np.full((B, 2 * (num + 1), H, W), np.nan, np.float32)
+    aff = np.full((B, num + 1, H, W), np.nan, np.float32)
+    scale_c, w_conf, b_conf = f32(g["aff_const"]), np.ones(1, np.float32), np.zeros(1, np.float32)
+    rc = lib.dd_nlspn_offset_affinity(_p(oa), _p(conf), _p(scale_c), _p(w_conf), _p(b_conf), _p(offset), _p(aff), B, H, W, k_f, AFFINITY_ID[affinity],
+                                      cp, lg, None)
+    assert rc == 0, lib.dd_dcn_last_error()
+    assert maxabs(offset, g["offset"]) < 2e-5 and maxabs(aff, g["aff"]) < 1e-5
+    feats = np.full((T, B, 1, H, W), np.nan, np.float32)
+    ws = None
+    if pi:
+        nb = ctypes.c_int64()
+        assert lib.dd_nlspn_workspace_bytes(B, H, W, 1, ctypes.byref(nb)) == 0
+        ws = np.zeros(nb.value // 4, np.float32)
+    w1, b1 = np.ones(k_f * k_f, np.float32), np.zeros(1, np.float32)
+    rc = lib.dd_nlspn_propagate(_p(f32(g["feat_init"])), _p(offset), _p(aff), _p(f32(g["feat_fix"])) if pi else None, _p(w1), _p(b1), _p(feats), _p(ws),
+                                B, H, W, k_f, T, pi, None)
+    assert rc == 0, lib.dd_dcn_last_error()
+    assert maxabs(feats, g["y_inter"]) < 2e-5 * np.abs(g["y_inter"]).max()
+
+
+def test_nlspn_guided_affinity_kernel_vs_oracle(lib):
+    """dd_nlspn_guided_offset_affinity (conv_offset_aff fused into the affinity kernel: LDS guidance tile + barrier) against the NumPy oracle"""
+    _bind_dcn(lib)
+    rs = np.random.RandomState(17)
+    B, H, W = 2, 13, 37
+    guide = rs.standard_normal((B, 8, H, W)).astype(np.float32)
+    cw = (0.2 * rs.standard_normal((24, 8, 3, 3))).astype(np.float32)
+    cb = (0.1 * rs.standard_normal(24)).astype(np.float32)
+    conf = rs.uniform(0, 1, (B, 1, H, W)).astype(np.float32)
+    scale_c, w_conf, b_conf = np.full(1, 4.0, np.float32), np.ones(1, np.float32), np.zeros(1, np.float32)
+    oa = O.conv2d(guide.astype(np.float64), cw.astype(np.float64), cb.astype(np.float64))
+    ro, ra = DO.nlspn_offset_affinity(oa, conf.astype(np.float64), 4.0, "TGASS", 3, True, False)
+    offset = np.full((B, 18, H, W), np.nan, np.float32)
+    aff = np.full((B, 9, H, W), np.nan, np.float32)
+    rc = lib.dd_nlspn_guided_offset_affinity(_p(guide), _p(cw), _p(cb), _p(conf), _p(scale_c), _p(w_conf), _p(b_conf), _p(offset), _p(aff),
+                                             B, 8, H, W, 3, 3, AFFINITY_ID["TGASS"], 1, 0, None)
+    assert rc == 0, lib.dd_dcn_last_error()
+    assert maxabs(offset, ro) < 5e-5 and maxabs(aff, ra) < 2e-5

@@ -10,26 +10,18 @@ conflicts, and the hardware's own timing of asynchronous copies.
 Test infrastructure only (like oracle/): nothing in the product path uses the host build."""
 from __future__ import annotations
 
-import ctypes
-import hashlib
-import os
-import shutil
-import subprocess
 
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from hostemu_util import (CSRC, have_f16c, EK_BF16, EK_F16, GN_GROUPS, STAT_SLOTS, STAT_STRIDE, _bind, _build, _clangxx, _compile, blocked, from16, ptr,
-                          to16, unblocked)
+from hostemu_util import EK_BF16, EK_F16, GN_GROUPS, STAT_SLOTS, STAT_STRIDE, bind_wino, blocked, build_library, build_mutant, from16, ptr, to16, unblocked
 
 
 @pytest.fixture(scope="module")
 def emu():
-    if not have_f16c():
-        pytest.skip("host without F16C")
-    return _bind(_build())
+    return bind_wino(build_library())
 
 
 LAYERS = {  # layer: (cin, cout, prologue, statistics)     dd_wino.hip launch_wino_layer_ek
@@ -183,20 +175,10 @@ MUTATIONS = {
 
 @pytest.mark.parametrize("name", list(MUTATIONS))
 def test_emulation_catches_mutation(emu, name, tmp_path):
-    """without this the 14 green cases above would prove little: the same cases must go red when the kernel is broken in the ways the emulation
+    """without this the green cases above would prove little: the same cases must go red when the kernel is broken in the ways the emulation
     is meant to catch (a wave that runs ahead past a missing barrier; an LDS image read differently from how it was written)"""
-    cxx = _clangxx()
     old, new = MUTATIONS[name]
-    src = open(os.path.join(CSRC, "dd_wino.hip")).read()
-    assert src.count(old) >= 1, "mutation anchor not found: dd_wino.hip changed, update MUTATIONS"
-    d = tmp_path / "csrc"
-    d.mkdir()
-    for f in ("dd_elem.h", "dd_kernels.h", "dd_gcn.h"):
-        shutil.copy(os.path.join(CSRC, f), d / f)
-    (d / "dd_wino.hip").write_text(src.replace(old, new))
-    so = str(tmp_path / "libmut.so")
-    _compile(cxx, str(d), so)
-    mut = _bind(ctypes.CDLL(so))
+    mut = bind_wino(build_mutant("dd_wino.hip", old, new, tmp_path))
     bad = 0
     for order in (0, 1):
         try:
