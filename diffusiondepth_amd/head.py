@@ -114,6 +114,11 @@ class DDIMDepthEstimate_Res(nn.Module):
         return x
 
     def forward(self, fp, depth_map, depth_mask, gt_depth_map=None, return_loss=False, **kwargs):
+        # parameters do not change inside one forward: verify / upload them once, not in front of each of its ~7 library calls
+        with self._bound.hold():
+            return self._forward(fp, depth_map, depth_mask, gt_depth_map=gt_depth_map, return_loss=return_loss, **kwargs)
+
+    def _forward(self, fp, depth_map, depth_mask, gt_depth_map=None, return_loss=False, **kwargs):
         if self.detach_fp is not False and self.detach_fp is not None:
             if isinstance(self.detach_fp, (list, tuple, range)):
                 fp = list(fp)

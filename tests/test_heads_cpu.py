@@ -59,3 +59,61 @@ def test_hahi_attention_is_refused_like_the_reference_cannot_run_it():
     n = dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, cross_att=False, self_att=False)
     with pytest.raises(NotImplementedError):
         n.multi_att(torch.zeros(1, 4, 16))
+
+
+class _FakeBackend:
+    """Stands in for HipDenoiser in the host-logic test below: records uploads, no device work."""
+
+    def __init__(self, device):
+        self.device = device
+        self.uploads = 0
+        self.schedules = 0
+
+    def load_state_dict(self, sd):
+        self.uploads += 1
+        self.keys = sorted(sd)
+
+    def set_schedule(self, acp):
+        self.schedules += 1
+
+
+def test_hipbound_uploads_on_change_and_checks_once_per_held_scope(monkeypatch):
+    """HipBound (modules.py): parameters reach the library when -- and only when -- a registered tensor changed (in-place update,
+    replaced storage); inside ``hold()`` (= one head.forward) the ~80-tensor walk runs once, not in front of every library call."""
+    head = dda.DDIMDepthEstimate_Res(precision="bf16", inference_steps=5).eval()
+    b = head._bound
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(b, "_make_backend", lambda dev: _FakeBackend(dev))
+    walks = []
+    real_sig = b._signature
+    monkeypatch.setattr(b, "_signature", lambda: (walks.append(1), real_sig())[1])
+    be = b.ensure("cuda:0", head.scheduler)
+    assert (be.uploads, be.schedules, len(walks)) == (1, 1, 1)
+    assert "model.pred.0.weight" in be.keys and "depth_transform.conv_inv_transform.0.weight" in be.keys and "conv_lateral.3.0.weight" in be.keys
+    b.ensure("cuda:0", head.scheduler)
+    assert (be.uploads, be.schedules, len(walks)) == (1, 1, 2)                  # unchanged: walked again, nothing uploaded
+    with torch.no_grad():
+        head.model.pred[0].weight.mul_(0.5)                                     # optimizer-style in-place update
+    b.ensure("cuda:0")
+    assert be.uploads == 2
+    head.model.time_embedding.weight.data = head.model.time_embedding.weight.data.clone()      # storage replaced (.to(), .data = ...)
+    b.ensure("cuda:0")
+    assert be.uploads == 3
+    head.conv_lateral[0][1].running_mean.add_(1.0)                              # buffers count too (BatchNorm statistics)
+    b.ensure("cuda:0")
+    assert be.uploads == 4
+    n = len(walks)
+    with b.hold():
+        for _ in range(5):
+            assert b.ensure("cuda:0", head.scheduler) is be
+        with b.hold():                                                          # re-entrant (a head calling a sub-module's forward)
+            b.ensure("cuda:0")
+        b.ensure("cuda:0")
+    assert len(walks) == n + 1 and be.uploads == 4
+    with torch.no_grad():
+        head.model.pred[3].bias.add_(1.0)
+    with b.hold():
+        b.ensure("cuda:0")
+    assert be.uploads == 5 and len(walks) == n + 2                              # a new scope looks again
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        b.ensure("cpu")
