@@ -132,7 +132,8 @@ def test_ragged_sizes_and_batch_vs_oracle(U, prec):
     c = {"wseed": 7244}
     be = U.backend_for(c)
     sd = U.sd_for(c)
-    for (B, h, w, T) in [(3, 9, 33, 3), (1, 1, 1, 2), (2, 17, 5, 3), (1, 8, 32, 2), (1, 40, 70, 2)]:
+    for (B, h, w, T) in [(3, 9, 33, 3), (1, 1, 1, 2), (2, 17, 5, 3), (1, 8, 32, 2), (1, 40, 70, 2),
+                         (1, 8, 19, 7), (1, 8, 19, 1)]:      # step counts that do not divide 1000 (ratio 142), a single step
         inp = synth.make_inputs(100 + h, B, h, w)
         x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), T, prec).cpu().numpy()
         ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], T)

@@ -137,6 +137,20 @@ def test_res_loop_vs_oracle_late_dma_last_wave_ahead(lib, prec):
     assert np.isfinite(x0).all() and maxabs(x0, ref) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("T", [1, 3, 7])
+def test_step_counts_that_do_not_divide_the_training_schedule(lib, T):
+    """The reference takes any --inference_steps: timesteps = (arange(T) * (1000 // T))[::-1], prev = t - 1000 // T, final alpha 1.0
+    (scheduling_ddim.py:215-229,285-289).  T = 1 (single step from t = 0), 3 (ratio 333) and 7 (ratio 142) through the plan's
+    (c1, c2) / timestep tables and the graph of that length, against the oracle's literal scheduler.step."""
+    be, inp, ref, _ = _loop_case(lib, h=8, w=19, T=T)
+    x0 = be.denoise(inp["x_T"], inp["cond"], T, "fp32")
+    assert np.isfinite(x0).all() and maxabs(x0, ref) < LATENT_TOL["fp32"] * max(np.abs(ref).max(), 1.0)
+    with pytest.raises(RuntimeError, match="num_inference_steps"):
+        be.denoise(inp["x_T"], inp["cond"], 0, "fp32")
+    with pytest.raises(RuntimeError, match="num_inference_steps"):
+        be.denoise(inp["x_T"], inp["cond"], 1001, "fp32")
+
+
 @pytest.mark.parametrize("wino,dma,order", [(4, 0, 0), (5, 1, 1)])
 def test_res_loop_winograd_options_end_to_end(lib, wino, dma, order):
     """options "winograd" 4 / 5 (conv2 + conv3 through dd_wino.hip: GroupNorm table kernel, prologue, statistics epilogue, weight packing,
