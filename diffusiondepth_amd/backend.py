@@ -17,9 +17,9 @@ VARIANTS = {"res": 0, "swin": 1}
 
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_commit_weights",
+    "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_set_weight_device", "dd_commit_weights",
     "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_trace", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
-    "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch", "dd_debug_wino_pack",
+    "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch", "dd_debug_weights_digest", "dd_debug_wino_pack",
 ]
 
 
@@ -46,6 +46,7 @@ def abi_signatures():
         "dd_last_error": (c_cp, [c_vp]),
         "dd_version": (c_cp, []),
         "dd_set_weight": (c_int, [c_vp, c_cp, c_vp, c_i64]),
+        "dd_set_weight_device": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
         "dd_commit_weights": (c_int, [c_vp, c_vp]),
         "dd_set_schedule": (c_int, [c_vp, c_vp, c_int]),
         "dd_condition": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_vp, c_int, c_vp]),
@@ -64,6 +65,7 @@ def abi_signatures():
         "dd_get_counter": (c_int, [c_vp, c_cp, ctypes.POINTER(c_i64)]),
         "dd_get_layer_ms": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
         "dd_debug_fetch": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
+        "dd_debug_weights_digest": (c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
         "dd_debug_wino_pack": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_i64]),
     }
 
@@ -176,31 +178,55 @@ class HipDenoiser:
         return float(tot.value), int(cnt.value)
 
     # -- parameters ---------------------------------------------------------------------------
-    def load_state_dict(self, sd: Dict[str, object], prefix: str = ""):
+    def load_state_dict(self, sd: Dict[str, object], prefix: str = "", device_route: Optional[bool] = None):
         """sd: {key: tensor | ndarray} using the reference's key names below ``prefix`` (e.g.
-        'depth_head.').  Keys the library does not own (backbone, convup_fp, num_batches_tracked) are ignored."""
+        'depth_head.').  Keys the library does not own (backbone, convup_fp, num_batches_tracked) are ignored.  ``sd`` may hold any
+        subset of the three parameter groups (model.* / depth_transform.* / conv_lateral.* + conv_up.*); each group must be complete.
+
+        device_route: denoiser parameters (model.*) that are tensors on this device go to the library without leaving HBM
+        (dd_set_weight_device: fp32 -> kernel layouts by pack kernels) instead of D2H copy + host-side packing -- what a training loop
+        needs after every optimizer.step().  None = the environment variable DDEPTH_DEVICE_WEIGHTS (default "0": the route has been
+        validated against the host packer bit for bit under host emulation, not yet on a GPU)."""
         torch = _torch()
+        if device_route is None:
+            device_route = os.environ.get("DDEPTH_DEVICE_WEIGHTS", "0") == "1"
         n = 0
         owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.")
-        saw_fpn = False
-        for k, v in sd.items():
-            if not k.startswith(prefix):
-                continue
-            name = k[len(prefix):]
-            if not name.startswith(owned) or name.endswith("num_batches_tracked"):
-                continue
-            saw_fpn = saw_fpn or name.startswith("conv_")
-            if isinstance(v, torch.Tensor):
-                v = v.detach().to("cpu", torch.float32).contiguous().numpy()
-            a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
-            self._ck(self._lib.dd_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
-                     f"dd_set_weight({name})")
-            n += 1
-        self._ck(self._lib.dd_commit_weights(self._h, ctypes.c_void_p(_stream_ptr(self.device))), "dd_commit_weights")
-        self._have_weights = True
+        saw_fpn = saw_model = False
+        stream = ctypes.c_void_p(_stream_ptr(self.device))
+        with torch.cuda.device(self.device):
+            for k, v in sd.items():
+                if not k.startswith(prefix):
+                    continue
+                name = k[len(prefix):]
+                if not name.startswith(owned) or name.endswith("num_batches_tracked"):
+                    continue
+                saw_fpn = saw_fpn or name.startswith("conv_")
+                saw_model = saw_model or name.startswith("model.")
+                if device_route and name.startswith("model.") and isinstance(v, torch.Tensor) and v.device == self.device:
+                    d = v.detach().to(torch.float32).contiguous()      # no-op for fp32 parameters; a temporary otherwise (same stream)
+                    self._ck(self._lib.dd_set_weight_device(self._h, name.encode(), d.data_ptr(), d.numel(), stream),
+                             f"dd_set_weight_device({name})")
+                    n += 1
+                    continue
+                if isinstance(v, torch.Tensor):
+                    v = v.detach().to("cpu", torch.float32).contiguous().numpy()
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.float32))
+                self._ck(self._lib.dd_set_weight(self._h, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.size),
+                         f"dd_set_weight({name})")
+                n += 1
+            self._ck(self._lib.dd_commit_weights(self._h, stream), "dd_commit_weights")
+        self._have_weights = self._have_weights or saw_model
         self._have_fpn = self._have_fpn or saw_fpn
         self._cond_token = None
         return n
+
+    def weights_digest(self) -> int:
+        """Test hook (dd_debug_weights_digest): digest of every packed denoiser weight buffer in HBM."""
+        d = ctypes.c_uint64()
+        with _torch().cuda.device(self.device):
+            self._ck(self._lib.dd_debug_weights_digest(self._h, ctypes.byref(d)), "dd_debug_weights_digest")
+        return int(d.value)
 
     def set_schedule(self, alphas_cumprod):
         torch = _torch()

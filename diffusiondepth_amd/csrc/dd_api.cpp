@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -141,6 +142,8 @@ struct dd_handle_s {
   int variant = DD_VARIANT_RES;
   std::string err;
   std::map<std::string, std::vector<float>> host_w;
+  std::map<std::string, std::unique_ptr<DevBuf>> dev_w;   // dd_set_weight_device: fp32 device copies (denoiser group)
+  std::set<std::string> dev_newer;                        // names whose device copy is newer than host_w's (or that have no host copy)
   bool committed = false;      // denoiser group (model.*) packed
   bool codec_committed = false; // codec group (depth_transform.*) packed
   ConvLayer L[4];
@@ -565,7 +568,10 @@ int enqueue_loop_body(dd_handle_t h, Plan* pl, hipStream_t s) {
 
 // Winograd weight images for the experimental kernels of dd_wino.hip (conv2, conv3 / Swin pred.0, Swin convA / convB; bf16 and f16).
 // Built only while option "winograd" is on -- the default path never executes this -- from the host copies dd_set_weight keeps.
+int pull_device_weights_to_host(dd_handle_t h, hipStream_t s);
+
 int pack_wino_weights(dd_handle_t h, hipStream_t s) {
+  { int rc = pull_device_weights_to_host(h, s); if (rc) return rc; }    // the images are built on the host from host_w
   struct Item { ConvLayer* L; const char* name; int cout, cin; };
   std::vector<Item> items = {{&h->L[1], "model.noise_embedding.3.weight", COND_C, HID_C}, {&h->L[2], "model.pred.0.weight", HID_C, COND_C}};
   if (h->variant == DD_VARIANT_SWIN) {
@@ -667,6 +673,7 @@ int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t nu
         return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight: ") + name + " expects " + std::to_string(ws.numel) +
                                                " elements, got " + std::to_string(numel));
       h->host_w[name].assign(data, data + numel);
+      h->dev_newer.erase(name);
       const int grp = weight_group(name);
       if (grp == 0) h->committed = false; else if (grp == 1) h->codec_committed = false; else h->fpn_committed = false;
       return DD_OK;
@@ -675,6 +682,118 @@ int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t nu
   return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight: unknown parameter name '") + name + "'");
 }
 
+int dd_set_weight_device(dd_handle_t h, const char* name, const float* data, int64_t numel, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!name || !data || numel <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_set_weight_device: null name/data or non-positive numel");
+  if (weight_group(name) != 0)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string("dd_set_weight_device: '") + name + "' is not a denoiser parameter (model.*): the codec and "
+                                       "FPN groups are folded on the host, use dd_set_weight");
+  for (const auto& ws : required_weights(h->variant, h->fpn_pyramid)) {
+    if (ws.name != name) continue;
+    if (ws.numel != numel)
+      return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight_device: ") + name + " expects " + std::to_string(ws.numel) +
+                                             " elements, got " + std::to_string(numel));
+    DD_HIP(hipSetDevice(h->device));
+    std::unique_ptr<DevBuf>& b = h->dev_w[name];
+    if (!b) b.reset(new DevBuf());
+    if (b->bytes != (size_t)numel * 4) DD_HIP(b->alloc((size_t)numel * 4));
+    DD_HIP(hipMemcpyAsync(b->p, data, (size_t)numel * 4, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+    h->dev_newer.insert(name);
+    h->committed = false;
+    return DD_OK;
+  }
+  return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight_device: unknown parameter name '") + name + "'");
+}
+
+namespace {
+
+// host_w <- the device copies that are newer (mixed host / device updates of one group, and the host-only consumers: Winograd images)
+int pull_device_weights_to_host(dd_handle_t h, hipStream_t s) {
+  if (h->dev_newer.empty()) return DD_OK;
+  DD_HIP(hipStreamSynchronize(s));
+  for (const std::string& name : h->dev_newer) {
+    const DevBuf& b = *h->dev_w[name];
+    std::vector<float>& v = h->host_w[name];
+    v.resize(b.bytes / 4);
+    DD_HIP(hipMemcpy(v.data(), b.p, b.bytes, hipMemcpyDeviceToHost));
+  }
+  h->dev_newer.clear();
+  return DD_OK;
+}
+
+int ensure_bytes(dd_handle_t h, DevBuf& dst, size_t bytes) {
+  if (dst.bytes < bytes || !dst.p) DD_HIP(dst.alloc(bytes));
+  return DD_OK;
+}
+
+// One convolution's weights from a device fp32 OIHW tensor into every layout the forward / backward kernels read -- the device twin of the
+// host loops in dd_commit_weights (same geometries, same buffers), all on stream `s`.
+int pack_conv_layer_device(dd_handle_t h, ConvLayer& L, const float* w, int fwd_layer, int dgrad_layer, bool with_v1, bool with_naive,
+                           hipStream_t s) {
+  for (int ek = 0; ek < NUM_EK; ++ek) {
+    if (with_v1) {
+      const PackGeom g1 = conv_pack_geom(fwd_layer, ek);
+      int rc = ensure_bytes(h, L.wpack[ek], pack_weights_bytes(g1, ek)); if (rc) return rc;
+      DD_HIP(launch_pack_weights(w, L.wpack[ek].p, g1, ek, false, false, s));
+    }
+    const PackGeom g2 = conv_pack_geom2(fwd_layer, ek);
+    int rc = ensure_bytes(h, L.wpack2[ek], pack_weights_bytes(g2, ek)); if (rc) return rc;
+    DD_HIP(launch_pack_weights(w, L.wpack2[ek].p, g2, ek, true, false, s));
+    const PackGeom gt = conv_pack_geom2(dgrad_layer, ek);
+    rc = ensure_bytes(h, L.wpackT[ek], pack_weights_bytes(gt, ek)); if (rc) return rc;
+    DD_HIP(launch_pack_weights(w, L.wpackT[ek].p, gt, ek, true, true, s));
+  }
+  if (with_naive) {
+    const size_t bytes = (size_t)L.cout * L.cin * 9 * 4;
+    int rc = ensure_bytes(h, L.w_oihw, bytes); if (rc) return rc;
+    rc = ensure_bytes(h, L.wT_oihw, bytes); if (rc) return rc;
+    DD_HIP(hipMemcpyAsync(L.w_oihw.p, w, bytes, hipMemcpyDeviceToDevice, s));
+    DD_HIP(launch_transpose_flip(w, L.wT_oihw.as<float>(), L.cout, L.cin, 9, s));
+  }
+  return DD_OK;
+}
+
+// The denoiser group when every one of its parameters came through dd_set_weight_device: no host copy is touched.
+int commit_model_from_device(dd_handle_t h, hipStream_t s) {
+  auto D = [&](const std::string& n) { return h->dev_w[n]->as<float>(); };
+  auto copy_small = [&](DevBuf& dst, const std::string& n, size_t pad_elems) -> int {
+    const DevBuf& src = *h->dev_w[n];
+    const size_t bytes = std::max(src.bytes, pad_elems * 4);
+    int rc = ensure_bytes(h, dst, bytes); if (rc) return rc;
+    if (bytes > src.bytes) DD_HIP(hipMemsetAsync(dst.p, 0, bytes, s));
+    DD_HIP(hipMemcpyAsync(dst.p, src.p, src.bytes, hipMemcpyDeviceToDevice, s));
+    return DD_OK;
+  };
+  for (int l = 0; l < 4; ++l) {
+    ConvLayer& L = h->L[l];
+    L.cin = kCins[l]; L.cout = kCouts[l];
+    int rc = pack_conv_layer_device(h, L, D(std::string(kConvNames[l]) + ".weight"), l + 1, 23 - l, true, true, s); if (rc) return rc;
+    rc = copy_small(L.bias, std::string(kConvNames[l]) + ".bias", 32); if (rc) return rc;
+    rc = copy_small(L.gamma, std::string(kGnNames[l]) + ".weight", 0); if (rc) return rc;
+    rc = copy_small(L.beta, std::string(kGnNames[l]) + ".bias", 0); if (rc) return rc;
+  }
+  if (h->variant == DD_VARIANT_SWIN) {
+    const char* names[2] = {"model.upsample_fuse.convA.conv", "model.upsample_fuse.convB.conv"};
+    ConvLayer* Ls[2] = {&h->LA, &h->LB};
+    for (int i = 0; i < 2; ++i) {
+      ConvLayer& L = *Ls[i];
+      L.cin = COND_C; L.cout = COND_C;
+      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, false, false, s); if (rc) return rc;
+      rc = copy_small(L.bias, std::string(names[i]) + ".bias", 0); if (rc) return rc;
+    }
+  }
+  int rc = copy_small(h->emb, "model.time_embedding.weight", 0); if (rc) return rc;
+  if (h->etab.bytes == 0) {
+    DD_HIP(h->etab.alloc((size_t)EMB_ROWS * 10 * HID_C * 4));
+    DD_HIP(h->zero_bias.alloc(COND_C * 4));
+    DD_HIP(hipMemsetAsync(h->zero_bias.p, 0, COND_C * 4, s));
+  }
+  DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
+  return DD_OK;
+}
+
+}  // namespace
+
 int dd_commit_weights(dd_handle_t h, void* stream) {
   if (!h) return DD_ERR_INVALID_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -682,22 +801,37 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   // independent groups: "model." (denoiser), "depth_transform." (codec) and "conv_lateral." / "conv_up." (condition FPN,
   // Res variant).  A group is packed when all of its keys are present; a partially provided group is an error; at least
   // one must be complete.
-  int have[3] = {0, 0, 0}, need[3] = {0, 0, 0};
+  int have[3] = {0, 0, 0}, need[3] = {0, 0, 0}, n_dev = 0, n_host = 0;     // n_dev / n_host: denoiser parameters whose newest value is on the device / host
   std::string first_missing[3];
   for (const auto& ws : required_weights(h->variant, h->fpn_pyramid)) {
     const int grp = weight_group(ws.name);
     need[grp]++;
-    if (h->host_w.count(ws.name)) have[grp]++;
+    if (h->host_w.count(ws.name) || h->dev_newer.count(ws.name)) have[grp]++;
     else if (first_missing[grp].empty()) first_missing[grp] = ws.name;
+    if (grp == 0) { if (h->dev_newer.count(ws.name)) n_dev++; else n_host++; }
   }
   for (int grp = 0; grp < 3; ++grp)
     if (have[grp] != 0 && have[grp] != need[grp])
       return h->fail(DD_ERR_STATE, "dd_commit_weights: missing parameter '" + first_missing[grp] + "'");
   if (have[0] == 0 && have[1] == 0 && have[2] == 0) return h->fail(DD_ERR_STATE, "dd_commit_weights: no parameters were set");
-  const bool do_model = have[0] == need[0], do_codec = have[1] == need[1], do_fpn = need[2] > 0 && have[2] == need[2];
+  // only the groups that changed since their last commit (dd_set_weight / dd_set_weight_device clear the group's flag)
+  bool do_model = have[0] == need[0] && !h->committed;
+  const bool do_codec = have[1] == need[1] && !h->codec_committed, do_fpn = need[2] > 0 && have[2] == need[2] && !h->fpn_committed;
+  if (!do_model && !do_codec && !do_fpn) return DD_OK;
   // graphs bake weight pointers; buffers are reused when sizes match, so existing graphs stay valid,
   // but make sure nothing is in flight while we overwrite them.
   DD_HIP(hipDeviceSynchronize());
+  if (do_model && n_dev > 0) {
+    if (n_host == 0) {
+      // every denoiser parameter came through dd_set_weight_device: fp32 -> kernel layouts by the pack kernels, all on `s`
+      int rc = commit_model_from_device(h, s); if (rc) return rc;
+      if (h->winograd) { rc = pack_wino_weights(h, s); if (rc) return rc; }     // experimental kernels only (host-built images)
+      h->committed = true;
+      do_model = false;
+    } else {
+      int rc = pull_device_weights_to_host(h, s); if (rc) return rc;            // mixed update: newest values to the host, host route
+    }
+  }
   const char* conv_names[4] = {"model.noise_embedding.0", "model.noise_embedding.3", "model.pred.0", "model.pred.3"};
   const char* gn_names[4] = {"model.noise_embedding.1", "model.noise_embedding.4", "model.pred.1", "model.pred.4"};
   const int cins[4] = {LATENT_C, HID_C, COND_C, HID_C}, couts[4] = {HID_C, COND_C, HID_C, LATENT_C};
@@ -1594,6 +1728,43 @@ int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, v
   if (numel != (int64_t)pl->key.B * C * pl->key.h * pl->key.w) return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: numel mismatch");
   DD_HIP(launch_nhwc_to_nchw_f32(src, ek, out, pl->key.B, C, pl->key.h, pl->key.w, pl->key.prec != DD_PREC_NAIVE_FP32,
                                  reinterpret_cast<hipStream_t>(stream)));
+  return DD_OK;
+}
+
+// FNV-1a over every packed / staged denoiser weight buffer as it sits in HBM (buffer sizes included): two handles fed the same
+// parameters through different routes (dd_set_weight vs dd_set_weight_device) must agree.
+int dd_debug_weights_digest(dd_handle_t h, uint64_t* digest) {
+  if (!h || !digest) return DD_ERR_INVALID_ARG;
+  if (!h->committed) return h->fail(DD_ERR_STATE, "dd_debug_weights_digest: model.* weights not committed");
+  DD_HIP(hipSetDevice(h->device));
+  DD_HIP(hipDeviceSynchronize());
+  uint64_t d = 1469598103934665603ull;
+  std::vector<uint8_t> tmp;
+  auto eat = [&](const DevBuf& b) -> hipError_t {
+    uint64_t n = b.bytes;
+    for (int i = 0; i < 8; ++i) { d ^= (n >> (8 * i)) & 0xFF; d *= 1099511628211ull; }
+    if (!b.p || !b.bytes) return hipSuccess;
+    tmp.resize(b.bytes);
+    hipError_t e = hipMemcpy(tmp.data(), b.p, b.bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    for (uint8_t c : tmp) { d ^= c; d *= 1099511628211ull; }
+    return hipSuccess;
+  };
+  auto eat_layer = [&](const ConvLayer& L) -> hipError_t {
+    for (int ek = 0; ek < NUM_EK; ++ek) {
+      hipError_t e = eat(L.wpack[ek]); if (e != hipSuccess) return e;
+      e = eat(L.wpack2[ek]); if (e != hipSuccess) return e;
+      e = eat(L.wpackT[ek]); if (e != hipSuccess) return e;
+    }
+    const DevBuf* rest[5] = {&L.bias, &L.w_oihw, &L.wT_oihw, &L.gamma, &L.beta};
+    for (const DevBuf* b : rest) { hipError_t e = eat(*b); if (e != hipSuccess) return e; }
+    return hipSuccess;
+  };
+  for (int l = 0; l < 4; ++l) DD_HIP(eat_layer(h->L[l]));
+  if (h->variant == DD_VARIANT_SWIN) { DD_HIP(eat_layer(h->LA)); DD_HIP(eat_layer(h->LB)); }
+  DD_HIP(eat(h->emb));
+  DD_HIP(eat(h->etab));
+  *digest = d;
   return DD_OK;
 }
 

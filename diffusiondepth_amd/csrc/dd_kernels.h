@@ -91,6 +91,11 @@ hipError_t launch_wino_gn_table(const ConvParams& p, int C, float* tab, bool wit
 size_t wino_pack_bytes(int cout, int cin);
 void wino_pack_u(const float* w_oihw, int cout, int cin, uint16_t (*cvt)(float), uint16_t* out);
 
+// ---- weights into kernel layout on the device (dd_misc.hip): the packed image of pack_conv_weights() in dd_api.cpp, bit for bit ----
+size_t pack_weights_bytes(const PackGeom& g, int ek);
+hipError_t launch_pack_weights(const float* src_oihw, void* dst, const PackGeom& g, int ek, bool swizzle, bool transposed, hipStream_t s);
+hipError_t launch_transpose_flip(const float* w, float* wt, int cout, int cin, int kk, hipStream_t s);
+
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
 // dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h
 hipError_t launch_nchw_to_nhwc(const float* src, void* dst, int ek, int B, int C, int h, int w, int blocked, hipStream_t s);

@@ -717,4 +717,64 @@ hipError_t launch_decode(const CodecWeights& cw, const float* latent_nchw, float
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weights into kernel layout ON THE DEVICE (training: the optimizer updates the fp32 parameters in HBM every step; repacking them
+// on the host costs a D2H copy per tensor plus ~25 ns per packed element, single-threaded, for every element kind and kernel
+// family -- hundreds of ms per iteration).  One thread per PACKED element; same index map, zero padding, LDS swizzle and
+// round-to-nearest-even conversions as the host packer pack_conv_weights() in dd_api.cpp (the two are compared bit for bit in
+// tests/test_library_host_emulation.py).
+//   transposed == 0: src = W[cout][cin][ks][ks]
+//   transposed == 1: the data-gradient convolution of W: value(co, ci, dy, dx) = W[ci][co][ks-1-dy][ks-1-dx], W = [g.cin][g.cout][ks][ks]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ src, void* __restrict__ dst, PackGeom g, int ek,
+                                                            int swizzle, int transposed, long long n_el) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_el) return;
+  const int ks = g.ks, kk = ks * ks, n_chunks = g.cin / g.ck, n_tg = kk / g.tg;
+  const int esz = ek == EK_F32 ? 4 : 2;
+  const int rowb = g.ck * esz, ppp = rowb / 16, rpb = 256 / rowb, epp = 16 / esz;
+  // idx = ((((nt * n_chunks + ch) * n_tg + tg) * g.tg) * g.nt * g.ck)  +  row * g.ck + piece_sw * epp + within,  row = t * g.nt + n
+  const long long blk = (long long)g.tg * g.nt * g.ck;
+  const long long outer = idx / blk;
+  const int inner = (int)(idx - outer * blk);
+  const int tg = (int)(outer % n_tg);
+  const int ch = (int)((outer / n_tg) % n_chunks);
+  const int nt = (int)(outer / ((long long)n_tg * n_chunks));
+  const int row = inner / g.ck, col = inner - row * g.ck;
+  const int piece_sw = col / epp, within = col - piece_sw * epp;
+  const int piece = swizzle ? (piece_sw ^ ((row / rpb) & (ppp - 1))) : piece_sw;      // the XOR is its own inverse
+  const int k = piece * epp + within;
+  const int t = row / g.nt, n = row - t * g.nt;
+  const int tap = tg * g.tg + t, co = nt * g.nt + n, ci = ch * g.ck + k;
+  float v = 0.f;
+  if (co < g.cout)
+    v = transposed ? src[((size_t)ci * g.cout + co) * kk + (kk - 1 - tap)] : src[((size_t)co * g.cin + ci) * kk + tap];
+  if (ek == EK_F32) reinterpret_cast<float*>(dst)[idx] = v;
+  else reinterpret_cast<uint16_t*>(dst)[idx] = (uint16_t)(ek == EK_BF16 ? f32_to_bf16(v) : f32_to_f16(v));
+}
+
+size_t pack_weights_bytes(const PackGeom& g, int ek) {
+  return (size_t)(g.cout_pad / g.nt) * (g.cin / g.ck) * (size_t)(g.ks * g.ks) * g.nt * g.ck * (ek == EK_F32 ? 4 : 2);
+}
+
+hipError_t launch_pack_weights(const float* src, void* dst, const PackGeom& g, int ek, bool swizzle, bool transposed, hipStream_t s) {
+  const long long n_el = (long long)(pack_weights_bytes(g, ek) / (ek == EK_F32 ? 4 : 2));
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, src, dst, g, ek, swizzle ? 1 : 0,
+                     transposed ? 1 : 0, n_el);
+  return hipGetLastError();
+}
+
+// W[co][ci][k] -> W'[ci][co][kk-1-k] (fp32; the naive backward's data-gradient weights)
+__global__ void __launch_bounds__(256) transpose_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int cin, int kk) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)cout * cin * kk) return;
+  const int k = (int)(i % kk), ci = (int)((i / kk) % cin), co = (int)(i / ((long long)kk * cin));
+  wt[((size_t)ci * cout + co) * kk + (kk - 1 - k)] = w[i];
+}
+hipError_t launch_transpose_flip(const float* w, float* wt, int cout, int cin, int kk, hipStream_t s) {
+  const long long n = (long long)cout * cin * kk;
+  hipLaunchKernelGGL(transpose_flip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, wt, cout, cin, kk);
+  return hipGetLastError();
+}
+
 }  // namespace dd

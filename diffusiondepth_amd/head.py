@@ -101,7 +101,7 @@ class DDIMDepthEstimate_Res(nn.Module):
     def aggregate_condition(self, fp):
         if self._hip_fpn and not self.training and len(fp) == 4 and all(f.is_cuda for f in fp) and self.model.precision != "naive_fp32":
             # eval-mode BatchNorm is folded into the convolutions inside the library (dd_condition)
-            be = self._bound.ensure(fp[0].device, self.scheduler)
+            be = self._bound.ensure(fp[0].device, self.scheduler, need=("fpn",))
             return be.condition([f.float() for f in fp], self.model.precision)
         x = None
         n = len(fp)
@@ -161,7 +161,7 @@ class DDIMDepthEstimate_Res(nn.Module):
             noise = torch.randn(blur_depth_t.shape, device=blur_depth_t.device)
         bs = blur_depth_t.shape[0]
         timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bs,), device=gt_depth.device).long()
-        be = self._bound.ensure(blur_depth_t.device, self.scheduler)
+        be = self._bound.ensure(blur_depth_t.device, self.scheduler, need=())        # q_sample needs the schedule only
         # the loop output is not detached in the reference: when it carries gradient, q_sample stays a torch op so that
         # autograd reaches the loop through it; otherwise dd_add_noise
         keep_graph = torch.is_grad_enabled() and blur_depth_t.requires_grad

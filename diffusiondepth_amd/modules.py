@@ -24,26 +24,39 @@ DEFAULT_PRECISION = os.environ.get("DDEPTH_PRECISION", "fp32")
 
 class HipBound:
     """Shares one HipDenoiser between the modules of a head and re-uploads parameters when any of
-    them changed (torch bumps ``Tensor._version`` on every in-place update, e.g. optimizer.step())."""
+    them changed (torch bumps ``Tensor._version`` on every in-place update, e.g. optimizer.step()).
+
+    Parameters are tracked per GROUP of the library (include/ddepth.h: the denoiser "model.*", the codec "depth_transform.*", the
+    condition FPN "conv_lateral.* / conv_up.*") and a group travels only when a call that needs it is about to run: a training
+    iteration changes every parameter, but in .train() mode only the denoiser runs in the library (codec and FPN use batch-statistics
+    BatchNorm in PyTorch), so only that group is refreshed per step -- and with ``DDEPTH_DEVICE_WEIGHTS=1`` without leaving the device
+    (HipDenoiser.load_state_dict(device_route=True))."""
+
+    GROUPS = ("model", "codec", "fpn")
 
     def __init__(self, variant: str = "res"):
         self.variant = variant
         self.backend: Optional[HipDenoiser] = None
         self._modules = []
-        self._sig = None
+        self._sig = {}             # group -> signature of what the backend holds
         self._sched_sig = None
         self._hold_depth = 0
-        self._held = None          # backend whose parameters were verified inside the current hold() scope
+        self._held = set()         # groups verified inside the current hold() scope
+
+    @staticmethod
+    def _group_of(prefix: str) -> str:
+        return "model" if prefix.startswith("model.") else "codec" if prefix.startswith("depth_transform.") else "fpn"
 
     def register(self, prefix: str, module: nn.Module):
         self._modules.append((prefix, weakref.ref(module)))
 
-    def _signature(self):
-        """(data_ptr, version) of every parameter and buffer of the registered modules, in traversal order.  Walks the modules' own
-        ``_parameters`` / ``_buffers`` dicts (what ``state_dict()`` would visit, without building the prefixed OrderedDict: ~4x cheaper,
-        and this runs in front of every library call)."""
+    def _signature(self, group: str):
+        """(data_ptr, version) of every parameter and buffer of the group's registered modules, in traversal order.  Walks the modules'
+        own ``_parameters`` / ``_buffers`` dicts (what ``state_dict()`` would visit, without building the prefixed OrderedDict)."""
         sig = []
-        for _, ref in self._modules:
+        for prefix, ref in self._modules:
+            if self._group_of(prefix) != group:
+                continue
             for m in ref().modules():
                 for v in m._parameters.values():
                     if v is not None:
@@ -55,18 +68,19 @@ class HipBound:
 
     @contextlib.contextmanager
     def hold(self):
-        """Scope in which the parameters are known not to change (one head.forward): the first ``ensure`` inside it checks / uploads
-        as usual, the following ones reuse its verdict instead of re-walking ~80 tensors each (0.13 ms x 7 library calls per forward
-        otherwise -- a fifth of the B=1 head latency).  Re-entrant; leaving the outermost scope drops the verdict."""
+        """Scope in which the parameters are known not to change (one head.forward): the first ``ensure`` for a group inside it checks /
+        uploads as usual, the following ones reuse its verdict instead of re-walking the tensors each time (0.13 ms x 7 library calls per
+        forward otherwise -- a fifth of the B=1 head latency).  Re-entrant; leaving the outermost scope drops the verdicts."""
         self._hold_depth += 1
         try:
             yield self
         finally:
             self._hold_depth -= 1
             if self._hold_depth == 0:
-                self._held = None
+                self._held.clear()
 
-    def ensure(self, device, scheduler: Optional[DDIMScheduler] = None) -> HipDenoiser:
+    def ensure(self, device, scheduler: Optional[DDIMScheduler] = None, need=GROUPS) -> HipDenoiser:
+        """The backend for ``device`` with the parameter groups ``need`` (subset of GROUPS) up to date; registered groups only."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(f"the DDIM hot path runs only on a HIP device (got tensors on {device}); "
@@ -74,19 +88,23 @@ class HipBound:
         want = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
         if self.backend is None or self.backend.device != want:
             self.backend = self._make_backend(want)
-            self._sig = None
+            self._sig = {}
             self._sched_sig = None
-            self._held = None
-        if self._hold_depth == 0 or self._held is not self.backend:
-            sig = self._signature()
-            if sig != self._sig:
+            self._held.clear()
+        registered = {self._group_of(p) for p, _ in self._modules}
+        for group in need:
+            if group not in registered or group in self._held:
+                continue
+            sig = self._signature(group)
+            if sig != self._sig.get(group):
                 sd = {}
                 for prefix, ref in self._modules:
-                    sd.update({prefix + k: v for k, v in ref().state_dict().items()})
+                    if self._group_of(prefix) == group:
+                        sd.update({prefix + k: v for k, v in ref().state_dict().items()})
                 self.backend.load_state_dict(sd)
-                self._sig = sig
+                self._sig[group] = sig
             if self._hold_depth > 0:
-                self._held = self.backend
+                self._held.add(group)
         if scheduler is not None:
             ssig = (id(scheduler), scheduler.config.num_train_timesteps)
             if ssig != self._sched_sig:
@@ -205,7 +223,7 @@ class ScheduledCNNRefine(nn.Module):
     def forward(self, noisy_image, t, *args):
         """forward(noisy_image, t, feat, blur_depth, sparse_depth, sparse_mask) -> eps (…res.py:324-344)."""
         feat = args[0]
-        be = self.bound.ensure(noisy_image.device)
+        be = self.bound.ensure(noisy_image.device, need=("model",))
         t = torch.as_tensor(t, device=noisy_image.device)
         if _wants_grad(self, noisy_image, feat):
             tt = t.to(torch.int64).reshape(-1)
@@ -233,7 +251,7 @@ class CNNDDIMPipiline:
         self.scheduler.set_timesteps(num_inference_steps)
         why_not = self.scheduler.hip_supported(eta)
         if why_not is None:
-            be = self.model.bound.ensure(image.device, self.scheduler)
+            be = self.model.bound.ensure(image.device, self.scheduler, need=("model",))
             if _wants_grad(self.model, image, input_args[0]):
                 image = _DenoiseLoopFn.apply(be, self.model.precision, int(num_inference_steps), image.float().contiguous(),
                                              input_args[0].float().contiguous(), *_ordered_params(self.model)).to(dtype)
@@ -259,7 +277,7 @@ class CNNDDIMPipilineVis(CNNDDIMPipiline):
         image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
         self.scheduler.set_timesteps(num_inference_steps)
         if self.scheduler.hip_supported(eta) is None and not _wants_grad(self.model, image, input_args[0]):
-            be = self.model.bound.ensure(image.device, self.scheduler)
+            be = self.model.bound.ensure(image.device, self.scheduler, need=("model",))
             states = be.denoise_trace(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
             image_list = list(states.unbind(0))
             image = image_list[-1]
@@ -308,9 +326,9 @@ class DeepDepthTransformWithUpsampling(nn.Module):
     def t(self, depth):
         if self._torch_path(depth):
             return self.conv_transform(depth)                                        # depth_transform.py:29-31
-        return self.bound.ensure(depth.device).encode(depth.float())
+        return self.bound.ensure(depth.device, need=("codec",)).encode(depth.float())
 
     def inv_t(self, value):
         if self._torch_path(value):
             return 1.0 / self.conv_inv_transform(value).clamp(self.eps) - 1          # depth_transform.py:33-35
-        return self.bound.ensure(value.device).decode(value.float())
+        return self.bound.ensure(value.device, need=("codec",)).decode(value.float())

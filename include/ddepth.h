@@ -85,6 +85,15 @@ const char* dd_version(void);
 int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t numel);
 int dd_commit_weights(dd_handle_t h, void* stream);
 
+/* Same as dd_set_weight for parameters that already live in HBM: `data` is a DEVICE pointer (the nn.Parameter's own storage; borrowed
+ * for the call, copied on `stream`).  Replaces the parameter refresh that nn.Module gets for free after optimizer.step() in the
+ * reference's training loop (src/main.py:232-241): with this entry point the denoiser's weights go fp32 -> kernel layouts entirely on
+ * the device at the next dd_commit_weights (pack kernels on `stream`; no host copy, no host-side packing).  Denoiser group ("model.*")
+ * only: the codec and FPN groups are folded with their eval-mode BatchNorm on the host (dd_set_weight) and only run in eval mode.
+ * The two routes may be mixed freely; the newest value of every parameter wins.  dd_commit_weights repacks only the groups that
+ * changed since the last commit. */
+int dd_set_weight_device(dd_handle_t h, const char* name, const float* data, int64_t numel, void* stream);
+
 /* Replaces: DDIMScheduler.__init__ (src/model/diffusers/schedulers/scheduling_ddim.py:107-157).
  * `alphas_cumprod` is the HOST fp32 table of length num_train_timesteps that the scheduler built
  * (torch.cumprod(1 - linspace(beta_start, beta_end))), so table bits are the reference's own. */
@@ -196,6 +205,8 @@ int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launche
  * fp32 NCHW: name in {"y1","y2","y3","y4"} = raw conv outputs before GroupNorm (B,C,h,w).
  * Test hook for locating a failing layer. */
 int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, void* stream);
+/* Test hook: 64-bit FNV-1a digest of every packed denoiser weight buffer in HBM (the two parameter routes must agree bit for bit). */
+int dd_debug_weights_digest(dd_handle_t h, uint64_t* digest);
 
 /* Host-only test hook: writes the Winograd F(2x2,3x3) weight image of a (cout, cin, 3, 3) fp32 OIHW filter as the experimental kernel
  * of option "winograd" streams it -- [cout/64][cin/16][16 positions][64][16] 16-bit elements of G g G^T, rounded once from double;

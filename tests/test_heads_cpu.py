@@ -66,54 +66,66 @@ class _FakeBackend:
 
     def __init__(self, device):
         self.device = device
-        self.uploads = 0
+        self.uploads = []          # per load_state_dict call: the set of groups its keys belong to
         self.schedules = 0
 
     def load_state_dict(self, sd):
-        self.uploads += 1
+        grp = lambda k: "model" if k.startswith("model.") else "codec" if k.startswith("depth_transform.") else "fpn"
+        self.uploads.append({grp(k) for k in sd})
         self.keys = sorted(sd)
 
     def set_schedule(self, acp):
         self.schedules += 1
 
 
-def test_hipbound_uploads_on_change_and_checks_once_per_held_scope(monkeypatch):
-    """HipBound (modules.py): parameters reach the library when -- and only when -- a registered tensor changed (in-place update,
-    replaced storage); inside ``hold()`` (= one head.forward) the ~80-tensor walk runs once, not in front of every library call."""
+def test_hipbound_uploads_changed_groups_when_needed_and_checks_once_per_held_scope(monkeypatch):
+    """HipBound (modules.py): a parameter group reaches the library when -- and only when -- one of its tensors changed (in-place update,
+    replaced storage) AND a call that needs the group is about to run; inside ``hold()`` (= one head.forward) each group's tensor walk runs
+    once, not in front of every library call."""
     head = dda.DDIMDepthEstimate_Res(precision="bf16", inference_steps=5).eval()
     b = head._bound
     monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
     monkeypatch.setattr(b, "_make_backend", lambda dev: _FakeBackend(dev))
     walks = []
     real_sig = b._signature
-    monkeypatch.setattr(b, "_signature", lambda: (walks.append(1), real_sig())[1])
-    be = b.ensure("cuda:0", head.scheduler)
-    assert (be.uploads, be.schedules, len(walks)) == (1, 1, 1)
-    assert "model.pred.0.weight" in be.keys and "depth_transform.conv_inv_transform.0.weight" in be.keys and "conv_lateral.3.0.weight" in be.keys
-    b.ensure("cuda:0", head.scheduler)
-    assert (be.uploads, be.schedules, len(walks)) == (1, 1, 2)                  # unchanged: walked again, nothing uploaded
-    with torch.no_grad():
-        head.model.pred[0].weight.mul_(0.5)                                     # optimizer-style in-place update
+    monkeypatch.setattr(b, "_signature", lambda g: (walks.append(g), real_sig(g))[1])
+    be = b.ensure("cuda:0", head.scheduler, need=("codec",))                    # e.g. depth_transform.t() first
+    assert (be.uploads, be.schedules, walks) == ([{"codec"}], 1, ["codec"])
+    assert "depth_transform.conv_inv_transform.0.weight" in be.keys and "model.pred.0.weight" not in be.keys
+    b.ensure("cuda:0", head.scheduler)                                          # everything
+    assert be.uploads == [{"codec"}, {"model"}, {"fpn"}] and be.schedules == 1
+    assert "conv_lateral.3.0.weight" in be.keys
     b.ensure("cuda:0")
-    assert be.uploads == 2
+    assert len(be.uploads) == 3 and len(walks) == 1 + 3 + 3                    # unchanged: walked again, nothing uploaded
+    with torch.no_grad():                                                       # an optimizer step touches every group ...
+        head.model.pred[0].weight.mul_(0.5)
+        head.conv_lateral[0][0].weight.mul_(0.5)
+        head.depth_transform.conv_inv_transform[0].bias.add_(1.0)
+    b.ensure("cuda:0", need=("model",))                                         # ... a training forward needs the denoiser only
+    assert be.uploads[3:] == [{"model"}]
+    b.ensure("cuda:0", need=("model",))
+    assert len(be.uploads) == 4
+    b.ensure("cuda:0", need=("fpn", "codec"))                                   # eval later: the rest follows
+    assert be.uploads[4:] == [{"fpn"}, {"codec"}]
     head.model.time_embedding.weight.data = head.model.time_embedding.weight.data.clone()      # storage replaced (.to(), .data = ...)
-    b.ensure("cuda:0")
-    assert be.uploads == 3
+    b.ensure("cuda:0", need=("model",))
+    assert be.uploads[6:] == [{"model"}]
     head.conv_lateral[0][1].running_mean.add_(1.0)                              # buffers count too (BatchNorm statistics)
-    b.ensure("cuda:0")
-    assert be.uploads == 4
-    n = len(walks)
+    b.ensure("cuda:0", need=("fpn",))
+    assert be.uploads[7:] == [{"fpn"}]
+    n, u = len(walks), len(be.uploads)
     with b.hold():
         for _ in range(5):
-            assert b.ensure("cuda:0", head.scheduler) is be
+            assert b.ensure("cuda:0", head.scheduler, need=("model",)) is be
         with b.hold():                                                          # re-entrant (a head calling a sub-module's forward)
-            b.ensure("cuda:0")
-        b.ensure("cuda:0")
-    assert len(walks) == n + 1 and be.uploads == 4
+            b.ensure("cuda:0", need=("codec",))
+        b.ensure("cuda:0", need=("codec", "model"))
+        b.ensure("cuda:0", need=())                                             # schedule only (q_sample)
+    assert walks[n:] == ["model", "codec"] and len(be.uploads) == u
     with torch.no_grad():
         head.model.pred[3].bias.add_(1.0)
     with b.hold():
-        b.ensure("cuda:0")
-    assert be.uploads == 5 and len(walks) == n + 2                              # a new scope looks again
+        b.ensure("cuda:0", need=("model",))
+    assert len(be.uploads) == u + 1 and walks[n + 2:] == ["model"]              # a new scope looks again
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         b.ensure("cpu")
