@@ -789,6 +789,7 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s) {
     DD_HIP(hipMemsetAsync(h->zero_bias.p, 0, COND_C * 4, s));
   }
   DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
+  DD_HIP(hipStreamSynchronize(s));     // as the host route: the new images are in place when the call returns, whatever stream runs next
   return DD_OK;
 }
 
