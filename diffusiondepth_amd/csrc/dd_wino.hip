@@ -339,7 +339,6 @@ __global__ void __launch_bounds__(W_THREADS) conv_wino_raw_v2_kernel(ConvParams 
   bool in0, in1;
   item_geom(tid, goff0, in0);
   item_geom(have1 ? item1 : 0, goff1, in1);
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   auto gload = [&](int chunk) {
     const char* cb = in_b + (((size_t)(chunk >> 1) * HW) * ACT_CB + (size_t)(chunk & 1) * W_CK) * 2;
     const uint4 a0 = *reinterpret_cast<const uint4*>(cb + goff0);
