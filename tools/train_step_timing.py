@@ -58,3 +58,20 @@ try:
     print(f"           PyTorch-ROCm autograd, same modules: fp32 {t_t32:.1f} ms | autocast bf16 {t_t16:.1f} ms   -> HIP is {t_t32 / t_hip:.1f}x / {t_t16 / t_hip:.1f}x faster")
 except Exception as e:
     print("           PyTorch-ROCm baseline failed:", repr(e)[:200])
+
+# ---- the whole iteration: forward + backward + optimizer.step() + the parameter refresh the next forward triggers (HipBound) ----
+# The figures above leave the weights untouched between iterations, so the refresh never runs; a real training loop pays it every step.
+opt = torch.optim.SGD(model.parameters(), lr=1e-6)
+
+def hip_iteration():
+    hip_step()
+    opt.step()
+
+for route in ("0", "1"):
+    os.environ["DDEPTH_DEVICE_WEIGHTS"] = route
+    try:
+        t_it = timeit(hip_iteration)
+        print(f"           iteration with optimizer.step(), parameter refresh by the {'device' if route == '1' else 'host'} route: {t_it:.1f} ms "
+              f"(+{t_it - t_hip:.1f} ms over forward+backward alone)")
+    except Exception as e:
+        print(f"           iteration with the {'device' if route == '1' else 'host'} route failed:", repr(e)[:200])
