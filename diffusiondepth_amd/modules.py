@@ -81,11 +81,7 @@ class HipBound:
 
     def ensure(self, device, scheduler: Optional[DDIMScheduler] = None, need=GROUPS) -> HipDenoiser:
         """The backend for ``device`` with the parameter groups ``need`` (subset of GROUPS) up to date; registered groups only."""
-        device = torch.device(device)
-        if device.type != "cuda":
-            raise RuntimeError(f"the DDIM hot path runs only on a HIP device (got tensors on {device}); "
-                               "diffusiondepth_amd has no CPU fallback")
-        want = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        want = self._hip_device(device)
         if self.backend is None or self.backend.device != want:
             self.backend = self._make_backend(want)
             self._sig = {}
@@ -111,6 +107,15 @@ class HipBound:
                 self.backend.set_schedule(scheduler._acp_host)
                 self._sched_sig = ssig
         return self.backend
+
+    @staticmethod
+    def _hip_device(device) -> torch.device:
+        """The HIP device (with index) the tensors live on; anything else is an error -- there is no CPU path."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"the DDIM hot path runs only on a HIP device (got tensors on {device}); "
+                               "diffusiondepth_amd has no CPU fallback")
+        return torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
 
     def _make_backend(self, device) -> HipDenoiser:
         return HipDenoiser(device, self.variant)

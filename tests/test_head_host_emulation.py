@@ -1,0 +1,168 @@
+"""The drop-in head END TO END on the CPU: diffusiondepth_amd.head / modules / scheduler / backend (the product's own Python, incl. the
+ctypes binding and the autograd Functions) driving the host-emulated build of the library (tests/host_emul: the library's own sources
+compiled for x86), against the goldens minted from the reference's head class (tests/golden/make_golden.py).
+
+Test infrastructure only.  The product binding refuses CPU tensors and loads only libddepth_hip.so; here the TEST patches its private
+guards (tensor check, stream lookup, device scope) and hands it the emulated library, so that the host logic that otherwise first runs on
+the GPU box -- parameter groups and their refresh (HipBound), RNG draw order, the 13-key output contract, loss.backward() through the loop
+and the ddim_loss call -- is exercised in the CPU suite.  Under emulation "device" memory is host memory."""
+from __future__ import annotations
+
+import contextlib
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import backend as B_, modules as M_, synth
+from hostemu_util import build_library
+
+FULL = os.environ.get("DD_EMU_FULL") == "1"
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = build_library()
+    for name, (res, args) in B_.abi_signatures().items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+@pytest.fixture()
+def on_host(lib, monkeypatch):
+    """Patch the binding's guards for the duration of one test; returns a factory of HipDenoiser objects bound to the emulated library."""
+    def check_tensor(t, name, shape=None, dtype=None):
+        assert isinstance(t, torch.Tensor), name
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t.contiguous()
+    monkeypatch.setattr(B_, "_check_tensor", check_tensor)
+    monkeypatch.setattr(B_, "_stream_ptr", lambda device: 0)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    made = []
+
+    def make(device, variant="res"):
+        be = object.__new__(B_.HipDenoiser)
+        be._lib, be.device, be.variant = lib, CPU, variant
+        h = ctypes.c_void_p()
+        assert lib.dd_create(ctypes.byref(h), 0, B_.VARIANTS[variant]) == 0
+        be._h = h
+        be._have_schedule = be._have_weights = be._have_fpn = False
+        be._cond_token = None
+        made.append(be)
+        return be
+    monkeypatch.setattr(M_.HipBound, "_hip_device", staticmethod(lambda device: CPU))
+    monkeypatch.setattr(M_.HipBound, "_make_backend", lambda self, device: make(device, self.variant))
+    yield make
+    for be in made:
+        lib.dd_destroy(be._h)
+        be._h = None
+
+
+def _head(c, precision, T=None):
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    head = dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=T or c["T"], num_train_timesteps=1000,
+                                     depth_feature_dim=16, loss_cfgs=[], precision=precision)
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    return head
+
+
+def _inputs(c, grad=False):
+    Bn, H, W = c["B"], c["H"], c["W"]
+    fp = [torch.from_numpy(f).requires_grad_(grad) for f in synth.make_backbone_features(c["iseed"], Bn, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(c["iseed"] + 1, Bn, H, W))
+    h, w = synth.latent_hw(H, W)
+    return fp, gt, synth.make_inputs(c["iseed"] + 2, Bn, h, w)
+
+
+@contextlib.contextmanager
+def _draws(inp):
+    """The reference's RNG draws, injected in its order: device randn for x_T (...res.py:277), CPU randn for the loss noise (:203), randint (:207)."""
+    draws = [torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["noise"])]
+    real_randn, real_randint = torch.randn, torch.randint
+    torch.randn = lambda *a, **k: draws.pop(0)
+    torch.randint = lambda *a, **k: torch.from_numpy(inp["timesteps"])
+    try:
+        yield
+    finally:
+        torch.randn, torch.randint = real_randn, real_randint
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_vis_head_forward_vs_reference_golden(on_host, golden, cases):
+    """DDIMDepthEstimate_ResVis.forward in eval mode (encoder, torch FPN, 5-step loop through dd_denoise_trace, decoder of every
+    intermediate sample, ddim_loss through dd_add_noise-less q_sample + dd_denoise_once) against the reference head's outputs.
+    16-bit operands keep the emulation short: the bound is the f16 class, the fp32 gate (1e-3 abs on depth) runs with DD_EMU_FULL=1."""
+    c, g = cases["head_res_vis"], golden("head_res_vis")
+    prec = "fp32" if FULL else "f16"
+    head = dda.DDIMDepthEstimate_ResVis(in_channels=[64, 128, 256, 512], inference_steps=c["T"], precision=prec).eval()
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    fp, gt, inp = _inputs(c)
+    with _draws(inp), torch.no_grad():
+        out = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+    assert set(out) == set(cases["head_res"]["output_keys"])
+    be = head._bound.backend
+    assert be is not None and be._lib.emu_launch_count() > 0, "the library did not run"
+    tol = 1e-3 if FULL else 2e-2 * float(np.abs(g["pred"]).max())
+    assert float(np.abs(out["pred"].numpy() - g["pred"]).max()) < tol
+    assert len(out["pred_inter"]) == c["T"]
+    for k in range(c["T"]):                                           # every intermediate sample, decoded (...res_vis.py:141-143)
+        assert float(np.abs(out["pred_inter"][k].numpy() - g["pred_inter"][k]).max()) < tol * (1.0 if FULL else max(1.0, float(np.abs(g["pred_inter"][k]).max()) / float(np.abs(g["pred"]).max())))
+    assert torch.equal(out["pred_init"], out["gt_map_t"]) and out["pred_init"].shape == (c["B"], 16, c["H"] // 2, c["W"] // 2)
+    gl = float(g["ddim_loss"][0])
+    assert abs(float(out["ddim_loss"]) - gl) < (1e-4 if FULL else 2e-2) * max(1.0, abs(gl))
+
+
+def test_training_step_with_optimizer_refresh_vs_reference_golden(on_host, golden, cases, monkeypatch):
+    """One .train() step of DDIMDepthEstimate_Res (loop + ddim_loss forward AND backward in the library through the autograd Functions,
+    BatchNorm FPN / codec in torch) against the reference head under autograd (head_train_res.npz), then optimizer.step() and a second
+    forward: the denoiser group -- and only it -- is refreshed, here through dd_set_weight_device."""
+    monkeypatch.setenv("DDEPTH_DEVICE_WEIGHTS", "1")
+    c, g = cases["head_train_res"], golden("head_train_res")
+    head = _head(c, "naive_fp32" if not FULL else "fp32").train()
+    fp, gt, inp = _inputs(c, grad=True)
+    with _draws(inp):
+        out = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+        loss = (out["pred"] - gt).abs().mean() + out["ddim_loss"]
+        loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"][0])) <= 1e-4 * abs(float(g["loss"][0]))
+    errs = {"pred": _rel(out["pred"].detach().numpy(), g["pred"]), "grad_fp3": _rel(fp[3].grad.numpy(), g["grad_fp3"]),
+            "grad_fp0": _rel(fp[0].grad.numpy()[:, :4], g["grad_fp0_ch0_4"])}
+    named = dict(head.named_parameters())
+    for k in c["grad_keys"]:
+        got = named[k].grad.numpy()
+        if got.size > 5000:
+            got = got.reshape(-1)[::c["grad_stride"]]
+        errs[k] = _rel(got, g["grad." + k])
+    bad = {k: v for k, v in errs.items() if v > 1e-2}
+    assert not bad, bad
+    # optimizer step -> the next forward refreshes the denoiser group only (codec and FPN run in torch while training)
+    be = head._bound.backend
+    uploads = []
+    real = be.load_state_dict
+    monkeypatch.setattr(be, "load_state_dict", lambda sd, **k: (uploads.append(sorted({n.split(".")[0] for n in sd})), real(sd, **k))[1])
+    d0 = be.weights_digest()
+    torch.optim.SGD(head.parameters(), lr=1e-2).step()
+    with _draws(inp):
+        out2 = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+    assert uploads == [["model"]]
+    assert be.weights_digest() != d0
+    fresh = on_host(CPU)
+    fresh.load_state_dict({"model." + k: v for k, v in head.model.state_dict().items()}, device_route=False)
+    assert fresh.weights_digest() == be.weights_digest()           # device route == host route on the updated values
+    assert not torch.equal(out2["pred"], out["pred"])
