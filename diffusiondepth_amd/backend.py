@@ -218,7 +218,8 @@ class HipDenoiser:
             self._ck(self._lib.dd_commit_weights(self._h, stream), "dd_commit_weights")
         self._have_weights = self._have_weights or saw_model
         self._have_fpn = self._have_fpn or saw_fpn
-        self._cond_token = None
+        if saw_fpn:
+            self._cond_token = None       # new FPN weights: the map dd_condition left in the handle is stale (the other groups do not touch it)
         return n
 
     def weights_digest(self) -> int:

@@ -97,9 +97,13 @@ class DDIMDepthEstimate_Res(nn.Module):
             bound.register("conv_lateral.", self.conv_lateral)
             bound.register("conv_up.", self.conv_up)
 
+    @staticmethod
+    def _on_hip(tensors) -> bool:
+        return all(t.is_cuda for t in tensors)
+
     # -- condition aggregation (…res.py:108-118) --------------------------------------------------
     def aggregate_condition(self, fp):
-        if self._hip_fpn and not self.training and len(fp) == 4 and all(f.is_cuda for f in fp) and self.model.precision != "naive_fp32":
+        if self._hip_fpn and not self.training and len(fp) == 4 and self._on_hip(fp) and self.model.precision != "naive_fp32":
             # eval-mode BatchNorm is folded into the convolutions inside the library (dd_condition)
             be = self._bound.ensure(fp[0].device, self.scheduler, need=("fpn",))
             return be.condition([f.float() for f in fp], self.model.precision)

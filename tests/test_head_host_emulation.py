@@ -102,8 +102,8 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def test_vis_head_forward_vs_reference_golden(on_host, golden, cases):
-    """DDIMDepthEstimate_ResVis.forward in eval mode (encoder, torch FPN, 5-step loop through dd_denoise_trace, decoder of every
+def test_vis_head_forward_vs_reference_golden(on_host, golden, cases, monkeypatch):
+    """DDIMDepthEstimate_ResVis.forward in eval mode (encoder, condition FPN by dd_condition, 5-step loop through dd_denoise_trace, decoder of every
     intermediate sample, ddim_loss through dd_add_noise-less q_sample + dd_denoise_once) against the reference head's outputs.
     16-bit operands keep the emulation short: the bound is the f16 class, the fp32 gate (1e-3 abs on depth) runs with DD_EMU_FULL=1."""
     c, g = cases["head_res_vis"], golden("head_res_vis")
@@ -113,11 +113,16 @@ def test_vis_head_forward_vs_reference_golden(on_host, golden, cases):
     sd.update(synth.make_fpn_state_dict(c["fseed"]))
     head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     fp, gt, inp = _inputs(c)
+    monkeypatch.setattr(type(head), "_on_hip", staticmethod(lambda tensors: True))       # condition FPN in the library too (dd_condition)
+    seen = []
+    real_cond_arg = B_.HipDenoiser._cond_arg
+    monkeypatch.setattr(B_.HipDenoiser, "_cond_arg", lambda self, cond, precision: (seen.append(real_cond_arg(self, cond, precision)), seen[-1])[1])
     with _draws(inp), torch.no_grad():
         out = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
     assert set(out) == set(cases["head_res"]["output_keys"])
     be = head._bound.backend
     assert be is not None and be._lib.emu_launch_count() > 0, "the library did not run"
+    assert seen == [None, None], "the loop and the ddim_loss call must pick up the map dd_condition left in the handle (no re-conversion)"
     tol = 1e-3 if FULL else 2e-2 * float(np.abs(g["pred"]).max())
     assert float(np.abs(out["pred"].numpy() - g["pred"]).max()) < tol
     assert len(out["pred_inter"]) == c["T"]
