@@ -171,3 +171,33 @@ def test_training_step_with_optimizer_refresh_vs_reference_golden(on_host, golde
     fresh.load_state_dict({"model." + k: v for k, v in head.model.state_dict().items()}, device_route=False)
     assert fresh.weights_digest() == be.weights_digest()           # device route == host route on the updated values
     assert not torch.equal(out2["pred"], out["pred"])
+
+
+@pytest.mark.skipif(not FULL, reason="T = 20 on the UpSample_add denoiser: minutes of emulation, set DD_EMU_FULL=1")
+@pytest.mark.parametrize("case,cls,chans", [("head_mpvit_hahi", "DDIMDepthEstimate_MPVIT_ADDHAHI", (128, 216, 288, 288)),
+                                            ("head_swin_hahi", "DDIMDepthEstimate_Swin_ADDHAHI", (192, 384, 768, 1536))], ids=["mpvit", "swin"])
+def test_hahi_head_forward_vs_reference_golden(on_host, golden, cases, monkeypatch, case, cls, chans):
+    """The reference's headline head (HAHI neck in torch -> dd_condition at the Swin-L / MPViT-small widths -> bilinear upsample +
+    UpSample_add denoiser, 20 steps -> decoder -> ddim_loss), f16 operands, against the reference head's outputs."""
+    c, g = cases[case], golden(case)
+    sd = synth.make_state_dict(c["wseed"], "swin", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update({k: v for k, v in synth.make_fpn_state_dict(c["fseed"], in_channels=chans).items() if not k.startswith("convup_fp")})
+    sd.update(synth.make_hahi_state_dict(c["hseed"], chans))
+    head = getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16, loss_cfgs=[],
+                             precision="f16", neck_autocast=False).eval()
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    monkeypatch.setattr(type(head), "_on_hip", staticmethod(lambda tensors: True))
+    Bn, H, W = c["B"], c["H"], c["W"]
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(c["iseed"], Bn, H // 2, W // 2, in_channels=chans)]
+    gt = torch.from_numpy(synth.make_gt_depth(c["iseed"] + 1, Bn, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, Bn, h, w, (fp[0].shape[2], fp[0].shape[3]))
+    with _draws(inp), torch.no_grad():
+        out = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False)
+    assert set(out) == set(cases["head_res"]["output_keys"]) and out["pred_inter"] is None
+    scale = float(np.abs(g["pred"]).max())
+    assert float(np.abs(out["pred"].numpy() - g["pred"]).max()) < 2e-2 * scale
+    assert float(np.abs(out["pred_init"].numpy() - g["pred_init"]).max()) < 2e-5
+    gl = float(g["ddim_loss"][0])
+    assert abs(float(out["ddim_loss"]) - gl) < 2e-2 * max(1.0, abs(gl))
