@@ -201,3 +201,34 @@ def test_hahi_head_forward_vs_reference_golden(on_host, golden, cases, monkeypat
     assert float(np.abs(out["pred_init"].numpy() - g["pred_init"]).max()) < 2e-5
     gl = float(g["ddim_loss"][0])
     assert abs(float(out["ddim_loss"]) - gl) < 2e-2 * max(1.0, abs(gl))
+
+
+def test_model_facade_on_the_plumbing_configuration(on_host, monkeypatch):
+    """BASELINE.json configs[0] -- "ResNet-18 backbone + 64x64 latent, 5-step DDIM, batch=1 on CPU (plumbing)": the model facade's
+    forward(sample) -> dict (reference src/model/diffusion_dcbase_model.py:186-224) with mmbev_res18 in torch and the whole head in the
+    (emulated) library, f16 operands, against the fp64 oracle run on the same condition map and the same x_T."""
+    from diffusiondepth_amd import model as MD
+    from oracle import ddim_oracle as O
+    torch.manual_seed(7240)                                                       # reference default seed (src/config.py:44)
+    net = MD.Diffusion_DCbase_Model(MD.default_args(backbone_name="mmbev_res18", inference_steps=5, precision="f16")).eval()
+    head = net.depth_head
+    monkeypatch.setattr(type(head), "_on_hip", staticmethod(lambda tensors: True))
+    rs = np.random.RandomState(5)
+    rgb = torch.from_numpy(rs.standard_normal((1, 3, 128, 128)).astype(np.float32))
+    gt = torch.from_numpy(synth.make_gt_depth(6, 1, 128, 128))
+    inp = synth.make_inputs(7, 1, 64, 64)
+    with _draws(inp), torch.no_grad():
+        out = net({"rgb": rgb, "gt": gt, "dep": gt, "depth_map": gt, "depth_mask": gt > 0})
+    assert out["pred"].shape == (1, 1, 128, 128) and out["pred_init"].shape == (1, 16, 64, 64)
+    assert torch.isfinite(out["pred"]).all() and torch.isfinite(out["ddim_loss"])
+    assert head._bound.backend.counter("graph_launches") >= 1, "the 5-step loop did not run as one (recorded) graph"
+    # the same computation restated: torch backbone + torch FPN -> oracle loop + decoder (fp64) on the same x_T
+    with torch.no_grad():
+        fp = net.depth_backbone(rgb)
+        monkeypatch.setattr(head, "_hip_fpn", False)
+        cond = head.aggregate_condition(fp).numpy()
+    sd = {k: v.numpy() for k, v in head.state_dict().items()}
+    lat = O.ddim_loop(sd, inp["x_T"], cond, 5)
+    want = O.decode(sd, lat)
+    got = out["pred"].numpy()
+    assert float(np.abs(got - want).max()) < 2e-2 * max(float(np.abs(want).max()), 1e-3), (float(np.abs(got - want).max()), float(np.abs(want).max()))
