@@ -3,7 +3,7 @@
 DDIMDepthEstimate_Res.ddim_loss one by one at KITTI size (hipEvents around each stage, median of 7), with the loss noise on the device.
     python tools/ddim_loss_timing.py [batch] [precision]
 Run it under `rocprofv3 --kernel-trace --stats` for the kernel view."""
-import os, sys
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import torch.nn.functional as F
@@ -22,13 +22,14 @@ gt = torch.from_numpy(synth.make_gt_depth(2, B, H, W)).cuda()
 
 
 def stage_times(n=7):
-    names, rows = None, []
+    names, rows, hrows = None, [], []
     with torch.no_grad():
         for it in range(n + 2):
             ev = [torch.cuda.Event(enable_timing=True)]
             ev[0].record()
+            host = [time.perf_counter()]
             def mark():
-                e = torch.cuda.Event(enable_timing=True); e.record(); ev.append(e)
+                e = torch.cuda.Event(enable_timing=True); e.record(); ev.append(e); host.append(time.perf_counter())
             lab = []
             with head._bound.hold():
                 g = head.depth_transform.t(gt); mark(); lab.append("encode")
@@ -45,13 +46,16 @@ def stage_times(n=7):
             torch.cuda.synchronize()
             if it >= 2:
                 rows.append([ev[i].elapsed_time(ev[i + 1]) for i in range(len(ev) - 1)])
+                hrows.append([(host[i + 1] - host[i]) * 1e3 for i in range(len(host) - 1)])
             names = lab
     med = [sorted(r[i] for r in rows)[len(rows) // 2] for i in range(len(names))]
-    return names, med
+    hmed = [sorted(r[i] for r in hrows)[len(hrows) // 2] for i in range(len(names))]
+    return names, med, hmed
 
 
-names, med = stage_times()
-print(f"B={B} {prec}, KITTI {H}x{W}: stage medians (GPU time between hipEvents on the current stream)")
-for n_, m in zip(names, med):
-    print(f"  {n_:34s} {m:8.3f} ms")
-print(f"  {'sum':34s} {sum(med):8.3f} ms")
+names, med, hmed = stage_times()
+print(f"B={B} {prec}, KITTI {H}x{W}: stage medians -- GPU time between hipEvents on the current stream | HOST time the call took to return")
+print("  (a host time close to the GPU backlog = a hidden synchronisation in that stage; the host must stay ahead of the GPU)")
+for n_, m, hm in zip(names, med, hmed):
+    print(f"  {n_:34s} {m:8.3f} ms | host {hm:8.3f} ms")
+print(f"  {'sum':34s} {sum(med):8.3f} ms | host {sum(hmed):8.3f} ms")
