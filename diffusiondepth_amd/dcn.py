@@ -62,6 +62,13 @@ def _dev_f32(t, name):
     return t
 
 
+def require_hip(t, what):
+    """The module-level guard of nlspn.NLSPN.forward: like the reference's extension, there is no CPU path."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} runs only on a HIP device (the reference's DCN extension has no CPU path either: "
+                           "src/model/deformconv/src/modulated_deform_conv.h:39-43)")
+
+
 def _stream(t):
     return ctypes.c_void_p(int(torch.cuda.current_stream(t.device).cuda_stream))
 

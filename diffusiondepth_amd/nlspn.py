@@ -104,9 +104,7 @@ class NLSPN(nn.Module):
         assert self.ch_f == feat_init.shape[1]
         if self.args.conf_prop:
             assert confidence is not None
-        if not feat_init.is_cuda:
-            raise RuntimeError("NLSPN runs only on a HIP device (the reference's DCN extension has no CPU path either: "
-                               "src/model/deformconv/src/modulated_deform_conv.h:39-43)")
+        dcn.require_hip(feat_init, "NLSPN")
         if self.args.preserve_input:
             assert feat_init.shape == feat_fix.shape
         if not self._needs_autograd(feat_init, guidance, confidence):

@@ -52,6 +52,26 @@ def install(lib, setattr_fn):
     return make, made
 
 
+def install_dcn(lib, setattr_fn):
+    """Same for diffusiondepth_amd.dcn (the DCN-extension drop-in under nlspn.NLSPN): its tensor guard, stream lookup and library handle."""
+    from diffusiondepth_amd import dcn
+
+    def dev_f32(t, name):
+        assert isinstance(t, torch.Tensor), name
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")
+        return t
+    setattr_fn(dcn, "_dev_f32", dev_f32)
+    setattr_fn(dcn, "_stream", lambda t: ctypes.c_void_p(0))
+    setattr_fn(dcn, "require_hip", lambda t, what: None)
+    setattr_fn(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    setattr_fn(B_, "load_library", lambda: lib)
+    setattr_fn(dcn, "_bound", None)                  # dcn._lib() then binds (and types) the emulated library's dd_dcn_* / dd_nlspn_* entries
+    return dcn
+
+
 def destroy(lib, made):
     for be in made:
         if be._h is not None:
