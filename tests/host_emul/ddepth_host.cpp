@@ -43,4 +43,6 @@ void emu_set_order(int order) { hostemu::st().order = order; }
 // 0 = an LDS-DMA lands when it is issued, 1 = only when an s_waitcnt retires it
 void emu_set_dma_late(int late) { hostemu::st().dma_late = late; }
 unsigned long emu_launch_count() { return hostemu::st().n_launches; }
+// host-blocking runtime calls so far (hipDeviceSynchronize / hipStreamSynchronize / hipEventSynchronize / blocking hipMemcpy / hipMalloc / hipFree)
+unsigned long emu_blocking_calls() { return hostemu::blocking_calls(); }
 }

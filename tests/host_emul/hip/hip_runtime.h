@@ -64,26 +64,30 @@ static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }   // a 4-CU "device": persistent grids stay small
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+// calls after which the HOST would wait for the device (synchronise, blocking copy, allocation): counted so that tests can assert that a
+// steady-state entry point never blocks the host (the host must stay ahead of the GPU)
+namespace hostemu { inline unsigned long& blocking_calls() { static unsigned long n = 0; return n; } }
+static inline hipError_t hipDeviceSynchronize() { ++hostemu::blocking_calls(); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { ++hostemu::blocking_calls(); return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = malloc(8); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 // "device" memory is host memory, handed out filled with 0xFF (NaN as float / double): a kernel that reads what nobody wrote shows up
 static inline hipError_t hipMalloc(void** p, size_t n) {
+  ++hostemu::blocking_calls();
   *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256);
   if (!*p) return hipErrorOutOfMemory;
   memset(*p, 0xFF, n);
   return hipSuccess;
 }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { ++hostemu::blocking_calls(); free(p); return hipSuccess; }
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 struct hostemu_event { double t; };
 typedef hostemu_event* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hostemu_event{0.0}; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { ++hostemu::blocking_calls(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 struct hostemu_graph { std::vector<std::function<void()>> nodes; };
 typedef hostemu_graph* hipGraph_t;
@@ -352,7 +356,7 @@ inline void wait_vm(int n) {                    // s_waitcnt vmcnt(n): at most n
 }  // namespace hostemu
 
 // ---- copies, events, stream capture / graphs --------------------------------------------------------------------------------------------------
-static inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind) { memcpy(d, s_, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind) { ++hostemu::blocking_calls(); memcpy(d, s_, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) {
   hostemu::State& s = hostemu::st();
   if (s.capturing) { s.capturing->nodes.push_back([d, s_, n]() { memcpy(d, s_, n); }); return hipSuccess; }

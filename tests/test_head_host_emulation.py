@@ -268,3 +268,43 @@ def test_two_rank_data_parallel_training_step_equals_the_average_of_its_shards(o
         assert float(want.abs().max()) > 0
         checked += 1
     assert checked == 8
+
+
+def test_the_host_never_blocks_in_steady_state(on_host, lib, monkeypatch):
+    """Runtime calls after which the HOST waits for the device (hipDeviceSynchronize / hipStreamSynchronize / hipEventSynchronize, blocking
+    hipMemcpy, hipMalloc / hipFree; counted by the emulated runtime): once plans, graphs and workspaces exist, an eval forward of the head
+    -- encoder, dd_condition, the loop, decoder, the ddim_loss call -- makes NONE, nor does a training step's backward; the per-step
+    parameter refresh costs 2 by the device route (one device sync before the images are overwritten, one stream sync after) against dozens
+    by the host route (a synchronous upload per packed image)."""
+    lib.emu_blocking_calls.restype = ctypes.c_ulong
+    sd = synth.make_state_dict(7240)
+    sd.update(synth.make_fpn_state_dict(7241))
+    Bn, H, W = 1, 16, 48
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(1, Bn, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(2, Bn, H, W))
+    head = dda.DDIMDepthEstimate_Res(precision="f16", inference_steps=3, loss_noise_device="device").eval()
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    monkeypatch.setattr(type(head), "_on_hip", staticmethod(lambda tensors: True))
+    with torch.no_grad():
+        head(fp, gt, gt > 0, gt_depth_map=gt)                                   # first call: uploads, plans, graph capture
+        n0 = lib.emu_blocking_calls()
+        head(fp, gt, gt > 0, gt_depth_map=gt)
+    assert lib.emu_blocking_calls() == n0
+    train = dda.DDIMDepthEstimate_Res(precision="f16", inference_steps=2).train()
+    train.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    opt = torch.optim.SGD(train.parameters(), lr=1e-4)
+    per_route = {}
+    for route in ("0", "1"):
+        monkeypatch.setenv("DDEPTH_DEVICE_WEIGHTS", route)
+        for it in range(2):
+            fpg = [f.clone().requires_grad_(True) for f in fp]
+            c0 = lib.emu_blocking_calls()
+            out = train(fpg, gt, gt > 0, gt_depth_map=gt)
+            c1 = lib.emu_blocking_calls()
+            ((out["pred"] - gt).abs().mean() + out["ddim_loss"]).backward()
+            c2 = lib.emu_blocking_calls()
+            opt.step()
+            opt.zero_grad()
+        per_route[route] = (c1 - c0, c2 - c1)                                   # second iteration = steady state
+    assert per_route["1"] == (2, 0), per_route
+    assert per_route["0"][1] == 0 and per_route["0"][0] > 20, per_route
