@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddepth_hip.so")
 SOURCES = ["dd_api.cpp", "dd_igemm.hip", "dd_igemm2.hip", "dd_igemm2ws.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_dcn.hip", "dd_wino.hip"]
-HEADERS = ["dd_kernels.h", "dd_elem.h", "dd_igemm2_cfg.h", os.path.join("..", "..", "include", "ddepth.h"),
-           os.path.join("..", "..", "include", "ddepth_dcn.h")]
+# every header under csrc/ and include/ (a stale-check that misses one -- dd_gcn.h in round 1 -- reuses an old .so after an edit)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + \
+          [os.path.join("..", "..", "include", f) for f in sorted(os.listdir(os.path.join(HERE, "..", "include"))) if f.endswith(".h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 

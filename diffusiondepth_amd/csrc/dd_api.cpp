@@ -300,10 +300,12 @@ int upload(dd_handle_t h, DevBuf& dst, const void* src, size_t bytes, hipStream_
   return DD_OK;
 }
 
-int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw) {
+// need_schedule: the T-step loop (and its backward) reads the DDIM tables; ONE epsilon-network evaluation does not
+// (reference ...res.py:324-344 has no scheduler dependency), so dd_denoise_once / _backward run on a handle without a schedule.
+int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw, bool need_schedule) {
   if (!h) return DD_ERR_INVALID_ARG;
   if (!h->committed) return h->fail(DD_ERR_STATE, "model.* weights not committed (call dd_set_weight for every key, then dd_commit_weights)");
-  if (h->n_train <= 0) return h->fail(DD_ERR_STATE, "schedule not set (dd_set_schedule)");
+  if (need_schedule && h->n_train <= 0) return h->fail(DD_ERR_STATE, "schedule not set (dd_set_schedule)");
   if (B <= 0 || lh <= 0 || lw <= 0) return h->fail(DD_ERR_INVALID_ARG, "B, lat_h, lat_w must be positive");
   if (h->variant == DD_VARIANT_RES && (ch != lh || cw != lw))
     return h->fail(DD_ERR_INVALID_ARG, "DD_VARIANT_RES needs cond_h,cond_w == lat_h,lat_w (reference ...res.py:340 adds them elementwise)");
@@ -1028,6 +1030,9 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
 int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_timesteps) {
   if (!h) return DD_ERR_INVALID_ARG;
   if (!alphas_cumprod || num_train_timesteps <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_set_schedule: null table or non-positive length");
+  if (num_train_timesteps > EMB_ROWS)
+    return h->fail(DD_ERR_INVALID_ARG, "dd_set_schedule: num_train_timesteps exceeds the time embedding's " + std::to_string(EMB_ROWS) +
+                                       " rows (reference ...res.py:313 nn.Embedding(1280, 256))");
   for (int i = 0; i < num_train_timesteps; ++i)
     if (!(alphas_cumprod[i] > 0.f && alphas_cumprod[i] <= 1.f))
       return h->fail(DD_ERR_INVALID_ARG, "dd_set_schedule: alphas_cumprod must lie in (0, 1]");
@@ -1212,7 +1217,7 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
 
 int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
                int cond_h, int cond_w, int T, int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
   if (rc) return rc;
   if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
@@ -1300,7 +1305,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
 
 int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* states, int B, int lat_h, int lat_w,
                      int cond_h, int cond_w, int T, int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
   if (rc) return rc;
   if (!x_T || !states) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: num_inference_steps must be in [1, num_train_timesteps]");
@@ -1349,7 +1354,7 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
 
 int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, float* eps, int B, int lat_h,
                     int lat_w, int cond_h, int cond_w, int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, false);
   if (rc) return rc;
   if (!x_t || !t || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
@@ -1587,7 +1592,7 @@ int check_bwd(dd_handle_t h, int precision, const char* who) {
 int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, const float* cond, const float* grad_eps,
                              float* grad_x, float* grad_cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
                              int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, false);
   if (rc) return rc;
   if (!x_t || !t || !grad_eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once_backward: null pointer");
   rc = check_bwd(h, precision, "dd_denoise_once_backward");
@@ -1612,7 +1617,7 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
 
 int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
                         int B, int lat_h, int lat_w, int cond_h, int cond_w, int T, int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w);
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
   if (rc) return rc;
   if (!x_T || !grad_x0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: null pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: num_inference_steps must be in [1, num_train_timesteps]");

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(ActView ga, ActView y
   }
   __syncthreads();
   const long long total = y.HW * C;
-  const long long t = tvec ? tvec[t_base + b * t_bstride] : 0;
+  const long long t = tvec ? clamp_t(tvec[t_base + b * t_bstride]) : 0;
   for (long long i = (long long)blockIdx.x * 256 + tid; i < total; i += (long long)gridDim.x * 256) {
     const long long p = i / C;
     const int c = (int)(i - p * C);
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) channel_sum_kernel(ActView v, float* __re
   if (tid < C) {
     double t = 0.0;
     for (int k = 0; k < np; ++k) t += s_red[k * C + tid];
-    const long long row = rows ? rows[t_base + b * t_bstride] : 0;
+    const long long row = rows ? clamp_t(rows[t_base + b * t_bstride]) : 0;
     atomicAdd(out + (size_t)row * C + tid, (float)t);
   }
 }
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
   const int grp = c0 / CG;
   const float mean = s_mean[grp], rstd = s_rstd[grp], pg = s_p[grp], qg = s_q[grp];
   float ta[8], tb[8], te[8];
-  const long long t = tvec ? tvec[t_base + b * t_bstride] : 0;
+  const long long t = tvec ? clamp_t(tvec[t_base + b * t_bstride]) : 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     ta[k] = gamma[c0 + k] * rstd;
@@ -360,7 +360,7 @@ __global__ void gn_param_grad4_kernel(const double* __restrict__ sums, const dou
     const double qg = -(double)rstd * rstd * s2 * inv_n;
     const double pg = -(double)rstd * s1 * inv_n - (double)mean * qg;
     sbias += (double)gamma[c] * rstd * sc[0] + (double)HW * pg + qg * sc[2];
-    if (demb) atomicAdd(demb + (size_t)tvec[t_base + b * t_bstride] * C + c, (float)sc[3]);
+    if (demb) atomicAdd(demb + (size_t)clamp_t(tvec[t_base + b * t_bstride]) * C + c, (float)sc[3]);
   }
   dbeta[c] += (float)sb;
   dgamma[c] += (float)sg;

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(C::THREADS) conv_igemm_kernel(ConvParams p) {
       tab_a[c] = (float)a;
       tab_b[c] = (float)((double)p.gn_beta[c] - mean * a);
       if constexpr (C::PRO == PRO_GN_ADD) {
-        const long long t = p.tvec[p.t_base + b * p.t_bstride];
+        const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
         tab_e[c] = p.emb[(size_t)t * COND_C + c];
       }
     }

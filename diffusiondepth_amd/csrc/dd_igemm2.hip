@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   issue_weights(0);
   if (tid < C::NT) tab_bias[tid] = p.bias[n0 + tid];     // visible after the first barrier below
   if constexpr (C::ADD_C) {
-    const long long t = p.tvec[p.t_base + b * p.t_bstride];
+    const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
     for (int i = tid; i < 10 * HID_C; i += C::THREADS) tab_et[i] = p.etab[(size_t)t * 10 * HID_C + i];
   }
   double2 sv0 = make_double2(0.0, 0.0), sv1 = make_double2(0.0, 0.0);
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       my_gamma = p.gn_gamma[tid];
       my_beta = p.gn_beta[tid];
       if constexpr (C::PRO == PRO_GN_ADD) {
-        const long long t = p.tvec[p.t_base + b * p.t_bstride];
+        const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
         my_emb = p.emb[(size_t)t * COND_C + tid];
       }
     }

@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
   // ================================= MFMA role ================================================================
   if (tid < C::NT) tab_bias[tid] = p.bias[n0 + tid];
   if constexpr (C::ADD_C) {
-    const long long t = p.tvec[p.t_base + b * p.t_bstride];
+    const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
     for (int i = tid; i < 10 * HID_C; i += 256) tab_et[i] = p.etab[(size_t)t * 10 * HID_C + i];
   }
   if constexpr (have_norm) {
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(512, 4) conv_igemm2ws_kernel(ConvParams p) {
     const float my_gamma = p.gn_gamma[tid], my_beta = p.gn_beta[tid];
     float my_emb = 0.f;
     if constexpr (C::PRO == PRO_GN_ADD) {
-      const long long t = p.tvec[p.t_base + b * p.t_bstride];
+      const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
       my_emb = p.emb[(size_t)t * COND_C + tid];
     }
 #pragma unroll

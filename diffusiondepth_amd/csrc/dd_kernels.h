@@ -17,6 +17,9 @@ constexpr int HID_C = 64;      // hidden width        (reference src/model/head/
 constexpr int COND_C = 256;    // channels_in/fpn_dim (reference ...res.py:27-28)
 constexpr int GN_GROUPS = 4;   // nn.GroupNorm(4, C)  (reference ...res.py:305,309,317,321)
 constexpr int EMB_ROWS = 1280; // nn.Embedding(1280, 256) (reference ...res.py:313)
+// timestep -> row of the time embedding / etab tables.  The reference's nn.Embedding raises on an out-of-range index; a device
+// kernel cannot, so rows are clamped (dd_set_schedule rejects num_train_timesteps > EMB_ROWS, so loop timesteps never clamp).
+__host__ __device__ inline long long clamp_t(long long t) { return t < 0 ? 0 : (t >= EMB_ROWS ? EMB_ROWS - 1 : t); }
 constexpr float GN_EPS = 1e-5f;
 constexpr float BN_EPS = 1e-5f;
 

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) naive_gn_apply_kernel(const float* __rest
   float v = (y[i] - (float)mean) * rstd * gamma[c] + beta[c];
   v = fmaxf(v, 0.f);
   if (cond) {
-    const long long t = tvec[t_base + b * t_bstride];
+    const long long t = clamp_t(tvec[t_base + b * t_bstride]);
     v = (cond[i] + emb[(size_t)t * C + c]) + v;        // feat = feat + E[t]; feat = feat + NE(x)
   }
   out[i] = v;

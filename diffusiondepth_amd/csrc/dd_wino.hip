@@ -644,7 +644,7 @@ __global__ void __launch_bounds__(256) wino_gn_table_kernel(const double* __rest
   var = var > 0.0 ? var : 0.0;
   const double a = (double)gamma[c] / sqrt(var + (double)GN_EPS);
   float e = 0.f;
-  if (emb != nullptr) e = emb[(size_t)tvec[t_base + b * t_bstride] * COND_C + c];
+  if (emb != nullptr) e = emb[(size_t)clamp_t(tvec[t_base + b * t_bstride]) * COND_C + c];
   reinterpret_cast<float4*>(tab)[(size_t)b * C + c] = make_float4((float)a, (float)((double)beta[c] - mean * a), e, 0.f);
 }
 

@@ -58,7 +58,8 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = Tr
     """Averages .grad of `params` over all ranks (gradient all-reduce of data-parallel training, reference
     src/main.py:106-114 via apex DDP).  Gradients are packed into flat buckets of ~bucket_bytes in parameter order (the
     same order on every rank), one all_reduce per bucket, and unpacked in place.  Parameters without .grad contribute
-    zeros so that the collective sequence is identical on every rank.  Returns the number of collectives issued."""
+    zeros so that the collective sequence is identical on every rank; a parameter NO rank has a gradient for keeps .grad = None.
+    Returns the number of collectives issued."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
         return 0
     world = dist.get_world_size()
@@ -72,19 +73,24 @@ def allreduce_gradients(params, bucket_bytes: int = 64 << 20, average: bool = Tr
             j += 1
         group = params[i:j]
         dev = group[0].device
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in group]).to(dev)
+        # one extra element per parameter: 1 where this rank has a gradient.  After the SUM, 0 means NO rank produced one (a branch
+        # that never executes, e.g. the HAHI attention parameters or convup_fp): its .grad stays None, as under the reference's apex
+        # DDP, instead of becoming zeros that weight decay / Adam would then act on.
+        flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in group], dtype=torch.float32, device=dev)
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in group] + [flags]).to(dev)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         n_coll += 1
+        used = flat[-len(group):].tolist()
         if average:
             flat /= world
         off = 0
-        for p in group:
+        for p, u in zip(group, used):
             n = p.numel()
             g = flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
+            if p.grad is not None:
                 p.grad.copy_(g)
+            elif u > 0:
+                p.grad = g.clone()
             off += n
         i = j
     return n_coll
@@ -132,7 +138,13 @@ class OverlappedGradReducer:
     order, so a never-ready parameter would hold back every bucket behind it until finish(): the first finish() therefore learns
     (and agrees across ranks on) the set of parameters no rank produced a gradient for, and later iterations treat them as ready
     from the start; if one of them does receive a gradient later, finish() raises instead of silently dropping it
-    (``relearn_unused()`` starts over).  Not distributed (world size 1): every method is a no-op."""
+    (``relearn_unused()`` starts over); their .grad is left untouched (None stays None, as under apex DDP).
+
+    Gradient accumulation over several backward passes: wrap all but the last micro-batch in ``no_sync()`` (hooks idle, gradients
+    accumulate locally, nothing is sent) -- the last backward then reduces the accumulated sums, overlapped as usual.  Without
+    ``no_sync()`` the result is still correct: a bucket whose parameters receive another gradient after its all-reduce was issued is
+    marked stale and reduced AGAIN in finish() from the accumulated ``.grad`` (the first transfer is wasted, not the gradient).
+    Not distributed (world size 1): every method is a no-op."""
 
     def __init__(self, params, bucket_bytes: int = 64 << 20, average: bool = True):
         self.params = [p for p in params if p.requires_grad]
@@ -157,6 +169,8 @@ class OverlappedGradReducer:
         self._unused = None                # indices no rank had a gradient for in the first iteration (None = not learned yet)
         self._violation = None
         self._next = 0                     # buckets are launched strictly in order (identical collective sequence on all ranks)
+        self._stale = [False] * len(self.buckets)   # a gradient arrived after the bucket's all-reduce was issued (second backward pass)
+        self._sync = True                  # False inside no_sync()
         self.launched_in_backward = 0      # statistics: buckets whose all-reduce started from a hook (i.e. overlapped)
         self._handles = []
         if self.active:
@@ -168,10 +182,15 @@ class OverlappedGradReducer:
             if self._unused is not None and i in self._unused:
                 self._violation = i        # declared unused after the first iteration, yet it has a gradient now: finish() raises
                 return
-            if self._ready[i]:
-                return                     # gradient accumulation over several backward passes: only the first call counts
-            self._ready[i] = True
+            if not self._sync:
+                return                     # no_sync(): accumulate locally, send nothing
             b = self._bucket_of[i]
+            if self._ready[i]:
+                # another backward pass without no_sync(): .grad now holds more than what was (or will be) flattened
+                if b < self._next:
+                    self._stale[b] = True  # already on the wire: finish() reduces this bucket again from the accumulated .grad
+                return
+            self._ready[i] = True
             self._pending[b] -= 1
             self._launch_ready(from_hook=True)
         return hook
@@ -208,6 +227,15 @@ class OverlappedGradReducer:
             used = used.to(dev)
             dist.all_reduce(used, op=dist.ReduceOp.MAX)
             self._unused = {i for i, u in enumerate(used.tolist()) if u == 0.0}
+        # stale buckets (same on every rank only if every rank ran the same number of backward passes -- agree on the union)
+        st = torch.tensor([1.0 if x else 0.0 for x in self._stale], device=self.params[0].device if self.params else torch.device("cpu"))
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        n = len(self.buckets)
+        for b, x in enumerate(st.tolist()):
+            if x > 0:
+                self._work[b].wait()       # the superseded transfer
+                self._launch(b)            # .grad has not been written back yet: it still holds the locally accumulated sum
+                n += 1
         for b, idx in enumerate(self.buckets):
             self._work[b].wait()
             flat = self._flat[b]
@@ -216,15 +244,28 @@ class OverlappedGradReducer:
             off = 0
             for i in idx:
                 p = self.params[i]
-                g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+                if i not in self._unused:          # nobody trained it: leave .grad alone (None stays None)
+                    g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
                 off += p.numel()
-        n = len(self.buckets)
         self._rearm()
         return n
+
+    def no_sync(self):
+        """Context for the micro-batches of a gradient-accumulation step that are NOT the last one (the name DDP uses)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._sync = self._sync, False
+            try:
+                yield self
+            finally:
+                self._sync = prev
+        return ctx()
 
     def _rearm(self):
         n = len(self.buckets)
@@ -235,6 +276,7 @@ class OverlappedGradReducer:
             self._pending[self._bucket_of[i]] -= 1
         self._work = [None] * n
         self._flat = [None] * n
+        self._stale = [False] * n
         self._next = 0
 
     def relearn_unused(self):

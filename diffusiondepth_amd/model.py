@@ -70,18 +70,41 @@ def default_args(**over):
     return SimpleNamespace(**a)
 
 
+def resolve_backbone(args):
+    """The reference's rule (src/model/backbone/__init__.py:5-11): ``getattr(import_module('model.backbone.' +
+    args.backbone_module.lower()), args.backbone_name)`` -- a zero-argument factory.  The bundled mmbev_res* family is served from
+    BACKBONES (no mmdet needed); any other name is imported from ``args.backbone_package`` (default 'model.backbone', i.e. the
+    reference tree this package is dropped into: swin.py / depthformerswin.py / mpvit.py stay upstream PyTorch per the north star)."""
+    from importlib import import_module
+    name = args.backbone_name
+    if name in BACKBONES:
+        return BACKBONES[name]
+    pkg = getattr(args, "backbone_package", None) or "model.backbone"
+    modname = f"{pkg}.{str(args.backbone_module).lower()}"
+    try:
+        module = import_module(modname)
+    except ImportError as e:
+        raise ImportError(f"backbone {name!r}: cannot import {modname!r} ({e}); only the mmbev_res* family is bundled -- run inside the "
+                          "reference tree (its src/ on sys.path), set args.backbone_package, or pass depth_backbone=<nn.Module>") from e
+    return getattr(module, name)
+
+
 class Diffusion_DCbase_Model(nn.Module):
-    def __init__(self, args=None):
+    def __init__(self, args=None, depth_backbone=None, depth_head=None, **kwargs):
+        """As the reference (diffusion_dcbase_model.py:28-91): ``depth_backbone`` / ``depth_head`` may be injected as built modules;
+        otherwise the backbone is resolved from args.backbone_module / args.backbone_name and the head from args.head_specify.  The
+        head classes fix their own pyramid widths (the reference passes in_channels=[64,128,256,512] to every head and each head
+        overrides it, ...res.py:31, ...res_swin_add.py:31), so any backbone emitting that head's 4 maps composes."""
         super().__init__()
         self.args = args if args is not None else default_args()
-        name = self.args.backbone_name
-        if name not in BACKBONES:
-            raise NotImplementedError(f"backbone {name!r}: only the mmbev_res* family is bundled; Swin/MPViT stay upstream PyTorch")
-        self.depth_backbone = BACKBONES[name]()
-        self.depth_head = build_head(dict(type=self.args.head_specify, in_channels=[64, 128, 256, 512],
-                                          inference_steps=self.args.inference_steps,
-                                          num_train_timesteps=self.args.num_train_timesteps, depth_feature_dim=16,
-                                          loss_cfgs=[], init_cfg=None, precision=getattr(self.args, "precision", None)))
+        self.depth_backbone = depth_backbone if depth_backbone is not None else resolve_backbone(self.args)()
+        if depth_head is not None:
+            self.depth_head = depth_head
+        else:
+            self.depth_head = build_head(dict(type=self.args.head_specify, in_channels=[64, 128, 256, 512],
+                                              inference_steps=getattr(self.args, "inference_steps", 20),
+                                              num_train_timesteps=getattr(self.args, "num_train_timesteps", 1000), depth_feature_dim=16,
+                                              loss_cfgs=[], init_cfg=None, precision=getattr(self.args, "precision", None)))
 
     def extract_depth(self, img, depth_map, depth_mask, gt_depth_map=None, return_loss=False, **kw):
         fp = self.depth_backbone(img)                                                   # :125

@@ -73,14 +73,15 @@ def _grad_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     ddist.init_from_env("gloo")
     torch.manual_seed(0)
-    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(64, 16, 3, 3), (64,), (256, 64, 3, 3), (1280, 256), (16,)]]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(64, 16, 3, 3), (64,), (256, 64, 3, 3), (1280, 256), (16,), (7,)]]
     for k, p in enumerate(params):
-        if k == 4 and rank == 1:
-            continue                                   # a parameter that received no gradient on this rank
+        if (k == 4 and rank == 1) or k == 5:
+            continue                                   # 4: no gradient on this rank;  5: no gradient on ANY rank (a never-executed branch)
         p.grad = torch.full_like(p, float(rank + 1) * (k + 1))
     n = ddist.allreduce_gradients(params, bucket_bytes=1 << 20)      # 1 MiB buckets -> several collectives
+    assert params[5].grad is None                      # stays None on every rank, as under the reference's apex DDP (no zeros for Adam / decay)
     if rank == 0:
-        torch.save({"n": n, "g": [p.grad.clone() for p in params]}, out)
+        torch.save({"n": n, "g": [p.grad.clone() for p in params[:5]]}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -114,7 +115,22 @@ def _overlap_worker(rank, world, port, out):
         net(x).square().mean().backward()
         res[f"launched_in_backward_{it}"] = red.launched_in_backward
         res[f"n_{it}"] = red.finish()
-        res[f"g_{it}"] = [p.grad.clone() for p in params]
+        assert unused.grad is None                             # nobody trained it: not materialised as zeros
+        res[f"g_{it}"] = [p.grad.clone() for p in params[:-1]]
+    # gradient accumulation, two micro-batches per step: (a) the first under no_sync(), (b) both plain -- the buckets that
+    # were already on the wire when the second backward ran are reduced again in finish().  Both must give the rank-average of the SUMS.
+    for mode in ("no_sync", "plain"):
+        for p in params:
+            p.grad = None
+        for mb in range(2):
+            x = torch.from_numpy(np.random.RandomState(100 + 10 * mb + rank).standard_normal((2, 3, 12, 12)).astype(np.float32))
+            if mode == "no_sync" and mb == 0:
+                with red.no_sync():
+                    net(x).square().mean().backward()
+            else:
+                net(x).square().mean().backward()
+        res[f"n_acc_{mode}"] = red.finish()
+        res[f"g_acc_{mode}"] = [p.grad.clone() for p in params[:-1]]
     red.close()
     if rank == 0:
         torch.save(res, out)
@@ -124,7 +140,8 @@ def _overlap_worker(rank, world, port, out):
 
 def test_two_rank_gloo_overlapped_gradient_reducer(tmp_path):
     """OverlappedGradReducer: buckets are all-reduced from autograd hooks while backward is still running; the result equals the
-    average of the two ranks' gradients computed in one process; unused parameters are reduced as zeros; the reducer re-arms."""
+    average of the two ranks' gradients computed in one process; a parameter nobody trained keeps .grad None; the reducer re-arms;
+    gradient accumulation (with and without no_sync()) reduces the accumulated sums."""
     out = str(tmp_path / "o.pt")
     mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = torch.load(out)
@@ -141,13 +158,25 @@ def test_two_rank_gloo_overlapped_gradient_reducer(tmp_path):
                 w += p.grad / 2
         got = r[f"g_{it}"]
         assert r[f"n_{it}"] >= 3
-        for k, (g, w) in enumerate(zip(got[:-1], want)):
+        for k, (g, w) in enumerate(zip(got, want)):
             assert torch.allclose(g, w, rtol=1e-5, atol=1e-7), (it, k)
-        assert torch.equal(got[-1], torch.zeros(5))                       # the unused parameter: zeros averaged
     # iteration 0: the unused parameter sits in the first bucket and holds the in-order launches back until finish(); finish() learns
     # (across ranks) that nobody has a gradient for it, so in iteration 1 EVERY bucket starts its all-reduce from a hook inside backward
     assert r["launched_in_backward_0"] == 0
     assert r["launched_in_backward_1"] - r["launched_in_backward_0"] == r["n_1"]
+    # accumulation over two micro-batches: average over ranks of (g_mb0 + g_mb1)
+    want = [torch.zeros_like(p) for p in net.parameters()]
+    for rank in range(2):
+        net.zero_grad()
+        for mb in range(2):
+            x = torch.from_numpy(np.random.RandomState(100 + 10 * mb + rank).standard_normal((2, 3, 12, 12)).astype(np.float32))
+            net(x).square().mean().backward()
+        for w, p in zip(want, net.parameters()):
+            w += p.grad / 2
+    for mode in ("no_sync", "plain"):
+        for k, (g, w) in enumerate(zip(r[f"g_acc_{mode}"], want)):
+            assert torch.allclose(g, w, rtol=1e-5, atol=1e-7), (mode, k)
+    assert r["n_acc_plain"] > r["n_acc_no_sync"]            # the plain form paid for re-sending the stale buckets
 
 
 def test_overlapped_reducer_is_a_noop_without_a_process_group():
