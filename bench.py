@@ -1,12 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- depth-maps/second of the DDIM denoise hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--precision bf16] [--batch B] [--size kitti|nyu]
+    python bench.py --gpus N --steps K --warmup W [--precision bf16] [--batch B] [--size kitti|nyu] [--mode infer|train-dp]
 
 One "step" = one pass of the hot path over one batch of B synthetic depth maps resident in HBM:
-latent encoder -> T-step DDIM loop (one hipGraph replay) -> latent decoder.  N > 1 is launched by
-torch.distributed.run, one process per GPU; the path shards by independent images, so there is no
-data-path collective (scaling "weak": B maps per GPU per step).  Rank 0 prints ONE JSON line.
+latent encoder -> T-step DDIM loop (one hipGraph replay) -> latent decoder.  N > 1 = one process per GPU over RCCL: either
+launched by `python -m torch.distributed.run ... bench.py --gpus N` (RANK / WORLD_SIZE in the environment) or, when invoked
+plainly as `python bench.py --gpus N`, bench.py starts the N ranks ITSELF (re-executes under torch.distributed.run on
+127.0.0.1, as the reference self-spawns at src/main.py:501-502).  The path shards by independent images, so inference has no
+data-path collective (scaling "weak": B maps per GPU per step); the barriers and the max-over-ranks of the timed region are
+the only collectives.  Rank 0 prints ONE JSON line, whose `n_gpus` is the world size the process group reported.
+
+--mode train-dp   one data-parallel TRAINING step of the drop-in Swin head (BASELINE config 4: per-GPU batch 4): forward (torch FPN /
+                  codec in .train(), the T-step loop and the ddim_loss call in the library), loss.backward() through
+                  dd_denoise_backward / dd_denoise_once_backward, gradient all-reduce overlapped with backward
+                  (dist.OverlappedGradReducer on the nccl backend), optimizer step; reports step ms and the exposed all-reduce time.
+--dist-selftest   no hot path: spawn / rendezvous / barrier / reductions only (what the 2-rank gloo CPU test drives).
 
 Extra objects in the line (tier contract):
   roofline      dominant kernel (conv3x3 implicit GEMM) measured live with hipEvents on the launch
@@ -132,6 +141,140 @@ def head_extra(dev, B, H, W, precision, T):
             "inference_only_maps_per_s": round(B / t_inf * 1e3, 1)}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (torch.distributed.run, one node, rendezvous on 127.0.0.1 --
+    the container hostname may not resolve) and wait.  The children see WORLD_SIZE and take the rank path below."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+    print(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def dist_selftest(args, world, rank, local_rank):
+    """The multi-rank plumbing of this file without the hot path: process group, barrier-bracketed timed region, MAX over ranks,
+    rank census.  Runs on any backend (gloo on a CPU-only host: tests/test_bench_dist_cpu.py)."""
+    import torch.distributed as dist
+    use_cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if use_cuda:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = torch.zeros(world, dtype=torch.int64, device=dev)
+    seen[rank] = 1
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))                    # rank-dependent "work": the MAX over ranks must pick the slowest
+    if world > 1:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        n = dist.get_world_size() if world > 1 else 1
+        print(json.dumps({"dist_selftest": True, "n_gpus": n, "requested_gpus": args.gpus, "ranks_seen": int(seen.sum()),
+                          "backend": (dist.get_backend() if world > 1 else None), "steps": args.steps,
+                          "ms_per_step": round(float(el.item()) / max(args.steps, 1) * 1e3, 4)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def train_dp(args, dev, dist, world, rank):
+    """--mode train-dp: see the module docstring.  Returns the JSON object (rank 0) or None."""
+    import diffusiondepth_amd as dda
+    from diffusiondepth_amd import dist as ddist
+    from diffusiondepth_amd import synth
+    H, W = SIZES[args.size]
+    B, T = args.batch, args.T
+    swin = args.variant == "swin"
+    chans = (192, 384, 768, 1536) if swin else (64, 128, 256, 512)
+    os.environ.setdefault("DDEPTH_DEVICE_WEIGHTS", "1")     # parameter refresh after optimizer.step() without leaving HBM
+    cls = dda.DDIMDepthEstimate_Swin_ADD if swin else dda.DDIMDepthEstimate_Res
+    head = cls(precision=args.precision, inference_steps=T, loss_noise_device="device")
+    sd = synth.make_state_dict(7240, args.variant)
+    sd.update(synth.make_fpn_state_dict(7241, in_channels=chans))
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    head = head.to(dev).train()
+    params = [p for p in head.parameters() if p.requires_grad]
+    if dist is not None:
+        ddist.broadcast_state_dict({k: v for k, v in head.state_dict().items()})      # rank 0's parameters everywhere (apex DDP at wrap time)
+    opt = torch.optim.SGD(params, lr=1e-4)
+    reducer = ddist.OverlappedGradReducer(params)             # no-op when not distributed
+    stride0 = 4 if swin else 2
+    fp = [torch.from_numpy(f).to(dev) for f in synth.make_backbone_features(7240 + rank, B, H // (stride0 // 2), W // (stride0 // 2), in_channels=chans)]
+    gt = torch.from_numpy(synth.make_gt_depth(7240 + rank, B, H, W)).to(dev)
+    cs = torch.cuda.current_stream(dev)
+    exposed = []
+
+    def step(measure=False):
+        opt.zero_grad(set_to_none=True)
+        out = head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=True)
+        loss = (out["pred"] - gt).abs().mean() + out["ddim_loss"]        # depth loss + DDIM loss (reference src/main.py:232, loss/ddim_loss terms)
+        loss.backward()
+        if measure:
+            cs.synchronize()                   # backward kernels done; collectives (own stream) may still be running
+            t = time.perf_counter()
+        reducer.finish()
+        if measure:
+            torch.cuda.synchronize(dev)
+            exposed.append((time.perf_counter() - t) * 1e3)
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    for _ in range(3):
+        step(measure=True)
+    assert torch.isfinite(loss).all()
+    n_world = dist.get_world_size() if dist is not None else 1
+    if rank != 0:
+        return None
+    h, w = synth.latent_hw(H, W)
+    FPS = FLOP_PER_PIXEL_STEP[args.variant]
+    nbytes = sum(p.numel() for p in params) * 4
+    return {"metric": f"training samples/sec ({T}-step DDIM head, {args.size.upper()} {H}x{W} {args.precision}, B={B}/GPU, fwd+bwd+all-reduce+SGD)",
+            "value": round(B * args.steps * n_world / elapsed, 3), "unit": "samples/s", "n_gpus": n_world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
+            "config": {"workload": f"{cls.__name__}.forward(.train()) + loss.backward() + gradient all-reduce + SGD step on synthetic backbone features "
+                                   f"{chans} (the backbone itself stays PyTorch and is not part of this path), latent 16x{h}x{w}, T={T}",
+                       "maps_per_gpu_per_step": B, "global_batch": B * n_world, "parallelism": f"dp{n_world} (RCCL all-reduce of {nbytes / 1e6:.1f} MB of head gradients per step, "
+                                                                                              f"{len(reducer.buckets)} bucket(s), overlapped with backward)",
+                       "variant": args.variant},
+            "allreduce_exposed_ms": round(sorted(exposed)[len(exposed) // 2], 3), "collectives_launched_in_backward": reducer.launched_in_backward,
+            "loop_fwd_bwd_tflops": round(4.0 * B * T * h * w * FPS / (elapsed / args.steps) / 1e12, 1),
+            "roofline": None, "cpu_baseline": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,22 +292,30 @@ def main():
     ap.add_argument("--no-train-extra", action="store_true", help="skip the training-step timing (loop forward + backward, batch 1)")
     ap.add_argument("--no-head-extra", action="store_true", help="skip the whole-head forward timing")
     ap.add_argument("--no-nlspn-extra", action="store_true", help="skip the NLSPN refinement timing (SURVEY.md 8f rank 4)")
-    ap.add_argument("--kernel-version", type=int, default=2, choices=[1, 2])
-    ap.add_argument("--wave-spec", action="store_true", help="use the wave-specialised conv3 kernel (A/B switch; measured slower)")
-    ap.add_argument("--winograd", type=int, default=0, choices=[0, 1, 2, 3, 4, 5],
-                    help="EXPERIMENTAL (bf16 / f16): Winograd F(2x2,3x3) kernels (csrc/dd_wino.hip); 1..3 = the Swin convB only: 1 = validated but slow, "
-                         "2 = double-buffered, 3 = 2 + packed-f16 transform; 4 / 5 = every large convolution of either variant (all unvalidated).  Off in every quoted number.")
-    ap.add_argument("--winograd-dma", action="store_true", help="with --winograd >= 2: weight images by LDS-DMA (experimental)")
-    ap.add_argument("--hoist", action="store_true", help="hoist conv3(cond)+conv3(E[t]) out of the loop (A/B switch; measured slower)")
+    ap.add_argument("--hoist", type=int, default=-1, choices=[-1, 0, 1],
+                    help="conv3(cond)+conv3(E[t]) out of the loop: -1 = the library default (on in the bf16 mode), 0 / 1 = forced (A/B switch)")
+    ap.add_argument("--bf16-storage", action="store_true", help="A/B: all-bf16 tensors in --precision bf16 (default: f16 storage / thin layers)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train-dp"])
+    ap.add_argument("--dist-selftest", action="store_true", help="multi-rank plumbing only, no hot path (any backend)")
+    ap.add_argument("--no-parity-gate", action="store_true", help="do not fail when the timed precision misses the depth-RMSE tolerance")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # invoked plainly: this process becomes the launcher of N ranks (each re-enters main() with WORLD_SIZE set)
+        if not args.dist_selftest:
+            n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if n_dev < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} HIP device(s) visible; the hot path has no CPU fallback")
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dist_selftest:
+        return dist_selftest(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the hot path)")
     torch.cuda.set_device(local_rank)
@@ -174,6 +325,17 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group reports {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        if rank == 0:
+            print(f"[bench] RCCL process group up: world size {dist.get_world_size()} (backend {dist.get_backend()})", file=sys.stderr, flush=True)
+    if args.mode == "train-dp":
+        out = train_dp(args, dev, dist, world, rank)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import diffusiondepth_amd as dda
     from diffusiondepth_amd import synth
@@ -189,13 +351,10 @@ def main():
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
     if args.no_graph:
         be.set_option("graph", 0)
-    be.set_option("kernel_version", args.kernel_version)
-    be.set_option("hoist_cond", 1 if args.hoist else 0)
-    be.set_option("wave_spec", 1 if args.wave_spec else 0)
-    if args.winograd:
-        be.set_option("winograd_dma", 1 if args.winograd_dma else 0)
-        be.set_option("winograd", args.winograd)
-    layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if (args.hoist and args.kernel_version == 2) else "res_nohoist")]
+    be.set_option("hoist_cond", args.hoist)
+    be.set_option("bf16_storage", 1 if args.bf16_storage else 0)
+    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and args.precision == "bf16" and not args.bf16_storage))
+    layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
     cond = torch.from_numpy(inp["cond"]).to(dev)
@@ -279,7 +438,7 @@ def main():
                 traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": f"conv_igemm{'2' if args.kernel_version == 2 else ''}_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
+        roof = {"bound": "mfma", "kernel": f"conv_igemm2_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL.get(dom, 0) * ({"bf16": 1, "f16": 1, "fp32": 2}[args.precision]) * B * h * w,
@@ -311,8 +470,7 @@ def main():
 
     # ---- training extra: one T-step loop forward + backward (dd_denoise + dd_denoise_backward) ----
     train = None
-    if (rank == 0 and world == 1 and args.precision in ("bf16", "f16") and args.variant == "res" and args.kernel_version == 2
-            and not args.no_train_extra):
+    if (rank == 0 and world == 1 and args.precision in ("bf16", "f16") and args.variant == "res" and not args.no_train_extra):
         g0 = torch.randn_like(x_T[:1])
         xb, cb = x_T[:1].contiguous(), cond[:1].contiguous()
 
@@ -349,18 +507,29 @@ def main():
 
     if rank == 0:
         maps = B * args.steps * world
+        n_world = dist.get_world_size() if dist is not None else 1
         out = {
-            "metric": f"depth-maps/sec ({T}-step DDIM, {args.size.upper()} {H}x{W} {args.precision})",
-            "value": round(maps / elapsed, 3), "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": f"depth-maps/sec ({T}-step DDIM, {args.size.upper()} {H}x{W} {args.precision}, B={B} maps per GPU per step)",
+            "value": round(maps / elapsed, 3), "unit": "maps/s", "n_gpus": n_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
-                       "graph": be.counter("graph_launches") > 0, "kernel_version": args.kernel_version, "flops_per_map": T * h * w * FPS, "variant": args.variant, "winograd": args.winograd},
+                       "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant},
             "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
         }
         print(json.dumps(out), flush=True)
+        # parity gate of the TIMED configuration (north star: depth RMSE within 1e-3 of the reference): a fast number out of tolerance
+        # is not a result.  fp32 additionally holds the 1e-3 abs reading.
+        if cpu is not None and not args.no_parity_gate:
+            rmse, mx = cpu["gpu_vs_cpu_depth_rmse"], cpu["gpu_vs_cpu_depth_maxabs"]
+            if rmse > 1e-3 or (args.precision in ("fp32", "naive_fp32") and mx > 1e-3):
+                print(f"[bench] PARITY GATE FAILED: {args.precision} depth RMSE {rmse:.3e} (max abs {mx:.3e}) vs the CPU reference path exceeds 1e-3",
+                      file=sys.stderr, flush=True)
+                if dist is not None:
+                    dist.destroy_process_group()
+                raise SystemExit(3)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -19,7 +19,7 @@ VARIANTS = {"res": 0, "swin": 1}
 ABI_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_set_weight_device", "dd_commit_weights",
     "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_trace", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
-    "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch", "dd_debug_weights_digest", "dd_debug_wino_pack",
+    "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch", "dd_debug_weights_digest",
 ]
 
 
@@ -66,7 +66,6 @@ def abi_signatures():
         "dd_get_layer_ms": (c_int, [c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
         "dd_debug_fetch": (c_int, [c_vp, c_cp, c_vp, c_i64, c_vp]),
         "dd_debug_weights_digest": (c_int, [c_vp, ctypes.POINTER(ctypes.c_uint64)]),
-        "dd_debug_wino_pack": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_i64]),
     }
 
 

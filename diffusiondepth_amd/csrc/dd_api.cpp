@@ -51,15 +51,18 @@ inline uint16_t host_f32_to_f16(float f) {
 }
 
 constexpr int NUM_EK = 3;
-inline int ek_of_precision(int prec) {
+// precision -> element kind / mode of the fused kernels.  DD_PREC_BF16 is the mode EK_BF16M (bf16 operands on the large convolutions, f16
+// storage and thin layers: dd_kernels.h) unless the handle option "bf16_storage" = 1 selects all-bf16 tensors (A/B and error budget).
+inline int ek_of_precision(int prec, bool bf16_pure) {
   switch (prec) {
     case DD_PREC_FP32: return EK_F32;
-    case DD_PREC_BF16: return EK_BF16;
+    case DD_PREC_BF16: return bf16_pure ? EK_BF16 : EK_BF16M;
     case DD_PREC_F16: return EK_F16;
     default: return -1;
   }
 }
 inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
+inline int thin_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek; }      // conv1 / conv4 / once-per-image conv3(cond): kernels and weights
 
 constexpr int FPN_LEVELS = 4;
 constexpr int FPN_CIN_RES[FPN_LEVELS] = {64, 128, 256, 512};       // ResNet pyramid widths (reference ...res.py:31 in_channels)
@@ -81,20 +84,18 @@ inline int fpn_lat_layer(int variant, int pyr, int level) {      // kernel layer
 
 struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   int cin = 0, cout = 0;
-  DevBuf wpack[NUM_EK];             // packed for the fused path, v1 kernels
-  DevBuf wpack2[NUM_EK];            // v2 kernels (pre-swizzled for LDS-DMA)
+  DevBuf wpack2[NUM_EK];            // packed for the fused kernels (pre-swizzled for LDS-DMA)
   DevBuf bias;                      // [cout padded to 32]
   DevBuf w_oihw;                    // naive path
   DevBuf wpackT[NUM_EK];            // fused backward: W' packed for the dgrad layer (23 - conv index) of dd_igemm2.hip
   DevBuf wT_oihw;                   // naive backward: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] (dgrad as a forward conv)
-  DevBuf wino[NUM_EK];              // conv2 / conv3 / convA / convB: Winograd-transformed weights (dd_wino.hip), 16-bit element kinds
   DevBuf gamma, beta;               // GroupNorm affine [cout]
 };
 
 struct PlanKey {
-  int B, h, w, ch, cw, T, prec, kver, hoist;
+  int B, h, w, ch, cw, T, prec, hoist;
   bool operator<(const PlanKey& o) const {
-    return std::tie(B, h, w, ch, cw, T, prec, kver, hoist) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.kver, o.hoist);
+    return std::tie(B, h, w, ch, cw, T, prec, hoist) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist);
   }
 };
 
@@ -111,7 +112,6 @@ struct Plan {
   DevBuf xstash;           // loop backward: the T states entering each step + the running gradient, fp32 NHWC16
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
-  DevBuf wtab;             // experimental Winograd kernels: (a, b, e) prologue table [B][256][4] floats (wino_gn_table_kernel)
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
@@ -151,10 +151,10 @@ struct dd_handle_s {
   DevBuf emb;
   DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
   DevBuf zero_bias;          // 256 zeros
-  bool wino_dma = false;     // EXPERIMENTAL, with winograd >= 2: weight images by LDS-DMA (option "winograd_dma")
-  int winograd = 0;          // EXPERIMENTAL (dd_wino.hip): Swin convB in Winograd F(2x2,3x3) form in the 16-bit modes; off by default
-  bool hoist_cond = false;   // Res variant, v2 kernels: conv3(cond) once per image instead of re-adding cond every step.
-                             // Correct (tested) but measured slower on MI355X (conv3 174 -> 183..195 us at B=4), so off by default.
+  int hoist_cond = -1;       // Res variant: conv3(cond) once per image (f16 in the bf16 mode) instead of re-adding cond in conv3's prologue every
+                             // step.  -1 = automatic: on in the default bf16 mode (EK_BF16M), where it carries precision (the condition
+                             // term never passes through bf16 operands: DESIGN.md section 4) and saves 256 B / pixel / step; 0 / 1 = forced
+  bool bf16_pure = false;    // option "bf16_storage": DD_PREC_BF16 with all-bf16 tensors and kernels (no f16 anywhere)
   DevBuf codec_buf;          // all folded codec weights in one allocation
   CodecWeights codec{};
   DevBuf codec_tmp;          // scratch for encode/decode intermediates (grown on demand)
@@ -162,11 +162,8 @@ struct dd_handle_s {
   DevBuf d_acp;
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
-  int kernel_version = 2;     // 1 = dd_igemm.hip, 2 = dd_igemm2.hip (pipelined)
   int ablate = 0;             // timing experiments only (ConvParams::ablate)
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
-  int wave_spec = 0;          // use the wave-specialised kernels (dd_igemm2ws.hip) where they exist.  Correct (tested);
-                              // measured on MI355X at B=4: conv3 179 -> 209 us (slower), Swin pred.0 131 -> 123 us (faster): off by default
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   DevBuf wgrad_ws;            // per-slab partial weight gradients of dd_wgrad.hip
   std::map<std::string, std::unique_ptr<DevBuf>> grads;   // parameter gradients (fp32, reference shapes), accumulated like torch .grad
@@ -328,13 +325,20 @@ int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::share
       h->cond_bufs.erase(victim);
     }
     auto buf = std::make_shared<DevBuf>();
-    const size_t es = precision == DD_PREC_NAIVE_FP32 ? 4 : ek_size(ek_of_precision(precision));
+    const size_t es = precision == DD_PREC_NAIVE_FP32 ? 4 : ek_size(ek_of_precision(precision, h->bf16_pure));
     DD_HIP(buf->alloc((size_t)B * lh * lw * COND_C * es));
     it = h->cond_bufs.emplace(key, std::make_pair(buf, (uint64_t)0)).first;
   }
   it->second.second = ++h->tick;
   *out = it->second.first;
   return DD_OK;
+}
+
+// conv3's condition term out of the loop?  (Res variant, fused modes; option "hoist_cond": -1 = in the default bf16 mode only)
+int want_hoist(dd_handle_t h, int precision) {
+  if (h->variant != DD_VARIANT_RES || precision == DD_PREC_NAIVE_FP32) return 0;
+  if (h->hoist_cond >= 0) return h->hoist_cond;
+  return ek_of_precision(precision, h->bf16_pure) == EK_BF16M ? 1 : 0;
 }
 
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
@@ -352,7 +356,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   std::unique_ptr<Plan> pl(new Plan());
   pl->key = key;
   const bool naive = key.prec == DD_PREC_NAIVE_FP32;
-  pl->ek = naive ? EK_F32 : ek_of_precision(key.prec);
+  pl->ek = naive ? EK_F32 : ek_of_precision(key.prec, h->bf16_pure);
   const size_t px = (size_t)key.B * key.h * key.w;
   const size_t es = ek_size(pl->ek);
   DD_HIP(pl->x[0].alloc(px * LATENT_C * 4));
@@ -415,31 +419,11 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + 7) / 8;
   p.ablate = h->ablate;
-  const int ek = pl->ek;
+  const int ek = pl->ek, ok = opnd_kind(ek), tk = thin_kind(ek);    // mode; operand kind of the large convolutions; kind of conv1 / conv4
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](ConvParams q) {
-      const bool ws = pl->key.kver == 2 && h->wave_spec && !h->ablate && conv_igemm2ws_supports(layer);
-      const int th = ws ? 8 : (pl->key.kver == 2 ? conv_pack_geom2(layer, ek) : conv_pack_geom(layer, ek)).th;
-      q.tiles_y = (k.h + th - 1) / th;
-      if (ws) return launch_conv_igemm2ws(layer, ek, q, s);
-      if (h->winograd && ek != EK_F32 && !h->ablate && pl->key.kver == 2) {
-        // EXPERIMENTAL (dd_wino.hip).  1..3: the Swin convB only (1 = the validated-but-slow v1, 2 = double-buffered, 3 = 2 + packed-f16
-        // transform); 4 / 5: every large convolution of the denoiser on the double-buffered kernel (5: packed-f16 transform in f16 mode)
-        q.wino_flags = h->wino_dma ? 1 : 0;
-        if (h->winograd <= 3 && layer == 6) { q.wpack = h->LB.wino[ek].p; return launch_conv_wino_raw(ek, q, s, h->winograd); }
-        if (h->winograd >= 4 && conv_wino_supports(layer)) {
-          ConvLayer& WL = layer == 2 ? h->L[1] : layer == 5 ? h->LA : layer == 6 ? h->LB : h->L[2];
-          q.wpack = WL.wino[ek].p;
-          if (layer == 2 || layer == 3 || layer == 5) {       // GroupNorm (+ condition) prologue: table first, on the same stream
-            if (pl->wtab.bytes < (size_t)k.B * COND_C * 16) { hipError_t e = pl->wtab.alloc((size_t)k.B * COND_C * 16); if (e != hipSuccess) return e; }
-            hipError_t e = launch_wino_gn_table(q, layer == 2 ? HID_C : COND_C, pl->wtab.as<float>(), layer != 2, s);
-            if (e != hipSuccess) return e;
-            q.wino_tab = pl->wtab.as<float>();
-          }
-          return launch_conv_wino_layer(layer, ek, q, s, h->winograd == 5);
-        }
-      }
-      return pl->key.kver == 2 ? launch_conv_igemm2(layer, ek, q, s) : launch_conv_igemm(layer, ek, q, s);
+      q.tiles_y = (k.h + conv_pack_geom2(layer, ek).th - 1) / conv_pack_geom2(layer, ek).th;
+      return launch_conv_igemm2(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
     hipEvent_t a, b;
@@ -452,33 +436,33 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     return e;
   };
   // conv1: state (+ fused DDIM update of the previous step) -> y1
-  p.in = x_in; p.wpack = (k.kver == 2 ? h->L[0].wpack2[ek] : h->L[0].wpack[ek]).p; p.bias = h->L[0].bias.as<float>(); p.out = pl->y1.p;
+  p.in = x_in; p.wpack = h->L[0].wpack2[tk].p; p.bias = h->L[0].bias.as<float>(); p.out = pl->y1.p;
   p.stats_out = pl->stat_ptr(step, 0);
   p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
   p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
   p.y4 = pl->y4.as<float>(); p.xout = x_out; p.c1c2 = pl->c1c2.as<float>(); p.step = apply_update ? step : 0;
   DD_HIP(timed_launch(1, p));
   // conv2: relu(gn1(y1)) -> y2
-  p.in = pl->y1.p; p.wpack = (k.kver == 2 ? h->L[1].wpack2[ek] : h->L[1].wpack[ek]).p; p.bias = h->L[1].bias.as<float>(); p.out = pl->y2.p;
+  p.in = pl->y1.p; p.wpack = h->L[1].wpack2[ok].p; p.bias = h->L[1].bias.as<float>(); p.out = pl->y2.p;
   p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
   p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
   DD_HIP(timed_launch(2, p));
   if (h->variant == DD_VARIANT_SWIN) {
     // upsample_fuse: convB(convA(relu(gn2(y2)) + up(cond) + E[t]))  then pred.0 on the raw result
-    p.in = pl->y2.p; p.wpack = h->LA.wpack2[ek].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
+    p.in = pl->y2.p; p.wpack = h->LA.wpack2[ok].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
     p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
     p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
     DD_HIP(timed_launch(5, p));
-    p.in = pl->sa.p; p.wpack = h->LB.wpack2[ek].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
+    p.in = pl->sa.p; p.wpack = h->LB.wpack2[ok].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
     p.stats_in = nullptr;
     DD_HIP(timed_launch(6, p));
-    p.in = pl->sf.p; p.wpack = h->L[2].wpack2[ek].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+    p.in = pl->sf.p; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
     p.stats_out = pl->stat_ptr(step, 2);
     DD_HIP(timed_launch(7, p));
   } else {
   // conv3: relu(gn2(y2)) + cond + E[t] -> y3   (hoisted form: conv3(relu(gn2(y2))) + [conv3(cond) + conv3(E[t])])
-  p.in = pl->y2.p; p.wpack = (k.kver == 2 ? h->L[2].wpack2[ek] : h->L[2].wpack[ek]).p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+  p.in = pl->y2.p; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
@@ -486,7 +470,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
-  p.in = pl->y3.p; p.wpack = (k.kver == 2 ? h->L[3].wpack2[ek] : h->L[3].wpack[ek]).p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
+  p.in = pl->y3.p; p.wpack = h->L[3].wpack2[tk].p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
   p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
   p.gn_gamma = h->L[2].gamma.as<float>(); p.gn_beta = h->L[2].beta.as<float>();
   DD_HIP(timed_launch(4, p));
@@ -528,7 +512,7 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
   p.ablate = 0;
-  p.in = pl->cond->p; p.wpack = h->L[2].wpack2[pl->ek].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
+  p.in = pl->cond->p; p.wpack = h->L[2].wpack2[thin_kind(pl->ek)].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
   DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
   return DD_OK;
 }
@@ -538,14 +522,14 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
 int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
                     int precision, hipStream_t s) {
   if (cond) {
-    if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
-    else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+    if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+    else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
     if (h->fpn_cond == pl->cond) { h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; }    // overwritten
   } else if (h->variant == DD_VARIANT_SWIN) {
     const int* k = h->fpn_cond_key;
     if (!h->fpn_cond || h->fpn_cond != h->fpn_out || k[0] != B || k[1] != cond_h || k[2] != cond_w || k[3] != precision)
       return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, condition size and precision");
-    DD_HIP(launch_upsample_blocked(h->fpn_out->p, pl->cond->p, pl->ek, B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+    DD_HIP(launch_upsample_blocked(h->fpn_out->p, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
   } else {
     const int* k = h->fpn_cond_key;
     if (!h->fpn_cond || h->fpn_cond != pl->cond || k[0] != B || k[1] != lat_h || k[2] != lat_w || k[3] != precision)
@@ -564,32 +548,6 @@ int enqueue_loop_body(dd_handle_t h, Plan* pl, hipStream_t s) {
     float* xout = pl->x[k & 1].as<float>();
     int rc = enqueue_fused_step(h, pl, k, xin, xout, k > 0, pl->tsteps.as<long long>(), k, 0, s);
     if (rc != DD_OK) return rc;
-  }
-  return DD_OK;
-}
-
-// Winograd weight images for the experimental kernels of dd_wino.hip (conv2, conv3 / Swin pred.0, Swin convA / convB; bf16 and f16).
-// Built only while option "winograd" is on -- the default path never executes this -- from the host copies dd_set_weight keeps.
-int pull_device_weights_to_host(dd_handle_t h, hipStream_t s);
-
-int pack_wino_weights(dd_handle_t h, hipStream_t s) {
-  { int rc = pull_device_weights_to_host(h, s); if (rc) return rc; }    // the images are built on the host from host_w
-  struct Item { ConvLayer* L; const char* name; int cout, cin; };
-  std::vector<Item> items = {{&h->L[1], "model.noise_embedding.3.weight", COND_C, HID_C}, {&h->L[2], "model.pred.0.weight", HID_C, COND_C}};
-  if (h->variant == DD_VARIANT_SWIN) {
-    items.push_back({&h->LA, "model.upsample_fuse.convA.conv.weight", COND_C, COND_C});
-    items.push_back({&h->LB, "model.upsample_fuse.convB.conv.weight", COND_C, COND_C});
-  }
-  for (const Item& it : items) {
-    auto f = h->host_w.find(it.name);
-    if (f == h->host_w.end()) return h->fail(DD_ERR_STATE, std::string("winograd: parameter '") + it.name + "' was never set");
-    std::vector<uint16_t> u(wino_pack_bytes(it.cout, it.cin) / 2);
-    for (int ek = EK_BF16; ek <= EK_F16; ++ek) {
-      wino_pack_u(f->second.data(), it.cout, it.cin, ek == EK_BF16 ? host_f32_to_bf16 : host_f32_to_f16, u.data());
-      int rc = upload(h, it.L->wino[ek], u.data(), u.size() * 2, s);
-      if (rc) return rc;
-      DD_HIP(hipStreamSynchronize(s));     // `u` is reused
-    }
   }
   return DD_OK;
 }
@@ -730,14 +688,8 @@ int ensure_bytes(dd_handle_t h, DevBuf& dst, size_t bytes) {
 
 // One convolution's weights from a device fp32 OIHW tensor into every layout the forward / backward kernels read -- the device twin of the
 // host loops in dd_commit_weights (same geometries, same buffers), all on stream `s`.
-int pack_conv_layer_device(dd_handle_t h, ConvLayer& L, const float* w, int fwd_layer, int dgrad_layer, bool with_v1, bool with_naive,
-                           hipStream_t s) {
+int pack_conv_layer_device(dd_handle_t h, ConvLayer& L, const float* w, int fwd_layer, int dgrad_layer, bool with_naive, hipStream_t s) {
   for (int ek = 0; ek < NUM_EK; ++ek) {
-    if (with_v1) {
-      const PackGeom g1 = conv_pack_geom(fwd_layer, ek);
-      int rc = ensure_bytes(h, L.wpack[ek], pack_weights_bytes(g1, ek)); if (rc) return rc;
-      DD_HIP(launch_pack_weights(w, L.wpack[ek].p, g1, ek, false, false, s));
-    }
     const PackGeom g2 = conv_pack_geom2(fwd_layer, ek);
     int rc = ensure_bytes(h, L.wpack2[ek], pack_weights_bytes(g2, ek)); if (rc) return rc;
     DD_HIP(launch_pack_weights(w, L.wpack2[ek].p, g2, ek, true, false, s));
@@ -769,7 +721,7 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s) {
   for (int l = 0; l < 4; ++l) {
     ConvLayer& L = h->L[l];
     L.cin = kCins[l]; L.cout = kCouts[l];
-    int rc = pack_conv_layer_device(h, L, D(std::string(kConvNames[l]) + ".weight"), l + 1, 23 - l, true, true, s); if (rc) return rc;
+    int rc = pack_conv_layer_device(h, L, D(std::string(kConvNames[l]) + ".weight"), l + 1, 23 - l, true, s); if (rc) return rc;
     rc = copy_small(L.bias, std::string(kConvNames[l]) + ".bias", 32); if (rc) return rc;
     rc = copy_small(L.gamma, std::string(kGnNames[l]) + ".weight", 0); if (rc) return rc;
     rc = copy_small(L.beta, std::string(kGnNames[l]) + ".bias", 0); if (rc) return rc;
@@ -780,7 +732,7 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s) {
     for (int i = 0; i < 2; ++i) {
       ConvLayer& L = *Ls[i];
       L.cin = COND_C; L.cout = COND_C;
-      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, false, false, s); if (rc) return rc;
+      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, false, s); if (rc) return rc;
       rc = copy_small(L.bias, std::string(names[i]) + ".bias", 0); if (rc) return rc;
     }
   }
@@ -828,7 +780,6 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     if (n_host == 0) {
       // every denoiser parameter came through dd_set_weight_device: fp32 -> kernel layouts by the pack kernels, all on `s`
       int rc = commit_model_from_device(h, s); if (rc) return rc;
-      if (h->winograd) { rc = pack_wino_weights(h, s); if (rc) return rc; }     // experimental kernels only (host-built images)
       h->committed = true;
       do_model = false;
     } else {
@@ -845,14 +796,10 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     const std::vector<float>& b = h->host_w[std::string(conv_names[l]) + ".bias"];
     for (int ek = 0; ek < NUM_EK; ++ek) {
       std::vector<uint8_t> packed;
-      pack_conv_weights(w.data(), conv_pack_geom(l + 1, ek), ek, false, packed);
-      int rc = upload(h, L.wpack[ek], packed.data(), packed.size(), s);
+      pack_conv_weights(w.data(), conv_pack_geom2(l + 1, ek), ek, true, packed);
+      int rc = upload(h, L.wpack2[ek], packed.data(), packed.size(), s);
       if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));     // `packed` is a temporary
-      pack_conv_weights(w.data(), conv_pack_geom2(l + 1, ek), ek, true, packed);
-      rc = upload(h, L.wpack2[ek], packed.data(), packed.size(), s);
-      if (rc) return rc;
-      DD_HIP(hipStreamSynchronize(s));
     }
     std::vector<float> bpad(std::max(32, L.cout), 0.f);
     std::copy(b.begin(), b.end(), bpad.begin());
@@ -920,7 +867,6 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     }
     DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
     DD_HIP(hipStreamSynchronize(s));
-    if (h->winograd) { int rc = pack_wino_weights(h, s); if (rc) return rc; }     // experimental kernels only; never in the default path
     h->committed = true;
   }
   if (do_fpn) {
@@ -1061,31 +1007,19 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     }
     h->ablate = (int)value;
   }
-  else if (k == "hoist_cond") h->hoist_cond = value != 0;
-  else if (k == "winograd_dma") {
-    if (h->wino_dma != (value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
-    h->wino_dma = value != 0;
+  else if (k == "hoist_cond") {
+    if (value < -1 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: hoist_cond must be -1 (automatic), 0 or 1");
+    h->hoist_cond = (int)value;
   }
-  else if (k == "winograd") {
-    if (value < 0 || value > 5) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: winograd must be 0 (off), 1..3 (Swin convB: validated-slow / double-buffered / + packed-f16 transform) or 4 / 5 (all large convolutions, never run)");
-    if (h->winograd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }   // kernels are baked into graphs
-    const bool turn_on = h->winograd == 0 && value != 0;
-    h->winograd = (int)value;
-    if (turn_on && h->committed) {            // weights are already on the device: build the Winograd images now (otherwise at commit)
-      DD_HIP(hipSetDevice(h->device));
-      int rc = pack_wino_weights(h, nullptr);
-      if (rc) { h->winograd = 0; return rc; }
+  else if (k == "bf16_storage") {
+    if (h->bf16_pure != (value != 0)) {       // buffers and graphs are laid out for the element kinds
+      DD_HIP(hipDeviceSynchronize());
+      h->plans.clear(); h->last_once_plan = nullptr;
+      h->cond_bufs.clear(); h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; h->fpn_out.reset(); h->fpn_work.reset();
     }
+    h->bf16_pure = value != 0;
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
-  else if (k == "wave_spec") {
-    if (h->wave_spec != (int)(value != 0)) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
-    h->wave_spec = value != 0;
-  }
-  else if (k == "kernel_version") {
-    if (value != 1 && value != 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: kernel_version must be 1 or 2");
-    h->kernel_version = (int)value;
-  }
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
@@ -1135,7 +1069,8 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
-  const int ek = ek_of_precision(precision);
+  const int ek = ek_of_precision(precision, h->bf16_pure);      // EK_BF16M: inner tensors bf16, the result (level-0 lateral conv) f16
+  const int ok = opnd_kind(ek), sk = store_kind(ek);
   const size_t es = ek_size(ek);
   // workspace for this pyramid shape
   FpnWork* fw = h->fpn_work.get();
@@ -1186,14 +1121,14 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   // top-down pass (reference ...res.py:108-118): x_3 = lat_3(f_3);  x_i = lat_i(f_i) + pool(up_i(x_{i+1}))
   for (int i = FPN_LEVELS - 1; i >= 0; --i) {
     const int hh = feat_h[i], ww = feat_w[i];
-    DD_HIP(launch_nchw_to_nhwc_padded(feats[i], fw->fin[i].p, ek, B, fpn_cin(h->variant, h->fpn_pyramid)[i],
+    DD_HIP(launch_nchw_to_nhwc_padded(feats[i], fw->fin[i].p, ok, B, fpn_cin(h->variant, h->fpn_pyramid)[i],
                                       fpn_cin_pad(h->variant, h->fpn_pyramid)[i], hh, ww, 1, s));
     const int lat_layer = fpn_lat_layer(h->variant, h->fpn_pyramid, i);
     ConvParams p{};
     p.B = B; p.h = hh; p.w = ww;
     p.tiles_x = (ww + 31) / 32;
     p.tiles_y = (hh + conv_pack_geom2(lat_layer, ek).th - 1) / conv_pack_geom2(lat_layer, ek).th;
-    p.in = fw->fin[i].p; p.wpack = h->fpn_lat_w[i][ek].p; p.bias = h->fpn_lat_b[i].as<float>();
+    p.in = fw->fin[i].p; p.wpack = h->fpn_lat_w[i][ok].p; p.bias = h->fpn_lat_b[i].as<float>();
     p.out = (i == 0) ? cbuf->p : fw->lat[i].p;
     p.addend = (i == FPN_LEVELS - 1) ? nullptr : (fw->pooled[i].p ? fw->pooled[i].p : fw->up[i].p);
     DD_HIP(launch(lat_layer, p));
@@ -1202,14 +1137,14 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
       u.B = B; u.h = hh; u.w = ww;
       u.tiles_x = (ww + 31) / 32;
       u.tiles_y = (hh + conv_pack_geom2(14, ek).th - 1) / conv_pack_geom2(14, ek).th;
-      u.in = fw->lat[i].p; u.wpack = h->fpn_up_w[i - 1][ek].p; u.bias = h->fpn_up_b[i - 1].as<float>(); u.out = fw->up[i - 1].p;
+      u.in = fw->lat[i].p; u.wpack = h->fpn_up_w[i - 1][ok].p; u.bias = h->fpn_up_b[i - 1].as<float>(); u.out = fw->up[i - 1].p;
       DD_HIP(launch(14, u));
       if (fw->pooled[i - 1].p)
-        DD_HIP(launch_adaptive_pool_blocked(fw->up[i - 1].p, fw->pooled[i - 1].p, ek, B, COND_C, 2 * hh, 2 * ww, feat_h[i - 1], feat_w[i - 1], s));
+        DD_HIP(launch_adaptive_pool_blocked(fw->up[i - 1].p, fw->pooled[i - 1].p, ok, B, COND_C, 2 * hh, 2 * ww, feat_h[i - 1], feat_w[i - 1], s));
     }
     if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   }
-  if (cond_out) DD_HIP(launch_blocked_to_nchw(cbuf->p, ek, cond_out, B, COND_C, feat_h[0], feat_w[0], 0, s));
+  if (cond_out) DD_HIP(launch_blocked_to_nchw(cbuf->p, sk, cond_out, B, COND_C, feat_h[0], feat_w[0], 0, s));
   h->fpn_cond = cbuf;
   h->fpn_cond_key[0] = B; h->fpn_cond_key[1] = feat_h[0]; h->fpn_cond_key[2] = feat_w[0]; h->fpn_cond_key[3] = precision;
   return DD_OK;
@@ -1222,12 +1157,12 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
-  if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
-    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
+  if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version, (h->hoist_cond && h->variant == DD_VARIANT_RES && h->kernel_version == 2 && precision != DD_PREC_NAIVE_FP32) ? 1 : 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision)}, &pl);
   if (rc) return rc;
 
   DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
@@ -1310,12 +1245,12 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
   if (!x_T || !states) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: num_inference_steps must be in [1, num_train_timesteps]");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: unknown precision");
-  if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
-    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
+  if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version, 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, 0}, &pl);
   if (rc) return rc;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
@@ -1358,12 +1293,12 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   if (rc) return rc;
   if (!x_t || !t || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
-  if (h->variant == DD_VARIANT_SWIN && (precision == DD_PREC_NAIVE_FP32 || h->kernel_version != 2))
-    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the v2 fused kernels only (no naive / v1 path)");
+  if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version, (h->hoist_cond && h->variant == DD_VARIANT_RES && h->kernel_version == 2 && precision != DD_PREC_NAIVE_FP32) ? 1 : 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision)}, &pl);
   if (rc) return rc;
   const long long* tv = reinterpret_cast<const long long*>(t);
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
@@ -1446,7 +1381,9 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   const int B = pl->key.B, lat_h = pl->key.h, lat_w = pl->key.w, precision = pl->key.prec;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const long long HW = (long long)lat_h * lat_w;
-  const int ek = pl->ek;
+  const int mode = pl->ek;                  // kernels of the recomputed forward pass and of the data gradients
+  const int ek = opnd_kind(mode);           // gradients, materialised activations, weight-gradient operands: bf16 in the mode EK_BF16M
+  const int yk = store_kind(mode);          // the stored conv outputs y1..y3 and the condition map (f16 in that mode)
   int rc = DD_OK;
   DD_HIP(hipMemsetAsync(pl->stat_ptr(0, 0), 0, (size_t)4 * B * STAT_SLOTS * STAT_STRIDE * sizeof(double), s));
   const int lay = naive ? 0 : 1;                    // activation layout flag of the views: plain NHWC fp32 / channel-blocked
@@ -1465,7 +1402,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
     for (int l = 0; l < 3; ++l) {
       const int C = kCouts[l];
       if (ek != EK_F32) {
-        DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l]->p, ek, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
+        DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l]->p, ek, yk, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
                                            nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond->p : nullptr, h->emb.as<float>(), tv, t_base,
                                            t_bstride, B, C, HW, s));
         continue;
@@ -1497,8 +1434,8 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
     const bool vec = !naive && ek != EK_F32 && l < 3;
     if (vec) {
       DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 4 * sizeof(double), s));
-      DD_HIP(launch_gn_bwd_reduce_blocked(pl->gA.p, ybuf[l]->p, ek, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, C, HW, s));
-      DD_HIP(launch_gn_bwd_apply_blocked(pl->gA.p, ybuf[l]->p, ek, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), pl->gY.p, nullptr,
+      DD_HIP(launch_gn_bwd_reduce_blocked(pl->gA.p, ybuf[l]->p, ek, yk, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, C, HW, s));
+      DD_HIP(launch_gn_bwd_apply_blocked(pl->gA.p, ybuf[l]->p, ek, yk, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), pl->gY.p, nullptr,
                                          nullptr, nullptr, nullptr, 0, 0, B, C, HW, s));
       float* demb = nullptr;
       if (l == 1) { demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e); }
@@ -1529,7 +1466,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       q.tiles_x = (lat_w + 31) / 32;
       q.tiles_y = (lat_h + conv_pack_geom2(layer, ek).th - 1) / conv_pack_geom2(layer, ek).th;
       q.in = pl->gY.p; q.wpack = h->L[l].wpackT[ek].p; q.bias = h->zero_bias.as<float>(); q.out = pl->gA.p;
-      DD_HIP(launch_conv_igemm2(layer, ek, q, s));
+      DD_HIP(launch_conv_igemm2(layer, ek, q, s));          // data gradients: plain kinds (bf16 in the mode EK_BF16M)
     }
     if (l == 2 && swin) {
       // Swin fuse (reference ...swin_addHAHI.py:321-333,378): sf = convB(sa), sa = convA(u), u = relu(gn2(y2)) + up(cond) + E[t];
@@ -1583,7 +1520,6 @@ int check_bwd(dd_handle_t h, int precision, const char* who) {
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_SWIN has no unfused path (use fp32 / bf16 / f16)");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
-  if (precision != DD_PREC_NAIVE_FP32 && h->kernel_version != 2) return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": the fused path needs kernel_version 2");
   return DD_OK;
 }
 
@@ -1600,7 +1536,7 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, h->kernel_version, 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, 0}, &pl);
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1626,7 +1562,7 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, h->kernel_version, 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, 0}, &pl);
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1711,21 +1647,12 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
   return DD_OK;
 }
 
-int dd_debug_wino_pack(const float* w_oihw, int cout, int cin, int precision, uint16_t* out, int64_t out_elems) {
-  // host-only: the Winograd weight image dd_commit_weights uploads for the experimental kernel (tests check the layout on the CPU)
-  if (!w_oihw || !out || cout <= 0 || cin <= 0 || cout % 64 || cin % 16) return DD_ERR_INVALID_ARG;
-  if (precision != DD_PREC_BF16 && precision != DD_PREC_F16) return DD_ERR_INVALID_ARG;
-  if (out_elems != (int64_t)(wino_pack_bytes(cout, cin) / 2)) return DD_ERR_INVALID_ARG;
-  wino_pack_u(w_oihw, cout, cin, precision == DD_PREC_BF16 ? host_f32_to_bf16 : host_f32_to_f16, out);
-  return DD_OK;
-}
-
 int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, void* stream) {
   if (!h || !name || !out) return DD_ERR_INVALID_ARG;
   Plan* pl = h->last_once_plan;
   if (!pl) return h->fail(DD_ERR_STATE, "dd_debug_fetch: no dd_denoise_once call to inspect");
   const std::string n(name);
-  const void* src = nullptr; int C = 0; int ek = pl->ek;
+  const void* src = nullptr; int C = 0; int ek = store_kind(pl->ek);
   if (n == "y1") { src = pl->y1.p; C = HID_C; }
   else if (n == "y2") { src = pl->y2.p; C = COND_C; }
   else if (n == "y3") { src = pl->y3.p; C = HID_C; }
@@ -1758,8 +1685,7 @@ int dd_debug_weights_digest(dd_handle_t h, uint64_t* digest) {
   };
   auto eat_layer = [&](const ConvLayer& L) -> hipError_t {
     for (int ek = 0; ek < NUM_EK; ++ek) {
-      hipError_t e = eat(L.wpack[ek]); if (e != hipSuccess) return e;
-      e = eat(L.wpack2[ek]); if (e != hipSuccess) return e;
+      hipError_t e = eat(L.wpack2[ek]); if (e != hipSuccess) return e;
       e = eat(L.wpackT[ek]); if (e != hipSuccess) return e;
     }
     const DevBuf* rest[5] = {&L.bias, &L.w_oihw, &L.wT_oihw, &L.gamma, &L.beta};

@@ -193,7 +193,8 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) { Piece<E
 
 // per (b, c):  out[0] += sum g_z,  out[1] += sum g_z * yh,  out[2] += sum y  (for the analytic conv-bias gradient),
 // out[3] += sum g_a (unmasked: the time-embedding gradient when g_a is dLoss/df)
-template <int EK>
+// EK = kind of the gradient tensor, YK = kind of the stored conv output (they differ in the mode EK_BF16M: bf16 gradients, f16 y)
+template <int EK, int YK>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16_t* __restrict__ ga, const uint16_t* __restrict__ y,
                                                                     const double* __restrict__ stats, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, double* __restrict__ out, int C,
@@ -221,7 +222,7 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16
     const uint4 gv = *reinterpret_cast<const uint4*>(ga + base + (size_t)p * ACT_CB);
     const uint4 yv = *reinterpret_cast<const uint4*>(y + base + (size_t)p * ACT_CB);
     float g[8], yy[8];
-    unpack8<EK>(gv, g); unpack8<EK>(yv, yy);
+    unpack8<EK>(gv, g); unpack8<YK>(yv, yy);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float yh = (yy[k] - mean) * rstd;
@@ -239,21 +240,23 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16
     atomicAdd(out + ((size_t)b * C + cb * ACT_CB + c) * 4 + kind, t);
   }
 }
-hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, int yk, const double* stats, const float* gamma, const float* beta,
                                         double* out_bc4, int B, int C, long long HW, hipStream_t s) {
-  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16)) return hipErrorInvalidValue;
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16))) return hipErrorInvalidValue;
   const int slab = 1024;                                   // 16 passes of 64 pixels: fp32 partials of <= 16 values per thread
   dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
-  if (ek == EK_BF16) hipLaunchKernelGGL(gn_bwd_reduce_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
+  if (ek == EK_BF16 && yk == EK_F16) hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_BF16, EK_F16>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
                                         reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
-  else hipLaunchKernelGGL(gn_bwd_reduce_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
+  else if (ek == EK_BF16) hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_BF16, EK_BF16>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
+                                        reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
+  else hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_F16, EK_F16>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
                           reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
   return hipGetLastError();
 }
 
 // g_y = A_c g_z + P_g + Q_g y   with A_c = gamma_c rstd_g,  Q_g = -rstd^2 S2/N,  P_g = -rstd S1/N - mean Q_g  (the same
 // expression as gn_bwd_apply_kernel, regrouped);  optional  act = relu(A_c y + B_c) [+ cond + E[t]].   sums: [b][c][4].
-template <int EK>
+template <int EK, int YK>      // EK: g_a, g_y and act;  YK: y and cond
 __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_t* __restrict__ ga, const uint16_t* __restrict__ y,
                                                                    const double* __restrict__ stats, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, const double* __restrict__ sums,
@@ -300,7 +303,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
   for (long long p = p0 + pl; p < p1; p += 64) {
     const size_t off = base + (size_t)p * ACT_CB;
     float yy[8];
-    unpack8<EK>(*reinterpret_cast<const uint4*>(y + off), yy);
+    unpack8<YK>(*reinterpret_cast<const uint4*>(y + off), yy);
     if (gy) {
       float g[8], o[8];
       unpack8<EK>(*reinterpret_cast<const uint4*>(ga + off), g);
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
       for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaf(ta[k], yy[k], tb[k]), 0.f);
       if (cond) {
         float cv[8];
-        unpack8<EK>(*reinterpret_cast<const uint4*>(cond + off), cv);
+        unpack8<YK>(*reinterpret_cast<const uint4*>(cond + off), cv);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = o[k] + (cv[k] + te[k]);
       }
@@ -325,16 +328,18 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
     }
   }
 }
-hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, int yk, const double* stats, const float* gamma, const float* beta,
                                        const double* sums_bc4, void* gy, void* act, const void* cond, const float* emb,
                                        const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s) {
-  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16)) return hipErrorInvalidValue;
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16))) return hipErrorInvalidValue;
   const int slab = 512;
   dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
   auto U16 = [](const void* p) { return reinterpret_cast<const uint16_t*>(p); };
-  if (ek == EK_BF16) hipLaunchKernelGGL(gn_bwd_apply_blocked_kernel<EK_BF16>, grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
+  if (ek == EK_BF16 && yk == EK_F16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_F16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
                                         reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
-  else hipLaunchKernelGGL(gn_bwd_apply_blocked_kernel<EK_F16>, grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
+  else if (ek == EK_BF16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_BF16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
+                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
+  else hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_F16, EK_F16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
                           reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
   return hipGetLastError();
 }

@@ -1,6 +1,5 @@
-// dd_elem.h -- element-kind helpers shared by the fused convolution kernels (dd_igemm.hip = v1,
-// dd_igemm2.hip = v2): bf16/f16/f32 <-> fp32 conversion of 16-byte pieces, the MFMA step, and the
-// channel-blocked activation layout.
+// dd_elem.h -- element-kind helpers shared by the fused convolution kernels (dd_igemm2.hip) and the backward kernels:
+// bf16/f16/f32 <-> fp32 conversion of 16-byte pieces, the MFMA step, and the channel-blocked activation layout.
 #pragma once
 #include "dd_kernels.h"
 
@@ -82,15 +81,16 @@ template <int EK> struct Piece {
 // pair as a signed 16-bit integer max with 0 (v_pk_max_i16: negative bf16/f16 values have the sign bit set, and rounding
 // commutes with the ReLU) -- 20 VALU per 8 elements instead of 28.
 typedef __attribute__((ext_vector_type(2))) short i16x2_t;
-template <int EK>
+// INK = kind of the stored input, EK = kind of the packed result (the MFMA operand)
+template <int INK, int EK>
 __device__ __forceinline__ uint4 affine_relu_pack(const uint4& raw, const float (&ta)[8], const float (&tb)[8]) {
-  static_assert(EK != EK_F32, "2-byte element kinds only");
+  static_assert(EK != EK_F32 && INK != EK_F32, "2-byte element kinds only");
   const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
   uint32_t o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x2_t y;
-    if constexpr (EK == EK_BF16) { y.x = __builtin_bit_cast(float, w[i] << 16); y.y = __builtin_bit_cast(float, w[i] & 0xFFFF0000u); }
+    if constexpr (INK == EK_BF16) { y.x = __builtin_bit_cast(float, w[i] << 16); y.y = __builtin_bit_cast(float, w[i] & 0xFFFF0000u); }
     else { y.x = f16_to_f32(w[i] & 0xFFFFu); y.y = f16_to_f32(w[i] >> 16); }
     const f32x2_t a = {ta[2 * i], ta[2 * i + 1]}, b = {tb[2 * i], tb[2 * i + 1]};
     const f32x2_t u = __builtin_elementwise_fma(a, y, b);

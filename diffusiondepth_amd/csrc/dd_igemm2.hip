@@ -1,5 +1,8 @@
-// dd_igemm2.hip -- v2 of the fused 3x3 convolution (see dd_igemm.hip for the algorithm): same tiling
-// and MFMA mapping, re-structured as a software pipeline.
+// dd_igemm2.hip -- the fused 3x3 convolution: implicit GEMM on MFMA (D[cout][pixel] += W[cout][k] . P[k][pixel]: weights are the
+// A operand, a tile row of 32 pixels the B operand of v_mfma_f32_32x32x16_{bf16,f16} / 4 x v_mfma_f32_32x32x2_f32, so a lane owns
+// one pixel and 4 consecutive couts per register quad), GroupNorm + ReLU (+ condition + E[t] / DDIM update) of the PREVIOUS layer
+// applied while the halo'd input patch is staged into LDS, bias + this layer's GroupNorm partial sums in the epilogue.
+// Structured as a software pipeline:
 //
 //   * weights never touch VGPRs: each (channel-chunk, tap-group) stage is copied global -> LDS with
 //     `global_load_lds_dwordx4` (LDS-DMA, 1 KiB per wave-instruction) into a 2-deep ring, issued one
@@ -55,17 +58,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);     // bijective for any nwg
   }
-  // PERSIST (conv1 / conv4): the grid is one resident wave of workgroups and each walks tiles wgid, wgid + gridDim.x, ...;
-  // otherwise one workgroup per (tile, cout split).  Everything below that depends on the tile is (re)set by set_tile().
-  const int nsplit = C::PERSIST ? 0 : wgid % NSPLIT;
+  // one workgroup per (tile, cout split)
+  const int nsplit = wgid % NSPLIT;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
-  const int n_work = tiles_per_img * p.B;             // tiles of this launch (PERSIST: the loop bound)
   const int n0 = nsplit * C::NT;
   const int h = p.h, w = p.w;
   const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
   const int abl = DD_ABLATE ? p.ablate : 0;   // timing experiments are compiled in with -DDD_ABLATE=1 only
   if (abl & 256) return;                  // timing floor: launch + dispatch only
-  int tile = C::PERSIST ? wgid : wgid / NSPLIT;
+  int tile = wgid / NSPLIT;
   int b, y0, x0;
   const char *in_b, *cond_b, *y4_b;
   char* xout_b;
@@ -206,15 +207,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
       } else {
         if constexpr (C::PRO == PRO_GN && EK != EK_F32) {
-          *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = affine_relu_pack<EK>(raw[slot][u][0], ta, tb);
+          *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = affine_relu_pack<C::IN_K, EK>(raw[slot][u][0], ta, tb);
           return;
         }
-        Piece<EK>::unpack(raw[slot][u][0], v);
+        Piece<C::IN_K>::unpack(raw[slot][u][0], v);
 #pragma unroll
         for (int i = 0; i < EPP; ++i) v[i] = fmaxf(fmaf(ta[i], v[i], tb[i]), 0.f);
         if constexpr (C::PRO == PRO_GN_ADD) {
           float cv[EPP];
-          Piece<EK>::unpack(aux[u][0], cv);
+          Piece<C::IN_K>::unpack(aux[u][0], cv);
 #pragma unroll
           for (int i = 0; i < EPP; ++i) v[i] = v[i] + (cv[i] + te[i]);
         }
@@ -274,14 +275,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
   for (int kq = 0; kq < NKQ; ++kq) wkt[kq] = C::W_OFF + li * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li));
 
-  // ---- tile loop: a single pass, or (PERSIST) tiles tile, tile + gridDim.x, ... ------------------------------------------
-  int tab_img = b;                 // image whose GroupNorm table is in LDS
-  bool first_tile = true;
-  bool has_next = false;           // PERSIST: another tile follows, its raw patch is being prefetched
-  int e_b = b, e_y0 = y0, e_x0 = x0, e_tile = tile;     // the tile the accumulators / epilogue belong to
+  const int e_b = b, e_y0 = y0, e_x0 = x0, e_tile = tile;     // the tile the accumulators / epilogue belong to
   f32x16_t acc[C::WN][C::WM];
-  do {
-  if (C::PERSIST && !first_tile && b != tab_img) load_norm_inputs();
   // accumulators.  With the hoisted condition term they START at conv3(cond)[pixel][cout] (fp32, D-fragment order): the
   // loads fly with everything else above and need no extra registers or epilogue traffic.
 #pragma unroll
@@ -304,8 +299,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   if (abl & 512) { DD_WAIT_VM(0); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
-  if (have_norm && (first_tile || b != tab_img)) {
-    tab_img = b;
+  if (have_norm) {
 #pragma unroll
     for (int off = 2; off <= 32; off <<= 1) {
       sv0.x += __shfl_xor(sv0.x, off, 64); sv0.y += __shfl_xor(sv0.y, off, 64);
@@ -338,20 +332,6 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   DD_WAIT_VM(0);   // this wave's DMA pieces of weight stage 0 have landed
   __syncthreads();                                    // patch 0 and weight stage 0 are in LDS for everybody
   if (abl & 1024) return;
-  e_b = b; e_y0 = y0; e_x0 = x0; e_tile = tile;
-  if constexpr (C::PERSIST) {
-    // the current tile's raw registers and staging geometry are free now: point them at the next tile and (single-stage
-    // layers) start its loads; conv4 issues them behind its last weight DMA instead (VMEM retires in order: a later wait
-    // for a weight stage would otherwise drain them)
-    const int next = tile + (int)gridDim.x;
-    has_next = next < n_work;
-    if (has_next) {
-      set_tile_base(next);
-      set_tile_geometry();
-      if constexpr (C::NSTAGE == 1) load_raw(0, 0);
-    }
-  }
-
   // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
   auto mfma_block = [&](int chunk, int tg) {
     const int s = chunk * C::NTG + tg;
@@ -422,11 +402,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     if (s + 1 < C::NSTAGE && !(abl & 4)) issue_weights(s + 1);
     asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
     if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && !(abl & 2)) load_raw(chunk + RD, par);
-    // PERSIST with several weight stages (conv4): the next tile's raw patch is requested right behind the LAST weight DMA
-    constexpr bool PF_HERE = C::PERSIST && C::NSTAGE > 1;
-    if (PF_HERE && s == C::NSTAGE - 2 && has_next) load_raw(0, 0);
     if (!(abl & 8)) mfma_block(chunk, tg);
-    if (!C::INTERLEAVE && C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
+    if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, (par + 1) % RD);
     // The next stage's weights (this wave's DMA pieces) must have landed before the barrier.  VMEM ops retire in
     // issue order and the DMA was issued BEFORE this stage's raw patch loads, so when those loads were issued in
@@ -434,10 +411,6 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     // two more stages (cdna guide T4: counted vmcnt).  Every wave issues exactly NRAW loads (clamped addresses).
     if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && (C::NTG > 1 || RD == 2) && !(abl & (2 | 128))) {
       DD_WAIT_VM_LGKM0(NRAW);
-    } else if (PF_HERE && s == C::NSTAGE - 2 && has_next) {
-      DD_WAIT_VM_LGKM0(NRAW);      // last weight stage landed, prefetch flies on
-    } else if (C::PERSIST && s == C::NSTAGE - 1) {
-      DD_WAIT_LGKM0();                          // no DMA pending: leave the prefetch alone
     } else {
       DD_WAIT_VM_LGKM0(0);
     }
@@ -446,47 +419,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     asm volatile("" ::: "memory");
   };
 
-  if constexpr (C::PINGPONG) {
-    // Ping-pong halves (MI355X guide "two waves per SIMD"): the 8 waves are two 4-wave halves, one wave of each per SIMD.
-    // Every channel chunk runs as two barrier-separated phases; in phase 1 half A issues its 72 MFMAs while half B
-    // normalises ITS items of the next chunk's patch (VALU / VMEM / LDS-write work only), in phase 2 the roles swap.  Each
-    // SIMD's matrix pipe therefore always has exactly one wave feeding it and that wave's partner never competes for it.
-    //   patch buffer (chunk+1)&1 : written in both phases of `chunk` (B's items, then A's), last read in chunk-1
-    //   weight slot  (chunk+1)&1 : DMA issued at the top of `chunk`, awaited before its closing barrier
-    //   raw registers            : A loads at the top of phase 1 (consumed in phase 2); B loads the chunk after next at the
-    //                              top of phase 2 (consumed in phase 1 of the following chunk)
-    static_assert(C::NTG == 1 && C::WAVES == 8 && C::NPB == 2 && C::NWB == 2, "ping-pong layout");
-    const int half = wave >> 2;
-    static_assert(RD == 1, "ping-pong keeps one raw slot");
-    if (half == 1 && C::NCHUNK > 1) load_raw(1, 0);
-#pragma unroll 1
-    for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
-      const bool more = chunk + 1 < C::NCHUNK;
-      const int nbuf = ((chunk + 1) & 1) * C::PATCH_BYTES;
-      if (half == 0) {
-        if (more) { issue_weights(chunk + 1); asm volatile("" ::: "memory"); load_raw(chunk + 1, 0); }
-        mfma_block(chunk, 0);
-      } else if (more) {
-        transform_write(chunk + 1, nbuf, 0);
-        asm volatile("" ::: "memory");
-        issue_weights(chunk + 1);           // behind the transform: its compiler-counted vmcnt waits then do not cover the DMA
-      }
-      DD_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (half == 1) {
-        if (chunk + 2 < C::NCHUNK) load_raw(chunk + 2, 0);
-        mfma_block(chunk, 0);
-        if (chunk + 2 < C::NCHUNK) DD_WAIT_VM_LGKM0(NRAW);   // DMA landed, raw loads fly on
-        else DD_WAIT_VM_LGKM0(0);
-      } else {
-        if (more) transform_write(chunk + 1, nbuf, 0);
-        DD_WAIT_VM_LGKM0(0);
-      }
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-  } else if constexpr (RD == 2) {
+  if constexpr (RD == 2) {
     // two raw slots: the chunk loop advances two chunks per trip so that the slot index is a constant
     static_assert(C::NCHUNK % 2 == 0, "even number of channel chunks");
 #pragma unroll 1
@@ -599,8 +532,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             }
           }
         } else {
-          pk[q].x = pack2<EK>(v[0], v[1]);
-          pk[q].y = pack2<EK>(v[2], v[3]);
+          pk[q].x = pack2<C::OUT_K>(v[0], v[1]);
+          pk[q].y = pack2<C::OUT_K>(v[2], v[3]);
         }
       }
       if constexpr (C::OUT_ESZ == 2) {
@@ -653,14 +586,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
     for (int wv = 0; wv < C::WAVES; ++wv) tot += s_red[wv * 8 + tid];
     const int gbase = (C::COUT == COND_C) ? (n0 / (COND_C / GN_GROUPS)) : 0;
-    double* dst = p.stats_out + ((size_t)e_b * STAT_SLOTS + ((C::PERSIST ? e_tile : wgid) % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
+    double* dst = p.stats_out + ((size_t)e_b * STAT_SLOTS + (wgid % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
     atomicAdd(dst, tot);
   }
-  first_tile = false;
-  if (!(C::PERSIST && has_next)) break;
-  __syncthreads();                                  // the statistics scratch and every LDS image of this tile are done with
-  if constexpr (C::NSTAGE > 1) issue_weights(0);    // restart the weight ring for the next tile (slot 0 was read by the last stage)
-  } while (true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -675,15 +603,6 @@ static hipError_t launch_one2(const ConvParams& p, hipStream_t s) {
     attr_set = true;
   }
   unsigned n_wg = (unsigned)(p.tiles_x * p.tiles_y * p.B * (C::COUT_PAD / C::NT));
-  if constexpr (C::PERSIST) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
-    const unsigned resident = (unsigned)(n_cu * C::PERSIST_WGS_PER_CU);      // one resident wave of workgroups, each walks several tiles
-    if (n_wg > resident) n_wg = resident;
-  }
   dim3 grid(n_wg, 1);
   hipLaunchKernelGGL(conv_igemm2_kernel<C>, grid, dim3(C::THREADS), C::SMEM_BYTES, s, p);
   return hipGetLastError();
@@ -719,11 +638,28 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 }
+// EK_BF16M (bf16 operands, f16 storage; dd_kernels.h): the layers that change kind have their own instantiations, the thin / once-per-
+// image layers run as f16 kernels, everything else (Swin convB, inner FPN layers, data gradients) as bf16 kernels.
+static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_t s) {
+  switch (layer) {
+    case 1: case 4: case 8: return launch_layer2<EK_F16>(layer, p, s);
+    case 2: return launch_one2<EK_BF16M, 2>(p, s);
+    case 3: return launch_one2<EK_BF16M, 3>(p, s);
+    case 5: return launch_one2<EK_BF16M, 5>(p, s);
+    case 7: return launch_one2<EK_BF16M, 7>(p, s);
+    case 9: return launch_one2<EK_BF16M, 9>(p, s);
+    case 10: return launch_one2<EK_BF16M, 10>(p, s);
+    case 15: return launch_one2<EK_BF16M, 15>(p, s);
+    case 24: return launch_one2<EK_BF16M, 24>(p, s);
+    default: return launch_layer2<EK_BF16>(layer, p, s);
+  }
+}
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s) {
   switch (ek) {
     case EK_F32: return launch_layer2<EK_F32>(layer, p, s);
     case EK_BF16: return launch_layer2<EK_BF16>(layer, p, s);
     case EK_F16: return launch_layer2<EK_F16>(layer, p, s);
+    case EK_BF16M: return launch_layer2_mixed(layer, p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -764,7 +700,7 @@ template <int EK> static PackGeom geom2_layer(int layer) {
 PackGeom conv_pack_geom2(int layer, int ek) {
   switch (ek) {
     case EK_F32: return geom2_layer<EK_F32>(layer);
-    case EK_BF16: return geom2_layer<EK_BF16>(layer);
+    case EK_BF16: case EK_BF16M: return geom2_layer<EK_BF16>(layer);     // 2-byte kinds share one geometry
     default: return geom2_layer<EK_F16>(layer);
   }
 }

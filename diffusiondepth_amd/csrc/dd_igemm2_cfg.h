@@ -1,27 +1,17 @@
-// dd_igemm2_cfg.h -- per-layer tiling constants of the v2 fused convolution kernels, shared by dd_igemm2.hip (every
-// wave stages and computes) and dd_igemm2ws.hip (wave-specialised: 4 MFMA waves + 4 staging waves per workgroup).
+// dd_igemm2_cfg.h -- per-layer tiling constants of the fused convolution kernels (dd_igemm2.hip).
+// Variants that were measured slower on MI355X and removed in round 2 (profiles/r01_run30_power_and_variants.md,
+// profiles/r02_run1_ddimloss_and_winograd.md): wave-specialised staging waves, a 16x32 / 8-wave / 9-taps-per-stage conv3 tile with
+// and without ping-pong halves, persistent conv1 / conv4 workgroups, in-loop interleaving of the prologue, Winograd F(2x2,3x3).
 #pragma once
 #include "dd_elem.h"
 
-// measured on MI355X: the FAT tiling (16x32 pixels, 8 waves, 9 taps per stage, one workgroup per CU) is slower than two
-// 8x32 / 4-wave workgroups per CU at B=4 (conv3 203 vs 175 us) and equal at B=1 (50 vs 52 us) -> off
-#ifndef DD_FAT_CONV3
-#define DD_FAT_CONV3 0
-#endif
-
 // ConvParams::ablate (timing experiments: skip parts of the kernel) is honoured only in builds with -DDD_ABLATE=1;
 // the default build folds every check away so the main loop is straight-line code.
-#ifndef DD_PINGPONG
-#define DD_PINGPONG 1
-#endif
 #ifndef DD_FRAG_DEPTH
 #define DD_FRAG_DEPTH 2
 #endif
 #ifndef DD_RAW_DEPTH
 #define DD_RAW_DEPTH 2
-#endif
-#ifndef DD_PERSIST
-#define DD_PERSIST 0
 #endif
 #ifndef DD_ABLATE
 #define DD_ABLATE 0
@@ -29,9 +19,17 @@
 
 namespace dd {
 
-template <int EK_, int LAYER_> struct Cfg2 {
-  static constexpr int EK = EK_;
+template <int EKM_, int LAYER_> struct Cfg2 {
+  // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands
+  // are instantiated here -- conv2 / conv3 / hoisted conv3 / Swin convA (f16 in, bf16 operands), the producers of f16 tensors in front
+  // of them (conv2, conv3, Swin pred.0, the level-0 lateral conv of the condition FPN); the launcher sends every other layer to its
+  // plain f16 (conv1, conv4, once-per-image conv3(cond)) or bf16 (Swin convB, inner FPN layers, data gradients) instantiation.
+  static constexpr bool MX = EKM_ == EK_BF16M;
+  static constexpr int EK = MX ? (int)EK_BF16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
   static constexpr int LAYER = LAYER_;
+  static constexpr int IN_K = (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)
+  static constexpr int OUT_K = (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
+  static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
   static constexpr int ESZ = ElemSize<EK>::V;
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
   //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
@@ -61,11 +59,7 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
   static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (64 / ESZ);
-  // FAT (conv3-shaped layers 3 / 7 / 9): one 16x32-pixel, 8-wave workgroup per CU with ALL nine taps of a channel chunk per
-  // stage -> one barrier per chunk (8 instead of 24), weights DMA'd once per 512 pixels, 1.2x instead of 1.33x halo.
-  static constexpr bool FAT = DD_FAT_CONV3 && (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);   // 8 shares 9's tile geometry
-  static constexpr bool PINGPONG = FAT && DD_PINGPONG;          // the two 4-wave halves alternate MFMA / staging phases
-  static constexpr int TG = (LAYER == 1 || LAYER == 20 || FAT) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
+  static constexpr int TG = (LAYER == 1 || LAYER == 20) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
                           : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
@@ -73,8 +67,8 @@ template <int EK_, int LAYER_> struct Cfg2 {
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
-  static constexpr int TH = FAT ? 16 : 8, TW = 32;
-  static constexpr int WAVES = (LAYER == 1 || LAYER == 4 || LAYER == 20 || LAYER == 23 || FAT) ? 8 : 4;
+  static constexpr int TH = 8, TW = 32;
+  static constexpr int WAVES = (LAYER == 1 || LAYER == 4 || LAYER == 20 || LAYER == 23) ? 8 : 4;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;
@@ -103,20 +97,11 @@ template <int EK_, int LAYER_> struct Cfg2 {
   static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
   static constexpr int NLD = EPP * IN_ESZ / 16;
   static constexpr int PIXSTRIDE = (CIN >= ACT_CB) ? ACT_CB : CIN; // elements between pixels of one channel block
-  // Placing the next chunk's prologue items between the taps (instead of one burst before the chunk's last barrier)
-  // was measured SLOWER on MI355X (conv3 181 -> 191 us at B=4: the in-loop vmcnt waits stall the MFMA stream), so off.
-  // conv1 / conv4 (one channel chunk, latency-bound at 2-3 workgroups per CU): persistent workgroups that walk several
-  // tiles and fetch the next tile's raw patch while the current tile computes and stores.  Measured on MI355X (B=4):
-  // conv1 39 -> 51 us, conv4 38 -> 55 us (the hardware dispatcher's own tile queue overlaps better than one resident wave of
-  // workgroups with 5-25 spilled registers), so off by default (-DDD_PERSIST=1 to build it; parity-tested)
-  static constexpr bool PERSIST = DD_PERSIST && (LAYER == 1 || LAYER == 4);
-  static constexpr int PERSIST_WGS_PER_CU = (LAYER == 1) ? 3 : 2;
-  static constexpr bool INTERLEAVE = false;
   // two-deep fragment registers in the MFMA loop (next group's ds_reads issued between this group's MFMAs); the Swin convA
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
   // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
   // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
-  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22) && !(FAT && DD_PINGPONG)) ? 2 : 1;
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22)) ? 2 : 1;
   static constexpr int FRAG_DEPTH = (LAYER == 5) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)

@@ -1,5 +1,5 @@
 // dd_kernels.h -- device-side parameter blocks and host launchers shared by the C-ABI layer
-// (dd_api.cpp) and the kernel translation units (dd_igemm.hip, dd_naive.hip, dd_misc.hip).
+// (dd_api.cpp) and the kernel translation units (dd_igemm2.hip, dd_naive.hip, dd_misc.hip, dd_bwd.hip, dd_wgrad.hip).
 //
 // Internal data layout in HBM (DESIGN.md "Data layout"):
 //   activations  NHWC  [B][h][w][C]   element type per precision mode (bf16 / f16 / f32)
@@ -28,7 +28,15 @@ constexpr float BN_EPS = 1e-5f;
 constexpr int STAT_SLOTS = 32;
 constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2+1]=sumsq, g<4; rest pad
 
-enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2 };
+// Element kinds.  EK_F32 / EK_BF16 / EK_F16 name both a storage type and an MFMA operand type.  EK_BF16M is a MODE of the fused path, not a
+// type: "bf16 operands, f16 storage" -- the two large convolutions (conv2 / conv3 and the Swin fuse convs: 94 % of the FLOPs) contract
+// bf16 operands on v_mfma_f32_32x32x16_bf16, every tensor that crosses a kernel boundary in front of a GroupNorm (y1, y2, y3) and the
+// condition map are STORED as f16 (same bytes, 11-bit mantissa; GroupNorm bounds their range), and the two thin layers conv1 / conv4
+// (16 <-> 64 channels, 6 % of the FLOPs) and the once-per-image conv3(cond) run as f16 kernels.  Why: DESIGN.md section 4 (the error
+// budget of tools/bf16_error_budget.py: pure bf16 sits at 1.2e-3 depth RMSE, above the 1e-3 tolerance; this mode at ~0.4x of it).
+enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3 };
+__host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : ek; }    // MFMA operands of the large convolutions / gradients
+__host__ __device__ constexpr int store_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek; }    // y1 / y2 / y3 / condition map in HBM
 
 enum Prologue : int {
   PRO_X = 0,       // conv1: input = DDIM-updated state (c1*x + c2*relu(gn4(y4))), also written back
@@ -62,37 +70,17 @@ struct ConvParams {
   const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
   const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
-  const float* wino_tab;    // dd_wino.hip (experimental): [B][CIN][4] floats (a, b, e, -) of the GroupNorm (+ condition) prologue
-  int wino_flags;           // dd_wino.hip: bit 0 = weight images by LDS-DMA
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
                             // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
                             // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier
 };
 
-// ---- fused implicit-GEMM path (dd_igemm.hip) -------------------------------------------------
-// layer: 1..4 (conv1 16->64, conv2 64->256, conv3 256->64, conv4 64->16); ek: element kind.
-hipError_t launch_conv_igemm(int layer, int ek, const ConvParams& p, hipStream_t s);
-// Packed-weight geometry of (layer, ek): elements and tile parameters (host side packing).
-struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks; };   // th = output tile height (tile width is 32), ks = kernel size
-PackGeom conv_pack_geom(int layer, int ek);
-// v2 (dd_igemm2.hip): software-pipelined variant; weights are packed with the LDS swizzle pre-applied
+// ---- fused implicit-GEMM path (dd_igemm2.hip) ------------------------------------------------
+// layer ids: see dd_igemm2_cfg.h; ek: element kind.  Weights are packed with the LDS swizzle pre-applied
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
+struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks; };   // th = output tile height (tile width is 32), ks = kernel size
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
 PackGeom conv_pack_geom2(int layer, int ek);
-// wave-specialised variant (dd_igemm2ws.hip: 4 MFMA waves + 4 staging waves) of the 256->64 multi-chunk layers; same packed
-// weights and buffers as launch_conv_igemm2
-bool conv_igemm2ws_supports(int layer);
-hipError_t launch_conv_igemm2ws(int layer, int ek, const ConvParams& p, hipStream_t s);
-
-// ---- Winograd F(2x2,3x3) form of the raw-input 256->256 convolution (dd_wino.hip; experimental, option "winograd") -------------
-// p.in / p.out: channel-blocked 16-bit activations (256 ch), p.wpack: wino_pack_u image, p.bias: [256] fp32; p.B / p.h / p.w set
-hipError_t launch_conv_wino_raw(int ek, const ConvParams& p, hipStream_t s, int version = 1);   // version 2: double-buffered, never run yet
-// generalised double-buffered kernel (never run): layers 2, 3 (Res conv2 / conv3), 5, 6, 7 (Swin convA / convB / pred.0)
-bool conv_wino_supports(int layer);
-hipError_t launch_conv_wino_layer(int layer, int ek, const ConvParams& p, hipStream_t s, bool packed_f16_transform);
-hipError_t launch_wino_gn_table(const ConvParams& p, int C, float* tab, bool with_emb, hipStream_t s);
-size_t wino_pack_bytes(int cout, int cin);
-void wino_pack_u(const float* w_oihw, int cout, int cin, uint16_t (*cvt)(float), uint16_t* out);
 
 // ---- weights into kernel layout on the device (dd_misc.hip): the packed image of pack_conv_weights() in dd_api.cpp, bit for bit ----
 size_t pack_weights_bytes(const PackGeom& g, int ek);
@@ -146,10 +134,12 @@ hipError_t launch_gn_bwd_reduce(const ActView& ga, const ActView& y, const doubl
 hipError_t launch_gn_bwd_apply(const ActView& ga, const ActView& y, const double* stats, const float* gamma, const float* beta,
                                const double* dgb, const ActView& gy, const ActView& act, const ActView& cond, const float* emb,
                                const long long* tvec, int t_base, int t_bstride, int B, hipStream_t s);
-// vectorised forms for channel-blocked bf16 / f16 tensors with C = 64 / 256; sums are [B][C][4] doubles (see dd_bwd.hip)
-hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+// vectorised forms for channel-blocked bf16 / f16 tensors with C = 64 / 256; sums are [B][C][4] doubles (see dd_bwd.hip).
+// ek = kind of the gradients / materialised activations, yk = kind of the stored conv output y and of the condition map
+// (yk == ek, or ek bf16 with yk f16: the mode EK_BF16M)
+hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, int yk, const double* stats, const float* gamma, const float* beta,
                                         double* out_bc4, int B, int C, long long HW, hipStream_t s);
-hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, const double* stats, const float* gamma, const float* beta,
+hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, int yk, const double* stats, const float* gamma, const float* beta,
                                        const double* sums_bc4, void* gy, void* act, const void* cond, const float* emb,
                                        const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s);
 hipError_t launch_gn_param_grad4(const double* sums_bc4, const double* stats, const float* gamma, float* dgamma, float* dbeta, float* dbias,

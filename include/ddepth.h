@@ -187,10 +187,9 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * Time of the last dd_denoise graph launch measured with hipEvents recorded on `stream` around
  * the graph (0 if timing is off).  dd_set_option("timing", 1) enables it; other options:
  * "graph" (1 = hipGraph replay [default], 0 = eager launches), "debug_sync" (1 = sync + check
- * after every launch), "kernel_version" (2 = pipelined kernels [default], 1 = first-generation kernels),
- * "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
- * condition map is re-added in conv3's prologue every step - measured faster), "wave_spec" (1 = wave-specialised
- * kernels for conv3 / Swin pred.0, 0 [default] = every wave stages and computes), "winograd" (EXPERIMENTAL Winograd F(2x2,3x3) kernels of dd_wino.hip, bf16 / f16 modes: 0 [default] = off; 1 = Swin convB, first version (ran once: correct, slow); 2 / 3 = Swin convB double-buffered / + packed-f16 input transform; 4 / 5 = every large convolution of either variant -- 2..5 have never run), "winograd_dma" (1 = with winograd >= 2 the weight images reach LDS by LDS-DMA; never run), "layer_timing", "ablate" (timing experiments), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
+ * after every launch), "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
+ * condition map is re-added in conv3's prologue every step), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
+ * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
@@ -207,11 +206,6 @@ int dd_get_layer_ms(dd_handle_t h, int layer, double* total_ms, int64_t* launche
 int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, void* stream);
 /* Test hook: 64-bit FNV-1a digest of every packed denoiser weight buffer in HBM (the two parameter routes must agree bit for bit). */
 int dd_debug_weights_digest(dd_handle_t h, uint64_t* digest);
-
-/* Host-only test hook: writes the Winograd F(2x2,3x3) weight image of a (cout, cin, 3, 3) fp32 OIHW filter as the experimental kernel
- * of option "winograd" streams it -- [cout/64][cin/16][16 positions][64][16] 16-bit elements of G g G^T, rounded once from double;
- * precision bf16 or f16; out_elems must be cout*cin*16.  No device is touched. */
-int dd_debug_wino_pack(const float* w_oihw, int cout, int cin, int precision, uint16_t* out, int64_t out_elems);
 
 #ifdef __cplusplus
 }

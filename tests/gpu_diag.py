@@ -46,8 +46,7 @@ def main():
     say(be.version)
     be.load_state_dict(sd)
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
-    for (B, h, w, kver) in [(2, 12, 20, 2), (1, 19, 45, 2), (2, 12, 20, 1)]:
-        be.set_option("kernel_version", kver)
+    for (B, h, w) in [(2, 12, 20), (1, 19, 45)]:
         inp = synth.make_inputs(11, B, h, w)
         ref = oracle_layers(sd, inp["x_T"], inp["timesteps"], inp["cond"])
         x, cond, t = (torch.from_numpy(inp[k]).cuda() for k in ("x_T", "cond", "timesteps"))
@@ -55,7 +54,7 @@ def main():
             try:
                 eps = be.denoise_once(x, t, cond, prec)
                 torch.cuda.synchronize()
-                row = [f"v{kver} B{B} {h}x{w} {prec:10s}"]
+                row = [f"B{B} {h}x{w} {prec:10s}"]
                 for name in ("y1", "y2", "y3", "y4"):
                     got = be.debug_fetch(name, B, h, w).cpu().numpy()
                     err = np.abs(got - ref[name]).max() / np.abs(ref[name]).max()
@@ -69,7 +68,6 @@ def main():
     inp = synth.make_inputs(1, 1, 24, 40)
     x, cond = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
     ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], 20)
-    be.set_option("kernel_version", 2)
     for prec in ("naive_fp32", "fp32", "bf16", "f16"):
         for graph in (0, 1):
             try:

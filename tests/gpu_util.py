@@ -11,7 +11,6 @@ from diffusiondepth_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT_DIR = os.path.join(ROOT, "gpurun_out")
 _backends = {}
-KVER = 2          # kernel version under test (set by the autouse fixture in test_gpu_parity.py)
 
 
 def sd_for(c):
@@ -26,7 +25,6 @@ def backend_for(c):
         be.load_state_dict(sd_for(c))
         be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
         _backends[key] = be
-    _backends[key].set_option("kernel_version", KVER)
     return _backends[key]
 
 

@@ -1,4 +1,4 @@
-"""Shared helpers of the host-emulation tests (tests/test_wino_host_emulation.py, tests/test_igemm2_host_emulation.py): building a kernel
+"""Shared helpers of the host-emulation tests (tests/test_igemm2_host_emulation.py, tests/test_library_host_emulation.py): building a kernel
 translation unit for the host on top of tests/host_emul/hip/hip_runtime.h, the 16-bit element kinds and the activation layouts."""
 from __future__ import annotations
 
@@ -62,9 +62,8 @@ def ptr(a):
 
 
 # ---- the whole library for the host: every csrc source + the harness units of tests/host_emul ------------------------------------------------------
-LIB_SOURCES = ("dd_api.cpp", "dd_igemm.hip", "dd_igemm2.hip", "dd_igemm2ws.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip",
-               "dd_dcn.hip", "dd_wino.hip")
-HARNESS_UNITS = ("ddepth_host.cpp", "igemm2_host.cpp", "wino_host.cpp")
+LIB_SOURCES = ("dd_api.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_dcn.hip")
+HARNESS_UNITS = ("ddepth_host.cpp", "igemm2_host.cpp")
 _FLAGS = ["-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-fPIC", "-c"]
 
 
@@ -149,18 +148,6 @@ def build_mutant(unit, old, new, tmp_path, count=None):
     so = os.path.join(str(tmp_path), "libmut.so")
     _link(cxx, [obj if k == unit else o for k, o in objs.items()], so)
     return ctypes.CDLL(so)
-
-
-def bind_wino(lib):
-    P = ctypes.c_void_p
-    lib.emu_wino_pack_bytes.restype = ctypes.c_longlong
-    lib.emu_wino_pack.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, P]
-    lib.emu_wino_pack.restype = None
-    lib.emu_wino_table.argtypes = [P, P, P, P, P] + [ctypes.c_int] * 6 + [P]
-    lib.emu_wino_layer.argtypes = [ctypes.c_int] * 5 + [P] * 7 + [ctypes.c_int] * 3
-    lib.emu_set_order.argtypes = [ctypes.c_int]
-    lib.emu_set_dma_late.argtypes = [ctypes.c_int]
-    return lib
 
 
 def bind_igemm2(lib):

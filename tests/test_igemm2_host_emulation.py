@@ -256,11 +256,11 @@ def test_batch_two_images(emu):
 
 
 def test_emulation_catches_a_lax_counted_wait(emu, tmp_path):
-    """The checker's own sensitivity (the missing-barrier class is covered by tests/test_wino_host_emulation.py on the same shim): the stage's
+    """The checker's own sensitivity (a removed loop barrier turns the same cases red: that mutant lived in round 1's Winograd harness, deleted with those kernels): the stage's
     `s_waitcnt vmcnt(NRAW)` leaves exactly the NRAW raw-patch loads in flight and so retires the weight DMA issued before them.  With
     NRAW + 1 the wave's last DMA piece may still be in flight at the barrier: only the late-landing model can see that, and it must."""
-    old = "      DD_WAIT_VM_LGKM0(NRAW);\n    } else if (PF_HERE"
-    mut = bind_igemm2(build_mutant("dd_igemm2.hip", old, "      DD_WAIT_VM_LGKM0(NRAW + 1);\n    } else if (PF_HERE", tmp_path, count=1))
+    old = "      DD_WAIT_VM_LGKM0(NRAW);\n    } else {"
+    mut = bind_igemm2(build_mutant("dd_igemm2.hip", old, "      DD_WAIT_VM_LGKM0(NRAW + 1);\n    } else {", tmp_path, count=1))
     run_layer(mut, 3, EK_F16, order=0, late=0)              # DMA lands at issue: the lax wait is invisible
     with pytest.raises(AssertionError):
         run_layer(mut, 3, EK_F16, order=0, late=1)          # DMA lands as late as the waits allow: stale weights

@@ -47,9 +47,7 @@ def backend_for(lib, c):
         be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
         _cache[key] = (be, sd)
     be, sd = _cache[key]
-    for k in ("winograd", "winograd_dma", "wave_spec", "hoist_cond"):
-        be.set_option(k, 0)
-    be.set_option("kernel_version", 2)
+    be.set_option("hoist_cond", 0)
     be.timing(0, 0)
     return be, sd
 
@@ -151,44 +149,19 @@ def test_step_counts_that_do_not_divide_the_training_schedule(lib, T):
         be.denoise(inp["x_T"], inp["cond"], 1001, "fp32")
 
 
-@pytest.mark.parametrize("wino,dma,order", [(4, 0, 0), (5, 1, 1)])
-def test_res_loop_winograd_options_end_to_end(lib, wino, dma, order):
-    """options "winograd" 4 / 5 (conv2 + conv3 through dd_wino.hip: GroupNorm table kernel, prologue, statistics epilogue, weight packing,
-    all of dd_api.cpp's plumbing) have never run on a GPU: here they run end to end.  f16; the bound is the f16 loop bound."""
+def test_res_loop_with_the_hoisted_condition_term(lib):
+    """option hoist_cond (layers 8 / 9: conv3(cond) once per image, two raw-patch register slots and their counted waits: late landing)"""
     be, inp, ref, T = _loop_case(lib)
-    n0 = lib.emu_launch_count()
-    direct = be.denoise(inp["x_T"], inp["cond"], T, "f16")
-    n_direct = lib.emu_launch_count() - n0
-    be.set_option("winograd", wino)
-    be.set_option("winograd_dma", dma)
-    be.timing(order=order, dma_late=dma)
-    n0 = lib.emu_launch_count()
-    x0 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
-    assert lib.emu_launch_count() - n0 > n_direct, "the Winograd path adds its table kernels: it was not taken"
-    scale = np.abs(ref).max()
-    assert maxabs(x0, ref) < LATENT_TOL["f16"] * scale
-    assert maxabs(x0, direct) > 0.0                                   # and it is a different computation
-
-
-@pytest.mark.parametrize("opt", ["kernel_version_1", "wave_spec", "hoist_cond"])
-def test_res_loop_other_kernel_families(lib, opt):
-    """dd_igemm.hip (v1), the wave-specialised dd_igemm2ws.hip (its own LDS-DMA ring and counted waits: late landing) and the hoisted condition term"""
-    be, inp, ref, T = _loop_case(lib)
-    if opt == "kernel_version_1":
-        be.set_option("kernel_version", 1)
-    else:
-        be.set_option(opt, 1)
+    be.set_option("hoist_cond", 1)
     be.timing(order=1, dma_late=1)
     x0 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("wino,dma", [(0, 0), (3, 1)] + ([(2, 0), (5, 1)] if FULL else []))
-def test_swin_loop_vs_oracle(lib, wino, dma):
+@pytest.mark.parametrize("late", [0, 1])
+def test_swin_loop_vs_oracle(lib, late):
     be, inp, ref, T = _loop_case(lib, "swin", cond_hw=(3, 9), h=5, w=17, T=1)
-    be.set_option("winograd", wino)
-    be.set_option("winograd_dma", dma)
-    be.timing(order=dma, dma_late=dma)
+    be.timing(order=late, dma_late=late)
     x0 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 

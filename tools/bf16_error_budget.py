@@ -71,8 +71,15 @@ def denoiser_emul(sd, x, t, cond, R, step=0):
     a1 = gn_relu(y1, rnd(y1, R.get("s1")), "model.noise_embedding.1")
     y2 = F.conv2d(rnd(a1, R.get("a1")), W("model.noise_embedding.3", "w2", 2), sd["model.noise_embedding.3.bias"], padding=1)
     a2 = gn_relu(y2, rnd(y2, R.get("s2")), "model.noise_embedding.4")
-    f = a2 + rnd(cond, R.get("c")) + emb
-    y3 = F.conv2d(rnd(f, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1)
+    if R.get("hoist"):
+        # conv3 is linear: conv3(a2 + cond + E) = conv3(a2) + [conv3(cond) + conv3(E)]; the bracket is computed once per image / per
+        # step outside the MFMA loop ("hoistc": dtype of cond and of the weights in that once-per-image convolution)
+        hc = R.get("hoistc")
+        y3 = F.conv2d(rnd(a2, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1) + \
+            F.conv2d(rnd(cond, hc) + emb, rnd(sd["model.pred.0.weight"], hc), None, padding=1)
+    else:
+        f = a2 + rnd(cond, R.get("c")) + emb
+        y3 = F.conv2d(rnd(f, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1)
     a3 = gn_relu(y3, rnd(y3, R.get("s3")), "model.pred.1")
     y4 = F.conv2d(rnd(a3, R.get("a3")), W("model.pred.3", "w4", 4), sd["model.pred.3.bias"], padding=1)
     return F.relu(F.group_norm(y4, 4, sd["model.pred.4.weight"], sd["model.pred.4.bias"]))
@@ -94,12 +101,12 @@ def parse_plan(spec):
     name, body = spec.split("=", 1)
     R = {}
     for part in body.split("/"):
-        if part == "sr":
-            R["sr"] = True
+        if part in ("sr", "hoist"):
+            R[part] = True
             continue
         srcs, dt = part.split(":")
-        for s in (SOURCES if srcs == "all" else srcs.split("+")):
-            R[s] = "bf16x2" if dt == "bf16x2" else DT[dt]
+        for s in (SOURCES if srcs == "all" else srcs.split("+")):     # plus the pseudo-source "hoistc"
+            R[s] = dt if dt == "bf16x2" else DT[dt]
     return name, R
 
 

@@ -13,7 +13,7 @@ echo "== smoke";  timeout 300 python -c "import __graft_entry__ as g; g.smoke()"
 tail -n 5 gpurun_out/smoke.log
 echo "== bench";  timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_bf16.log 2>&1; echo "bench rc=$?"
 tail -n 3 gpurun_out/bench_bf16.log
-timeout 300 python bench.py --steps 10 --warmup 2 --kernel-version 1 --no-cpu-baseline > gpurun_out/bench_bf16_v1.log 2>&1; tail -n 1 gpurun_out/bench_bf16_v1.log
+
 timeout 300 python bench.py --steps 10 --warmup 2 --batch 16 --no-cpu-baseline > gpurun_out/bench_bf16_b16.log 2>&1; tail -n 1 gpurun_out/bench_bf16_b16.log
 timeout 300 python bench.py --steps 5 --warmup 2 --variant swin --no-cpu-baseline > gpurun_out/bench_bf16_swin.log 2>&1; tail -n 1 gpurun_out/bench_bf16_swin.log
 for b in 1 4; do timeout 300 python tools/head_timing.py $b bf16 2>&1 | grep "B=" ; done | tee gpurun_out/head_timing.log
