@@ -163,6 +163,8 @@ struct dd_handle_s {
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
   int ablate = 0;             // timing experiments only (ConvParams::ablate)
+  unsigned long long* prof_buf = nullptr;   // tools/phase_prof.py (-DDD_PHASE_PROF=1 builds): caller-owned device buffer, 8 x u64 per workgroup
+  int prof_layer = 0;         // the kernel layer id whose launches write it
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   DevBuf wgrad_ws;            // per-slab partial weight gradients of dd_wgrad.hip
@@ -422,6 +424,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   const int ek = pl->ek, ok = opnd_kind(ek), tk = thin_kind(ek);    // mode; operand kind of the large convolutions; kind of conv1 / conv4
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](ConvParams q) {
+      q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
       q.tiles_y = (k.h + conv_pack_geom2(layer, ek).th - 1) / conv_pack_geom2(layer, ek).th;
       return launch_conv_igemm2(layer, ek, q, s);
     };
@@ -1020,6 +1023,8 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->bf16_pure = value != 0;
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
+  else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
+  else if (k == "phase_prof_layer") h->prof_layer = (int)value;
   else if (k == "layer_timing") {
     drain_layer_events(h);
     h->layer_timing = value != 0;
@@ -1250,7 +1255,7 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision)}, &pl);    // the kernels dd_denoise runs: same bits
   if (rc) return rc;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;

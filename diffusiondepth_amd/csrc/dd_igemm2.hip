@@ -30,6 +30,16 @@
 
 namespace dd {
 
+#if DD_PHASE_PROF && !defined(DD_HOST_EMULATION)
+#define DD_PROF_MARK(i) do { if (p.prof != nullptr && threadIdx.x == 0) p.prof[(size_t)blockIdx.x * 8 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#define DD_PROF_HWID() do { if (p.prof != nullptr && threadIdx.x == 0) {                                                     \
+    unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));   \
+    p.prof[(size_t)blockIdx.x * 8 + 6] = hw_; p.prof[(size_t)blockIdx.x * 8 + 7] = xcc_; } } while (0)
+#else
+#define DD_PROF_MARK(i) ((void)0)
+#define DD_PROF_HWID() ((void)0)
+#endif
+
 template <class C>
 __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2_kernel(ConvParams p) {
   constexpr int EK = C::EK;
@@ -47,6 +57,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, g = lane >> 5;
+  DD_PROF_MARK(0);
+  DD_PROF_HWID();
 
   // XCD-aware workgroup -> tile map (cdna guide T1): the dispatcher places block b on XCD b % 8, each XCD has its own
   // L2.  Remap so that every XCD owns one contiguous run of (tile, cout-split) work items: the cout halves of a tile
@@ -328,9 +340,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       if (tid < HID_C) tab_bias[tid] += tab_et[9 * HID_C + tid];     // read again only in the epilogue (many barriers later)
     }
   }
+  DD_PROF_MARK(1);
   transform_write(0, 0, 0);
   DD_WAIT_VM(0);   // this wave's DMA pieces of weight stage 0 have landed
   __syncthreads();                                    // patch 0 and weight stage 0 are in LDS for everybody
+  DD_PROF_MARK(2);
   if (abl & 1024) return;
   // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
   auto mfma_block = [&](int chunk, int tg) {
@@ -450,6 +464,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     }
   }
 
+  DD_PROF_MARK(3);
   // ---- epilogue: bias, GroupNorm partial sums, store --------------------------------------------------
   constexpr int NG_LOCAL = (C::COUT == COND_C) ? C::NT / (COND_C / GN_GROUPS) : 4;
   float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -556,7 +571,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       }
     }
   }
-  if constexpr (!C::STATS) return;
+  DD_PROF_MARK(4);
+  if constexpr (!C::STATS) { DD_PROF_MARK(5); return; }
   // wave-level butterfly in fp32 (64 fp32 lane partials of <= 64 values each; the cross-wave / cross-workgroup
   // accumulation below is fp64).  COUT=16: lanes of half g hold groups {g, 2+g} -> reduce inside each half only.
   constexpr int TOP = (C::COUT < 32) ? 16 : 32;
@@ -589,6 +605,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     double* dst = p.stats_out + ((size_t)e_b * STAT_SLOTS + (wgid % STAT_SLOTS)) * STAT_STRIDE + gbase * 2 + tid;
     atomicAdd(dst, tot);
   }
+  DD_PROF_MARK(5);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,10 @@
 #ifndef DD_ABLATE
 #define DD_ABLATE 0
 #endif
+// per-workgroup phase timestamps (ConvParams::prof); compiled in by tools/phase_prof.py only
+#ifndef DD_PHASE_PROF
+#define DD_PHASE_PROF 0
+#endif
 
 namespace dd {
 

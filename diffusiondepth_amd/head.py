@@ -54,7 +54,9 @@ class DDIMDepthEstimate_Res(nn.Module):
         super().__init__()
         if loss_noise_device not in ("cpu", "device"):
             raise ValueError("loss_noise_device must be 'cpu' or 'device'")
-        self.neck_autocast = bool(kwargs.pop("neck_autocast", True))      # HAHI heads only: see forward()
+        # HAHI heads only: True runs the PyTorch neck under autocast in the kernels' 16-bit type.  Default False = the reference's fp32
+        # arithmetic (the reference never autocasts the neck)
+        self.neck_autocast = bool(kwargs.pop("neck_autocast", False))
         self.eval_ddim_loss = bool(eval_ddim_loss)
         self.loss_noise_device = loss_noise_device
         if depth_transform_cfg is not None and depth_transform_cfg.get("type", "DeepDepthTransformWithUpsampling") != \
@@ -103,7 +105,12 @@ class DDIMDepthEstimate_Res(nn.Module):
 
     # -- condition aggregation (…res.py:108-118) --------------------------------------------------
     def aggregate_condition(self, fp):
-        if self._hip_fpn and not self.training and len(fp) == 4 and self._on_hip(fp) and self.model.precision != "naive_fp32":
+        # the library's FPN is inference-only: when autograd has to reach the backbone features or the FPN weights (e.g. fine-tuning with
+        # the head in .eval() for frozen BatchNorm) the torch modules below run instead -- never a silently dropped gradient
+        needs_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in fp) or any(p.requires_grad for p in self.conv_lateral.parameters())
+                                                  or any(p.requires_grad for p in self.conv_up.parameters()))
+        if (self._hip_fpn and not self.training and not needs_grad and len(fp) == 4 and self._on_hip(fp)
+                and self.model.precision != "naive_fp32"):
             # eval-mode BatchNorm is folded into the convolutions inside the library (dd_condition)
             be = self._bound.ensure(fp[0].device, self.scheduler, need=("fpn",))
             return be.condition([f.float() for f in fp], self.model.precision)

@@ -26,6 +26,15 @@ class HipBound:
     """Shares one HipDenoiser between the modules of a head and re-uploads parameters when any of
     them changed (torch bumps ``Tensor._version`` on every in-place update, e.g. optimizer.step()).
 
+    Staleness is detected from (data_ptr, Tensor._version) of every parameter and buffer.  That signature does NOT see writes that bypass
+    the version counter: ``p.data.copy_()`` / ``p.data.mul_()`` / ``weight.data.zero_()`` idioms and raw-pointer updaters (apex
+    multi_tensor_applier behind amp O2 and FusedAdam -- the reference trains with apex amp).  Three guards cover them:
+      * in .train() mode the denoiser group is re-uploaded in front of EVERY forward (one refresh per iteration, which a training step
+        needs anyway; with DDEPTH_DEVICE_WEIGHTS=1 it is ~40 small launches and no host copy) -- no reliance on the counter at all;
+      * ``invalidate()`` drops every signature (call it after any out-of-band write in eval mode); ``attach_optimizer(opt)`` registers it
+        as a step post-hook; the modules' ``_load_from_state_dict`` calls it too;
+      * eval mode without such writes keeps the cheap signature check.
+
     Parameters are tracked per GROUP of the library (include/ddepth.h: the denoiser "model.*", the codec "depth_transform.*", the
     condition FPN "conv_lateral.* / conv_up.*") and a group travels only when a call that needs it is about to run: a training
     iteration changes every parameter, but in .train() mode only the denoiser runs in the library (codec and FPN use batch-statistics
@@ -49,6 +58,23 @@ class HipBound:
 
     def register(self, prefix: str, module: nn.Module):
         self._modules.append((prefix, weakref.ref(module)))
+        # load_state_dict() copies under no_grad (that does bump the version counter); hooking it anyway costs nothing and also covers
+        # custom _load_from_state_dict paths that assign .data
+        bound = weakref.ref(self)
+        module.register_load_state_dict_post_hook(lambda *_a, **_k: bound() is not None and bound().invalidate())
+
+    def invalidate(self):
+        """Forget what the library holds: the next call that needs a group uploads it again.  For updates the version counter cannot
+        see (``.data`` writes, apex multi-tensor kernels)."""
+        self._sig = {}
+        self._held.clear()
+
+    def attach_optimizer(self, optimizer):
+        """invalidate() after every optimizer.step() (also fused / multi-tensor optimizers that write through raw pointers)."""
+        return optimizer.register_step_post_hook(lambda *_a, **_k: self.invalidate())
+
+    def _any_training(self, group: str) -> bool:
+        return any(ref().training for prefix, ref in self._modules if self._group_of(prefix) == group and ref() is not None)
 
     def _signature(self, group: str):
         """(data_ptr, version) of every parameter and buffer of the group's registered modules, in traversal order.  Walks the modules'
@@ -92,7 +118,8 @@ class HipBound:
             if group not in registered or group in self._held:
                 continue
             sig = self._signature(group)
-            if sig != self._sig.get(group):
+            # .train(): never trust the version counter (see the class docstring); once per hold() scope / per call
+            if sig != self._sig.get(group) or self._any_training(group):
                 sd = {}
                 for prefix, ref in self._modules:
                     if self._group_of(prefix) == group:

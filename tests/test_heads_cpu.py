@@ -160,3 +160,64 @@ def test_facade_resolves_an_external_backbone_like_the_reference(tmp_path, monke
     assert m2.depth_backbone is bb and m2.depth_head is hd
     with pytest.raises(ImportError, match="only the mmbev_res"):
         dda.Diffusion_DCbase_Model(dda.model.default_args(backbone_module="swin", backbone_name="swin_large_naive"))
+
+
+def test_hipbound_sees_parameter_updates_that_bypass_the_version_counter(monkeypatch):
+    """`p.data.copy_()` / apex multi-tensor updates do not bump Tensor._version.  In .train() the group is re-uploaded in front
+    of every call; in .eval() `invalidate()` (also wired to optimizer.step() and load_state_dict) forces the refresh."""
+    from diffusiondepth_amd import modules as M
+
+    class FakeBackend:
+        def __init__(self, device):
+            self.device, self.loads = device, []
+
+        def load_state_dict(self, sd):
+            self.loads.append({k: v.detach().clone() for k, v in sd.items()})
+
+        def set_schedule(self, acp):
+            pass
+
+    monkeypatch.setattr(M.HipBound, "_hip_device", staticmethod(lambda d: torch.device("cpu")))
+    monkeypatch.setattr(M.HipBound, "_make_backend", lambda self, d: FakeBackend(d))
+    model = dda.ScheduledCNNRefine(precision="bf16").eval()
+    b = model.bound
+    be = b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 1
+    b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 1                                            # unchanged parameters: no upload
+    w = model.pred[0].weight
+    v0 = w._version
+    w.data.mul_(2.0)                                                     # the idiom the version counter cannot see ...
+    assert w._version == v0
+    b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 1                                            # ... and eval mode (documented) trusts the counter
+    b.invalidate()
+    b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 2 and torch.equal(be.loads[-1]["model.pred.0.weight"], w.detach())
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    b.attach_optimizer(opt)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 3                                            # optimizer.step() post-hook invalidated
+    model.load_state_dict(model.state_dict())
+    b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 4                                            # load_state_dict post-hook
+    model.train()
+    w.data.add_(1.0)
+    b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 5 and torch.equal(be.loads[-1]["model.pred.0.weight"], w.detach())   # .train(): always refreshed
+    with b.hold():
+        b.ensure("cpu", need=("model",)); b.ensure("cpu", need=("model",))
+    assert len(be.loads) == 6                                            # once per hold() scope, not per library call
+
+
+def test_fpn_falls_back_to_torch_when_autograd_must_reach_it():
+    """head in .eval() with grad mode on and trainable FPN weights / backbone features: the inference-only dd_condition must not be
+    taken (it would drop the gradient silently).  CPU tensors + the torch path: runs here without the library."""
+    head = dda.DDIMDepthEstimate_Res(inference_steps=5).eval()
+    fp = [torch.from_numpy(f).requires_grad_(True) for f in synth.make_backbone_features(3, 1, 32, 48)]
+    x = head.aggregate_condition(fp)                                     # must not raise "no CPU fallback": the torch FPN ran
+    x.sum().backward()
+    assert fp[0].grad is not None and head.conv_lateral[0][0].weight.grad is not None
