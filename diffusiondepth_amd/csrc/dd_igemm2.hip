@@ -35,9 +35,21 @@ namespace dd {
 #define DD_PROF_HWID() do { if (p.prof != nullptr && threadIdx.x == 0) {                                                     \
     unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));   \
     p.prof[(size_t)blockIdx.x * 8 + 6] = hw_; p.prof[(size_t)blockIdx.x * 8 + 7] = xcc_; } } while (0)
+// per-wave cycle accounting inside the main loop (shader clock): [0] MFMA blocks (fragment reads + MFMA issue), [1] next-chunk prologue
+// transform, [2] waits + barrier, [3] DMA / raw-load issue; stored behind the per-workgroup records: prof[gridDim.x * 8 + (wg * WAVES + wave) * 4 + k]
+#define DD_PROF_CLK() ((unsigned long long)__builtin_amdgcn_s_memtime())
+#define DD_PROF_LOOP_DECL unsigned long long pl_acc_[4] = {0, 0, 0, 0}, pl_t_ = 0
+#define DD_PROF_LOOP_START() do { if (p.prof != nullptr) pl_t_ = DD_PROF_CLK(); } while (0)
+#define DD_PROF_LOOP_ADD(k) do { if (p.prof != nullptr) { const unsigned long long n_ = DD_PROF_CLK(); pl_acc_[k] += n_ - pl_t_; pl_t_ = n_; } } while (0)
+#define DD_PROF_LOOP_STORE() do { if (p.prof != nullptr && lane == 0) { for (int k_ = 0; k_ < 4; ++k_)                          \
+    p.prof[(size_t)gridDim.x * 8 + ((size_t)blockIdx.x * C::WAVES + wave) * 4 + k_] = pl_acc_[k_]; } } while (0)
 #else
 #define DD_PROF_MARK(i) ((void)0)
 #define DD_PROF_HWID() ((void)0)
+#define DD_PROF_LOOP_DECL
+#define DD_PROF_LOOP_START() ((void)0)
+#define DD_PROF_LOOP_ADD(k) ((void)0)
+#define DD_PROF_LOOP_STORE() ((void)0)
 #endif
 
 template <class C>
@@ -51,7 +63,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   float* tab_b = s_tab + C::CTAB;
   float* tab_e = s_tab + 2 * C::CTAB;
   float* tab_bias = s_tab + 3 * C::CTAB;
-  float* tab_et = tab_bias + C::NT;           // [10][64] (ADD_C only)
+  float* tab_et = tab_bias + C::NT * C::SPW;  // [10][64] (ADD_C only)
+  double* s_red = reinterpret_cast<double*>(tab_et + (C::ADD_C ? 10 * HID_C : 0));   // [WAVES][8] statistics scratch (16-B aligned: every term is)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -70,15 +83,17 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);     // bijective for any nwg
   }
-  // one workgroup per (tile, cout split)
-  const int nsplit = wgid % NSPLIT;
+  // one workgroup per (tile, SPW consecutive cout splits)
+  constexpr int NSPLIT_G = NSPLIT / C::SPW;
+  const int nsplit = (wgid % NSPLIT_G) * C::SPW;      // first split of this workgroup
   const int tiles_per_img = p.tiles_x * p.tiles_y;
-  const int n0 = nsplit * C::NT;
+  int n0 = nsplit * C::NT;                            // first cout of the split being computed
+  int sbase = 0;                                      // weight stages consumed by the splits already done (ring slots run on across splits)
   const int h = p.h, w = p.w;
   const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
   const int abl = DD_ABLATE ? p.ablate : 0;   // timing experiments are compiled in with -DDD_ABLATE=1 only
   if (abl & 256) return;                  // timing floor: launch + dispatch only
-  int tile = wgid / NSPLIT;
+  int tile = wgid / NSPLIT_G;
   int b, y0, x0;
   const char *in_b, *cond_b, *y4_b;
   char* xout_b;
@@ -246,10 +261,19 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // ---- kick off every independent load at once: weights of stage 0 (LDS-DMA), the GroupNorm partial sums
   //      of the producing layer, this thread's gamma/beta/embedding entries, the raw patch of chunk 0 ------
   issue_weights(0);
-  if (tid < C::NT) tab_bias[tid] = p.bias[n0 + tid];     // visible after the first barrier below
+  if (tid < C::NT * C::SPW) tab_bias[tid] = p.bias[n0 + tid];     // visible after the first barrier below
+  // hoisted condition term: this thread's entries of the E[t] tap-sum row.  Only the LOADS are issued here (into registers): the LDS
+  // image is written behind the GroupNorm butterfly and read in the epilogue, so the timestep -> etab row -> LDS dependency does
+  // not sit in front of the partial-sum / patch / accumulator loads (it cost ~4 us of every workgroup: profiles/r02_run3_phase_profile.md)
+  constexpr int NET = C::ADD_C ? (10 * HID_C + C::THREADS - 1) / C::THREADS : 1;
+  float et_r[NET];
   if constexpr (C::ADD_C) {
     const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
-    for (int i = tid; i < 10 * HID_C; i += C::THREADS) tab_et[i] = p.etab[(size_t)t * 10 * HID_C + i];
+#pragma unroll
+    for (int k = 0; k < NET; ++k) {
+      const int i = k * C::THREADS + tid;
+      et_r[k] = (i < 10 * HID_C) ? p.etab[(size_t)t * 10 * HID_C + i] : 0.f;
+    }
   }
   double2 sv0 = make_double2(0.0, 0.0), sv1 = make_double2(0.0, 0.0);
   float my_gamma = 0.f, my_beta = 0.f, my_emb = 0.f;
@@ -291,6 +315,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   f32x16_t acc[C::WN][C::WM];
   // accumulators.  With the hoisted condition term they START at conv3(cond)[pixel][cout] (fp32, D-fragment order): the
   // loads fly with everything else above and need no extra registers or epilogue traffic.
+  auto init_acc = [&]() {
 #pragma unroll
   for (int m = 0; m < C::WM; ++m) {
     const int gy = y0 + wave * C::WM + m, gx = x0 + li;
@@ -308,6 +333,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }
   }
+  };
+  init_acc();
   if (abl & 512) { DD_WAIT_VM(0); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
@@ -335,6 +362,13 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       tab_b[tid] = (float)((double)my_beta - mean * a);
       if constexpr (C::PRO == PRO_GN_ADD) tab_e[tid] = my_emb;
     }
+    if constexpr (C::ADD_C) {
+#pragma unroll
+      for (int k = 0; k < NET; ++k) {
+        const int i = k * C::THREADS + tid;
+        if (i < 10 * HID_C) tab_et[i] = et_r[k];
+      }
+    }
     __syncthreads();                       // table visible
     if constexpr (C::ADD_C) {
       if (tid < HID_C) tab_bias[tid] += tab_et[9 * HID_C + tid];     // read again only in the epilogue (many barriers later)
@@ -348,7 +382,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   if (abl & 1024) return;
   // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
   auto mfma_block = [&](int chunk, int tg) {
-    const int s = chunk * C::NTG + tg;
+    const int s = sbase + chunk * C::NTG + tg;
     const int poff = (chunk & (C::NPB - 1)) * C::PATCH_BYTES;
     const int woff = (s & (C::NWB - 1)) * C::W_BYTES;
     int wa[NKQ];
@@ -411,14 +445,19 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   static_assert(NRAW <= 63, "vmcnt field");
 
   // par = chunk % RD as a compile-time constant at every call site (static register indexing of the raw slots)
+  DD_PROF_LOOP_DECL;
+  DD_PROF_LOOP_START();
   auto stage = [&](int chunk, int tg, int par) {
-    const int s = chunk * C::NTG + tg;
-    if (s + 1 < C::NSTAGE && !(abl & 4)) issue_weights(s + 1);
+    const int s = sbase + chunk * C::NTG + tg;
+    if (s + 1 < C::NSTAGE * C::SPW && !(abl & 4)) issue_weights(s + 1);
     asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
     if (C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && !(abl & 2)) load_raw(chunk + RD, par);
+    DD_PROF_LOOP_ADD(3);
     if (!(abl & 8)) mfma_block(chunk, tg);
+    DD_PROF_LOOP_ADD(0);
     if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, (par + 1) % RD);
+    DD_PROF_LOOP_ADD(1);
     // The next stage's weights (this wave's DMA pieces) must have landed before the barrier.  VMEM ops retire in
     // issue order and the DMA was issued BEFORE this stage's raw patch loads, so when those loads were issued in
     // this stage it is enough to wait until at most NRAW (= the raw loads) are outstanding: they keep flying for
@@ -431,8 +470,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     // raw s_barrier: __syncthreads() would make hipcc drain vmcnt(0) because an LDS-DMA may be pending
     if (!(abl & 64)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    DD_PROF_LOOP_ADD(2);
   };
 
+#pragma unroll 1
+  for (int sp = 0;; ++sp) {        // the cout splits of this workgroup (one pass unless C::SPW > 1)
   if constexpr (RD == 2) {
     // two raw slots: the chunk loop advances two chunks per trip so that the slot index is a constant
     static_assert(C::NCHUNK % 2 == 0, "even number of channel chunks");
@@ -465,7 +507,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   }
 
   DD_PROF_MARK(3);
+  DD_PROF_LOOP_STORE();
   // ---- epilogue: bias, GroupNorm partial sums, store --------------------------------------------------
+#ifndef DD_HOST_EMULATION
+  if constexpr (C::SPW > 1) asm volatile("" : "+s"(n0));      // keeps the epilogue's store addresses from being hoisted across the MFMA loop (register pressure)
+#endif
   constexpr int NG_LOCAL = (C::COUT == COND_C) ? C::NT / (COND_C / GN_GROUPS) : 4;
   float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
   char* out_b = reinterpret_cast<char*>(p.out) + (size_t)e_b * h * w * C::COUT * C::OUT_ESZ;
@@ -486,7 +532,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       for (int q = 0; q < 4; ++q) {
         if (C::COUT < 32 && q >= 2) continue;            // conv4: couts 16..31 are zero padding
         const int co = n0 + n * 32 + 8 * q + 4 * g;
-        float4 bv = *reinterpret_cast<const float4*>(tab_bias + n * 32 + 8 * q + 4 * g);
+        float4 bv = *reinterpret_cast<const float4*>(tab_bias + sp * C::NT + n * 32 + 8 * q + 4 * g);
         if constexpr (C::ADD_C) {
           // tab_bias already holds bias + the full 9-tap E[t] sum; pixels on the image border take the missing taps out
           if (tapmask != 0x1FFu) {
@@ -584,7 +630,6 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   double ds[4], dq[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) { ds[k] = (double)ls[k]; dq[k] = (double)lq[k]; }
-  double* s_red = reinterpret_cast<double*>(smem);                  // all LDS tile reads are behind the last barrier
   if constexpr (C::COUT < 32) {
     if (li == 0) {
       s_red[wave * 8 + (0 + g) * 2 + 0] = ds[0]; s_red[wave * 8 + (0 + g) * 2 + 1] = dq[0];
@@ -606,6 +651,12 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     atomicAdd(dst, tot);
   }
   DD_PROF_MARK(5);
+  if (sp + 1 >= C::SPW) break;
+  // next cout split over the same patch: its first weight stage was requested during this split's last stage and has landed
+  n0 += C::NT;
+  sbase += C::NSTAGE;
+  init_acc();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,7 +670,7 @@ static hipError_t launch_one2(const ConvParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  unsigned n_wg = (unsigned)(p.tiles_x * p.tiles_y * p.B * (C::COUT_PAD / C::NT));
+  unsigned n_wg = (unsigned)(p.tiles_x * p.tiles_y * p.B * (C::COUT_PAD / C::NT / C::SPW));
   dim3 grid(n_wg, 1);
   hipLaunchKernelGGL(conv_igemm2_kernel<C>, grid, dim3(C::THREADS), C::SMEM_BYTES, s, p);
   return hipGetLastError();

@@ -16,6 +16,19 @@
 #ifndef DD_ABLATE
 #define DD_ABLATE 0
 #endif
+// tiling of the conv3-shaped layers (256 -> 64: layers 3, 7, 8, 9) in the 2-byte kinds:
+//   0 = 8x32 pixels, 32-channel chunks, 3 taps per stage (24 MFMAs per wave between barriers)
+//   1 = 8x32 pixels, 16-channel chunks, 9 taps per stage (36 MFMAs per wave between barriers)
+//   2 = 16x32 pixels, 4 waves x (128 pixels x 64 couts), 16-channel chunks, 9 taps per stage (72 MFMAs between barriers, 0.75 LDS reads per MFMA)
+#ifndef DD_C3
+#define DD_C3 1
+#endif
+// conv2 (64 -> 256, two 128-cout splits): 1 = ONE workgroup per tile walks both cout splits over the same staged input patch (one
+// prologue -- partial sums, table, patch fetch, normalisation -- per tile instead of two; the second split's weight stream follows
+// the first's without a gap); 0 = one workgroup per (tile, split)
+#ifndef DD_CONV2_DUAL
+#define DD_CONV2_DUAL 1
+#endif
 // per-workgroup phase timestamps (ConvParams::prof); compiled in by tools/phase_prof.py only
 #ifndef DD_PHASE_PROF
 #define DD_PHASE_PROF 0
@@ -62,16 +75,19 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr bool RELU_OUT = IS_LAT || IS_UP;              // epilogue: relu(acc + bias)
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
-  static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (64 / ESZ);
-  static constexpr int TG = (LAYER == 1 || LAYER == 20) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
+  static constexpr bool C3SHAPE = (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);
+  static constexpr int C3 = (C3SHAPE && ESZ == 2) ? DD_C3 : 0;
+  static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0) ? 16 : (64 / ESZ);
+  static constexpr int TG = (LAYER == 1 || LAYER == 20 || C3 != 0) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
                           : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = (COUT >= COND_C) ? 128 : COUT_PAD;
+  static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
-  static constexpr int TH = 8, TW = 32;
+  static constexpr int TH = (C3 == 2) ? 16 : 8, TW = 32;
   static constexpr int WAVES = (LAYER == 1 || LAYER == 4 || LAYER == 20 || LAYER == 23) ? 8 : 4;
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
@@ -95,7 +111,8 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int NWB = (NSTAGE > 1) ? 2 : 1;       // weight ring slots
   static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
   static constexpr int CTAB = (PRO == PRO_RAW) ? 0 : (LAYER == 1) ? LATENT_C : CIN;   // channels of the prologue GroupNorm table
-  static constexpr int TAB_FLOATS = 3 * CTAB + NT + (ADD_C ? 10 * HID_C : 0);   // a, b, e of the prologue GroupNorm, this tile's bias, E[t] tap sums
+  static constexpr int SCR_FLOATS = 2 * 8 * 8;                               // cross-wave scratch of the statistics epilogue: 8 doubles per wave
+  static constexpr int TAB_FLOATS = 3 * CTAB + NT * SPW + (ADD_C ? 10 * HID_C : 0) + SCR_FLOATS;   // a, b, e of the prologue GroupNorm, bias, E[t] tap sums, scratch
   static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + NWB * W_BYTES + TAB_FLOATS * 4;
   static constexpr int ITEMS = PH * PW * PPP;
   static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
@@ -112,7 +129,7 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);
   static_assert(CIN % CK == 0 && NTAPS % TG == 0 && COUT_PAD % NT == 0, "tiling");
   static_assert(PATCH_BYTES % 16 == 0 && W_BYTES % 1024 == 0, "LDS carve / DMA granularity");
-  static_assert(PATCH_BYTES >= STAT_SLOTS * 8 * 8 + 64 + WAVES * 8 * 8, "scratch fits in the patch region");
+  static_assert(WAVES <= 8 && (COUT_PAD / NT) % SPW == 0 && (SPW == 1 || NCHUNK == 1), "scratch size; splits per workgroup");
   static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128, "swizzle derivation");
   static_assert(TW == 32, "one 32-pixel MFMA block == one tile row (column-only swizzle, lane == column)");
   static_assert(THREADS % PPP == 0 && NIT <= 32, "per-thread piece index is constant; masks fit 32 bits");

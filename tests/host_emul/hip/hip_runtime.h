@@ -404,6 +404,7 @@ static inline int __shfl_xor(int v, int mask, int /*width*/ = 64) { return hoste
 template <class T> static inline T __shfl_down(T v, int delta, int /*width*/ = 64) {
   return hostemu::shfl_from(v, hostemu::lane_id() + delta);
 }
+static inline void __threadfence() {}      // one OS thread runs every work-item: memory is always coherent
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 static inline unsigned hostemu_alignbyte(unsigned hi, unsigned lo, unsigned n) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (n & 3))); }

@@ -20,7 +20,7 @@ def build():
     objs = []
     for src in b.SOURCES:
         obj = os.path.join(ROOT, "build_variants", "prof_" + os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc] + [f for f in b.FLAGS if f != "-shared"] + ["-DDD_PHASE_PROF=1", "-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj]
+        cmd = [hipcc] + [f for f in b.FLAGS if f != "-shared"] + ["-DDD_PHASE_PROF=1"] + os.environ.get("DDEPTH_CFLAGS", "").split() + ["-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj]
         if src not in ("dd_api.cpp", "dd_igemm2.hip") and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(os.path.join(b.CSRC, src)):
             objs.append(obj); continue
         print(" ".join(cmd), flush=True)
@@ -40,7 +40,7 @@ def run(layers, B, prec):
     be.set_option("graph", 0)
     inp = synth.make_inputs(7240, B, h, w)
     x, cond = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
-    buf = torch.zeros(8 * 16384, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(8 * 16384 + 4 * 8 * 16384, dtype=torch.int64, device="cuda")
     for _ in range(2):
         be.denoise(x, cond, T, prec)
     for layer in layers:
@@ -49,9 +49,12 @@ def run(layers, B, prec):
         be.denoise(x, cond, T, prec)
         torch.cuda.synchronize()
         be.set_option("phase_prof_buffer", 0)
-        a = buf.cpu().numpy().reshape(-1, 8)
-        a = a[a[:, 0] > 0]
-        n = len(a)
+        raw = buf.cpu().numpy()
+        a = raw.reshape(-1, 8)
+        n = int((a[:, 0] > 10 ** 9).sum())          # workgroup records (wall-clock values) are contiguous from 0; the per-wave cycle sums follow
+        if n == 0:
+            print(f"\n== layer {layer}: no launch of this layer in the loop"); continue
+        a = a[:n]
         t = (a[:, :6] - a[:, 0].min()) / 100.0            # us since the first workgroup started
         ph = np.diff(t, axis=1)
         names = ["entry->table", "table->patch0+W0 in LDS", "main loop", "epilogue stores", "stats+exit"]
@@ -74,6 +77,13 @@ def run(layers, B, prec):
         print(f"  time-average number of workgroups inside the main loop: {float((conc * dt).sum() / t[:, 5].max()):.1f} (of {2 * ncu} slots at 2 per CU)")
         starts = np.sort(t[:, 0])
         print(f"  workgroup start times: first wave of {int((starts < 1.0).sum())} within 1 us; 50 % started by {starts[n // 2]:.1f} us; last start {starts[-1]:.1f} us")
+        waves = 8 if layer in (1, 4) else 4
+        lw = raw[n * 8: n * 8 + n * waves * 4].reshape(-1, 4).astype(np.float64)
+        lw = lw[lw.sum(1) > 0]
+        if len(lw):
+            tot = lw.sum(1)
+            print(f"  per-wave shader-clock cycles inside the main loop (mean over {len(lw)} waves): MFMA blocks {lw[:, 0].mean():.0f}, prologue transform {lw[:, 1].mean():.0f}, "
+                  f"waits + barrier {lw[:, 2].mean():.0f}, DMA / raw-load issue {lw[:, 3].mean():.0f}; total {tot.mean():.0f} (= {tot.mean() / np.median(ph[:, 2]) / 1e3:.2f} GHz x main-loop median)")
         np.save(os.path.join(ROOT, "gpurun_out", f"phase_prof_layer{layer}_b{B}_{prec}.npy"), a)
 
 

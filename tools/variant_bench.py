@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""One library variant (DDEPTH_LIBRARY): quick parity against the fp64 oracle on ragged shapes, then loop / per-layer times at KITTI size.
+    DDEPTH_LIBRARY=build_variants/libddepth_x.so python tools/variant_bench.py [B ...]"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import synth
+from oracle import ddim_oracle as O
+
+name = os.path.basename(os.environ.get("DDEPTH_LIBRARY", "default"))
+sd = synth.make_state_dict(7240)
+be = dda.HipDenoiser(); be.load_state_dict(sd); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+for kv in filter(None, os.environ.get("DD_OPTS", "").split(",")):      # e.g. DD_OPTS=gn_table=0,hoist_cond=0
+    k, v = kv.split("="); be.set_option(k, int(v)); name += f" {k}={v}"
+ok = True
+for (B, h, w, T) in [(2, 9, 33, 3), (1, 24, 40, 5), (2, 17, 70, 2)]:
+    inp = synth.make_inputs(50 + h, B, h, w)
+    ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], T)
+    x, c = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
+    for prec, tol in (("fp32", 2e-5), ("bf16", 1e-2), ("f16", 1.5e-3)):
+        e = float(np.abs(be.denoise(x, c, T, prec).cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+        if not e < tol:
+            ok = False
+            print(f"[{name}] PARITY FAIL {B}x{h}x{w} T={T} {prec}: rel err {e:.3e}")
+print(f"[{name}] parity {'ok' if ok else 'FAILED'}")
+h, w, T = 176, 608, 20
+for B in [int(v) for v in sys.argv[1:]] or [4, 1]:
+    inp = synth.make_inputs(7240, B, h, w)
+    x, c = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
+    for prec in ("bf16",):
+        be.set_option("timing", 1)
+        lm = []
+        for _ in range(6):
+            be.denoise(x, c, T, prec); lm.append(be.last_loop_ms())
+        be.set_option("timing", 0)
+        be.set_option("layer_timing", 1)
+        for _ in range(2):
+            be.denoise(x, c, T, prec)
+        torch.cuda.synchronize()
+        per = {}
+        for l in (1, 2, 3, 9, 4):
+            ms, n = be.layer_ms(l)
+            if n:
+                per[l] = round(ms / n * 1e3, 1)
+        be.set_option("layer_timing", 0)
+        loop = sorted(lm)[len(lm) // 2]
+        print(f"[{name}] B={B} {prec}: loop {loop:.3f} ms = {B / loop * 1e3:.1f} maps/s (loop only), per-layer us {per}", flush=True)
