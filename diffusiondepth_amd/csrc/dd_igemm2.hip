@@ -186,14 +186,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // ---- registers -> normalise -> swizzled LDS patch buffer at byte offset pbuf_off ---------------------
   // One staging item (16-B piece `jfix` of patch pixel u).  This thread only ever touches channels [c0, c0+EPP), so its
   // slice of the GroupNorm table is (re)read from LDS as three/two float4 pairs.
-  auto transform_item = [&](int chunk, int pbuf_off, int u, int slot) {
-    if (!((m_valid >> u) & 1u)) return;
-    if constexpr (C::PRO == PRO_RAW) {
-      // no normalisation between the producer and this convolution: the stored elements are the operands
-      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[slot][u][0] : make_uint4(0u, 0u, 0u, 0u);
-      return;
-    }
-    float ta[EPP], tb[EPP], te[EPP];
+  // This thread's slice of the GroupNorm table for one channel chunk: read from LDS ONCE per chunk (every item of the chunk touches the
+  // same EPP channels).  Inside the item loop the compiler cannot keep it: the patch stores alias the table through `smem`.
+  float ta[EPP], tb[EPP], te[EPP];
+  auto load_table_slice = [&](int chunk) {
+    if constexpr (C::PRO == PRO_RAW) return;
     const int c0 = (C::PRO == PRO_X) ? jfix * EPP : chunk * CK + jfix * EPP;
     if (have_norm) {
 #pragma unroll
@@ -208,6 +205,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
       }
     }
+  };
+  auto transform_item = [&](int chunk, int pbuf_off, int u, int slot) {
+    if (!((m_valid >> u) & 1u)) return;
+    if constexpr (C::PRO == PRO_RAW) {
+      // no normalisation between the producer and this convolution: the stored elements are the operands
+      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[slot][u][0] : make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
+    const int c0 = (C::PRO == PRO_X) ? jfix * EPP : chunk * CK + jfix * EPP;
     float v[EPP];
     if ((m_inside >> u) & 1u) {
       if constexpr (C::PRO == PRO_X) {
@@ -254,6 +260,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = Piece<EK>::pack(v);
   };
   auto transform_write = [&](int chunk, int pbuf_off, int slot) {
+    load_table_slice(chunk);
 #pragma unroll
     for (int u = 0; u < NIT; ++u) transform_item(chunk, pbuf_off, u, slot);
   };

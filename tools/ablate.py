@@ -23,10 +23,10 @@ for mask in ([int(m) for m in os.environ["ABL_MASKS"].split(",")] if os.environ.
     for _ in range(2):
         be.denoise(x, cond, T, prec)
     torch.cuda.synchronize()
-    per = {l: be.layer_ms(l) for l in (1, 2, 3, 4)}
+    per = {l: be.layer_ms(l) for l in (1, 2, 3, 9, 4)}
     be.set_option("layer_timing", 0)
     row = {l: round(per[l][0] / max(per[l][1], 1) * 1e3, 2) for l in per}
-    print(f"ablate={mask:3d} {names.get(mask, ''):22s} conv1 {row[1]:7.2f}  conv2 {row[2]:7.2f}  conv3 {row[3]:7.2f}  conv4 {row[4]:7.2f}  sum {sum(row.values()):7.2f} us", flush=True)
+    print(f"ablate={mask:3d} {names.get(mask, ''):22s} conv1 {row[1]:7.2f}  conv2 {row[2]:7.2f}  conv3 {max(row[3], row[9]):7.2f}  conv4 {row[4]:7.2f}  sum {sum(row.values()):7.2f} us", flush=True)
     out[str(mask)] = row
 be.set_option("ablate", 0)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
