@@ -108,17 +108,23 @@ def nlspn_extra(dev, B, H, W, T=18):
     return out
 
 
-def head_extra(dev, B, H, W, precision, T):
-    """Whole DDIMDepthEstimate_Res.forward (encoder, HIP condition FPN on synthetic backbone maps, T-step loop, decoder, ddim_loss) in
-    the reference's eval behaviour and with the two documented switches (head.py: loss_noise_device, eval_ddim_loss)."""
+def head_extra(dev, B, H, W, precision, T, variant="res"):
+    """Whole head forward (encoder, [HAHI neck +] condition FPN in the library on synthetic backbone maps, T-step loop, decoder, ddim_loss)
+    in the reference's eval behaviour and with the two documented switches (head.py: loss_noise_device, eval_ddim_loss).  variant "res":
+    DDIMDepthEstimate_Res; "swin": DDIMDepthEstimate_Swin_ADDHAHI, the head of the reference's headline configuration (README.md:215)."""
     import diffusiondepth_amd as dda
     from diffusiondepth_amd import synth
-    sd = synth.make_state_dict(7240)
-    sd.update(synth.make_fpn_state_dict(7241))
-    head = dda.DDIMDepthEstimate_Res(precision=precision, condition_backend="hip", inference_steps=T).eval()
+    swin = variant == "swin"
+    chans = (192, 384, 768, 1536) if swin else (64, 128, 256, 512)
+    sd = synth.make_state_dict(7240, variant)
+    sd.update({k: v for k, v in synth.make_fpn_state_dict(7241, in_channels=chans).items() if not (swin and k.startswith("convup_fp"))})
+    if swin:
+        sd.update(synth.make_hahi_state_dict(7242, chans))
+    cls = dda.DDIMDepthEstimate_Swin_ADDHAHI if swin else dda.DDIMDepthEstimate_Res
+    head = cls(precision=precision, condition_backend="hip", inference_steps=T).eval()
     head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     head = head.to(dev)
-    fp = [torch.from_numpy(f).to(dev) for f in synth.make_backbone_features(1, B, H, W)]
+    fp = [torch.from_numpy(f).to(dev) for f in synth.make_backbone_features(1, B, H // 2 if swin else H, W // 2 if swin else W, in_channels=chans)]
     gt = torch.from_numpy(synth.make_gt_depth(2, B, H, W)).to(dev)
 
     def timed(n=5):
@@ -136,7 +142,8 @@ def head_extra(dev, B, H, W, precision, T):
     t_dev = timed()
     head.eval_ddim_loss = False
     t_inf = timed()
-    return {"what": f"DDIMDepthEstimate_Res.forward at {H}x{W}, {precision}, batch {B}: encoder + HIP FPN + {T}-step loop + decoder (+ ddim_loss)",
+    return {"what": f"{cls.__name__}.forward at {H}x{W}, {precision}, batch {B}: encoder + {'HAHI neck + ' if swin else ''}condition FPN + {T}-step loop + decoder "
+                    f"(+ ddim_loss), all in the library" + (f"; neck convolutions launched in the library: {head._bound.backend.counter('neck_launches')}" if swin else ""),
             "reference_eval_behaviour_ms": round(t_ref, 3), "loss_noise_on_device_ms": round(t_dev, 3), "inference_only_ms": round(t_inf, 3),
             "inference_only_maps_per_s": round(B / t_inf * 1e3, 1)}
 
@@ -499,9 +506,9 @@ def main():
             nlspn = {"error": f"{type(e).__name__}: {e}"}
 
     headx = None
-    if rank == 0 and world == 1 and args.variant == "res" and args.precision != "naive_fp32" and not args.no_head_extra:
+    if rank == 0 and world == 1 and args.precision != "naive_fp32" and not args.no_head_extra:
         try:
-            headx = head_extra(dev, B, H, W, args.precision, T)
+            headx = head_extra(dev, B, H, W, args.precision, T, args.variant)
         except Exception as e:  # noqa: BLE001
             headx = {"error": f"{type(e).__name__}: {e}"}
 

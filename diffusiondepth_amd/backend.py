@@ -18,7 +18,7 @@ VARIANTS = {"res": 0, "swin": 1}
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "dd_create", "dd_destroy", "dd_last_error", "dd_version", "dd_set_weight", "dd_set_weight_device", "dd_commit_weights",
-    "dd_set_schedule", "dd_condition", "dd_denoise", "dd_denoise_trace", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
+    "dd_set_schedule", "dd_condition", "dd_neck_condition", "dd_denoise", "dd_denoise_trace", "dd_denoise_once", "dd_denoise_once_backward", "dd_denoise_backward", "dd_zero_grad", "dd_get_grad", "dd_add_noise", "dd_encode", "dd_decode",
     "dd_set_option", "dd_last_loop_ms", "dd_get_counter", "dd_get_layer_ms", "dd_debug_fetch", "dd_debug_weights_digest",
 ]
 
@@ -50,6 +50,7 @@ def abi_signatures():
         "dd_commit_weights": (c_int, [c_vp, c_vp]),
         "dd_set_schedule": (c_int, [c_vp, c_vp, c_int]),
         "dd_condition": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_vp, c_int, c_vp]),
+        "dd_neck_condition": (c_int, [c_vp, ctypes.POINTER(c_vp), ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int, c_vp, c_int, c_vp]),
         "dd_denoise": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_trace": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
         "dd_denoise_once": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -136,6 +137,7 @@ class HipDenoiser:
         self._have_schedule = False
         self._have_weights = False
         self._have_fpn = False
+        self._have_neck = False
         self._cond_token = None      # (tensor, version, precision id) of the map the last condition() call returned
 
     # -- plumbing -----------------------------------------------------------------------------
@@ -190,7 +192,9 @@ class HipDenoiser:
         if device_route is None:
             device_route = os.environ.get("DDEPTH_DEVICE_WEIGHTS", "0") == "1"
         n = 0
-        owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.")
+        owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.", "hahineck.")
+        # of the neck only the executed convolutions travel (the attention / embedding parameters are dead in the reference: necks.py)
+        neck_live = ("hahineck.lateral_convs.", "hahineck.conv_proj.", "hahineck.trans_proj.", "hahineck.conv_fusion.", "hahineck.trans_fusion.")
         saw_fpn = saw_model = False
         stream = ctypes.c_void_p(_stream_ptr(self.device))
         with torch.cuda.device(self.device):
@@ -200,7 +204,10 @@ class HipDenoiser:
                 name = k[len(prefix):]
                 if not name.startswith(owned) or name.endswith("num_batches_tracked"):
                     continue
-                saw_fpn = saw_fpn or name.startswith("conv_")
+                if name.startswith("hahineck.") and not name.startswith(neck_live):
+                    continue
+                saw_fpn = saw_fpn or name.startswith("conv_") or name.startswith("hahineck.")
+                self._have_neck = self._have_neck or name.startswith("hahineck.")
                 saw_model = saw_model or name.startswith("model.")
                 if device_route and name.startswith("model.") and isinstance(v, torch.Tensor) and v.device == self.device:
                     d = v.detach().to(torch.float32).contiguous()      # no-op for fp32 parameters; a temporary otherwise (same stream)
@@ -237,8 +244,9 @@ class HipDenoiser:
         self._have_schedule = True
 
     # -- condition aggregation -----------------------------------------------------------------
-    def condition(self, fp, precision="fp32", export=True):
-        """The head's FPN (reference …res.py:108-118, …res_swin_add.py:117-127) on the 4 backbone maps ``fp`` (finest
+    def condition(self, fp, precision="fp32", export=True, neck=False):
+        """neck=True: the HAHI neck of the Swin-L heads first (dd_neck_condition: `fp` are the RAW backbone maps), then --
+        The head's FPN (reference …res.py:108-118, …res_swin_add.py:117-127) on the 4 backbone maps ``fp`` (finest
         first; widths 64..512 for the Res variant, 192..1536 for Swin).  Returns the (B,256,h,w) fp32 condition map (None
         with export=False); the same map stays in the handle in kernel layout and is picked up -- without conversion --
         when the returned tensor is passed to denoise / denoise_once unchanged."""
@@ -258,8 +266,8 @@ class HipDenoiser:
         out = torch.empty((B, 256, fp[0].shape[2], fp[0].shape[3]), device=self.device, dtype=torch.float32) if export else None
         pid = precision_id(precision)
         with torch.cuda.device(self.device):
-            self._ck(self._lib.dd_condition(self._h, ptrs, hs, ws, 4, B, out.data_ptr() if export else None, pid,
-                                            _stream_ptr(self.device)), "dd_condition")
+            fn, what = (self._lib.dd_neck_condition, "dd_neck_condition") if neck else (self._lib.dd_condition, "dd_condition")
+            self._ck(fn(self._h, ptrs, hs, ws, 4, B, out.data_ptr() if export else None, pid, _stream_ptr(self.device)), what)
         self._cond_token = (out, out._version, pid) if export else None
         return out
 

@@ -133,9 +133,26 @@ struct FpnWork {
   DevBuf lat[FPN_LEVELS];        // levels 1..3: x_i = relu(bn(conv(f_i))) [+ top-down term]
   DevBuf up[FPN_LEVELS - 1];     // conv_up[j](x_{j+1}) at 2h x 2w of level j+1
   DevBuf pooled[FPN_LEVELS - 1]; // adaptive_avg_pool2d(up[j]) when 2h_{j+1} x 2w_{j+1} != h_j x w_j
+  bool neck = false;             // HAHI neck buffers allocated
+  DevBuf nk_cat[FPN_LEVELS];     // channel concatenation the fusion conv reads: [lateral | projection] (level 0: [projection | lateral])
+  DevBuf nk_out[FPN_LEVELS];     // neck output = input of the FPN's lateral conv
 };
 
 }  // namespace
+
+// The HAHI neck's convolutions (reference src/model/necks/hahi.py:60-97; attention off): kernel layer 30 + 4 * kind + level.
+struct NeckConv { int layer; std::string name; int cout, cin, ks; };
+static std::vector<NeckConv> neck_convs() {
+  std::vector<NeckConv> v;
+  for (int i = 0; i < 4; ++i) {
+    const int C = 192 << i;
+    const std::string si = std::to_string(i), sj = std::to_string(i - 1);
+    v.push_back({30 + i, "hahineck.lateral_convs." + si, C, C, 1});
+    v.push_back({34 + i, i == 0 ? std::string("hahineck.conv_proj.0") : "hahineck.trans_proj." + sj, 512, C, 1});
+    v.push_back({38 + i, i == 0 ? std::string("hahineck.conv_fusion.0") : "hahineck.trans_fusion." + sj, C, C + 512, 3});
+  }
+  return v;
+}
 
 struct dd_handle_s {
   int device = 0;
@@ -171,6 +188,9 @@ struct dd_handle_s {
   std::map<std::string, std::unique_ptr<DevBuf>> grads;   // parameter gradients (fp32, reference shapes), accumulated like torch .grad
   std::map<std::tuple<int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
+  bool neck_committed = false;            // hahineck.* folded + packed (DD_VARIANT_SWIN with the Swin-L pyramid only)
+  DevBuf neck_w[12][NUM_EK], neck_b[12];  // index = kernel layer - 30
+  int64_t n_neck_launches = 0;
   bool fpn_committed = false;
   int fpn_pyramid = PYR_DEFAULT;  // PYR_MPVIT once MPViT-sized lateral weights were set (DD_VARIANT_SWIN only)
   DevBuf fpn_lat_w[FPN_LEVELS][NUM_EK], fpn_lat_b[FPN_LEVELS];
@@ -185,7 +205,7 @@ struct dd_handle_s {
   bool ev_valid = false;
   hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
   int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
-  static constexpr int N_LAYER_SLOTS = 32;   // kernel layer ids run up to 27 (see dd_igemm2_cfg.h)
+  static constexpr int N_LAYER_SLOTS = 48;   // kernel layer ids run up to 41 (see dd_igemm2_cfg.h)
   double layer_ms[N_LAYER_SLOTS] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3, 10..18 / 24..26 condition FPN, 20..23 dgrad)
   int64_t layer_cnt[N_LAYER_SLOTS] = {0};
   std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
@@ -208,10 +228,12 @@ const char* const kConvNames[4] = {"model.noise_embedding.0", "model.noise_embed
 const char* const kGnNames[4] = {"model.noise_embedding.1", "model.noise_embedding.4", "model.pred.1", "model.pred.4"};
 constexpr int kCins[4] = {LATENT_C, HID_C, COND_C, HID_C}, kCouts[4] = {HID_C, COND_C, HID_C, LATENT_C};
 
-// 0 = denoiser (model.*), 1 = latent codec (depth_transform.*), 2 = condition FPN (conv_lateral.* / conv_up.*)
+// 0 = denoiser (model.*), 1 = latent codec (depth_transform.*), 2 = condition FPN (conv_lateral.* / conv_up.*),
+// 3 = HAHI neck in front of the FPN (hahineck.*; Swin-L pyramid only)
 int weight_group(const std::string& name) {
   if (name.compare(0, 6, "model.") == 0) return 0;
   if (name.compare(0, 16, "depth_transform.") == 0) return 1;
+  if (name.compare(0, 9, "hahineck.") == 0) return 3;
   return 2;
 }
 
@@ -256,6 +278,14 @@ std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
       const std::string pre = "conv_up." + std::to_string(j);
       v.push_back({pre + ".0.weight", (int64_t)COND_C * COND_C * 4});
       for (const char* b : bn) v.push_back({pre + ".1." + b, COND_C});
+    }
+  }
+  if (variant == DD_VARIANT_SWIN && pyr == PYR_DEFAULT) {
+    // HAHI neck (optional 4th group): ConvModule = bias-free conv + BatchNorm + ReLU
+    const char* bn[4] = {"weight", "bias", "running_mean", "running_var"};
+    for (const NeckConv& c : neck_convs()) {
+      v.push_back({c.name + ".conv.weight", (int64_t)c.cout * c.cin * c.ks * c.ks});
+      for (const char* b : bn) v.push_back({c.name + ".bn." + b, c.cout});
     }
   }
   return v;
@@ -638,7 +668,7 @@ int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t nu
       h->host_w[name].assign(data, data + numel);
       h->dev_newer.erase(name);
       const int grp = weight_group(name);
-      if (grp == 0) h->committed = false; else if (grp == 1) h->codec_committed = false; else h->fpn_committed = false;
+      if (grp == 0) h->committed = false; else if (grp == 1) h->codec_committed = false; else if (grp == 3) h->neck_committed = false; else h->fpn_committed = false;
       return DD_OK;
     }
   }
@@ -759,8 +789,8 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   // independent groups: "model." (denoiser), "depth_transform." (codec) and "conv_lateral." / "conv_up." (condition FPN,
   // Res variant).  A group is packed when all of its keys are present; a partially provided group is an error; at least
   // one must be complete.
-  int have[3] = {0, 0, 0}, need[3] = {0, 0, 0}, n_dev = 0, n_host = 0;     // n_dev / n_host: denoiser parameters whose newest value is on the device / host
-  std::string first_missing[3];
+  int have[4] = {0, 0, 0, 0}, need[4] = {0, 0, 0, 0}, n_dev = 0, n_host = 0;     // n_dev / n_host: denoiser parameters whose newest value is on the device / host
+  std::string first_missing[4];
   for (const auto& ws : required_weights(h->variant, h->fpn_pyramid)) {
     const int grp = weight_group(ws.name);
     need[grp]++;
@@ -768,14 +798,15 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     else if (first_missing[grp].empty()) first_missing[grp] = ws.name;
     if (grp == 0) { if (h->dev_newer.count(ws.name)) n_dev++; else n_host++; }
   }
-  for (int grp = 0; grp < 3; ++grp)
+  for (int grp = 0; grp < 4; ++grp)
     if (have[grp] != 0 && have[grp] != need[grp])
       return h->fail(DD_ERR_STATE, "dd_commit_weights: missing parameter '" + first_missing[grp] + "'");
-  if (have[0] == 0 && have[1] == 0 && have[2] == 0) return h->fail(DD_ERR_STATE, "dd_commit_weights: no parameters were set");
+  if (have[0] == 0 && have[1] == 0 && have[2] == 0 && have[3] == 0) return h->fail(DD_ERR_STATE, "dd_commit_weights: no parameters were set");
   // only the groups that changed since their last commit (dd_set_weight / dd_set_weight_device clear the group's flag)
   bool do_model = have[0] == need[0] && !h->committed;
   const bool do_codec = have[1] == need[1] && !h->codec_committed, do_fpn = need[2] > 0 && have[2] == need[2] && !h->fpn_committed;
-  if (!do_model && !do_codec && !do_fpn) return DD_OK;
+  const bool do_neck = need[3] > 0 && have[3] == need[3] && !h->neck_committed;
+  if (!do_model && !do_codec && !do_fpn && !do_neck) return DD_OK;
   // graphs bake weight pointers; buffers are reused when sizes match, so existing graphs stay valid,
   // but make sure nothing is in flight while we overwrite them.
   DD_HIP(hipDeviceSynchronize());
@@ -926,6 +957,30 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     }
     h->fpn_committed = true;
   }
+  if (do_neck) {
+    // ---- HAHI neck: fold eval-mode BatchNorm into the bias-free convolutions (scale into the weights, shift = bias), pack ----
+    for (const NeckConv& c : neck_convs()) {
+      const auto &g = h->host_w[c.name + ".bn.weight"], &b = h->host_w[c.name + ".bn.bias"], &m = h->host_w[c.name + ".bn.running_mean"],
+                 &v = h->host_w[c.name + ".bn.running_var"];
+      const std::vector<float>& w0 = h->host_w[c.name + ".conv.weight"];
+      const size_t per = (size_t)c.cin * c.ks * c.ks;
+      std::vector<float> w(w0.size()), sh(c.cout);
+      for (int co = 0; co < c.cout; ++co) {
+        const double sc = (double)g[co] / std::sqrt((double)v[co] + (double)BN_EPS);
+        sh[co] = (float)((double)b[co] - (double)m[co] * sc);
+        for (size_t k = 0; k < per; ++k) w[co * per + k] = (float)((double)w0[co * per + k] * sc);
+      }
+      for (int ek = 0; ek < NUM_EK; ++ek) {
+        std::vector<uint8_t> packed;
+        pack_conv_weights(w.data(), conv_pack_geom2(c.layer, ek), ek, true, packed);
+        int rc = upload(h, h->neck_w[c.layer - 30][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        DD_HIP(hipStreamSynchronize(s));
+      }
+      int rc = upload(h, h->neck_b[c.layer - 30], sh.data(), sh.size() * 4, s); if (rc) return rc;
+      DD_HIP(hipStreamSynchronize(s));
+    }
+    h->neck_committed = true;
+  }
   if (!do_codec) return DD_OK;
   // ---- codec: fold eval-mode BatchNorm into the convolutions (reference depth_transform.py:15-26) ----
   auto W = [&](const char* n) -> const std::vector<float>& { return h->host_w[n]; };
@@ -1040,6 +1095,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   else if (k == "eager_loops") *value = h->n_eager_loops;
   else if (k == "graph_capture_failures") *value = h->n_capture_failures;
   else if (k == "plans") *value = (int64_t)h->plans.size();
+  else if (k == "neck_launches") *value = h->n_neck_launches;
   else return h->fail(DD_ERR_INVALID_ARG, "dd_get_counter: unknown key '" + k + "'");
   return DD_OK;
 }
@@ -1061,10 +1117,28 @@ int dd_last_loop_ms(dd_handle_t h, float* ms) {
   return DD_OK;
 }
 
+static int condition_impl(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
+                          float* cond_out, int precision, void* stream, bool with_neck);
+
 int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
                  float* cond_out, int precision, void* stream) {
+  return condition_impl(h, feats, feat_h, feat_w, n_levels, B, cond_out, precision, stream, false);
+}
+
+int dd_neck_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
+                      float* cond_out, int precision, void* stream) {
+  if (!h) return DD_ERR_INVALID_ARG;
+  if (!h->neck_committed) return h->fail(DD_ERR_STATE, "hahineck.* weights not committed (dd_set_weight for the lateral / projection / fusion convolutions, "
+                                                       "dd_commit_weights; DD_VARIANT_SWIN with the Swin-L pyramid only)");
+  return condition_impl(h, feats, feat_h, feat_w, n_levels, B, cond_out, precision, stream, true);
+}
+
+static int condition_impl(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
+                          float* cond_out, int precision, void* stream, bool with_neck) {
   if (!h) return DD_ERR_INVALID_ARG;
   if (!h->fpn_committed) return h->fail(DD_ERR_STATE, "conv_lateral.* / conv_up.* weights not committed (dd_set_weight, dd_commit_weights)");
+  if (with_neck && (h->variant != DD_VARIANT_SWIN || h->fpn_pyramid != PYR_DEFAULT))
+    return h->fail(DD_ERR_UNSUPPORTED, "dd_neck_condition: the HAHI neck kernels are built for the Swin-L pyramid (192/384/768/1536)");
   if (n_levels != FPN_LEVELS || !feats || !feat_h || !feat_w) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: expects 4 pyramid levels");
   if (precision < DD_PREC_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16 or f16");
   if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
@@ -1079,7 +1153,7 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
   const size_t es = ek_size(ek);
   // workspace for this pyramid shape
   FpnWork* fw = h->fpn_work.get();
-  bool same = fw && fw->B == B && fw->ek == ek && fw->pyr == h->fpn_pyramid;
+  bool same = fw && fw->B == B && fw->ek == ek && fw->pyr == h->fpn_pyramid && (fw->neck || !with_neck);
   for (int i = 0; same && i < FPN_LEVELS; ++i) same = fw->hs[i] == feat_h[i] && fw->ws[i] == feat_w[i];
   if (!same) {
     DD_HIP(hipDeviceSynchronize());
@@ -1090,6 +1164,11 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
       fw->hs[i] = feat_h[i]; fw->ws[i] = feat_w[i];
       const size_t px = (size_t)B * feat_h[i] * feat_w[i];
       DD_HIP(fw->fin[i].alloc(px * fpn_cin_pad(h->variant, h->fpn_pyramid)[i] * es));
+      if (with_neck) {
+        DD_HIP(fw->nk_cat[i].alloc(px * ((192 << i) + 512) * es));
+        DD_HIP(fw->nk_out[i].alloc(px * (192 << i) * es));
+        fw->neck = true;
+      }
       if (i > 0) {
         DD_HIP(fw->lat[i].alloc(px * COND_C * es));
         DD_HIP(fw->up[i - 1].alloc(px * 4 * COND_C * es));
@@ -1129,11 +1208,35 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
     DD_HIP(launch_nchw_to_nhwc_padded(feats[i], fw->fin[i].p, ok, B, fpn_cin(h->variant, h->fpn_pyramid)[i],
                                       fpn_cin_pad(h->variant, h->fpn_pyramid)[i], hh, ww, 1, s));
     const int lat_layer = fpn_lat_layer(h->variant, h->fpn_pyramid, i);
+    const void* lat_in = fw->fin[i].p;
+    if (with_neck) {
+      // HAHI neck of level i (reference hahi.py:170-173,196-197,226-272; attention off): l = lateral(x); e = proj(l);
+      // out = fusion(cat) with cat = [e | l] at level 0 (hahi.py:249: cat([fusion_res_conv, feat_conv])) and [l | e] above (:262)
+      const int C = 192 << i, CT = C + 512, l_off = (i == 0) ? 512 : 0, e_off = (i == 0) ? 0 : C;
+      ConvParams q{};
+      q.B = B; q.h = hh; q.w = ww;
+      q.tiles_x = (ww + 31) / 32;
+      q.tiles_y = (hh + 7) / 8;
+      q.in = fw->fin[i].p; q.in_cstride = C; q.in_coff = 0;
+      q.out = fw->nk_cat[i].p; q.out_cstride = CT; q.out_coff = l_off;
+      q.wpack = h->neck_w[i][ok].p; q.bias = h->neck_b[i].as<float>();
+      DD_HIP(launch(30 + i, q));
+      q.in = fw->nk_cat[i].p; q.in_cstride = CT; q.in_coff = l_off;
+      q.out = fw->nk_cat[i].p; q.out_cstride = CT; q.out_coff = e_off;
+      q.wpack = h->neck_w[4 + i][ok].p; q.bias = h->neck_b[4 + i].as<float>();
+      DD_HIP(launch(34 + i, q));
+      q.in = fw->nk_cat[i].p; q.in_cstride = CT; q.in_coff = 0;
+      q.out = fw->nk_out[i].p; q.out_cstride = C; q.out_coff = 0;
+      q.wpack = h->neck_w[8 + i][ok].p; q.bias = h->neck_b[8 + i].as<float>();
+      DD_HIP(launch(38 + i, q));
+      h->n_neck_launches += 3;
+      lat_in = fw->nk_out[i].p;
+    }
     ConvParams p{};
     p.B = B; p.h = hh; p.w = ww;
     p.tiles_x = (ww + 31) / 32;
     p.tiles_y = (hh + conv_pack_geom2(lat_layer, ek).th - 1) / conv_pack_geom2(lat_layer, ek).th;
-    p.in = fw->fin[i].p; p.wpack = h->fpn_lat_w[i][ok].p; p.bias = h->fpn_lat_b[i].as<float>();
+    p.in = lat_in; p.wpack = h->fpn_lat_w[i][ok].p; p.bias = h->fpn_lat_b[i].as<float>();
     p.out = (i == 0) ? cbuf->p : fw->lat[i].p;
     p.addend = (i == FPN_LEVELS - 1) ? nullptr : (fw->pooled[i].p ? fw->pooled[i].p : fw->up[i].p);
     DD_HIP(launch(lat_layer, p));

@@ -103,7 +103,12 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const int trem = t - b * tiles_per_img;
     const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
     y0 = ty * C::TH; x0 = tx * C::TW;
-    in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * C::CIN * IN_ESZ;
+    if constexpr (C::IS_NECK) {
+      const int cs = p.in_cstride ? p.in_cstride : C::CIN;
+      in_b = reinterpret_cast<const char*>(p.in) + ((size_t)b * cs + p.in_coff) * h * w * IN_ESZ;
+    } else {
+      in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * C::CIN * IN_ESZ;
+    }
     cond_b = (C::PRO == PRO_GN_ADD) ? reinterpret_cast<const char*>(p.cond) + (size_t)b * h * w * C::CIN * IN_ESZ : nullptr;
     y4_b = (C::PRO == PRO_X) ? reinterpret_cast<const char*>(p.y4) + (size_t)b * h * w * LATENT_C * 4 : nullptr;
     xout_b = (C::PRO == PRO_X) ? reinterpret_cast<char*>(p.xout) + (size_t)b * h * w * LATENT_C * 4 : nullptr;
@@ -522,6 +527,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   constexpr int NG_LOCAL = (C::COUT == COND_C) ? C::NT / (COND_C / GN_GROUPS) : 4;
   float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};
   char* out_b = reinterpret_cast<char*>(p.out) + (size_t)e_b * h * w * C::COUT * C::OUT_ESZ;
+  if constexpr (C::IS_NECK) {
+    const int cs = p.out_cstride ? p.out_cstride : C::COUT;
+    out_b = reinterpret_cast<char*>(p.out) + ((size_t)e_b * cs + p.out_coff) * h * w * C::OUT_ESZ;
+  }
 #pragma unroll
   for (int m = 0; m < C::WM; ++m) {
     const int gy = e_y0 + wave * C::WM + m, gx = e_x0 + li;
@@ -710,6 +719,18 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 24: return launch_one2<EK, 24>(p, s);
     case 25: return launch_one2<EK, 25>(p, s);
     case 26: return launch_one2<EK, 26>(p, s);
+    case 30: return launch_one2<EK, 30>(p, s);
+    case 31: return launch_one2<EK, 31>(p, s);
+    case 32: return launch_one2<EK, 32>(p, s);
+    case 33: return launch_one2<EK, 33>(p, s);
+    case 34: return launch_one2<EK, 34>(p, s);
+    case 35: return launch_one2<EK, 35>(p, s);
+    case 36: return launch_one2<EK, 36>(p, s);
+    case 37: return launch_one2<EK, 37>(p, s);
+    case 38: return launch_one2<EK, 38>(p, s);
+    case 39: return launch_one2<EK, 39>(p, s);
+    case 40: return launch_one2<EK, 40>(p, s);
+    case 41: return launch_one2<EK, 41>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -769,6 +790,18 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 24: return geom2_of<EK, 24>();
     case 25: return geom2_of<EK, 25>();
     case 26: return geom2_of<EK, 26>();
+    case 30: return geom2_of<EK, 30>();
+    case 31: return geom2_of<EK, 31>();
+    case 32: return geom2_of<EK, 32>();
+    case 33: return geom2_of<EK, 33>();
+    case 34: return geom2_of<EK, 34>();
+    case 35: return geom2_of<EK, 35>();
+    case 36: return geom2_of<EK, 36>();
+    case 37: return geom2_of<EK, 37>();
+    case 38: return geom2_of<EK, 38>();
+    case 39: return geom2_of<EK, 39>();
+    case 40: return geom2_of<EK, 40>();
+    case 41: return geom2_of<EK, 41>();
     default: return geom2_of<EK, 23>();
   }
 }

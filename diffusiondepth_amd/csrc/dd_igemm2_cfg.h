@@ -62,17 +62,27 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   //   W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] on the raw GroupNorm-backward result: 16->64, 64->256, 256->64, 64->16
   //   24..26 = lateral convs of the MPViT-small pyramid (reference ...res_mpvit_HAHI.py:32: 128 | 216 | 288 | 288 -> 256; 216 is carried
   //            as 224 = 7 blocks of 32 with zero channels / zero weights; levels 2 and 3 share layer 26)
+  // HAHI neck of the Swin-L heads with the attention off (reference src/model/necks/hahi.py:60-97,170-173,196-197,226-272; eval-mode BN
+  // folded): per pyramid level i (C_i = 192 << i, embedding 512)
+  //   30 + i = lateral_convs[i]: 1x1 C_i -> C_i        34 + i = conv_proj / trans_proj[i-1]: 1x1 C_i -> 512
+  //   38 + i = conv_fusion / trans_fusion[i-1]: 3x3 (C_i + 512) -> C_i on the channel concatenation
+  // all + ReLU, raw inputs.  The concatenation is free in the channel-blocked layout: the two 1x1 convs write their couts at a channel
+  // offset of ONE buffer (ConvParams::out_coff / out_cstride), the projection reads the lateral result from it (in_coff / in_cstride).
+  static constexpr bool IS_NECK = (LAYER >= 30 && LAYER <= 41);
+  static constexpr int NECK_LVL = IS_NECK ? (LAYER - 30) % 4 : 0;
+  static constexpr int NECK_KIND = IS_NECK ? (LAYER - 30) / 4 : -1;      // 0 lateral, 1 projection, 2 fusion
+  static constexpr int NECK_C = 192 << NECK_LVL;
   static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18) || (LAYER >= 24 && LAYER <= 26);
   static constexpr bool IS_DGRAD = (LAYER >= 20 && LAYER <= 23);
   static constexpr bool IS_UP = (LAYER == 14);
-  static constexpr int KS = IS_UP ? 1 : 3;                       // kernel size
+  static constexpr int KS = (IS_UP || (IS_NECK && NECK_KIND != 2)) ? 1 : 3;      // kernel size
   static constexpr int HALO = KS / 2;
   static constexpr int NTAPS = KS * KS;
-  static constexpr int CIN = (LAYER == 1 || LAYER == 20) ? LATENT_C : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? HID_C : IS_LAT ? (LAYER >= 24 ? (LAYER == 24 ? 128 : LAYER == 25 ? 224 : 288) : LAYER >= 15 ? (192 << (LAYER - 15)) : (64 << (LAYER - 10))) : COND_C;
-  static constexpr int COUT = IS_UP ? 4 * COND_C : IS_LAT ? COND_C
+  static constexpr int CIN = IS_NECK ? (NECK_KIND == 2 ? NECK_C + 512 : NECK_C) : (LAYER == 1 || LAYER == 20) ? LATENT_C : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? HID_C : IS_LAT ? (LAYER >= 24 ? (LAYER == 24 ? 128 : LAYER == 25 ? 224 : 288) : LAYER >= 15 ? (192 << ((LAYER - 15) & 3)) : (64 << ((LAYER - 10) & 3))) : COND_C;
+  static constexpr int COUT = IS_NECK ? (NECK_KIND == 1 ? 512 : NECK_C) : IS_UP ? 4 * COND_C : IS_LAT ? COND_C
                             : (LAYER == 21) ? COND_C : (LAYER == 23) ? LATENT_C
                             : (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
-  static constexpr bool RELU_OUT = IS_LAT || IS_UP;              // epilogue: relu(acc + bias)
+  static constexpr bool RELU_OUT = IS_LAT || IS_UP || IS_NECK;   // epilogue: relu(acc + bias)
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
   static constexpr bool C3SHAPE = (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);
@@ -80,7 +90,7 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0) ? 16 : (64 / ESZ);
   static constexpr int TG = (LAYER == 1 || LAYER == 20 || C3 != 0) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
                           : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
-  static constexpr int NT = (COUT >= COND_C) ? 128 : COUT_PAD;
+  static constexpr int NT = IS_NECK ? 64 : (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms

@@ -70,6 +70,9 @@ struct ConvParams {
   const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
   const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
+  // HAHI neck layers (30..41): the input / output tensor is a channel range of a wider channel-blocked buffer (the concatenation the
+  // fusion conv reads): buffer width and first channel, both multiples of 32; 0 = the tensor is the whole buffer (every other layer)
+  int in_cstride, in_coff, out_cstride, out_coff;
   unsigned long long* prof; // -DDD_PHASE_PROF=1 builds only (tools/phase_prof.py): 8 x u64 per workgroup: wall-clock (100 MHz) at kernel entry,
                             // GroupNorm table done, first patch + weights in LDS, main loop done, stores issued, exit; [6] = HW_ID, [7] = XCC_ID
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,

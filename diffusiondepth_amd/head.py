@@ -98,22 +98,31 @@ class DDIMDepthEstimate_Res(nn.Module):
         if self._hip_fpn:
             bound.register("conv_lateral.", self.conv_lateral)
             bound.register("conv_up.", self.conv_up)
+        # the HAHI neck's convolutions run in the library too (dd_neck_condition) at the Swin-L widths; other pyramids (MPViT) keep the
+        # PyTorch neck in front of the library's FPN
+        self._hip_neck = self._hip_fpn and self._HAHI and list(in_channels) == [192, 384, 768, 1536]
+        if self._hip_neck:
+            bound.register("hahineck.", self.hahineck)
 
     @staticmethod
     def _on_hip(tensors) -> bool:
         return all(t.is_cuda for t in tensors)
 
     # -- condition aggregation (…res.py:108-118) --------------------------------------------------
-    def aggregate_condition(self, fp):
-        # the library's FPN is inference-only: when autograd has to reach the backbone features or the FPN weights (e.g. fine-tuning with
-        # the head in .eval() for frozen BatchNorm) the torch modules below run instead -- never a silently dropped gradient
-        needs_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in fp) or any(p.requires_grad for p in self.conv_lateral.parameters())
-                                                  or any(p.requires_grad for p in self.conv_up.parameters()))
-        if (self._hip_fpn and not self.training and not needs_grad and len(fp) == 4 and self._on_hip(fp)
-                and self.model.precision != "naive_fp32"):
-            # eval-mode BatchNorm is folded into the convolutions inside the library (dd_condition)
+    def _library_fpn_ok(self, fp) -> bool:
+        """dd_condition / dd_neck_condition are inference-only: not when autograd has to reach the backbone features or the FPN / neck
+        weights (e.g. fine-tuning with the head in .eval() for frozen BatchNorm) -- never a silently dropped gradient."""
+        mods = [self.conv_lateral, self.conv_up] + ([self.hahineck] if self._HAHI else [])
+        needs_grad = torch.is_grad_enabled() and (any(f.requires_grad for f in fp) or any(p.requires_grad for m in mods for p in m.parameters()))
+        return (self._hip_fpn and not self.training and not needs_grad and len(fp) == 4 and self._on_hip(fp)
+                and self.model.precision != "naive_fp32")
+
+    def aggregate_condition(self, fp, neck_in_library=False):
+        if self._library_fpn_ok(fp):
+            # eval-mode BatchNorm is folded into the convolutions inside the library (dd_condition / dd_neck_condition)
             be = self._bound.ensure(fp[0].device, self.scheduler, need=("fpn",))
-            return be.condition([f.float() for f in fp], self.model.precision)
+            return be.condition([f.float() for f in fp], self.model.precision, neck=neck_in_library)
+        assert not neck_in_library
         x = None
         n = len(fp)
         for i in range(n):
@@ -138,16 +147,19 @@ class DDIMDepthEstimate_Res(nn.Module):
             else:
                 fp = [it.detach() for it in fp]
         gt_map_t = self.depth_transform.t(gt_depth_map)                         # …res.py:102  (HIP encoder)
+        neck_in_library = False
         if self._HAHI:
-            # the neck is PyTorch-ROCm (≈170 GFLOP per KITTI image at Swin-L widths); with 16-bit kernel operands selected for the hot
-            # path it runs under autocast in the same element type (fp32 precision modes keep the reference's fp32 arithmetic)
-            ac = {"bf16": torch.bfloat16, "f16": torch.float16}.get(self.model.precision) if (self.neck_autocast and fp[0].is_cuda and not self.training) else None
-            if ac is not None:
-                with torch.autocast("cuda", dtype=ac):
-                    fp = [f.float() for f in self.hahineck(fp)]
+            if self._hip_neck and self._library_fpn_ok(fp):
+                neck_in_library = True                                          # …swin_addHAHI.py:110 runs inside dd_neck_condition
             else:
-                fp = self.hahineck(fp)                                          # …swin_addHAHI.py:110
-        x = self.aggregate_condition(fp)                                        # …res.py:108-118
+                # PyTorch-ROCm neck (training, MPViT widths, autograd): fp32 as the reference, or under autocast when asked for
+                ac = {"bf16": torch.bfloat16, "f16": torch.float16}.get(self.model.precision) if (self.neck_autocast and fp[0].is_cuda and not self.training) else None
+                if ac is not None:
+                    with torch.autocast("cuda", dtype=ac):
+                        fp = [f.float() for f in self.hahineck(fp)]
+                else:
+                    fp = self.hahineck(fp)                                      # …swin_addHAHI.py:110
+        x = self.aggregate_condition(fp, neck_in_library)                       # …res.py:108-118
         res = self.pipeline(batch_size=x.shape[0], device=x.device, dtype=x.dtype, shape=gt_map_t.shape[-3:],
                             input_args=(x, None, None, None),
                             num_inference_steps=self.diffusion_inference_steps, return_dict=False)                # :124-138

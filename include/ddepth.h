@@ -114,6 +114,18 @@ int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_ti
 int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
                  float* cond_out, int precision, void* stream);
 
+/* Replaces: `fp = self.hahineck(fp)` followed by the same top-down loop in the HAHI heads (src/model/head/
+ * ddim_depth_estimate_res_swin_addHAHI.py:110-127): HAHIHeteroNeck.forward with cross_att = self_att = False, the only way any head
+ * builds it (ibid. :54-56) -- per pyramid level  l = lateral_convs[i](x),  e = conv_proj / trans_proj[i-1](l)  (1x1 -> 512),
+ * out = conv_fusion / trans_fusion[i-1](cat)  (3x3 over the channel concatenation; src/model/necks/hahi.py:170-173,196-197,226-272),
+ * every ConvModule = bias-free conv + eval-mode BatchNorm + ReLU (folded at dd_commit_weights) -- then dd_condition's FPN on the neck's
+ * outputs.  Parameters: the keys "hahineck.{lateral_convs.i, conv_proj.0, trans_proj.j, conv_fusion.0, trans_fusion.j}.{conv.weight,
+ * bn.weight, bn.bias, bn.running_mean, bn.running_var}" form a fourth optional group of dd_set_weight (the neck's attention / embedding
+ * parameters are never executed by the reference and are not part of it).  DD_VARIANT_SWIN with the Swin-L pyramid (192/384/768/1536).
+ * Same arguments and result hand-over as dd_condition; feats are the RAW backbone maps. */
+int dd_neck_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
+                      float* cond_out, int precision, void* stream);
+
 /* ---- the hot loop -----------------------------------------------------------------------------
  * Replaces: CNNDDIMPipiline.__call__ (…res.py:248-297) minus its torch.randn: `timesteps`-driven
  * loop of  eps = model(x_t, t, cond) ; x_{t-1} = scheduler.step(eps, t, x_t, eta=0,
@@ -193,7 +205,7 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * instead of the MFMA kernel, A/B check). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
-/* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans". */
+/* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches". */
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`

@@ -261,6 +261,7 @@ def test_emulation_catches_a_lax_counted_wait(emu, tmp_path):
     NRAW + 1 the wave's last DMA piece may still be in flight at the barrier: only the late-landing model can see that, and it must."""
     old = "      DD_WAIT_VM_LGKM0(NRAW);\n    } else {"
     mut = bind_igemm2(build_mutant("dd_igemm2.hip", old, "      DD_WAIT_VM_LGKM0(NRAW + 1);\n    } else {", tmp_path, count=1))
-    run_layer(mut, 3, EK_F16, order=0, late=0)              # DMA lands at issue: the lax wait is invisible
+    # layer 7 (Swin pred.0, 256 -> 64 on a raw input): two raw-patch register slots, i.e. the counted wait is on its path
+    run_layer(mut, 7, EK_F16, order=0, late=0)              # DMA lands at issue: the lax wait is invisible
     with pytest.raises(AssertionError):
-        run_layer(mut, 3, EK_F16, order=0, late=1)          # DMA lands as late as the waits allow: stale weights
+        run_layer(mut, 7, EK_F16, order=0, late=1)          # DMA lands as late as the waits allow: stale weights

@@ -1,6 +1,6 @@
 """GPU (`-m gpu`): the head variants added on top of Res / Swin_ADD, whole forward() against goldens minted from the reference's own
 head classes (tests/golden/make_golden_hahi.py):
-  DDIMDepthEstimate_Swin_ADDHAHI  (README.md:215 headline configuration): HAHI neck (PyTorch-ROCm) -> dd_condition (Swin-L widths) ->
+  DDIMDepthEstimate_Swin_ADDHAHI  (README.md:215 headline configuration): HAHI neck + condition FPN in the library (dd_neck_condition, Swin-L widths) ->
                                   dd_denoise (UpSample_add denoiser, 20 steps) -> dd_decode -> ddim_loss
   DDIMDepthEstimate_ResVis        'pred_inter' through dd_denoise_trace
 Tolerance: north-star 1e-3 abs on predicted depth (fp32 mode)."""
@@ -76,21 +76,30 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
         U.record("mpvit_fpn_hip_vs_torch", cond_maxabs=e_c, cond_max=float(c_torch.abs().max()))
         assert e_c < 1e-4 * max(1.0, float(c_torch.abs().max()))
     if case == "head_swin_hahi":
+        # the neck's 1x1 / 3x3 convolutions ran in the library (dd_neck_condition), not in MIOpen: 3 launches per
+        # pyramid level per forward -- and they equal the PyTorch neck + library FPN on the same features
+        assert head._hip_neck and head._bound.backend.counter("neck_launches") >= 12
+        with torch.no_grad():
+            c_lib = head.aggregate_condition(fp, neck_in_library=True)
+            c_ref = head.aggregate_condition(head.hahineck(fp))
+        e_c = float((c_lib - c_ref).abs().max())
+        U.record("swin_neck_hip_vs_torch", cond_maxabs=e_c, cond_max=float(c_ref.abs().max()))
+        assert e_c < 1e-4 * max(1.0, float(c_ref.abs().max()))
         # the Vis variant of the same head: same prediction, plus every intermediate sample decoded
         vis = _load(dda.DDIMDepthEstimate_Swin_ADDHAHIVis(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000,
                                                           depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval(), sd)
         ov = _run(vis, fp, gt, inp, U)
         assert len(ov["pred_inter"]) == c["T"] and torch.equal(ov["pred_inter"][-1], ov["pred"])
         assert U.maxabs(ov["pred"].cpu().numpy(), g["pred"]) < 1e-3
-        # bf16 operand mode: the PyTorch-ROCm neck runs under bf16 autocast, the rest on the bf16 kernels; error recorded and bounded
-        # (16-bit modes are judged on depth RMSE); neck_autocast=False keeps the neck in fp32
+        # 16-bit modes: neck, FPN and loop all on the library's bf16 / f16 kernels; error recorded and bounded (the Swin variant's 16-bit
+        # depth error is judged on RMSE)
         errs = {}
-        for ac in (True, False):
+        for prec in ("bf16", "f16"):
             hb = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
-                                         loss_cfgs=[], precision="bf16", neck_autocast=ac).eval(), sd)
-            errs[ac] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
-        U.record(case + "_bf16", depth_rmse_neck_autocast=errs[True], depth_rmse_neck_fp32=errs[False], pred_max=float(g["pred"].max()))
-        assert errs[True] < 0.1 and errs[False] < 0.1
+                                         loss_cfgs=[], precision=prec).eval(), sd)
+            errs[prec] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
+        U.record(case + "_16bit", depth_rmse_bf16=errs["bf16"], depth_rmse_f16=errs["f16"], pred_max=float(g["pred"].max()))
+        assert errs["bf16"] < 0.1 and errs["f16"] < 0.02
 
 
 def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):
