@@ -441,8 +441,11 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             want = f"--precision {args.precision} --batch {B} --size {args.size} --variant {args.variant}"
             if pt.get("bench_args", "").strip() == want:
-                ekid = {"fp32": 0, "bf16": 1, "f16": 2}[args.precision]
-                traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
+                # kernel names carry the element kind / mode: 0 fp32, 1 bf16, 2 f16, 3 = the default bf16 mode (dd_kernels.h EK_BF16M)
+                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,)}[args.precision]:
+                    if f"layer{dom}_ek{ekid}" in pt["kernels"]:
+                        traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
+                        break
         except Exception:
             traffic = None
         roof = {"bound": "mfma", "kernel": f"conv_igemm2_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),

@@ -186,11 +186,11 @@ class HipDenoiser:
 
         device_route: denoiser parameters (model.*) that are tensors on this device go to the library without leaving HBM
         (dd_set_weight_device: fp32 -> kernel layouts by pack kernels) instead of D2H copy + host-side packing -- what a training loop
-        needs after every optimizer.step().  None = the environment variable DDEPTH_DEVICE_WEIGHTS (default "0": the route has been
-        validated against the host packer bit for bit under host emulation, not yet on a GPU)."""
+        needs after every optimizer.step().  None = the environment variable DDEPTH_DEVICE_WEIGHTS (default "1": the route leaves the host
+        packer's bytes in HBM, digest-equal -- host emulation and, since round 2, tests/test_zzz_gpu_device_weights.py on an MI355X)."""
         torch = _torch()
         if device_route is None:
-            device_route = os.environ.get("DDEPTH_DEVICE_WEIGHTS", "0") == "1"
+            device_route = os.environ.get("DDEPTH_DEVICE_WEIGHTS", "1") == "1"
         n = 0
         owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.", "hahineck.")
         # of the neck only the executed convolutions travel (the attention / embedding parameters are dead in the reference: necks.py)

@@ -14,7 +14,7 @@ def per_kernel(d, counter):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d), (\d)>", row.get("Kernel_Name", ""))
+            m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d+), (\d+)>", row.get("Kernel_Name", ""))
             if not m:
                 continue
             rows[f"layer{m.group(2)}_ek{m.group(1)}"].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
