@@ -43,7 +43,7 @@ def install(lib, setattr_fn):
         h = ctypes.c_void_p()
         assert lib.dd_create(ctypes.byref(h), 0, B_.VARIANTS[variant]) == 0
         be._h = h
-        be._have_schedule = be._have_weights = be._have_fpn = False
+        be._have_schedule = be._have_weights = be._have_fpn = be._have_neck = False
         be._cond_token = None
         made.append(be)
         return be
