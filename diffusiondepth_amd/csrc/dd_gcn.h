@@ -15,6 +15,8 @@
 #define DD_WAIT_VM_LGKM0(n) hostemu::wait_vm(n)
 #define DD_WAIT_LGKM0() ((void)0)
 #define DD_VMEM_LOADS_ISSUED(n) hostemu::vmem_loads_issued(n)
+typedef hostemu::tr16_v2u dd_u32x2_t;
+#define DD_LDS_READ_TR16(smem, byte_off) hostemu::lds_read_tr16((smem) + (byte_off))
 
 #else
 
@@ -37,5 +39,11 @@
 #define DD_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // bookkeeping for the host model only: n ordinary global loads were just issued by this wave (they count in vmcnt)
 #define DD_VMEM_LOADS_ISSUED(n) ((void)0)
+// ds_read_b64_tr_b16: the lane's 8-byte-aligned LDS address -> 4 x 16 bit, transposed inside each group of 16 lanes (see dd_wgrad2.hip)
+typedef __attribute__((ext_vector_type(4))) short dd_s16x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned dd_u32x2_t;
+#define DD_LDS_READ_TR16(smem, byte_off)                                                                                              \
+  __builtin_bit_cast(dd_u32x2_t, __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                                             \
+      (__attribute__((address_space(3))) dd_s16x4_t*)((__attribute__((address_space(3))) char*)(smem) + (byte_off))))
 
 #endif

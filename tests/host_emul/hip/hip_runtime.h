@@ -332,6 +332,27 @@ inline v2u permlane32_swap(unsigned vdst, unsigned src0) {
   return r;
 }
 
+// ds_read_b64_tr_b16 (gfx950): every lane supplies the LDS address of 4 contiguous 16-bit elements; inside each group of 16 lanes the
+// 16 x 4 matrix M[lane r][element c] comes back transposed in 4-row blocks: lane l = 4 r0 + i receives (M[r0][i], M[r0+4][i], M[r0+8][i],
+// M[r0+12][i]) -- measured on an MI355X with tools/micro/tr16_probe.hip (the ISA manual is not in this image).
+typedef __attribute__((ext_vector_type(2))) unsigned tr16_v2u;
+inline tr16_v2u lds_read_tr16(const char* addr) {
+  State& s = st();
+  uint64_t* wx = &s.wave_x[wave_buf() * WAVE * 2];
+  const int l = lane_id();
+  uint64_t mine;
+  memcpy(&mine, addr, 8);
+  wx[l * 2] = mine;
+  wave_sync();
+  const int gb = l & ~15, r0 = (l & 15) >> 2, i = l & 3;
+  unsigned short e[4];
+  for (int j = 0; j < 4; ++j) e[j] = (unsigned short)(wx[(gb + r0 + 4 * j) * 2] >> (16 * i));
+  tr16_v2u r;
+  r[0] = (unsigned)e[0] | ((unsigned)e[1] << 16);
+  r[1] = (unsigned)e[2] | ((unsigned)e[3] << 16);
+  return r;
+}
+
 // ---- the wave's VMEM queue (dd_gcn.h) ------------------------------------------------------------------------------------------------------------
 inline void lds_dma16(char* smem, unsigned ldst, const char* gsrc) {
   State& s = st();
