@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "diffusiondepth_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-x", "hip", "-c", "--cuda-device-only",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-x", "hip", "-c", "--cuda-device-only",
          "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull]
 KEYS = ["VGPRs", "AGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill", "SGPRs Spill", "LDS Size [bytes/block]", "Occupancy [waves/SIMD]"]
 
