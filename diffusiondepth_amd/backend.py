@@ -117,6 +117,8 @@ class HipDenoiser:
     """Owner of one dd_handle_t (one per device/process).  All tensor arguments are torch CUDA
     (= HIP) tensors, fp32 NCHW, exactly what the reference modules exchange."""
 
+    last_trajectory_ticket = 0      # ticket of the last denoise(..., keep_trajectory=True) call (0 = none)
+
     def __init__(self, device=None, variant: str = "res"):
         torch = _torch()
         self._lib = load_library()
@@ -281,7 +283,9 @@ class HipDenoiser:
         return cond.data_ptr()
 
     # -- hot path -----------------------------------------------------------------------------
-    def denoise(self, x_T, cond, num_inference_steps: int, precision="fp32", out=None):
+    def denoise(self, x_T, cond, num_inference_steps: int, precision="fp32", out=None, keep_trajectory=False):
+        """The T-step loop (one hipGraph).  ``keep_trajectory=True`` (training forward): the library keeps the state entering every step
+        and ``self.last_trajectory_ticket`` names them; passed to ``denoise_backward`` it saves that call a second forward loop."""
         torch = _torch()
         x_T = _check_tensor(x_T, "x_T", dtype=torch.float32)
         cond_in = cond
@@ -292,10 +296,19 @@ class HipDenoiser:
         if C != 16 or cond.dim() != 4 or cond.shape[0] != B or cond.shape[1] != 256:
             raise ValueError(f"x_T must be (B,16,h,w) and cond (B,256,ch,cw); got {tuple(x_T.shape)}, {tuple(cond.shape)}")
         out = torch.empty_like(x_T) if out is None else _check_tensor(out, "out", x_T.shape, torch.float32)
-        with torch.cuda.device(self.device):
-            self._ck(self._lib.dd_denoise(self._h, x_T.data_ptr(), self._cond_arg(cond, precision), out.data_ptr(), B, h, w,
-                                          cond.shape[2], cond.shape[3], int(num_inference_steps),
-                                          precision_id(precision), _stream_ptr(self.device)), "dd_denoise")
+        self.last_trajectory_ticket = 0
+        if keep_trajectory:
+            self.set_option("keep_trajectory", 1)
+        try:
+            with torch.cuda.device(self.device):
+                self._ck(self._lib.dd_denoise(self._h, x_T.data_ptr(), self._cond_arg(cond, precision), out.data_ptr(), B, h, w,
+                                              cond.shape[2], cond.shape[3], int(num_inference_steps),
+                                              precision_id(precision), _stream_ptr(self.device)), "dd_denoise")
+            if keep_trajectory and precision != "naive_fp32":
+                self.last_trajectory_ticket = self.counter("trajectory_ticket")
+        finally:
+            if keep_trajectory:
+                self.set_option("keep_trajectory", 0)
         return out
 
     def denoise_trace(self, x_T, cond, num_inference_steps: int, precision="fp32"):
@@ -380,9 +393,12 @@ class HipDenoiser:
         self._cond_token = None
         return gx, gc
 
-    def denoise_backward(self, x_T, cond, grad_x0, num_inference_steps: int, precision="naive_fp32", need_grad_xT=False, need_grad_cond=True):
+    def denoise_backward(self, x_T, cond, grad_x0, num_inference_steps: int, precision="naive_fp32", need_grad_xT=False, need_grad_cond=True,
+                         trajectory_ticket=0):
         """Backward of the whole DDIM loop (autograd through ``self.pipeline(...)`` in the reference's training step):
-        returns (grad_xT, grad_cond); parameter gradients accumulate in the handle."""
+        returns (grad_xT, grad_cond); parameter gradients accumulate in the handle.  ``trajectory_ticket`` = the ticket of the forward
+        ``denoise(..., keep_trajectory=True)`` call on the same inputs: the library then reads the per-step states that call kept (if they
+        are still there and the parameters are unchanged) instead of running the forward loop again; 0 = always regenerate."""
         torch = _torch()
         x_T = _check_tensor(x_T, "x_T", dtype=torch.float32)
         cond = _check_tensor(cond, "cond", dtype=torch.float32)
@@ -390,6 +406,8 @@ class HipDenoiser:
         B, C, h, w = x_T.shape
         gx = torch.empty_like(x_T) if need_grad_xT else None
         gc = torch.empty_like(cond) if need_grad_cond else None
+        if trajectory_ticket:
+            self.set_option("use_trajectory", int(trajectory_ticket))
         with torch.cuda.device(self.device):
             self._ck(self._lib.dd_denoise_backward(
                 self._h, x_T.data_ptr(), cond.data_ptr(), grad_x0.data_ptr(), gx.data_ptr() if gx is not None else None,

@@ -94,8 +94,10 @@ struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
 
 struct PlanKey {
   int B, h, w, ch, cw, T, prec, hoist;
+  int keep = 0;        // option "keep_trajectory" (what dd_denoise_backward needs): 1 = the loop leaves every state x_k in Plan::xstash;
+                       // 2 = ... and every step's raw conv outputs y1..y4 (Swin: + convA / convB results) in per-step slots
   bool operator<(const PlanKey& o) const {
-    return std::tie(B, h, w, ch, cw, T, prec, hoist) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist);
+    return std::tie(B, h, w, ch, cw, T, prec, hoist, keep) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist, o.keep);
   }
 };
 
@@ -110,6 +112,8 @@ struct Plan {
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
   DevBuf bX, bA1, bF, bA3; // fused backward: the four convs' input activations, materialised for the weight gradients
   DevBuf xstash;           // loop backward: the T states entering each step + the running gradient, fp32 NHWC16
+  int64_t traj_ticket = 0;         // key.keep plans: ticket of the dd_denoise call whose states x_0 .. x_{T-1} xstash holds (0 = none)
+  int64_t traj_weights = -1;       // ... and the parameter generation (dd_handle_s::weights_serial) they were computed with
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
@@ -121,6 +125,8 @@ struct Plan {
   bool capture_failed = false;
   uint64_t last_use = 0;
   ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
+  int slots = 1;      // per-step copies of y1..y4 / sa / sf (key.keep == 2: T, the backward then recomputes nothing; else 1)
+  void* slot(const DevBuf& b, int step) const { return static_cast<char*>(b.p) + (slots > 1 ? (size_t)step * (b.bytes / slots) : 0); }
   double* stat_ptr(int step, int layer) const {   // layer 0..3
     return stats.as<double>() + ((size_t)(step * 4 + layer) * key.B) * STAT_SLOTS * STAT_STRIDE;
   }
@@ -182,6 +188,12 @@ struct dd_handle_s {
   int ablate = 0;             // timing experiments only (ConvParams::ablate)
   unsigned long long* prof_buf = nullptr;   // tools/phase_prof.py (-DDD_PHASE_PROF=1 builds): caller-owned device buffer, 8 x u64 per workgroup
   int prof_layer = 0;         // the kernel layer id whose launches write it
+  // Training: with option "keep_trajectory" dd_denoise keeps the states entering every step and hands out a ticket (counter
+  // "trajectory_ticket"); dd_denoise_backward called after set_option("use_trajectory", ticket) reads them instead of running the forward
+  // loop a second time -- if that ticket is still the plan's and the parameters have not changed since, else it regenerates as before.
+  bool keep_traj = false;
+  int64_t keep_act_mb = 65536;
+  int64_t traj_serial = 0, use_traj = 0, weights_serial = 0, n_traj_reuse = 0;
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   DevBuf wgrad_ws;            // per-slab partial weight gradients of dd_wgrad.hip
@@ -393,20 +405,23 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   const size_t es = ek_size(pl->ek);
   DD_HIP(pl->x[0].alloc(px * LATENT_C * 4));
   DD_HIP(pl->x[1].alloc(px * LATENT_C * 4));
+  if (key.keep) DD_HIP(pl->xstash.alloc((size_t)(key.T > 0 ? key.T : 1) * px * LATENT_C * 4));
   const bool swin = h->variant == DD_VARIANT_SWIN;
   // Swin: the condition map is bilinearly upsampled to the latent size once per call and kept at that size
   (void)swin;
   { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond); if (rc) return rc; }
-  if (swin) { DD_HIP(pl->sa.alloc(px * COND_C * es)); DD_HIP(pl->sf.alloc(px * COND_C * es)); }
+  pl->slots = (key.keep == 2 && key.T > 0) ? key.T : 1;
+  const size_t ns = (size_t)pl->slots;
+  if (swin) { DD_HIP(pl->sa.alloc(ns * px * COND_C * es)); DD_HIP(pl->sf.alloc(ns * px * COND_C * es)); }
   if (key.hoist)   // conv3(cond) in accumulator-fragment order: whole (th x 32)-pixel tiles
   {
     const int th = conv_pack_geom2(9, pl->ek).th;
     DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
   }
-  DD_HIP(pl->y1.alloc(px * HID_C * es));
-  DD_HIP(pl->y2.alloc(px * COND_C * es));
-  DD_HIP(pl->y3.alloc(px * HID_C * es));
-  DD_HIP(pl->y4.alloc(px * LATENT_C * 4));
+  DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
+  DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
+  DD_HIP(pl->y3.alloc(ns * px * HID_C * es));
+  DD_HIP(pl->y4.alloc(ns * px * LATENT_C * 4));
   if (naive) {
     DD_HIP(pl->a1.alloc(px * HID_C * 4));
     DD_HIP(pl->f.alloc(px * COND_C * 4));
@@ -468,34 +483,38 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     h->pending_ev.emplace_back(layer - 1, a, b);
     return e;
   };
+  // this step's activation buffers (per-step slots in the plans that keep them for the backward)
+  void *y1_ = pl->slot(pl->y1, step), *y2_ = pl->slot(pl->y2, step), *y3_ = pl->slot(pl->y3, step), *y4_ = pl->slot(pl->y4, step);
+  void *sa_ = pl->slot(pl->sa, step), *sf_ = pl->slot(pl->sf, step);
+  const float* y4_prev = static_cast<const float*>(pl->slot(pl->y4, step > 0 ? step - 1 : 0));     // read by the fused update of step - 1
   // conv1: state (+ fused DDIM update of the previous step) -> y1
-  p.in = x_in; p.wpack = h->L[0].wpack2[tk].p; p.bias = h->L[0].bias.as<float>(); p.out = pl->y1.p;
+  p.in = x_in; p.wpack = h->L[0].wpack2[tk].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
   p.stats_out = pl->stat_ptr(step, 0);
   p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
   p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
-  p.y4 = pl->y4.as<float>(); p.xout = x_out; p.c1c2 = pl->c1c2.as<float>(); p.step = apply_update ? step : 0;
+  p.y4 = y4_prev; p.xout = x_out; p.c1c2 = pl->c1c2.as<float>(); p.step = apply_update ? step : 0;
   DD_HIP(timed_launch(1, p));
   // conv2: relu(gn1(y1)) -> y2
-  p.in = pl->y1.p; p.wpack = h->L[1].wpack2[ok].p; p.bias = h->L[1].bias.as<float>(); p.out = pl->y2.p;
+  p.in = y1_; p.wpack = h->L[1].wpack2[ok].p; p.bias = h->L[1].bias.as<float>(); p.out = y2_;
   p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
   p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
   DD_HIP(timed_launch(2, p));
   if (h->variant == DD_VARIANT_SWIN) {
     // upsample_fuse: convB(convA(relu(gn2(y2)) + up(cond) + E[t]))  then pred.0 on the raw result
-    p.in = pl->y2.p; p.wpack = h->LA.wpack2[ok].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
+    p.in = y2_; p.wpack = h->LA.wpack2[ok].p; p.bias = h->LA.bias.as<float>(); p.out = sa_;
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
     p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
     p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
     DD_HIP(timed_launch(5, p));
-    p.in = pl->sa.p; p.wpack = h->LB.wpack2[ok].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
+    p.in = sa_; p.wpack = h->LB.wpack2[ok].p; p.bias = h->LB.bias.as<float>(); p.out = sf_;
     p.stats_in = nullptr;
     DD_HIP(timed_launch(6, p));
-    p.in = pl->sf.p; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+    p.in = sf_; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
     p.stats_out = pl->stat_ptr(step, 2);
     DD_HIP(timed_launch(7, p));
   } else {
   // conv3: relu(gn2(y2)) + cond + E[t] -> y3   (hoisted form: conv3(relu(gn2(y2))) + [conv3(cond) + conv3(E[t])])
-  p.in = pl->y2.p; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = pl->y3.p;
+  p.in = y2_; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
@@ -503,7 +522,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
-  p.in = pl->y3.p; p.wpack = h->L[3].wpack2[tk].p; p.bias = h->L[3].bias.as<float>(); p.out = pl->y4.p;
+  p.in = y3_; p.wpack = h->L[3].wpack2[tk].p; p.bias = h->L[3].bias.as<float>(); p.out = y4_;
   p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
   p.gn_gamma = h->L[2].gamma.as<float>(); p.gn_beta = h->L[2].beta.as<float>();
   DD_HIP(timed_launch(4, p));
@@ -579,6 +598,12 @@ int enqueue_loop_body(dd_handle_t h, Plan* pl, hipStream_t s) {
     // conv1 of step k applies the update of step k-1: reads x[(k-1)&1] (k>0) / x[0] (k=0), writes x[k&1]
     const float* xin = (k == 0) ? pl->x[0].as<float>() : pl->x[(k - 1) & 1].as<float>();
     float* xout = pl->x[k & 1].as<float>();
+    if (pl->key.keep) {      // X[k] = state entering step k, all T of them kept (X[0] is the input: step 0 writes nothing)
+      const size_t n16 = (size_t)pl->key.B * pl->key.h * pl->key.w * LATENT_C;
+      float* X = pl->xstash.as<float>();
+      xin = (k == 0) ? X : X + (size_t)(k - 1) * n16;
+      xout = X + (size_t)k * n16;
+    }
     int rc = enqueue_fused_step(h, pl, k, xin, xout, k > 0, pl->tsteps.as<long long>(), k, 0, s);
     if (rc != DD_OK) return rc;
   }
@@ -667,6 +692,7 @@ int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t nu
                                                " elements, got " + std::to_string(numel));
       h->host_w[name].assign(data, data + numel);
       h->dev_newer.erase(name);
+      h->weights_serial++;
       const int grp = weight_group(name);
       if (grp == 0) h->committed = false; else if (grp == 1) h->codec_committed = false; else if (grp == 3) h->neck_committed = false; else h->fpn_committed = false;
       return DD_OK;
@@ -693,6 +719,7 @@ int dd_set_weight_device(dd_handle_t h, const char* name, const float* data, int
     DD_HIP(hipMemcpyAsync(b->p, data, (size_t)numel * 4, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
     h->dev_newer.insert(name);
     h->committed = false;
+    h->weights_serial++;
     return DD_OK;
   }
   return h->fail(DD_ERR_INVALID_ARG, std::string("dd_set_weight_device: unknown parameter name '") + name + "'");
@@ -1078,6 +1105,9 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->bf16_pure = value != 0;
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
+  else if (k == "keep_trajectory") h->keep_traj = value != 0;
+  else if (k == "use_trajectory") h->use_traj = value;
+  else if (k == "keep_activations_mb") h->keep_act_mb = value < 0 ? 0 : value;
   else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
   else if (k == "phase_prof_layer") h->prof_layer = (int)value;
   else if (k == "layer_timing") {
@@ -1096,6 +1126,8 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   else if (k == "graph_capture_failures") *value = h->n_capture_failures;
   else if (k == "plans") *value = (int64_t)h->plans.size();
   else if (k == "neck_launches") *value = h->n_neck_launches;
+  else if (k == "trajectory_ticket") *value = h->traj_serial;
+  else if (k == "trajectory_reuses") *value = h->n_traj_reuse;
   else return h->fail(DD_ERR_INVALID_ARG, "dd_get_counter: unknown key '" + k + "'");
   return DD_OK;
 }
@@ -1270,10 +1302,22 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision)}, &pl);
+  int keep = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? 1 : 0;
+  if (keep) {
+    // ... and every step's raw activations as well when they fit the budget (option "keep_activations_mb", default 64 GiB of the 288):
+    // the backward then recomputes nothing.  KITTI, T = 20: 1.8 GB (Res) / 4.0 GB (Swin) per image
+    const size_t es = ek_size(store_kind(ek_of_precision(precision, h->bf16_pure)));
+    const size_t per_step = (size_t)B * lat_h * lat_w * ((2 * HID_C + COND_C + (h->variant == DD_VARIANT_SWIN ? 2 * COND_C : 0)) * es + LATENT_C * 4);
+    if (per_step * (size_t)T <= (size_t)h->keep_act_mb << 20) keep = 2;
+  }
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep}, &pl);
   if (rc) return rc;
+  const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
+  float* x_first = keep ? pl->xstash.as<float>() : pl->x[0].as<float>();                                        // state entering step 0
+  const float* x_last = keep ? pl->xstash.as<float>() + (size_t)(T - 1) * n16 : pl->x[(T - 1) & 1].as<float>();  // state entering step T-1
+  if (keep) pl->traj_ticket = 0;         // being overwritten
 
-  DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  DD_HIP(launch_nchw_to_nhwc(x_T, x_first, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
   if (rc) return rc;
 
@@ -1324,7 +1368,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
         h->n_capture_failures++;
       }
       // the eager pass above consumed x[0]: restore the input state before the real run
-      DD_HIP(launch_nchw_to_nhwc(x_T, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+      DD_HIP(launch_nchw_to_nhwc(x_T, x_first, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
       if (h->timing) DD_HIP(hipEventRecord(h->ev0, s));
     }
     if (pl->exec) {
@@ -1340,8 +1384,9 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   }
   if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
   // x_0 = c1*x + c2*relu(gn4(y4)) of the last step, written NCHW
-  DD_HIP(launch_final(pl->x[(T - 1) & 1].as<float>(), pl->y4.as<float>(), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
+  DD_HIP(launch_final(x_last, static_cast<const float*>(pl->slot(pl->y4, T - 1)), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
                       h->L[3].beta.as<float>(), pl->c1c2.as<float>(), T - 1, 0, x_0, B, lat_h, lat_w, s));
+  if (keep) { pl->traj_ticket = ++h->traj_serial; pl->traj_weights = h->weights_serial; }
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   return DD_OK;
 }
@@ -1485,7 +1530,12 @@ int ensure_bwd_buffers(dd_handle_t h, Plan* pl) {
 // (fp32 NHWC16).  Recomputes the forward pass (GroupNorm sums in stat slot 0), accumulates the parameter gradients into
 // h->grads, writes (or accumulates) dLoss/dcond as NCHW fp32 into grad_cond when that is not NULL.
 int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, int t_base, int t_bstride, float* grad_cond,
-             int accumulate_cond, hipStream_t s) {
+             int accumulate_cond, hipStream_t s, const Plan* kept = nullptr, int kstep = 0) {
+  // kept != NULL: the forward pass of this step is NOT recomputed -- its raw conv outputs and GroupNorm sums are read from slot `kstep`
+  // of the forward plan that kept them (PlanKey::keep == 2; same shape and element kinds as `pl`)
+  const Plan* src = kept ? kept : pl;
+  const int sstep = kept ? kstep : 0;
+  auto st = [&](int layer) { return src->stat_ptr(sstep, layer); };
   const int B = pl->key.B, lat_h = pl->key.h, lat_w = pl->key.w, precision = pl->key.prec;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const long long HW = (long long)lat_h * lat_w;
@@ -1493,46 +1543,48 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   const int ek = opnd_kind(mode);           // gradients, materialised activations, weight-gradient operands: bf16 in the mode EK_BF16M
   const int yk = store_kind(mode);          // the stored conv outputs y1..y3 and the condition map (f16 in that mode)
   int rc = DD_OK;
-  DD_HIP(hipMemsetAsync(pl->stat_ptr(0, 0), 0, (size_t)4 * B * STAT_SLOTS * STAT_STRIDE * sizeof(double), s));
+  if (!kept) DD_HIP(hipMemsetAsync(pl->stat_ptr(0, 0), 0, (size_t)4 * B * STAT_SLOTS * STAT_STRIDE * sizeof(double), s));
   const int lay = naive ? 0 : 1;                    // activation layout flag of the views: plain NHWC fp32 / channel-blocked
   const ActView nothing{nullptr, EK_F32, 0, 1, HW};
   if (naive) {
     rc = enqueue_naive_eps(h, pl, 0, x_nhwc, tv, t_base, t_bstride, s);
     if (rc) return rc;
   } else {
-    rc = enqueue_fused_step(h, pl, 0, x_nhwc, pl->x[1].as<float>(), false, tv, t_base, t_bstride, s);
+    if (!kept) rc = enqueue_fused_step(h, pl, 0, x_nhwc, pl->x[1].as<float>(), false, tv, t_base, t_bstride, s);
     if (rc) return rc;
     // the convs' input activations in the kernels' own element kind: x, a1 = relu(gn1(y1)), f = relu(gn2(y2)) + cond + E[t],
     // a3 = relu(gn3(y3))  (the weight gradients contract the conv-output gradients with these)
     DD_HIP(launch_view_copy(ActView{x_nhwc, EK_F32, 0, LATENT_C, HW}, ActView{pl->bX.p, ek, 0, LATENT_C, HW}, B, s));
-    const DevBuf* ys[3] = {&pl->y1, &pl->y2, &pl->y3};
+    const void* ys[3] = {src->slot(src->y1, sstep), src->slot(src->y2, sstep), src->slot(src->y3, sstep)};
     const DevBuf* as[3] = {&pl->bA1, &pl->bF, &pl->bA3};
     for (int l = 0; l < 3; ++l) {
       const int C = kCouts[l];
       if (ek != EK_F32) {
-        DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l]->p, ek, yk, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
+        DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l], ek, yk, st(l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
                                            nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond->p : nullptr, h->emb.as<float>(), tv, t_base,
                                            t_bstride, B, C, HW, s));
         continue;
       }
-      const ActView yv{ys[l]->p, ek, 1, C, HW}, av{as[l]->p, ek, 1, C, HW};
+      const ActView yv{ys[l], ek, 1, C, HW}, av{as[l]->p, ek, 1, C, HW};
       const ActView cv = (l == 1) ? ActView{pl->cond->p, ek, 1, C, HW} : nothing;
-      DD_HIP(launch_gn_bwd_apply(nothing, yv, pl->stat_ptr(0, l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(), pl->dgb.as<double>(),
+      DD_HIP(launch_gn_bwd_apply(nothing, yv, st(l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(), pl->dgb.as<double>(),
                                  nothing, av, cv, h->emb.as<float>(), tv, t_base, t_bstride, B, s));
     }
   }
   // ---- backward, last layer first ----
-  const DevBuf* ybuf[4] = {&pl->y1, &pl->y2, &pl->y3, &pl->y4};
+  const void* ybuf[4] = {src->slot(src->y1, sstep), src->slot(src->y2, sstep), src->slot(src->y3, sstep), src->slot(src->y4, sstep)};
+  const void* sa_buf = src->slot(src->sa, sstep);
+  const void* sf_buf = src->slot(src->sf, sstep);
   const bool swin = h->variant == DD_VARIANT_SWIN;     // fused modes only (checked by the callers)
   // the conv's input activation; Swin: pred.0 reads the raw convB output sf (and convB reads sa, convA reads bF = u)
   const void* inbuf[4] = {naive ? (const void*)x_nhwc : pl->bX.p, naive ? pl->a1.p : pl->bA1.p,
-                          naive ? pl->f.p : (swin ? pl->sf.p : pl->bF.p), naive ? pl->a3.p : pl->bA3.p};
+                          naive ? pl->f.p : (swin ? sf_buf : pl->bF.p), naive ? pl->a3.p : pl->bA3.p};
   hipError_t e = hipSuccess;
   for (int l = 3; l >= 0; --l) {
     const int C = kCouts[l], CI = kCins[l];
     // conv4's output y4 and the incoming grad_eps are fp32 NHWC in every mode; everything else is in the plan's element kind
     const int ek_y = (naive || l == 3) ? EK_F32 : ek, ek_g = naive ? EK_F32 : ek;
-    const ActView yv{ybuf[l]->p, ek_y, lay, C, HW}, gav{pl->gA.p, (l == 3) ? (int)EK_F32 : ek_g, lay, C, HW}, gyv{pl->gY.p, ek_g, lay, C, HW};
+    const ActView yv{ybuf[l], ek_y, lay, C, HW}, gav{pl->gA.p, (l == 3) ? (int)EK_F32 : ek_g, lay, C, HW}, gyv{pl->gY.p, ek_g, lay, C, HW};
     const float* gamma = h->L[l].gamma.as<float>();
     const float* beta = h->L[l].beta.as<float>();
     float* dgam = grad_buf(h, std::string(kGnNames[l]) + ".weight", C, s, &e); DD_HIP(e);
@@ -1542,16 +1594,16 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
     const bool vec = !naive && ek != EK_F32 && l < 3;
     if (vec) {
       DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 4 * sizeof(double), s));
-      DD_HIP(launch_gn_bwd_reduce_blocked(pl->gA.p, ybuf[l]->p, ek, yk, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, C, HW, s));
-      DD_HIP(launch_gn_bwd_apply_blocked(pl->gA.p, ybuf[l]->p, ek, yk, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), pl->gY.p, nullptr,
+      DD_HIP(launch_gn_bwd_reduce_blocked(pl->gA.p, ybuf[l], ek, yk, st(l), gamma, beta, pl->dgb.as<double>(), B, C, HW, s));
+      DD_HIP(launch_gn_bwd_apply_blocked(pl->gA.p, ybuf[l], ek, yk, st(l), gamma, beta, pl->dgb.as<double>(), pl->gY.p, nullptr,
                                          nullptr, nullptr, nullptr, 0, 0, B, C, HW, s));
       float* demb = nullptr;
       if (l == 1) { demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e); }
-      DD_HIP(launch_gn_param_grad4(pl->dgb.as<double>(), pl->stat_ptr(0, l), gamma, dgam, dbet, dbias, demb, tv, t_base, t_bstride, B, C, HW, s));
+      DD_HIP(launch_gn_param_grad4(pl->dgb.as<double>(), st(l), gamma, dgam, dbet, dbias, demb, tv, t_base, t_bstride, B, C, HW, s));
     } else {
       DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
-      DD_HIP(launch_gn_bwd_reduce(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), B, s));
-      DD_HIP(launch_gn_bwd_apply(gav, yv, pl->stat_ptr(0, l), gamma, beta, pl->dgb.as<double>(), gyv, nothing, nothing, nullptr, nullptr, 0, 0, B, s));
+      DD_HIP(launch_gn_bwd_reduce(gav, yv, st(l), gamma, beta, pl->dgb.as<double>(), B, s));
+      DD_HIP(launch_gn_bwd_apply(gav, yv, st(l), gamma, beta, pl->dgb.as<double>(), gyv, nothing, nothing, nullptr, nullptr, 0, 0, B, s));
       DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
       DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
     }
@@ -1581,7 +1633,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       // no norm / activation in between.  gA = dLoss/dsf on entry, dLoss/du on exit (gY is the scratch in between).
       const char* fuse[2] = {"model.upsample_fuse.convB.conv", "model.upsample_fuse.convA.conv"};
       ConvLayer* FL[2] = {&h->LB, &h->LA};
-      const void* fin[2] = {pl->sa.p, pl->bF.p};           // convB's input, convA's input
+      const void* fin[2] = {sa_buf, pl->bF.p};           // convB's input, convA's input
       void* gbuf[3] = {pl->gA.p, pl->gY.p, pl->gA.p};      // gradient w.r.t. sf -> sa -> u
       for (int i = 0; i < 2; ++i) {
         const ActView gout{gbuf[i], ek, 1, COND_C, HW}, fv{fin[i], ek, 1, COND_C, HW};
@@ -1676,36 +1728,48 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   if (rc) return rc;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
-  if (pl->xstash.bytes < (size_t)(T + 1) * n16 * 4) DD_HIP(pl->xstash.alloc((size_t)(T + 1) * n16 * 4));
-  float* X = pl->xstash.as<float>();                 // X[k] = state entering step k (k < T); X[T] = running dLoss/dx
-  float* G = X + (size_t)T * n16;
+  // The states entering each step: kept by the forward call (option "keep_trajectory" + the ticket passed through "use_trajectory": same
+  // shape, same parameters, nothing run on that plan since), else regenerated here by running the forward loop again.
+  const Plan* kept = nullptr;
+  for (int lvl = 2; lvl >= 1 && !kept && h->use_traj != 0 && !naive; --lvl) {
+    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), lvl});
+    if (it != h->plans.end() && it->second->traj_ticket == h->use_traj && it->second->traj_weights == h->weights_serial) kept = it->second.get();
+  }
+  const Plan* kept_act = (kept && kept->key.keep == 2 && kept->ek == pl->ek) ? kept : nullptr;      // activations too: no recompute
+  h->use_traj = 0;
+  const size_t need = (size_t)(kept ? 1 : T + 1) * n16 * 4;
+  if (pl->xstash.bytes < need) DD_HIP(pl->xstash.alloc(need));
+  float* Xown = pl->xstash.as<float>();
+  const float* X = kept ? kept->xstash.as<float>() : Xown;      // X[k] = state entering step k (k < T)
+  float* G = kept ? Xown : Xown + (size_t)T * n16;              // running dLoss/dx
   const long long* ts = pl->tsteps.as<long long>();
-  // ---- forward loop again, keeping every intermediate state (16 channels: T x 6.8 MB per KITTI image) ----
-  DD_HIP(launch_nchw_to_nhwc(x_T, X, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
   if (rc) return rc;
-  DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
-  for (int k = 0; k + 1 < T; ++k) {                  // the last step's epsilon is recomputed by its backward pass
+  if (kept) h->n_traj_reuse++;
+  // ---- forward loop again, keeping every intermediate state (16 channels: T x 6.8 MB per KITTI image) ----
+  if (!kept) DD_HIP(launch_nchw_to_nhwc(x_T, Xown, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
+  if (!kept) DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
+  for (int k = 0; !kept && k + 1 < T; ++k) {         // the last step's epsilon is recomputed by its backward pass
     if (naive) {
-      rc = enqueue_naive_eps(h, pl, k, X + (size_t)k * n16, ts, k, 0, s);
+      rc = enqueue_naive_eps(h, pl, k, Xown + (size_t)k * n16, ts, k, 0, s);
       if (rc) return rc;
-      DD_HIP(launch_naive_axpby(X + (size_t)k * n16, pl->eps.as<float>(), pl->c1c2.as<float>(), k, X + (size_t)(k + 1) * n16, (long long)n16, s));
+      DD_HIP(launch_naive_axpby(Xown + (size_t)k * n16, pl->eps.as<float>(), pl->c1c2.as<float>(), k, Xown + (size_t)(k + 1) * n16, (long long)n16, s));
     } else {
       // conv1 of step k applies the update of step k-1 (reads X[k-1], y4 of step k-1) and writes X[k]
-      rc = enqueue_fused_step(h, pl, k, (k == 0) ? X : X + (size_t)(k - 1) * n16, X + (size_t)k * n16, k > 0, ts, k, 0, s);
+      rc = enqueue_fused_step(h, pl, k, (k == 0) ? Xown : Xown + (size_t)(k - 1) * n16, Xown + (size_t)k * n16, k > 0, ts, k, 0, s);
       if (rc) return rc;
     }
   }
-  if (!naive && T > 1) {
+  if (!kept && !naive && T > 1) {
     // X[T-1] = update of step T-2 applied to X[T-2]: the fused path does that inside the NEXT step's conv1
-    rc = enqueue_fused_step(h, pl, T - 1, X + (size_t)(T - 2) * n16, X + (size_t)(T - 1) * n16, true, ts, T - 1, 0, s);
+    rc = enqueue_fused_step(h, pl, T - 1, Xown + (size_t)(T - 2) * n16, Xown + (size_t)(T - 1) * n16, true, ts, T - 1, 0, s);
     if (rc) return rc;
   }
   // ---- backward through the chain x_{k+1} = c1_k x_k + c2_k eps(x_k, t_k, cond) ----
   DD_HIP(launch_nchw_to_nhwc(grad_x0, G, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   for (int k = T - 1; k >= 0; --k) {
     DD_HIP(launch_bwd_chain(G, pl->gA.as<float>(), pl->c1c2.as<float>(), k, 0, (long long)n16, s));          // gA = c2_k G
-    rc = bwd_core(h, pl, X + (size_t)k * n16, ts, k, 0, grad_cond, k < T - 1 ? 1 : 0, s);
+    rc = bwd_core(h, pl, X + (size_t)k * n16, ts, k, 0, grad_cond, k < T - 1 ? 1 : 0, s, kept_act, k);
     if (rc) return rc;
     DD_HIP(launch_bwd_chain(G, pl->gA.as<float>(), pl->c1c2.as<float>(), k, 1, (long long)n16, s));          // G = c1_k G + gA
   }

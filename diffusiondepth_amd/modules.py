@@ -205,7 +205,9 @@ class _DenoiseLoopFn(torch.autograd.Function):
     def forward(ctx, be, precision, T, x_T, cond, *params):
         ctx.be, ctx.precision, ctx.T = be, precision, T
         ctx.save_for_backward(x_T, cond)
-        return be.denoise(x_T, cond, T, precision)
+        out = be.denoise(x_T, cond, T, precision, keep_trajectory=True)     # the backward reads the states of this very pass
+        ctx.ticket = be.last_trajectory_ticket
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -213,7 +215,8 @@ class _DenoiseLoopFn(torch.autograd.Function):
         be = ctx.be
         be.zero_grad()
         gx, gc = be.denoise_backward(x_T, cond, g.contiguous().float(), ctx.T, ctx.precision,
-                                     need_grad_xT=ctx.needs_input_grad[3], need_grad_cond=ctx.needs_input_grad[4])
+                                     need_grad_xT=ctx.needs_input_grad[3], need_grad_cond=ctx.needs_input_grad[4],
+                                     trajectory_ticket=ctx.ticket)
         grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_param_order(be.variant))]
         return (None, None, None, gx, gc, *grads)
 

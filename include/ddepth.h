@@ -175,7 +175,13 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
  * ...res.py:124-169).  Given grad_x0 = dLoss/dx_0 (B,16,h,w) it re-runs the forward loop keeping the T
  * intermediate states (16 channels each), then walks the chain x_{k+1} = c1_k x_k + c2_k eps(x_k, t_k, cond) backwards,
  * recomputing each step's activations instead of stashing them:
- *   grad_xT (B,16,h,w) or NULL;  grad_cond (B,256,h,w) = sum over the T steps, or NULL;  parameter gradients accumulate. */
+ *   grad_xT (B,16,h,w) or NULL;  grad_cond (B,256,h,w) = sum over the T steps, or NULL;  parameter gradients accumulate.
+ * The second forward loop is skipped when the forward call already kept the states: run the training forward as
+ *   dd_set_option(h, "keep_trajectory", 1); dd_denoise(...); dd_get_counter(h, "trajectory_ticket", &ticket);
+ * and the backward as  dd_set_option(h, "use_trajectory", ticket); dd_denoise_backward(...)  with the same x_T / cond / shape / T /
+ * precision.  The ticket is honoured only if those states are still the last thing that plan computed and no parameter was set since;
+ * otherwise (and always with ticket 0 or the naive precision) the states are regenerated -- same results either way, up to the 16-bit
+ * modes' hoisted condition term (the forward's own states are then the ones differentiated).  T x 16 fp32 channels per pixel are kept. */
 int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
                         int B, int lat_h, int lat_w, int cond_h, int cond_w, int num_inference_steps, int precision, void* stream);
 int dd_zero_grad(dd_handle_t h, void* stream);
@@ -202,10 +208,11 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * after every launch), "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
  * condition map is re-added in conv3's prologue every step), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
- * instead of the MFMA kernel, A/B check). */
+ * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
-/* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches". */
+/* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches", "trajectory_ticket" (ticket of the
+ * last dd_denoise call that kept its states), "trajectory_reuses" (dd_denoise_backward calls that read kept states). */
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`

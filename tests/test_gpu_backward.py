@@ -179,6 +179,38 @@ def test_loop_backward_matches_reference_autograd_golden(U, golden, cases, prec)
             assert _rel(fused[n], be.grad(n).cpu().numpy()) < 1e-4, n
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_loop_backward_on_the_states_the_forward_kept(U, cases, prec):
+    """Training path of modules._DenoiseLoopFn: dd_denoise(keep_trajectory) + dd_denoise_backward(use_trajectory = its ticket) skips the
+    second forward loop.  fp32: same numbers as the regenerating path (same kernels, same states).  bf16 mode: the kept states are the ones
+    of the timed forward (conv3's condition term hoisted), the regenerated ones come from the un-hoisted kernels -- they differ by 16-bit
+    rounding, the gradients accordingly (relative L2, recorded)."""
+    c = cases["loop_bwd_res"]
+    be = U.backend_for(c)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+    ge = U.cu(np.random.RandomState(c["gseed"]).standard_normal(inp["x_T"].shape).astype(np.float32))
+    names = list(be.PARAM_SHAPES)
+
+    def run(keep):
+        x0 = be.denoise(x, cond, c["T"], prec, keep_trajectory=keep)
+        tk = be.last_trajectory_ticket
+        assert (tk > 0) == keep
+        be.zero_grad()
+        n0 = be.counter("trajectory_reuses")
+        gx, gc = be.denoise_backward(x, cond, ge, c["T"], prec, need_grad_xT=True, trajectory_ticket=tk)
+        assert be.counter("trajectory_reuses") == n0 + (1 if keep else 0)
+        return [x0.cpu().numpy(), gx.cpu().numpy(), gc.cpu().numpy()] + [be.grad(n).cpu().numpy() for n in names]
+
+    regen, kept = run(False), run(True)
+    assert np.array_equal(regen[0], kept[0])                  # the forward result does not depend on where the states are written
+    errs = {k: _rel(a, b, prec) for k, a, b in zip(["x0", "grad_xT", "grad_cond"] + names, kept, regen)}
+    U.record("loop_bwd_kept_vs_regenerated", prec=prec, **{k.replace("model.", ""): v for k, v in errs.items()})
+    tol = 5e-3 if prec == "fp32" else 1e-1        # fp32: statistics atomics order -> 1e-7 on a state -> at worst one ReLU mask bit (see the golden test above)
+    bad = {k: v for k, v in errs.items() if v > tol}
+    assert not bad, bad
+
+
 def test_loop_backward_t1_equals_single_call(U, cases):
     """T = 1: x_0 = c1 x_T + c2 eps(x_T, t = 0)  ->  the loop backward is one denoiser VJP scaled by c2 plus c1 * g."""
     import diffusiondepth_amd as dda
@@ -345,11 +377,19 @@ def test_swin_loop_backward_matches_torch_port_autograd(U, cases):
     inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"], tuple(c["cond_hw"]))
     ge = np.random.RandomState(6).standard_normal(inp["x_T"].shape).astype(np.float32)
     x0, rgx, rgc, rgrads = P.ddim_loop_vjp(sd, inp["x_T"], inp["cond"], ge, T=2, variant="swin")
-    be.zero_grad()
-    gx, gc = be.denoise_backward(U.cu(inp["x_T"]), U.cu(inp["cond"]), U.cu(ge), 2, "fp32", need_grad_xT=True)
-    errs = {"grad_xT": _rel(gx.cpu().numpy(), rgx.numpy()), "grad_cond": _rel(gc.cpu().numpy(), rgc.numpy())}
-    for name, ref in rgrads.items():
-        errs[name] = _rel(be.grad(name).cpu().numpy(), ref.numpy())
-    U.record("loop_bwd_swin", **{k.replace("model.", ""): v for k, v in errs.items()})
-    bad = {k: v for k, v in errs.items() if v > 5e-3}       # ReLU-tie sensitivity over chained steps, see the Res loop test
-    assert not bad, bad
+    for keep in (False, True):       # True: the training path -- states and activations (incl. the convA / convB results) kept by the forward
+        tk = 0
+        if keep:
+            be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), 2, "fp32", keep_trajectory=True)
+            tk = be.last_trajectory_ticket
+            assert tk > 0
+        be.zero_grad()
+        n0 = be.counter("trajectory_reuses")
+        gx, gc = be.denoise_backward(U.cu(inp["x_T"]), U.cu(inp["cond"]), U.cu(ge), 2, "fp32", need_grad_xT=True, trajectory_ticket=tk)
+        assert be.counter("trajectory_reuses") == n0 + int(keep)
+        errs = {"grad_xT": _rel(gx.cpu().numpy(), rgx.numpy()), "grad_cond": _rel(gc.cpu().numpy(), rgc.numpy())}
+        for name, ref in rgrads.items():
+            errs[name] = _rel(be.grad(name).cpu().numpy(), ref.numpy())
+        U.record("loop_bwd_swin", kept=keep, **{k.replace("model.", ""): v for k, v in errs.items()})
+        bad = {k: v for k, v in errs.items() if v > 5e-3}       # ReLU-tie sensitivity over chained steps, see the Res loop test
+        assert not bad, (keep, bad)

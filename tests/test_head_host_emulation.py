@@ -308,3 +308,52 @@ def test_the_host_never_blocks_in_steady_state(on_host, lib, monkeypatch):
         per_route[route] = (c1 - c0, c2 - c1)                                   # second iteration = steady state
     assert per_route["1"] == (2, 0), per_route
     assert per_route["0"][1] == 0 and per_route["0"][0] > 20, per_route
+
+
+def test_loop_backward_reads_the_states_the_forward_kept(on_host):
+    """Training: dd_denoise with option keep_trajectory leaves the state entering every step behind and hands out a ticket;
+    dd_denoise_backward given that ticket skips its second forward loop (counter trajectory_reuses) -- and, the activations of every step
+    having been kept too (default), every per-step recompute -- and returns what the regenerating path returns.  A ticket whose states were overwritten by a later forward, or that predates a parameter update, is refused (regenerated)."""
+    be = on_host(CPU)
+    sd = synth.make_state_dict(7240)
+    be.load_state_dict(sd)
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    T, prec = 3, "fp32"
+    inp, inp2 = synth.make_inputs(5, 1, 8, 40), synth.make_inputs(6, 1, 8, 40)
+    x, cond, x2 = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"]), torch.from_numpy(inp2["x_T"])
+    g = torch.from_numpy(np.random.RandomState(3).standard_normal(inp["x_T"].shape).astype(np.float32))
+    names = ["model.pred.3.weight", "model.noise_embedding.0.weight", "model.pred.1.bias", "model.time_embedding.weight"]
+
+    def backward(ticket):
+        be.zero_grad()
+        gx, gc = be.denoise_backward(x, cond, g, T, prec, need_grad_xT=True, trajectory_ticket=ticket)
+        return [gx, gc] + [be.grad(n) for n in names]
+
+    def same(a, b):
+        return all(float((p - q).abs().max()) <= 1e-6 * float(q.abs().max()) for p, q in zip(a, b))    # fp64 atomics: summation order
+
+    x0 = be.denoise(x, cond, T, prec)
+    assert be.last_trajectory_ticket == 0
+    want = backward(0)
+    assert be.counter("trajectory_reuses") == 0
+    x0k = be.denoise(x, cond, T, prec, keep_trajectory=True)
+    tk = be.last_trajectory_ticket
+    assert tk > 0 and torch.equal(x0k, x0)
+    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 1
+    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 2          # retain_graph-style second backward
+    be.denoise(x2, cond, T, prec, keep_trajectory=True)                                # the plan's states are now another call's
+    assert be.last_trajectory_ticket == tk + 1
+    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 2
+    # the same with the states only (activation budget 0: every step's forward is recomputed from its kept state)
+    be.set_option("keep_activations_mb", 0)
+    plans = be.counter("plans")
+    assert torch.equal(be.denoise(x, cond, T, prec, keep_trajectory=True), x0) and be.counter("plans") == plans + 1
+    assert same(backward(be.last_trajectory_ticket), want) and be.counter("trajectory_reuses") == 3
+    be.set_option("keep_activations_mb", 65536)
+    be.denoise(x, cond, T, prec, keep_trajectory=True)
+    tk3 = be.last_trajectory_ticket
+    bumped = {"model.pred.4.weight": sd["model.pred.4.weight"] * 1.5}                   # the last GroupNorm's gamma
+    be.load_state_dict(bumped)                                                          # parameters changed after the forward
+    got = backward(tk3)
+    assert be.counter("trajectory_reuses") == 3
+    assert not same(got, want)                                                          # ... and the gradient is the new parameters' one

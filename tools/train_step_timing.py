@@ -51,7 +51,7 @@ def timeit(fn, n=3):
 
 flops = 626688.0 * B * h * w * T
 t_hip = timeit(hip_step)
-print(f"B={B} T={T} {prec}: HIP loop forward+backward {t_hip:.1f} ms ({4 * flops / t_hip / 1e9:.0f} TFLOP/s counting fwd + recompute + dgrad + wgrad)")
+print(f"B={B} T={T} {prec}: HIP loop forward+backward {t_hip:.1f} ms ({3 * flops / t_hip / 1e9:.0f} TFLOP/s counting fwd + dgrad + wgrad; nothing is recomputed)")
 try:
     t_t32 = timeit(lambda: torch_step(False), 2)
     t_t16 = timeit(lambda: torch_step(True), 2)
