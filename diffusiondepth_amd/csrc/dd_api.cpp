@@ -120,6 +120,7 @@ struct Plan {
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
+  std::vector<long long> tsteps_host;   // the same on the host
   size_t stats_bytes = 0;
   hipGraphExec_t exec = nullptr;
   bool capture_failed = false;
@@ -448,6 +449,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   }
   DD_HIP(pl->c1c2.alloc(c1c2.size() * 4));
   DD_HIP(pl->tsteps.alloc(ts.size() * 8));
+  pl->tsteps_host = ts;
   DD_HIP(hipMemcpy(pl->c1c2.p, c1c2.data(), c1c2.size() * 4, hipMemcpyHostToDevice));
   DD_HIP(hipMemcpy(pl->tsteps.p, ts.data(), ts.size() * 8, hipMemcpyHostToDevice));
   pl->last_use = ++h->tick;
@@ -466,6 +468,9 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + 7) / 8;
   p.ablate = h->ablate;
+  // the loop's timesteps are the plan's own schedule: pass the value, not the address (clamped as clamp_t does on the device)
+  if (tvec == pl->tsteps.as<long long>() && t_bstride == 0 && t_base >= 0 && t_base < (int)pl->tsteps_host.size())
+    p.t_known = clamp_t(pl->tsteps_host[t_base]);
   const int ek = pl->ek, ok = opnd_kind(ek), tk = thin_kind(ek);    // mode; operand kind of the large convolutions; kind of conv1 / conv4
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](ConvParams q) {

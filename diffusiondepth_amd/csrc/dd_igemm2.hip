@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   float* s_tab = reinterpret_cast<float*>(smem + C::NPB * C::PATCH_BYTES + C::NWB * C::W_BYTES);
   float* tab_a = s_tab;
   float* tab_b = s_tab + C::CTAB;
-  float* tab_e = s_tab + 2 * C::CTAB;
-  float* tab_bias = s_tab + 3 * C::CTAB;
+  float* tab_e = s_tab + 2 * C::CTAB;                 // PRO_GN_ADD only (NTABS == 3)
+  float* tab_bias = s_tab + C::NTABS * C::CTAB;
   float* tab_et = tab_bias + C::NT * C::SPW;  // [10][64] (ADD_C only)
   double* s_red = reinterpret_cast<double*>(tab_et + (C::ADD_C ? 10 * HID_C : 0));   // [WAVES][8] statistics scratch (16-B aligned: every term is)
 
@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   constexpr int NET = C::ADD_C ? (10 * HID_C + C::THREADS - 1) / C::THREADS : 1;
   float et_r[NET];
   if constexpr (C::ADD_C) {
-    const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
+    const long long t = (DD_T_KNOWN && p.t_known >= 0) ? p.t_known : clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
 #pragma unroll
     for (int k = 0; k < NET; ++k) {
       const int i = k * C::THREADS + tid;
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       my_gamma = p.gn_gamma[tid];
       my_beta = p.gn_beta[tid];
       if constexpr (C::PRO == PRO_GN_ADD) {
-        const long long t = clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
+        const long long t = (DD_T_KNOWN && p.t_known >= 0) ? p.t_known : clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
         my_emb = p.emb[(size_t)t * COND_C + tid];
       }
     }

@@ -26,8 +26,15 @@
 // conv2 (64 -> 256, two 128-cout splits): 1 = ONE workgroup per tile walks both cout splits over the same staged input patch (one
 // prologue -- partial sums, table, patch fetch, normalisation -- per tile instead of two; the second split's weight stream follows
 // the first's without a gap); 0 = one workgroup per (tile, split)
+#ifndef DD_C3_2_RD1
+#define DD_C3_2_RD1 1      // 16x32 conv3 tiles: raw patch one chunk ahead only (registers: two workgroups per CU need <= 128 VGPRs beside the accumulators)
+#endif
 #ifndef DD_CONV2_DUAL
 #define DD_CONV2_DUAL 1
+#endif
+// 1 = kernels take the timestep from ConvParams::t_known when the host knew it (0: always through the tvec load; A/B switch)
+#ifndef DD_T_KNOWN
+#define DD_T_KNOWN 1
 #endif
 // per-workgroup phase timestamps (ConvParams::prof); compiled in by tools/phase_prof.py only
 #ifndef DD_PHASE_PROF
@@ -122,7 +129,8 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
   static constexpr int CTAB = (PRO == PRO_RAW) ? 0 : (LAYER == 1) ? LATENT_C : CIN;   // channels of the prologue GroupNorm table
   static constexpr int SCR_FLOATS = 2 * 8 * 8;                               // cross-wave scratch of the statistics epilogue: 8 doubles per wave
-  static constexpr int TAB_FLOATS = 3 * CTAB + NT * SPW + (ADD_C ? 10 * HID_C : 0) + SCR_FLOATS;   // a, b, e of the prologue GroupNorm, bias, E[t] tap sums, scratch
+  static constexpr int NTABS = (PRO == PRO_GN_ADD) ? 3 : 2;                   // a, b (and the embedding row e) of the prologue GroupNorm
+  static constexpr int TAB_FLOATS = NTABS * CTAB + NT * SPW + (ADD_C ? 10 * HID_C : 0) + SCR_FLOATS;   // GroupNorm table, bias, E[t] tap sums, scratch
   static constexpr int SMEM_BYTES = NPB * PATCH_BYTES + NWB * W_BYTES + TAB_FLOATS * 4;
   static constexpr int ITEMS = PH * PW * PPP;
   static constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;      // staging items per thread
@@ -132,11 +140,11 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
   // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
   // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
-  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22)) ? 2 : 1;
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
   static constexpr int FRAG_DEPTH = (LAYER == 5) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
-  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);
+  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS
   static_assert(CIN % CK == 0 && NTAPS % TG == 0 && COUT_PAD % NT == 0, "tiling");
   static_assert(PATCH_BYTES % 16 == 0 && W_BYTES % 1024 == 0, "LDS carve / DMA granularity");
   static_assert(WAVES <= 8 && (COUT_PAD / NT) % SPW == 0 && (SPW == 1 || NCHUNK == 1), "scratch size; splits per workgroup");

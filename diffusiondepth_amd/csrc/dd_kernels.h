@@ -59,6 +59,8 @@ struct ConvParams {
   const float* emb;         // PRO_GN_ADD: time-embedding table [1280][256] fp32
   const long long* tvec;    // PRO_GN_ADD: timestep(s); t = tvec[t_base + b * t_bstride]
   int t_base, t_bstride;
+  long long t_known = -1;   // >= 0: the timestep of every image, known on the host when the launch was recorded (the DDIM loop: the schedule's
+                            // steps are fixed per plan) -- spares the kernel the load in front of its embedding / E[t] table addresses; -1: read tvec
   const float* y4;          // PRO_X: raw conv4 output of the previous step, fp32 NHWC [B][h][w][16]
   float* xout;              // PRO_X: updated state written here (interior pixels of each tile)
   const float* c1c2;        // PRO_X: [T][2] DDIM coefficients; entry (step-1) is applied when step > 0
