@@ -194,6 +194,7 @@ struct dd_handle_s {
   // loop a second time -- if that ticket is still the plan's and the parameters have not changed since, else it regenerates as before.
   bool keep_traj = false;
   int64_t keep_act_mb = 65536;
+  bool adjoint_tiled = true;  // Swin backward: tiled separable kernel for the adjoint of the condition upsampling (0 = the one-thread-per-piece kernel, A/B check)
   int64_t traj_serial = 0, use_traj = 0, weights_serial = 0, n_traj_reuse = 0;
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
@@ -1112,6 +1113,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
   else if (k == "keep_trajectory") h->keep_traj = value != 0;
   else if (k == "use_trajectory") h->use_traj = value;
+  else if (k == "adjoint_tiled") h->adjoint_tiled = value != 0;
   else if (k == "keep_activations_mb") h->keep_act_mb = value < 0 ? 0 : value;
   else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
   else if (k == "phase_prof_layer") h->prof_layer = (int)value;
@@ -1666,7 +1668,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       // (Swin: gA = dLoss/du and cond enters through the bilinear upsample, whose adjoint maps the gradient back to (ch, cw))
       const ActView gf{pl->gA.p, ek_g, lay, COND_C, HW};
       if (grad_cond && swin) {
-        DD_HIP(launch_upsample_adjoint(pl->gA.p, ek, grad_cond, B, COND_C, pl->key.ch, pl->key.cw, lat_h, lat_w, accumulate_cond, s));
+        DD_HIP(launch_upsample_adjoint(pl->gA.p, ek, grad_cond, B, COND_C, pl->key.ch, pl->key.cw, lat_h, lat_w, accumulate_cond, s, h->adjoint_tiled));
       } else if (grad_cond) {
         if (!naive && ek != EK_F32) DD_HIP(launch_blocked_to_nchw(pl->gA.p, ek, grad_cond, B, COND_C, lat_h, lat_w, accumulate_cond, s));
         else DD_HIP(launch_view_to_nchw(gf, grad_cond, B, accumulate_cond, s));

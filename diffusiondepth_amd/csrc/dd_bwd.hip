@@ -11,6 +11,7 @@
 //     g_a_prev = conv3x3(g_y, W^T flipped)                                                         (dgrad: the forward conv kernels)
 // The elementwise / reduction kernels here address activations through ActView, so one source serves the unfused fp32
 // cross-check path (plain NHWC fp32) and the fused path's channel-blocked bf16 / f16 / fp32 tensors.
+#include <cmath>
 #include "dd_elem.h"
 
 namespace dd {
@@ -300,31 +301,45 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
   }
   const size_t base = ((size_t)b * (C / ACT_CB) + cb) * HW * ACT_CB + q * 8;
   const long long p0 = (long long)blockIdx.x * slab, p1 = min(p0 + slab, HW);
-  for (long long p = p0 + pl; p < p1; p += 64) {
-    const size_t off = base + (size_t)p * ACT_CB;
-    float yy[8];
-    unpack8<YK>(*reinterpret_cast<const uint4*>(y + off), yy);
-    if (gy) {
-      float g[8], o[8];
-      unpack8<EK>(*reinterpret_cast<const uint4*>(ga + off), g);
+  // two pixels per trip: every load of both is issued before the first result is needed (the kernel streams 3-4 tensors and is bound by
+  // the bytes in flight: 12 waves per CU x one 16-B load per tensor reached 46 % of the HBM rate)
+  for (long long p = p0 + pl; p < p1; p += 128) {
+    const bool two = p + 64 < p1;
+    const size_t off[2] = {base + (size_t)p * ACT_CB, base + (size_t)(two ? p + 64 : p) * ACT_CB};
+    uint4 ry[2], rg[2], rc[2];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float gz = fmaf(ta[k], yy[k], tb[k]) > 0.f ? g[k] : 0.f;
-        o[k] = fmaf(ta[k], gz, fmaf(qg, yy[k], pg));
-      }
-      *reinterpret_cast<uint4*>(gy + off) = Piece<EK>::pack(o);
+    for (int j = 0; j < 2; ++j) {
+      ry[j] = *reinterpret_cast<const uint4*>(y + off[j]);
+      if (gy) rg[j] = *reinterpret_cast<const uint4*>(ga + off[j]);
+      if (act && cond) rc[j] = *reinterpret_cast<const uint4*>(cond + off[j]);
     }
-    if (act) {
-      float o[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaf(ta[k], yy[k], tb[k]), 0.f);
-      if (cond) {
-        float cv[8];
-        unpack8<YK>(*reinterpret_cast<const uint4*>(cond + off), cv);
+    for (int j = 0; j < 2; ++j) {
+      if (j == 1 && !two) break;
+      float yy[8];
+      unpack8<YK>(ry[j], yy);
+      if (gy) {
+        float g[8], o[8];
+        unpack8<EK>(rg[j], g);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = o[k] + (cv[k] + te[k]);
+        for (int k = 0; k < 8; ++k) {
+          const float gz = fmaf(ta[k], yy[k], tb[k]) > 0.f ? g[k] : 0.f;
+          o[k] = fmaf(ta[k], gz, fmaf(qg, yy[k], pg));
+        }
+        *reinterpret_cast<uint4*>(gy + off[j]) = Piece<EK>::pack(o);
       }
-      *reinterpret_cast<uint4*>(act + off) = Piece<EK>::pack(o);
+      if (act) {
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaf(ta[k], yy[k], tb[k]), 0.f);
+        if (cond) {
+          float cv[8];
+          unpack8<YK>(rc[j], cv);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = o[k] + (cv[k] + te[k]);
+        }
+        *reinterpret_cast<uint4*>(act + off[j]) = Piece<EK>::pack(o);
+      }
     }
   }
 }
@@ -332,7 +347,7 @@ hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, in
                                        const double* sums_bc4, void* gy, void* act, const void* cond, const float* emb,
                                        const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s) {
   if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16))) return hipErrorInvalidValue;
-  const int slab = 512;
+  const int slab = 2048;      // the per-workgroup prologue (group moments, gamma-weighted sums over C/4 channels in fp64) costs as much as 512 pixels of streaming
   dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
   auto U16 = [](const void* p) { return reinterpret_cast<const uint16_t*>(p); };
   if (ek == EK_BF16 && yk == EK_F16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_F16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
@@ -469,6 +484,94 @@ __global__ void __launch_bounds__(256) upsample_adjoint_kernel(const uint16_t* _
     *o = accumulate ? *o + acc[k] : acc[k];
   }
 }
+// Tiled separable form of the same sum for the 16-bit channel-blocked gradient: one workgroup per (image, 32-channel block, source row,
+// segment of ADJ_SXT source columns).  Pass 1 (vertical): thread (destination column, 16-B piece) sums wy * g over the destination rows
+// whose stencil touches source row sy -- consecutive lanes read consecutive 16-B pieces of ONE destination row (whole 64-B channel-block
+// lines; the lanes of upsample_adjoint_kernel sit h*w*64 B apart and every g element is fetched ~4 times in 64-B requests) -- and leaves
+// the fp32 row in LDS.  Pass 2 (horizontal): thread (source column, channel) sums wx * row; 16 consecutive floats per channel go to the
+// NCHW gradient.  The weights are the forward's own fp32 expressions; only the summation order differs from the kernel above.
+constexpr int ADJ_SXT = 64;        // source columns per workgroup
+constexpr int ADJ_MAXOX = 288;     // destination columns a segment may touch (scale factors up to ~4; beyond: the kernel above)
+constexpr int ADJ_MAXR = 20;       // destination rows with a non-zero weight for one source row (2 x scale + 1)
+template <int EK>
+__global__ void __launch_bounds__(256) upsample_adjoint_tiled_kernel(const uint16_t* __restrict__ g, float* __restrict__ dst, int C, int ch, int cw,
+                                                                    int h, int w, int accumulate, int n_seg) {
+  __shared__ float tmp[ADJ_MAXOX * 33];
+  const int tid = threadIdx.x;
+  int r = blockIdx.x;
+  const int seg = r % n_seg; r /= n_seg;
+  const int sy = r % ch; r /= ch;
+  const int ncb = C / ACT_CB;
+  const int cb = r % ncb;
+  const int b = r / ncb;
+  const float fsy = (h > 1) ? (float)(ch - 1) / (float)(h - 1) : 0.f;
+  const float fsx = (w > 1) ? (float)(cw - 1) / (float)(w - 1) : 0.f;
+  const int sx0 = seg * ADJ_SXT, sx1 = min(sx0 + ADJ_SXT, cw) - 1;
+  const int oy_lo = (fsy > 0.f) ? max(0, (int)floorf((float)(sy - 1) / fsy)) : 0;
+  const int oy_hi = (fsy > 0.f) ? min(h - 1, (int)ceilf((float)(sy + 1) / fsy)) : h - 1;
+  const int ox_lo = (fsx > 0.f) ? max(0, (int)floorf((float)(sx0 - 1) / fsx)) : 0;
+  const int ox_hi = (fsx > 0.f) ? min(w - 1, (int)ceilf((float)(sx1 + 1) / fsx)) : w - 1;
+  const int n_ox = ox_hi - ox_lo + 1;                       // <= ADJ_MAXOX (checked by the launcher)
+  const size_t gbase = ((size_t)b * ncb + cb) * (size_t)h * w * ACT_CB;
+  // the rows that contribute (uniform): collected first so that four row loads are in flight per thread
+  __shared__ int s_oy[ADJ_MAXR + 4];
+  __shared__ float s_wy[ADJ_MAXR + 4];
+  __shared__ int s_nr;
+  if (tid == 0) {
+    int nr = 0;
+    for (int oy = oy_lo; oy <= oy_hi && nr < ADJ_MAXR; ++oy) {
+      const float fy = fsy * (float)oy;
+      const int y0 = min((int)fy, ch - 1), y1 = min(y0 + 1, ch - 1);
+      const float ly = fy - (float)y0, hy = 1.f - ly;
+      const float wy = (y0 == sy ? hy : 0.f) + (y1 == sy ? ly : 0.f);
+      if (wy != 0.f) { s_oy[nr] = oy; s_wy[nr] = wy; ++nr; }
+    }
+    for (int k = 0; k < 4; ++k) { s_oy[nr + k] = oy_lo; s_wy[nr + k] = 0.f; }      // padding of the last group of four: a valid row, weight 0
+    s_nr = nr;
+  }
+  __syncthreads();
+  const int nr = s_nr;
+  for (int it = tid; it < n_ox * 4; it += 256) {
+    const int oxl = it >> 2, piece = it & 3;
+    const uint16_t* col = g + gbase + (size_t)(ox_lo + oxl) * ACT_CB + piece * 8;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int r0 = 0; r0 < nr; r0 += 4) {
+      uint4 raw[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) raw[j] = *reinterpret_cast<const uint4*>(col + (size_t)s_oy[r0 + j] * w * ACT_CB);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float f[8];
+        unpack8<EK>(raw[j], f);
+        const float wy = s_wy[r0 + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaf(wy, f[k], acc[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tmp[oxl * 33 + piece * 8 + k] = acc[k];
+  }
+  __syncthreads();
+  for (int it = tid; it < ADJ_SXT * ACT_CB; it += 256) {
+    const int sx = sx0 + it % ADJ_SXT, c = it / ADJ_SXT;
+    if (sx > sx1) continue;
+    const int lo = (fsx > 0.f) ? max(ox_lo, (int)floorf((float)(sx - 1) / fsx)) : ox_lo;
+    const int hi = (fsx > 0.f) ? min(ox_hi, (int)ceilf((float)(sx + 1) / fsx)) : ox_hi;
+    float acc = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) {
+      const float fx = fsx * (float)ox;
+      const int x0 = min((int)fx, cw - 1), x1 = min(x0 + 1, cw - 1);
+      const float lx = fx - (float)x0, hx = 1.f - lx;
+      const float wx = (x0 == sx ? hx : 0.f) + (x1 == sx ? lx : 0.f);
+      if (wx == 0.f) continue;
+      acc = fmaf(wx, tmp[(ox - ox_lo) * 33 + c], acc);
+    }
+    float* o = dst + (((size_t)b * C + cb * ACT_CB + c) * ch + sy) * cw + sx;
+    *o = accumulate ? *o + acc : acc;
+  }
+}
 // generic (any element kind, one thread per output element): the fp32 parity mode
 __global__ void upsample_adjoint_view_kernel(ActView g, float* __restrict__ dst, int ch, int cw, int h, int w, int accumulate, long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -503,13 +606,27 @@ __global__ void upsample_adjoint_view_kernel(ActView g, float* __restrict__ dst,
   dst[i] = accumulate ? dst[i] + acc : acc;
 }
 
-hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int C, int ch, int cw, int h, int w, int accumulate, hipStream_t s) {
+hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int C, int ch, int cw, int h, int w, int accumulate, hipStream_t s, bool tiled) {
   if (C % ACT_CB != 0) return hipErrorInvalidValue;
   if (ek == EK_F32) {
     const long long total = (long long)B * C * ch * cw;
     hipLaunchKernelGGL(upsample_adjoint_view_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
                        ActView{g, EK_F32, 1, C, (long long)h * w}, dst, ch, cw, h, w, accumulate, total);
     return hipGetLastError();
+  }
+  {
+    // tiled kernel when a segment's destination footprint fits its LDS row (every real configuration: scale factors 2 .. 8)
+    const float fsx = (w > 1) ? (float)(cw - 1) / (float)(w - 1) : 0.f;
+    const long long span = (fsx > 0.f) ? (long long)std::ceil((double)((cw < ADJ_SXT ? cw : ADJ_SXT) + 1) / (double)fsx) + 3 : (long long)w;
+    const int n_seg = (cw + ADJ_SXT - 1) / ADJ_SXT;
+    const long long blocks = (long long)B * (C / ACT_CB) * ch * n_seg;
+    const float fsy = (h > 1) ? (float)(ch - 1) / (float)(h - 1) : 0.f;
+    const long long rows = (fsy > 0.f) ? (long long)std::ceil(2.0 / (double)fsy) + 3 : (long long)h;      // >= the rows with a non-zero weight
+    if (tiled && span <= ADJ_MAXOX && rows <= ADJ_MAXR && blocks < (1LL << 31)) {
+      if (ek == EK_BF16) hipLaunchKernelGGL(upsample_adjoint_tiled_kernel<EK_BF16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(g), dst, C, ch, cw, h, w, accumulate, n_seg);
+      else hipLaunchKernelGGL(upsample_adjoint_tiled_kernel<EK_F16>, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const uint16_t*>(g), dst, C, ch, cw, h, w, accumulate, n_seg);
+      return hipGetLastError();
+    }
   }
   const long long total = (long long)B * ch * cw * (C / 8);
   dim3 grid((unsigned)((total + 255) / 256));

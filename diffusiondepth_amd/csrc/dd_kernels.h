@@ -153,7 +153,7 @@ hipError_t launch_gn_param_grad4(const double* sums_bc4, const double* stats, co
                                  float* demb, const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s);
 hipError_t launch_channel_sum_blocked(const void* v, int ek, float* out, int B, int C, long long HW, hipStream_t s);
 // adjoint of the align_corners bilinear upsample: blocked 2-byte (h, w) gradient -> NCHW fp32 (ch, cw) gradient
-hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int C, int ch, int cw, int h, int w, int accumulate, hipStream_t s);
+hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int C, int ch, int cw, int h, int w, int accumulate, hipStream_t s, bool tiled = true);
 hipError_t launch_channel_sum(const ActView& v, float* out, const long long* rows, int t_base, int t_bstride, int B, hipStream_t s);
 hipError_t launch_gn_param_grad(const double* dgb, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
 hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oihw, int B, int h, int w, hipStream_t s);

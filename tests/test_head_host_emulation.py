@@ -357,3 +357,60 @@ def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     got = backward(tk3)
     assert be.counter("trajectory_reuses") == 3
     assert not same(got, want)                                                          # ... and the gradient is the new parameters' one
+
+
+@pytest.mark.parametrize("shape", [((2, 7, 19), (4, 10)), ((1, 9, 33), (3, 5)), ((1, 6, 40), (6, 40)), ((1, 4, 141), (2, 70))],
+                         ids=["x2", "x4-ragged", "same-size", "two-segments"])
+def test_swin_condition_gradient_tiled_adjoint_equals_the_plain_one(on_host, shape):
+    """Swin variant, 16-bit backward: dLoss/dcond passes through the adjoint of the align_corners bilinear upsampling.  The tiled separable
+    kernel (dd_bwd.hip: upsample_adjoint_tiled_kernel) must return what the one-thread-per-piece kernel returns (same fp32 weights, other
+    summation order), at the condition map's own size, over several source-column segments and with accumulation over two loop steps."""
+    (B, h, w), (ch, cw) = shape
+    be = on_host(CPU, "swin")
+    be.load_state_dict(synth.make_state_dict(7301, "swin"))
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    inp = synth.make_inputs(11, B, h, w, (ch, cw))
+    x, cond = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"])
+    g = torch.from_numpy(np.random.RandomState(5).standard_normal(inp["x_T"].shape).astype(np.float32))
+    out = {}
+    for tiled in (0, 1):
+        be.set_option("adjoint_tiled", tiled)
+        be.zero_grad()
+        _, gc1 = be.denoise_once_backward(x, torch.full((B,), 300), cond, g, "bf16")
+        _, gc2 = be.denoise_backward(x, cond, g, 2, "bf16")                    # two steps: the second one accumulates
+        out[tiled] = (gc1, gc2)
+    for a, b in zip(out[1], out[0]):
+        assert a.shape == (B, 256, ch, cw) and float(b.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("variant,hw,cond_hw", [("res", (9, 21), None), ("swin", (7, 19), (4, 10))])
+def test_16bit_backward_close_to_the_fp32_backward(on_host, variant, hw, cond_hw):
+    """The vectorised GroupNorm-backward kernels of the 16-bit modes (gn_bwd_reduce_blocked / gn_bwd_apply_blocked: two pixels per trip,
+    ragged last pair, slabs) against the generic fp32 path of the same library on a pixel count that is no multiple of anything.  The
+    distance is dominated by ReLU-mask flips, not by rounding (a pre-activation within 16-bit distance of zero changes its whole gradient
+    contribution; measured on these inputs: relative L2 0.05-0.08 in f16, 0.07-0.10 in bf16, identical to four digits before and after the
+    kernels were vectorised further), so the gate only catches structural errors -- a wrong pixel, a dropped pair -- which show up as O(1)."""
+    be = on_host(CPU, variant)
+    be.load_state_dict(synth.make_state_dict(7240, variant))
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    B, (h, w) = 2, hw
+    inp = synth.make_inputs(17, B, h, w, cond_hw) if cond_hw else synth.make_inputs(17, B, h, w)
+    x, cond = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"])
+    g = torch.from_numpy(np.random.RandomState(9).standard_normal(inp["x_T"].shape).astype(np.float32))
+    t = torch.tensor([120, 700])
+    names = list(be.param_shapes())
+    res = {}
+    for prec in ("fp32", "bf16", "f16"):
+        be.zero_grad()
+        gx, gc = be.denoise_once_backward(x, t, cond, g, prec)
+        res[prec] = [gx, gc] + [be.grad(n) for n in names]
+    for prec, tol in (("bf16", 0.15), ("f16", 0.12)):
+        bad = {}
+        for k, a, b in zip(["grad_x", "grad_cond"] + names, res[prec], res["fp32"]):
+            if k == "model.time_embedding.weight":
+                a, b = a[t], b[t]
+            e = float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+            if e > tol:
+                bad[k] = e
+        assert not bad, (prec, bad)
