@@ -215,6 +215,11 @@ def train_dp(args, dev, dist, world, rank):
     sd.update(synth.make_fpn_state_dict(7241, in_channels=chans))
     head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
     head = head.to(dev).train()
+    sync_bn = dist is not None and not args.no_sync_bn
+    if sync_bn:
+        # every BatchNorm (FPN, latent codec) normalises with the statistics of the global batch, as under the reference's
+        # apex.parallel.convert_syncbn_model (src/main.py:128): two small all-reduces per layer, forward and backward
+        head = ddist.convert_sync_batchnorm(head)
     params = [p for p in head.parameters() if p.requires_grad]
     if dist is not None:
         ddist.broadcast_state_dict({k: v for k, v in head.state_dict().items()})      # rank 0's parameters everywhere (apex DDP at wrap time)
@@ -275,7 +280,8 @@ def train_dp(args, dev, dist, world, rank):
             "config": {"workload": f"{cls.__name__}.forward(.train()) + loss.backward() + gradient all-reduce + SGD step on synthetic backbone features "
                                    f"{chans} (the backbone itself stays PyTorch and is not part of this path), latent 16x{h}x{w}, T={T}",
                        "maps_per_gpu_per_step": B, "global_batch": B * n_world, "parallelism": f"dp{n_world} (RCCL all-reduce of {nbytes / 1e6:.1f} MB of head gradients per step, "
-                                                                                              f"{len(reducer.buckets)} bucket(s), overlapped with backward)",
+                                                                                              f"{len(reducer.buckets)} bucket(s), overlapped with backward"
+                                                                                              + ("; SyncBatchNorm over the global batch in the FPN / codec" if sync_bn else "") + ")",
                        "variant": args.variant},
             "allreduce_exposed_ms": round(sorted(exposed)[len(exposed) // 2], 3), "collectives_launched_in_backward": reducer.launched_in_backward,
             # executed convolution work of the loop per step: forward + data gradients + weight gradients (the forward keeps the states and
@@ -306,6 +312,7 @@ def main():
                     help="conv3(cond)+conv3(E[t]) out of the loop: -1 = the library default (on in the bf16 mode), 0 / 1 = forced (A/B switch)")
     ap.add_argument("--bf16-storage", action="store_true", help="A/B: all-bf16 tensors in --precision bf16 (default: f16 storage / thin layers)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train-dp"])
+    ap.add_argument("--no-sync-bn", action="store_true", help="train-dp with N > 1: keep per-rank BatchNorm statistics (default: synchronised, as the reference)")
     ap.add_argument("--dist-selftest", action="store_true", help="multi-rank plumbing only, no hot path (any backend)")
     ap.add_argument("--no-parity-gate", action="store_true", help="do not fail when the timed precision misses the depth-RMSE tolerance")
     ap.add_argument("--variant", default="res", choices=["res", "swin"],

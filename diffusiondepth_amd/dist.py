@@ -288,3 +288,103 @@ class OverlappedGradReducer:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Synchronised BatchNorm for data-parallel training.  The reference converts EVERY BatchNorm of the network before wrapping it in
+# apex DDP (`net = apex.parallel.convert_syncbn_model(net)`, reference src/main.py:128): in .train() the FPN, the latent codec and the
+# backbone normalise with the statistics of the GLOBAL batch (all ranks), forward and backward.  These modules stay PyTorch modules in
+# .train() mode here, so the exchange is two small all-reduces per layer on whatever backend the process group
+# has (RCCL on the GPUs; gloo in the CPU tests, which torch.nn.SyncBatchNorm refuses).
+# ------------------------------------------------------------------------------------------------------------------------------
+class _SyncBatchNormFn(torch.autograd.Function):
+    """y = (x - mean_G) * invstd_G * w + b with mean / biased variance over the batch and spatial dims of ALL ranks.
+    Forward exchange: [n * mean, n * (var + mean^2), n] per channel (summed); backward exchange: [sum dy, sum dy * (x - mean_G)]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group):
+        C = x.shape[1]
+        dims = [0] + list(range(2, x.dim()))
+        n = x.numel() // C
+        var, mean = torch.var_mean(x.float(), dim=dims, unbiased=False)
+        packed = torch.cat([mean * n, (var + mean * mean) * n, torch.full((1,), float(n), device=x.device)])
+        dist.all_reduce(packed, group=group)
+        N = packed[-1]
+        mean_g = packed[:C] / N
+        var_g = (packed[C:2 * C] / N - mean_g * mean_g).clamp_min_(0.0)
+        invstd = torch.rsqrt(var_g + eps)
+        if running_mean is not None:
+            with torch.no_grad():      # as nn.BatchNorm2d: running_var takes the unbiased estimate
+                running_mean.mul_(1 - momentum).add_(mean_g.to(running_mean.dtype), alpha=momentum)
+                running_var.mul_(1 - momentum).add_((var_g * (N / (N - 1).clamp_min(1.0))).to(running_var.dtype), alpha=momentum)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (x.float() - mean_g.view(shape)) * invstd.view(shape)
+        w = weight.float().view(shape) if weight is not None else None
+        y = xhat * w if w is not None else xhat
+        if bias is not None:
+            y = y + bias.float().view(shape)
+        ctx.save_for_backward(xhat, invstd, weight)
+        ctx.group, ctx.dims, ctx.shape, ctx.xdtype = group, dims, shape, x.dtype
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xhat, invstd, weight = ctx.saved_tensors
+        dims, shape = ctx.dims, ctx.shape
+        gy = gy.float()
+        sum_dy = gy.sum(dims)
+        sum_dy_xhat = (gy * xhat).sum(dims)
+        C = sum_dy.numel()
+        n = gy.numel() // C
+        packed = torch.cat([sum_dy, sum_dy_xhat, torch.full((1,), float(n), device=gy.device)])
+        dist.all_reduce(packed, group=ctx.group)
+        N = packed[-1]
+        w = weight.float() if weight is not None else torch.ones_like(invstd)
+        # dx = w * invstd * (dy - mean_G(dy) - xhat * mean_G(dy * xhat))
+        gx = (gy - (packed[:C] / N).view(shape) - xhat * (packed[C:2 * C] / N).view(shape)) * (w * invstd).view(shape)
+        gw = sum_dy_xhat.to(weight.dtype) if weight is not None and ctx.needs_input_grad[1] else None      # LOCAL sums: the gradient exchange
+        gb = sum_dy.to(weight.dtype) if ctx.needs_input_grad[2] else None                                     # averages parameters' gradients
+        return gx.to(ctx.xdtype), gw, gb, None, None, None, None, None
+
+
+class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
+    """BatchNorm over the global batch in .train() under an initialised process group of more than one rank; plain batch_norm otherwise
+    (eval mode, a single process).  Same parameters / buffers / state-dict keys as nn.BatchNorm{1,2,3}d."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.process_group = process_group
+
+    def _check_input_dim(self, input):
+        if input.dim() < 2:
+            raise ValueError(f"expected at least 2D input (got {input.dim()}D input)")
+
+    def forward(self, x):
+        self._check_input_dim(x)
+        sync = self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        if not sync:
+            return super().forward(x)
+        momentum = 0.0 if self.momentum is None else self.momentum
+        if self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+            if self.momentum is None:
+                momentum = 1.0 / float(self.num_batches_tracked)
+        return _SyncBatchNormFn.apply(x, self.weight, self.bias, self.running_mean if self.track_running_stats else None,
+                                      self.running_var if self.track_running_stats else None, self.eps, momentum, self.process_group)
+
+
+def convert_sync_batchnorm(module: torch.nn.Module, process_group=None) -> torch.nn.Module:
+    """Every nn.BatchNorm*d of `module` becomes a SyncBatchNorm holding the SAME parameter and buffer tensors (optimizers built before the
+    conversion stay valid; state-dict keys unchanged).  Replaces `apex.parallel.convert_syncbn_model(net)` (reference src/main.py:128)."""
+    out = module
+    if isinstance(module, torch.nn.modules.batchnorm._BatchNorm) and not isinstance(module, SyncBatchNorm):
+        out = SyncBatchNorm(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats, process_group)
+        if module.affine:
+            out.weight, out.bias = module.weight, module.bias
+        out.running_mean, out.running_var, out.num_batches_tracked = module.running_mean, module.running_var, module.num_batches_tracked
+        out.training = module.training
+    for name, child in module.named_children():
+        new = convert_sync_batchnorm(child, process_group)
+        if new is not child:
+            setattr(out, name, new)      # (a converted parent has no children: _BatchNorm modules are leaves)
+    return out

@@ -184,3 +184,73 @@ def test_overlapped_reducer_is_a_noop_without_a_process_group():
     red = ddist.OverlappedGradReducer([p])
     p.sum().backward()
     assert red.finish() == 0 and torch.equal(p.grad, torch.ones(3))
+
+
+# ---- SyncBatchNorm (reference src/main.py:128: apex.parallel.convert_syncbn_model before DDP) ----------------------------------------
+def _bn_net():
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3, padding=1), torch.nn.BatchNorm2d(6), torch.nn.ReLU(),
+                              torch.nn.ConvTranspose2d(6, 5, 2, stride=2), torch.nn.BatchNorm2d(5), torch.nn.ReLU(), torch.nn.Conv2d(5, 2, 1))
+    with torch.no_grad():
+        for m in net:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    return net
+
+
+def _bn_batch():
+    g = torch.Generator().manual_seed(11)
+    return torch.randn(6, 3, 9, 7, generator=g) * 2.0 + 0.5, torch.randn(6, 2, 18, 14, generator=g)
+
+
+def _syncbn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    ddist.init_from_env("gloo")
+    net = _bn_net()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)                   # built BEFORE the conversion: must keep pointing at the live tensors
+    net = ddist.convert_sync_batchnorm(net).train()
+    assert sum(isinstance(m, ddist.SyncBatchNorm) for m in net.modules()) == 2 and not any(type(m) is torch.nn.BatchNorm2d for m in net.modules())
+    x, tgt = _bn_batch()
+    sl = slice(0, 4) if rank == 0 else slice(4, 6)                   # UNEVEN shards: the statistics weigh ranks by their element counts
+    xr = x[sl].clone().requires_grad_(True)
+    # each rank's loss is a SUM over its samples divided by the global batch: the average over ranks x world == the full-batch mean loss
+    loss = ((net(xr) - tgt[sl]) ** 2).sum() / x.shape[0]
+    loss.backward()
+    ddist.allreduce_gradients(net.parameters(), average=False)
+    opt.step()
+    eval_out = net.eval()(x[:2])                                       # running statistics in use; no collective in eval mode
+    torch.save({"gx": xr.grad, "grads": [p.grad.clone() for p in net.parameters()], "params": [p.detach().clone() for p in net.parameters()],
+                "buffers": [b.clone() for b in net.buffers()], "eval": eval_out.detach()}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_batchnorm_equals_one_process_on_the_whole_batch(tmp_path):
+    """convert_sync_batchnorm: two ranks with uneven shards of a batch == one process with plain BatchNorm on the whole batch -- outputs
+    of the normalised net, input gradients, parameter gradients after the gradient exchange, the SGD update, running statistics."""
+    out = str(tmp_path / "sbn.pt")
+    mp.spawn(_syncbn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    net = _bn_net().train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x, tgt = _bn_batch()
+    xr = x.clone().requires_grad_(True)
+    (((net(xr) - tgt) ** 2).sum() / x.shape[0]).backward()
+    want_grads = [p.grad.clone() for p in net.parameters()]
+    opt.step()
+    want_eval = net.eval()(x[:2]).detach()
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    # (the conv biases in front of a BatchNorm have gradient 0: what is left there is the cancellation noise of sums of magnitude ~100)
+    close = lambda a, b: float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    assert close(torch.cat([r0["gx"], r1["gx"]]), xr.grad)
+    for r in (r0, r1):
+        assert all(close(a, b) for a, b in zip(r["grads"], want_grads))
+        assert all(close(a, b.detach()) for a, b in zip(r["params"], net.parameters()))
+        assert all(close(a.float(), b.float()) for a, b in zip(r["buffers"], net.buffers()))
+        assert close(r["eval"], want_eval)
+
+
+def test_sync_batchnorm_is_plain_batchnorm_in_one_process():
+    net, ref = ddist.convert_sync_batchnorm(_bn_net()).train(), _bn_net().train()
+    x, _ = _bn_batch()
+    assert torch.allclose(net(x), ref(x), atol=1e-6) and list(net.state_dict()) == list(ref.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(net.buffers(), ref.buffers()))

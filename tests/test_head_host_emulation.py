@@ -224,7 +224,7 @@ def _dp_step(head, c, rank_items, reducer=None):
     return {k: (p.grad.clone() if p.grad is not None else None) for k, p in head.named_parameters()}
 
 
-def _dp_worker(rank, world, port, out, case):
+def _dp_worker(rank, world, port, out, case, sync_bn=False):
     import torch.distributed as dist
     from diffusiondepth_amd import dist as ddist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -233,6 +233,8 @@ def _dp_worker(rank, world, port, out, case):
     lib = hostemu_head.load()
     hostemu_head.install(lib, setattr)
     head = _head(case, "naive_fp32").train()
+    if sync_bn:
+        head = ddist.convert_sync_batchnorm(head)          # reference src/main.py:128 (apex.parallel.convert_syncbn_model)
     red = ddist.OverlappedGradReducer(list(head.parameters()), bucket_bytes=1 << 20)     # several buckets, launched from the autograd hooks
     grads = _dp_step(head, case, ddist.shard_indices(case["B"], rank, world), red)
     red.close()
@@ -242,21 +244,27 @@ def _dp_worker(rank, world, port, out, case):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_training_step_equals_the_average_of_its_shards(on_host, cases, tmp_path):
+@pytest.mark.parametrize("sync_bn", [False, True], ids=["bn-per-rank", "sync-bn"])
+def test_two_rank_data_parallel_training_step_equals_the_average_of_its_shards(on_host, cases, tmp_path, sync_bn):
     """Two processes (gloo; RCCL on the GPU box), one image of the head_train_res case each: forward + backward through the library,
     gradient buckets all-reduced from autograd hooks while backward runs (dist.OverlappedGradReducer, replaces apex DDP:
     src/main.py:106-114,148).  What rank 0 ends with must equal the average of the two shards' gradients computed in ONE process
     (BatchNorm statistics per rank, as without SyncBN) -- for the denoiser parameters, whose gradients come out of dd_denoise_backward /
-    dd_denoise_once_backward, and for the torch-side FPN / codec."""
+    dd_denoise_once_backward, and for the torch-side FPN / codec.  With dist.convert_sync_batchnorm (what the reference does to every
+    BatchNorm before DDP) the two ranks must instead equal ONE process on the whole batch: the data-parallel step is then exactly the
+    large-batch step."""
     import socket
     import torch.multiprocessing as mp
     c = dict(cases["head_train_res"])
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "dp_grads.pt")
-    mp.spawn(_dp_worker, args=(2, port, out, c), nprocs=2, join=True)
+    mp.spawn(_dp_worker, args=(2, port, out, c, sync_bn), nprocs=2, join=True)
     got = torch.load(out)
     head = _head(c, "naive_fp32").train()
-    g0, g1 = _dp_step(head, c, [0]), _dp_step(head, c, [1])
+    if sync_bn:
+        g0 = g1 = _dp_step(head, c, [0, 1])
+    else:
+        g0, g1 = _dp_step(head, c, [0]), _dp_step(head, c, [1])
     checked = 0
     for k in ("model.pred.0.weight", "model.noise_embedding.3.weight", "model.pred.3.bias", "model.noise_embedding.1.weight", "model.time_embedding.weight",
               "conv_lateral.0.0.weight", "conv_up.1.0.weight", "depth_transform.conv_inv_transform.0.weight"):
