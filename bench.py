@@ -312,6 +312,8 @@ def main():
                     help="conv3(cond)+conv3(E[t]) out of the loop: -1 = the library default (on in the bf16 mode), 0 / 1 = forced (A/B switch)")
     ap.add_argument("--bf16-storage", action="store_true", help="A/B: all-bf16 tensors in --precision bf16 (default: f16 storage / thin layers)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train-dp"])
+    ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches inside dd_denoise (option 'streams'; 1 = one stream, the measured default)")
+    ap.add_argument("--no-streams-extra", action="store_true", help="skip the two-stream timing of the same step")
     ap.add_argument("--no-sync-bn", action="store_true", help="train-dp with N > 1: keep per-rank BatchNorm statistics (default: synchronised, as the reference)")
     ap.add_argument("--dist-selftest", action="store_true", help="multi-rank plumbing only, no hot path (any backend)")
     ap.add_argument("--no-parity-gate", action="store_true", help="do not fail when the timed precision misses the depth-RMSE tolerance")
@@ -370,6 +372,7 @@ def main():
         be.set_option("graph", 0)
     be.set_option("hoist_cond", args.hoist)
     be.set_option("bf16_storage", 1 if args.bf16_storage else 0)
+    be.set_option("streams", args.streams)
     hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and args.precision == "bf16" and not args.bf16_storage))
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
@@ -412,6 +415,27 @@ def main():
         lm.append(be.last_loop_ms())
     loop_ms = sorted(lm)[2]
     be.set_option("timing", 0)
+
+    # ---- the same step with the batch split over two concurrent HIP streams (dd_set_option "streams"; results bit-identical) ----
+    lanes = None
+    if rank == 0 and world == 1 and B >= 2 and args.streams == 1 and args.precision != "naive_fp32" and not args.no_streams_extra:
+        ref_x0 = x0.clone()
+        be.set_option("streams", 2)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        el2 = time.perf_counter() - t1
+        lanes = {"what": f"the same step with dd_set_option('streams', 2): the {B} images as two concurrent sub-batches on separate HIP streams "
+                         "(own plans and hipGraphs per lane, fork / join by events); not the default: per-launch durations (roofline object) are "
+                         "defined on one stream",
+                 "maps_per_s": round(B * args.steps / el2, 2), "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                 "bit_identical_to_one_stream": bool(torch.equal(x0, ref_x0))}
+        be.set_option("streams", 1)
+        step()
 
     # ---- B = 1 latency (the reference's test() feeds one image at a time, README.md:249) ----------------
     lat = None
@@ -537,7 +561,7 @@ def main():
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant},
-            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
+            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "two_streams": lanes, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
         }
         print(json.dumps(out), flush=True)
         # parity gate of the TIMED configuration (north star: depth RMSE within 1e-3 of the reference): a fast number out of tolerance

@@ -96,8 +96,9 @@ struct PlanKey {
   int B, h, w, ch, cw, T, prec, hoist;
   int keep = 0;        // option "keep_trajectory" (what dd_denoise_backward needs): 1 = the loop leaves every state x_k in Plan::xstash;
                        // 2 = ... and every step's raw conv outputs y1..y4 (Swin: + convA / convB results) in per-step slots
+  int lane = 0;        // dd_denoise with option "streams" > 1 runs a batch as concurrent sub-batches: one plan (buffers, graph) per lane
   bool operator<(const PlanKey& o) const {
-    return std::tie(B, h, w, ch, cw, T, prec, hoist, keep) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist, o.keep);
+    return std::tie(B, h, w, ch, cw, T, prec, hoist, keep, lane) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist, o.keep, o.lane);
   }
 };
 
@@ -107,6 +108,9 @@ struct Plan {
   DevBuf x[2];        // fp32 NHWC state ping-pong
   std::shared_ptr<DevBuf> cond;   // condition map at latent size (activation layout / element kind; fp32 NHWC for naive); shared by every
                                   // plan of one (B, h, w, element kind) so that dd_condition can write it in place
+  const void* cond_alias = nullptr;   // lanes of a batch whose condition map dd_condition left in the whole batch's buffer: this lane's images inside it
+  const void* graph_cond = nullptr;   // the condition pointer the captured graph holds
+  void* cond_ptr() const { return cond_alias ? const_cast<void*>(cond_alias) : cond->p; }
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
@@ -194,13 +198,18 @@ struct dd_handle_s {
   // loop a second time -- if that ticket is still the plan's and the parameters have not changed since, else it regenerates as before.
   bool keep_traj = false;
   int64_t keep_act_mb = 65536;
+  static constexpr int MAX_LANES = 4;
+  int n_streams = 1;          // option "streams": concurrent sub-batches of dd_denoise (1 = off)
+  hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  int64_t n_lane_calls = 0;
   bool adjoint_tiled = true;  // Swin backward: tiled separable kernel for the adjoint of the condition upsampling (0 = the one-thread-per-piece kernel, A/B check)
   int64_t traj_serial = 0, use_traj = 0, weights_serial = 0, n_traj_reuse = 0;
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   DevBuf wgrad_ws;            // per-slab partial weight gradients of dd_wgrad.hip
   std::map<std::string, std::unique_ptr<DevBuf>> grads;   // parameter gradients (fp32, reference shapes), accumulated like torch .grad
-  std::map<std::tuple<int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision) -> buffer, last use
+  std::map<std::tuple<int, int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision, lane) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
   bool neck_committed = false;            // hahineck.* folded + packed (DD_VARIANT_SWIN with the Swin-L pyramid only)
   DevBuf neck_w[12][NUM_EK], neck_b[12];  // index = kernel layer - 30
@@ -359,11 +368,11 @@ int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw, bool need
 
 // The condition map at latent size in the activation layout of `precision`: one buffer per (B, h, w, precision), shared by
 // all plans of that shape (graphs bake its address) and written in place by dd_condition.
-int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::shared_ptr<DevBuf>* out) {
-  const auto key = std::make_tuple(B, lh, lw, precision);
+int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::shared_ptr<DevBuf>* out, int lane = 0) {
+  const auto key = std::make_tuple(B, lh, lw, precision, lane);
   auto it = h->cond_bufs.find(key);
   if (it == h->cond_bufs.end()) {
-    while (h->cond_bufs.size() >= 8) {           // plans keep their buffer alive through the shared_ptr
+    while (h->cond_bufs.size() >= 12) {           // plans keep their buffer alive through the shared_ptr
       auto victim = h->cond_bufs.begin();
       for (auto j = h->cond_bufs.begin(); j != h->cond_bufs.end(); ++j)
         if (j->second.second < victim->second.second) victim = j;
@@ -390,8 +399,8 @@ int want_hoist(dd_handle_t h, int precision) {
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   auto it = h->plans.find(key);
   if (it != h->plans.end()) { it->second->last_use = ++h->tick; *out = it->second.get(); return DD_OK; }
-  // keep at most 6 plans alive: evict the least recently used
-  while (h->plans.size() >= 6) {
+  // keep at most 10 plans alive: evict the least recently used
+  while (h->plans.size() >= 10) {
     auto victim = h->plans.begin();
     for (auto j = h->plans.begin(); j != h->plans.end(); ++j)
       if (j->second->last_use < victim->second->last_use) victim = j;
@@ -411,7 +420,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   const bool swin = h->variant == DD_VARIANT_SWIN;
   // Swin: the condition map is bilinearly upsampled to the latent size once per call and kept at that size
   (void)swin;
-  { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond); if (rc) return rc; }
+  { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond, key.lane); if (rc) return rc; }
   pl->slots = (key.keep == 2 && key.T > 0) ? key.T : 1;
   const size_t ns = (size_t)pl->slots;
   if (swin) { DD_HIP(pl->sa.alloc(ns * px * COND_C * es)); DD_HIP(pl->sf.alloc(ns * px * COND_C * es)); }
@@ -510,7 +519,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     p.in = y2_; p.wpack = h->LA.wpack2[ok].p; p.bias = h->LA.bias.as<float>(); p.out = sa_;
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
     p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
-    p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
+    p.cond = pl->cond_ptr(); p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
     DD_HIP(timed_launch(5, p));
     p.in = sa_; p.wpack = h->LB.wpack2[ok].p; p.bias = h->LB.bias.as<float>(); p.out = sf_;
     p.stats_in = nullptr;
@@ -523,7 +532,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.in = y2_; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
-  p.cond = pl->cond->p; p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
+  p.cond = pl->cond_ptr(); p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
   p.cadd = pl->ccond.as<float>(); p.etab = h->etab.as<float>();
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
@@ -549,7 +558,7 @@ int enqueue_naive_eps(dd_handle_t h, Plan* pl, int step, const float* x_in, cons
   DD_HIP(launch_naive_conv3x3(pl->a1.as<float>(), L[1].w_oihw.as<float>(), L[1].bias.as<float>(), pl->y2.as<float>(), B, hh, ww, HID_C, COND_C, s));
   DD_HIP(launch_naive_gn_stats(pl->y2.as<float>(), pl->stat_ptr(step, 1), B, hh, ww, COND_C, s));
   DD_HIP(launch_naive_gn_apply(pl->y2.as<float>(), pl->stat_ptr(step, 1), L[1].gamma.as<float>(), L[1].beta.as<float>(),
-                               pl->cond->as<float>(), h->emb.as<float>(), tvec, t_base, t_bstride, pl->f.as<float>(), B, hh, ww, COND_C, s));
+                               static_cast<const float*>(pl->cond_ptr()), h->emb.as<float>(), tvec, t_base, t_bstride, pl->f.as<float>(), B, hh, ww, COND_C, s));
   DD_HIP(launch_naive_conv3x3(pl->f.as<float>(), L[2].w_oihw.as<float>(), L[2].bias.as<float>(), pl->y3.as<float>(), B, hh, ww, COND_C, HID_C, s));
   DD_HIP(launch_naive_gn_stats(pl->y3.as<float>(), pl->stat_ptr(step, 2), B, hh, ww, HID_C, s));
   DD_HIP(launch_naive_gn_apply(pl->y3.as<float>(), pl->stat_ptr(step, 2), L[2].gamma.as<float>(), L[2].beta.as<float>(),
@@ -570,28 +579,35 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
   p.ablate = 0;
-  p.in = pl->cond->p; p.wpack = h->L[2].wpack2[thin_kind(pl->ek)].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
+  p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[thin_kind(pl->ek)].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
   DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
   return DD_OK;
 }
 
 // Bring the condition map into the plan's (shared) buffer: convert the caller's NCHW fp32 tensor, or -- cond == NULL --
 // check that dd_condition left its result there.
+// A lane (img0 > 0 or B < whole_B) is handed its images of the caller's tensor by the caller; of dd_condition's result it takes its slice.
 int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h, int lat_w, int cond_h, int cond_w,
-                    int precision, hipStream_t s) {
+                    int precision, hipStream_t s, int img0 = 0, int whole_B = 0) {
+  if (whole_B <= 0) whole_B = B;
+  pl->cond_alias = nullptr;
   if (cond) {
     if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
     else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
     if (h->fpn_cond == pl->cond) { h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; }    // overwritten
   } else if (h->variant == DD_VARIANT_SWIN) {
     const int* k = h->fpn_cond_key;
-    if (!h->fpn_cond || h->fpn_cond != h->fpn_out || k[0] != B || k[1] != cond_h || k[2] != cond_w || k[3] != precision)
+    if (!h->fpn_cond || h->fpn_cond != h->fpn_out || k[0] != whole_B || k[1] != cond_h || k[2] != cond_w || k[3] != precision)
       return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, condition size and precision");
-    DD_HIP(launch_upsample_blocked(h->fpn_out->p, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+    const char* src = static_cast<const char*>(h->fpn_out->p) + (size_t)img0 * COND_C * cond_h * cond_w * ek_size(store_kind(pl->ek));
+    DD_HIP(launch_upsample_blocked(src, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
   } else {
     const int* k = h->fpn_cond_key;
-    if (!h->fpn_cond || h->fpn_cond != pl->cond || k[0] != B || k[1] != lat_h || k[2] != lat_w || k[3] != precision)
+    const bool whole = img0 == 0 && B == whole_B;
+    if (!h->fpn_cond || (whole && h->fpn_cond != pl->cond) || k[0] != whole_B || k[1] != lat_h || k[2] != lat_w || k[3] != precision)
       return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, latent size and precision");
+    if (!whole)     // this lane's images inside the whole batch's condition map (per-image contiguous in the activation layout)
+      pl->cond_alias = static_cast<const char*>(h->fpn_cond->p) + (size_t)img0 * lat_h * lat_w * COND_C * ek_size(store_kind(pl->ek));
   }
   if (pl->key.hoist) { int rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
   return DD_OK;
@@ -671,6 +687,11 @@ int dd_destroy(dd_handle_t h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  for (int l = 0; l < dd_handle_s::MAX_LANES; ++l) {
+    if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]);
+    if (h->lane_done[l]) (void)hipEventDestroy(h->lane_done[l]);
+  }
+  if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
   delete h;
   return DD_OK;
 }
@@ -1114,6 +1135,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "keep_trajectory") h->keep_traj = value != 0;
   else if (k == "use_trajectory") h->use_traj = value;
   else if (k == "adjoint_tiled") h->adjoint_tiled = value != 0;
+  else if (k == "streams") h->n_streams = value < 1 ? 1 : (int)value;
   else if (k == "keep_activations_mb") h->keep_act_mb = value < 0 ? 0 : value;
   else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
   else if (k == "phase_prof_layer") h->prof_layer = (int)value;
@@ -1134,6 +1156,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   else if (k == "plans") *value = (int64_t)h->plans.size();
   else if (k == "neck_launches") *value = h->n_neck_launches;
   else if (k == "trajectory_ticket") *value = h->traj_serial;
+  else if (k == "lane_calls") *value = h->n_lane_calls;
   else if (k == "trajectory_reuses") *value = h->n_traj_reuse;
   else return h->fail(DD_ERR_INVALID_ARG, "dd_get_counter: unknown key '" + k + "'");
   return DD_OK;
@@ -1297,17 +1320,15 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   return DD_OK;
 }
 
-int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
-               int cond_h, int cond_w, int T, int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
-  if (rc) return rc;
-  if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
-  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
-  if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
-    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  DD_HIP(hipSetDevice(h->device));
+}  // extern "C"
+
+namespace {
+// The loop on B images (a whole call, or one lane of it: images img0 .. img0 + B - 1 of a batch of whole_B whose tensors start at the
+// pointers given -- already offset to the lane's first image) on stream s.
+int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
+                 int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0, int whole_B) {
+  int rc = DD_OK;
+  const bool timed = h->timing && lane == 0 && B == whole_B;      // lanes: the caller brackets fork .. join
   Plan* pl = nullptr;
   int keep = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? 1 : 0;
   if (keep) {
@@ -1317,7 +1338,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
     const size_t per_step = (size_t)B * lat_h * lat_w * ((2 * HID_C + COND_C + (h->variant == DD_VARIANT_SWIN ? 2 * COND_C : 0)) * es + LATENT_C * 4);
     if (per_step * (size_t)T <= (size_t)h->keep_act_mb << 20) keep = 2;
   }
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep, lane}, &pl);
   if (rc) return rc;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
   float* x_first = keep ? pl->xstash.as<float>() : pl->x[0].as<float>();                                        // state entering step 0
@@ -1325,10 +1346,15 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (keep) pl->traj_ticket = 0;         // being overwritten
 
   DD_HIP(launch_nchw_to_nhwc(x_T, x_first, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s, img0, whole_B);
   if (rc) return rc;
+  if (pl->exec && pl->graph_cond != pl->cond_ptr()) {      // the graph holds another condition pointer (the whole batch's buffer moved)
+    DD_HIP(hipStreamSynchronize(s));
+    (void)hipGraphExecDestroy(pl->exec);
+    pl->exec = nullptr;
+  }
 
-  if (h->timing) {
+  if (timed) {
     if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
     DD_HIP(hipEventRecord(h->ev0, s));
   }
@@ -1342,7 +1368,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
       DD_HIP(launch_naive_axpby(xc, pl->eps.as<float>(), pl->c1c2.as<float>(), k, xn, (long long)B * lat_h * lat_w * LATENT_C, s));
     }
     h->n_eager_loops++;
-    if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+    if (timed) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
     DD_HIP(launch_nhwc_to_nchw_f32(pl->x[T & 1].p, EK_F32, x_0, B, LATENT_C, lat_h, lat_w, 0, s));
     return DD_OK;
   }
@@ -1366,6 +1392,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
         if (brc == DD_OK && e2 == hipSuccess && graph) {
           e = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0);
           if (e != hipSuccess) pl->exec = nullptr;
+          pl->graph_cond = pl->cond_ptr();
         }
         if (graph) (void)hipGraphDestroy(graph);
       }
@@ -1376,7 +1403,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
       }
       // the eager pass above consumed x[0]: restore the input state before the real run
       DD_HIP(launch_nchw_to_nhwc(x_T, x_first, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-      if (h->timing) DD_HIP(hipEventRecord(h->ev0, s));
+      if (timed) DD_HIP(hipEventRecord(h->ev0, s));
     }
     if (pl->exec) {
       DD_HIP(hipGraphLaunch(pl->exec, s));
@@ -1389,12 +1416,66 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
     if (rc) return rc;
     h->n_eager_loops++;
   }
-  if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
+  if (timed) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
   // x_0 = c1*x + c2*relu(gn4(y4)) of the last step, written NCHW
   DD_HIP(launch_final(x_last, static_cast<const float*>(pl->slot(pl->y4, T - 1)), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
                       h->L[3].beta.as<float>(), pl->c1c2.as<float>(), T - 1, 0, x_0, B, lat_h, lat_w, s));
   if (keep) { pl->traj_ticket = ++h->traj_serial; pl->traj_weights = h->weights_serial; }
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
+  return DD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
+               int cond_h, int cond_w, int T, int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
+  if (rc) return rc;
+  if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
+  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
+  if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  // Option "streams" = S > 1: the images of a batch are independent (GroupNorm is per sample), so the batch runs as S concurrent
+  // sub-batches, lane 0 on the caller's stream and the others on streams of the handle, forked and joined with events on the caller's
+  // stream.  Each lane has its own plan (activation buffers, hipGraph); the workgroups of one lane's kernels fill the tail of the
+  // other's and hide its kernel boundaries.  Not for the naive path, the per-launch timing mode, or a forward that keeps its
+  // activations for the backward (one plan must hold the whole batch).
+  int S = h->n_streams;
+  if (S > B) S = B;
+  if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
+  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->keep_traj || h->prof_buf) S = 1;
+  if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B);
+  for (int l = 1; l < S; ++l) {
+    if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    if (!h->lane_done[l]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
+  }
+  if (!h->lane_fork) DD_HIP(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
+  if (h->timing) {
+    if (!h->ev0) { DD_HIP(hipEventCreate(&h->ev0)); DD_HIP(hipEventCreate(&h->ev1)); }
+    DD_HIP(hipEventRecord(h->ev0, s));
+  }
+  DD_HIP(hipEventRecord(h->lane_fork, s));
+  const size_t n_x = (size_t)LATENT_C * lat_h * lat_w, n_c = (size_t)COND_C * cond_h * cond_w;
+  int img0 = 0;
+  for (int l = 0; l < S; ++l) {
+    const int n = B / S + (l < B % S ? 1 : 0);
+    hipStream_t ls = l == 0 ? s : h->lane_stream[l];
+    if (l > 0) DD_HIP(hipStreamWaitEvent(ls, h->lane_fork, 0));
+    rc = denoise_lane(h, x_T + img0 * n_x, cond ? cond + img0 * n_c : nullptr, x_0 + img0 * n_x, n, lat_h, lat_w, cond_h, cond_w, T, precision,
+                      ls, l, img0, B);
+    if (l > 0) {                                           // join even after an error: the caller's stream must not run ahead of a lane
+      (void)hipEventRecord(h->lane_done[l], ls);
+      (void)hipStreamWaitEvent(s, h->lane_done[l], 0);
+    }
+    if (rc) return rc;
+    img0 += n;
+  }
+  h->n_lane_calls++;
+  if (h->timing) { DD_HIP(hipEventRecord(h->ev1, s)); h->ev_valid = true; }
   return DD_OK;
 }
 
@@ -1568,12 +1649,12 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       const int C = kCouts[l];
       if (ek != EK_F32) {
         DD_HIP(launch_gn_bwd_apply_blocked(nullptr, ys[l], ek, yk, st(l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(),
-                                           nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond->p : nullptr, h->emb.as<float>(), tv, t_base,
+                                           nullptr, nullptr, as[l]->p, (l == 1) ? pl->cond_ptr() : nullptr, h->emb.as<float>(), tv, t_base,
                                            t_bstride, B, C, HW, s));
         continue;
       }
       const ActView yv{ys[l], ek, 1, C, HW}, av{as[l]->p, ek, 1, C, HW};
-      const ActView cv = (l == 1) ? ActView{pl->cond->p, ek, 1, C, HW} : nothing;
+      const ActView cv = (l == 1) ? ActView{pl->cond_ptr(), ek, 1, C, HW} : nothing;
       DD_HIP(launch_gn_bwd_apply(nothing, yv, st(l), h->L[l].gamma.as<float>(), h->L[l].beta.as<float>(), pl->dgb.as<double>(),
                                  nothing, av, cv, h->emb.as<float>(), tv, t_base, t_bstride, B, s));
     }

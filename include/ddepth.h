@@ -208,11 +208,15 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * after every launch), "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
  * condition map is re-added in conv3's prologue every step), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
- * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward). */
+ * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
+ * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
+ * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent, the result is bit-identical;
+ * default 1), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
+ * "keep_activations_mb" (budget of the per-step activation slots kept by a "keep_trajectory" forward, default 65536). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches", "trajectory_ticket" (ticket of the
- * last dd_denoise call that kept its states), "trajectory_reuses" (dd_denoise_backward calls that read kept states). */
+ * last dd_denoise call that kept its states), "trajectory_reuses" (dd_denoise_backward calls that read kept states), "lane_calls" (dd_denoise calls that ran as concurrent lanes). */
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`

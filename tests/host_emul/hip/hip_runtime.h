@@ -87,6 +87,10 @@ struct hostemu_event { double t; };
 typedef hostemu_event* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hostemu_event{0.0}; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+// every emulated stream executes at the call (or inside a captured graph, in order): an event is always complete when another stream waits for it
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { ++hostemu::blocking_calls(); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 struct hostemu_graph { std::vector<std::function<void()>> nodes; };

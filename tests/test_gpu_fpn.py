@@ -213,3 +213,34 @@ def test_swin_handle_resident_cond_equals_exported_cond(U, be_swin, cases, prec)
     a = be_swin.denoise(x_T, cond, 20, prec).cpu().numpy()
     b = be_swin.denoise(x_T, cond.clone(), 20, prec).cpu().numpy()
     assert U.maxabs(a, b) <= (2e-6 if prec == "fp32" else 2e-3) * float(np.abs(a).max())
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+def test_concurrent_lanes_on_the_handle_resident_cond(U, be, be_swin, cases, prec):
+    """dd_set_option("streams", S): the batch runs as S concurrent sub-batches on separate HIP streams (own plans / graphs; fork and join by
+    events on the caller's stream).  With the condition map left in the handle by dd_condition every lane reads ITS images of the whole
+    batch's map (Res: an alias into that buffer, no copy; Swin: its slice of the stride-4 map, upsampled into the lane's own buffer);
+    with an explicit tensor every lane converts its slice.  Bit-identical to one stream: the images are independent."""
+    for b, chans, lat in ((be, None, None), (be_swin, (192, 384, 768, 1536), (40, 72))):
+        B = 3
+        feats = synth.make_backbone_features(5, B, 48 if chans is None else 40, 80 if chans is None else 72, **({} if chans is None else {"in_channels": chans}))
+        fp = [U.cu(f) for f in feats]
+        h, w = lat if lat else (fp[0].shape[2], fp[0].shape[3])
+        x_T = U.cu(synth.make_inputs(9, B, h, w)["x_T"])
+        try:
+            b.set_option("streams", 1)
+            cond = b.condition(fp, prec)
+            want = b.denoise(x_T, cond, 5, prec)
+            want_explicit = b.denoise(x_T, cond.clone(), 5, prec)
+            for S in (2, 3):
+                b.set_option("streams", S)
+                n0 = b.counter("lane_calls")
+                cond = b.condition(fp, prec)
+                assert b._cond_arg(cond, prec) is None
+                got = b.denoise(x_T, cond, 5, prec)
+                again = b.denoise(x_T, b.condition(fp, prec), 5, prec)              # replayed lane graphs, refreshed condition map
+                got_explicit = b.denoise(x_T, cond.clone(), 5, prec)
+                assert b.counter("lane_calls") == n0 + 3
+                assert torch.equal(got, want) and torch.equal(again, want) and torch.equal(got_explicit, want_explicit), (prec, S)
+        finally:
+            b.set_option("streams", 1)

@@ -422,3 +422,30 @@ def test_16bit_backward_close_to_the_fp32_backward(on_host, variant, hw, cond_hw
             if e > tol:
                 bad[k] = e
         assert not bad, (prec, bad)
+
+
+@pytest.mark.parametrize("variant,cond_hw,precs,lanes", [("res", None, ("bf16",), (2, 3)), ("swin", (4, 10), ("fp32",), (2,))], ids=["res-bf16", "swin-fp32"])
+def test_concurrent_lanes_return_the_single_stream_result(on_host, variant, cond_hw, precs, lanes):
+    """dd_set_option("streams", S): dd_denoise runs a batch as S concurrent sub-batches (own plans, buffers and graphs per lane; fork / join
+    by events on the caller's stream).  Same bytes as one stream -- the images are independent -- with an explicit condition tensor (each
+    lane converts its slice; Swin: upsamples it), uneven split (3 images on 2 lanes), replayed lane graphs; the trajectory-keeping training
+    forward stays on one stream.  (The lanes' slices of a condition map left by dd_condition: tests/test_gpu_fpn.py.)"""
+    be = on_host(CPU, variant)
+    be.load_state_dict(synth.make_state_dict(7240, variant))
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    B, h, w, T = 3, 7, 19, 1
+    inp = synth.make_inputs(23, B, h, w, cond_hw) if cond_hw else synth.make_inputs(23, B, h, w)
+    x, cond = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"])
+    for prec in precs:
+        be.set_option("streams", 1)
+        want = be.denoise(x, cond, T, prec)
+        for S in lanes:
+            be.set_option("streams", S)
+            n0 = be.counter("lane_calls")
+            got = be.denoise(x, cond, T, prec)
+            assert be.counter("lane_calls") == n0 + 1
+            assert torch.equal(got, want), (prec, S)
+        assert torch.equal(be.denoise(x, cond, T, prec), want)               # second call: the lanes' graphs replay
+        n0 = be.counter("lane_calls")
+        assert torch.equal(be.denoise(x, cond, T, prec, keep_trajectory=True), want) and be.counter("lane_calls") == n0
+    be.set_option("streams", 1)
