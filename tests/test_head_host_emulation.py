@@ -326,8 +326,8 @@ def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     sd = synth.make_state_dict(7240)
     be.load_state_dict(sd)
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
-    T, prec = 3, "fp32"
-    inp, inp2 = synth.make_inputs(5, 1, 8, 40), synth.make_inputs(6, 1, 8, 40)
+    T, prec = 2, "fp32"
+    inp, inp2 = synth.make_inputs(5, 1, 6, 33), synth.make_inputs(6, 1, 6, 33)
     x, cond, x2 = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"]), torch.from_numpy(inp2["x_T"])
     g = torch.from_numpy(np.random.RandomState(3).standard_normal(inp["x_T"].shape).astype(np.float32))
     names = ["model.pred.3.weight", "model.noise_embedding.0.weight", "model.pred.1.bias", "model.time_embedding.weight"]
@@ -347,28 +347,27 @@ def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     x0k = be.denoise(x, cond, T, prec, keep_trajectory=True)
     tk = be.last_trajectory_ticket
     assert tk > 0 and torch.equal(x0k, x0)
-    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 1
-    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 2          # retain_graph-style second backward
+    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 1          # (a second backward on the same ticket reuses again)
     be.denoise(x2, cond, T, prec, keep_trajectory=True)                                # the plan's states are now another call's
     assert be.last_trajectory_ticket == tk + 1
-    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 2
+    assert same(backward(tk), want) and be.counter("trajectory_reuses") == 1
     # the same with the states only (activation budget 0: every step's forward is recomputed from its kept state)
     be.set_option("keep_activations_mb", 0)
     plans = be.counter("plans")
     assert torch.equal(be.denoise(x, cond, T, prec, keep_trajectory=True), x0) and be.counter("plans") == plans + 1
-    assert same(backward(be.last_trajectory_ticket), want) and be.counter("trajectory_reuses") == 3
+    assert same(backward(be.last_trajectory_ticket), want) and be.counter("trajectory_reuses") == 2
     be.set_option("keep_activations_mb", 65536)
     be.denoise(x, cond, T, prec, keep_trajectory=True)
     tk3 = be.last_trajectory_ticket
     bumped = {"model.pred.4.weight": sd["model.pred.4.weight"] * 1.5}                   # the last GroupNorm's gamma
     be.load_state_dict(bumped)                                                          # parameters changed after the forward
     got = backward(tk3)
-    assert be.counter("trajectory_reuses") == 3
+    assert be.counter("trajectory_reuses") == 2
     assert not same(got, want)                                                          # ... and the gradient is the new parameters' one
 
 
-@pytest.mark.parametrize("shape", [((2, 7, 19), (4, 10)), ((1, 9, 33), (3, 5)), ((1, 6, 40), (6, 40)), ((1, 4, 141), (2, 70))],
-                         ids=["x2", "x4-ragged", "same-size", "two-segments"])
+@pytest.mark.parametrize("shape", [((2, 7, 19), (4, 10)), ((1, 4, 141), (2, 70))] + ([((1, 9, 33), (3, 5)), ((1, 6, 40), (6, 40))] if FULL else []),
+                         ids=["x2", "two-segments"] + (["x4-ragged", "same-size"] if FULL else []))
 def test_swin_condition_gradient_tiled_adjoint_equals_the_plain_one(on_host, shape):
     """Swin variant, 16-bit backward: dLoss/dcond passes through the adjoint of the align_corners bilinear upsampling.  The tiled separable
     kernel (dd_bwd.hip: upsample_adjoint_tiled_kernel) must return what the one-thread-per-piece kernel returns (same fp32 weights, other
@@ -385,14 +384,14 @@ def test_swin_condition_gradient_tiled_adjoint_equals_the_plain_one(on_host, sha
         be.set_option("adjoint_tiled", tiled)
         be.zero_grad()
         _, gc1 = be.denoise_once_backward(x, torch.full((B,), 300), cond, g, "bf16")
-        _, gc2 = be.denoise_backward(x, cond, g, 2, "bf16")                    # two steps: the second one accumulates
+        gc2 = be.denoise_backward(x, cond, g, 2, "bf16")[1] if (B > 1 or FULL) else gc1      # two steps: the second one accumulates
         out[tiled] = (gc1, gc2)
     for a, b in zip(out[1], out[0]):
         assert a.shape == (B, 256, ch, cw) and float(b.abs().max()) > 0
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("variant,hw,cond_hw", [("res", (9, 21), None), ("swin", (7, 19), (4, 10))])
+@pytest.mark.parametrize("variant,hw,cond_hw", [("res", (9, 21), None)] + ([("swin", (7, 19), (4, 10))] if FULL else []))
 def test_16bit_backward_close_to_the_fp32_backward(on_host, variant, hw, cond_hw):
     """The vectorised GroupNorm-backward kernels of the 16-bit modes (gn_bwd_reduce_blocked / gn_bwd_apply_blocked: two pixels per trip,
     ragged last pair, slabs) against the generic fp32 path of the same library on a pixel count that is no multiple of anything.  The
@@ -424,7 +423,7 @@ def test_16bit_backward_close_to_the_fp32_backward(on_host, variant, hw, cond_hw
         assert not bad, (prec, bad)
 
 
-@pytest.mark.parametrize("variant,cond_hw,precs,lanes", [("res", None, ("bf16",), (2, 3)), ("swin", (4, 10), ("fp32",), (2,))], ids=["res-bf16", "swin-fp32"])
+@pytest.mark.parametrize("variant,cond_hw,precs,lanes", [("res", None, ("bf16",), (2, 3) if FULL else (2,)), ("swin", (3, 7), ("fp32",), (2,))], ids=["res-bf16", "swin-fp32"])
 def test_concurrent_lanes_return_the_single_stream_result(on_host, variant, cond_hw, precs, lanes):
     """dd_set_option("streams", S): dd_denoise runs a batch as S concurrent sub-batches (own plans, buffers and graphs per lane; fork / join
     by events on the caller's stream).  Same bytes as one stream -- the images are independent -- with an explicit condition tensor (each
@@ -433,7 +432,7 @@ def test_concurrent_lanes_return_the_single_stream_result(on_host, variant, cond
     be = on_host(CPU, variant)
     be.load_state_dict(synth.make_state_dict(7240, variant))
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
-    B, h, w, T = 3, 7, 19, 1
+    B, h, w, T = (3, 7, 19, 1) if variant == "res" else (2, 5, 13, 1)        # (the Swin denoiser is 5x the work per pixel)
     inp = synth.make_inputs(23, B, h, w, cond_hw) if cond_hw else synth.make_inputs(23, B, h, w)
     x, cond = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"])
     for prec in precs:
