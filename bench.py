@@ -209,6 +209,7 @@ def train_dp(args, dev, dist, world, rank):
     swin = args.variant == "swin"
     chans = (192, 384, 768, 1536) if swin else (64, 128, 256, 512)
     os.environ.setdefault("DDEPTH_DEVICE_WEIGHTS", "1")     # parameter refresh after optimizer.step() without leaving HBM
+    os.environ["DDEPTH_STREAMS"] = str(args.streams)        # forward + backward of the loop as concurrent sub-batches (bit-identical per image)
     cls = dda.DDIMDepthEstimate_Swin_ADD if swin else dda.DDIMDepthEstimate_Res
     head = cls(precision=args.precision, inference_steps=T, loss_noise_device="device")
     sd = synth.make_state_dict(7240, args.variant)
@@ -282,6 +283,7 @@ def train_dp(args, dev, dist, world, rank):
                        "maps_per_gpu_per_step": B, "global_batch": B * n_world, "parallelism": f"dp{n_world} (RCCL all-reduce of {nbytes / 1e6:.1f} MB of head gradients per step, "
                                                                                               f"{len(reducer.buckets)} bucket(s), overlapped with backward"
                                                                                               + ("; SyncBatchNorm over the global batch in the FPN / codec" if sync_bn else "") + ")",
+                       "streams": args.streams,
                        "variant": args.variant},
             "allreduce_exposed_ms": round(sorted(exposed)[len(exposed) // 2], 3), "collectives_launched_in_backward": reducer.launched_in_backward,
             # executed convolution work of the loop per step: forward + data gradients + weight gradients (the forward keeps the states and
@@ -312,7 +314,8 @@ def main():
                     help="conv3(cond)+conv3(E[t]) out of the loop: -1 = the library default (on in the bf16 mode), 0 / 1 = forced (A/B switch)")
     ap.add_argument("--bf16-storage", action="store_true", help="A/B: all-bf16 tensors in --precision bf16 (default: f16 storage / thin layers)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train-dp"])
-    ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches inside dd_denoise (option 'streams'; 1 = one stream, the measured default)")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent sub-batches inside dd_denoise / dd_denoise_backward (option 'streams'); default: 1 for "
+                    "the inference line (its roofline object is defined per launch on one stream), 2 for --mode train-dp")
     ap.add_argument("--no-streams-extra", action="store_true", help="skip the two-stream timing of the same step")
     ap.add_argument("--no-sync-bn", action="store_true", help="train-dp with N > 1: keep per-rank BatchNorm statistics (default: synchronised, as the reference)")
     ap.add_argument("--dist-selftest", action="store_true", help="multi-rank plumbing only, no hot path (any backend)")
@@ -320,6 +323,8 @@ def main():
     ap.add_argument("--variant", default="res", choices=["res", "swin"],
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
     args = ap.parse_args()
+    if args.streams is None:
+        args.streams = 2 if args.mode == "train-dp" else 1
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # invoked plainly: this process becomes the launcher of N ranks (each re-enters main() with WORLD_SIZE set)

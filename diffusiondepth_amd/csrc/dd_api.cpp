@@ -166,6 +166,7 @@ static std::vector<NeckConv> neck_convs() {
 }
 
 struct dd_handle_s {
+  static constexpr int MAX_LANES = 4;     // concurrent sub-batches of one dd_denoise / dd_denoise_backward call (option "streams")
   int device = 0;
   int variant = DD_VARIANT_RES;
   std::string err;
@@ -198,7 +199,6 @@ struct dd_handle_s {
   // loop a second time -- if that ticket is still the plan's and the parameters have not changed since, else it regenerates as before.
   bool keep_traj = false;
   int64_t keep_act_mb = 65536;
-  static constexpr int MAX_LANES = 4;
   int n_streams = 1;          // option "streams": concurrent sub-batches of dd_denoise (1 = off)
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -207,8 +207,10 @@ struct dd_handle_s {
   int64_t traj_serial = 0, use_traj = 0, weights_serial = 0, n_traj_reuse = 0;
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
-  DevBuf wgrad_ws;            // per-slab partial weight gradients of dd_wgrad.hip
-  std::map<std::string, std::unique_ptr<DevBuf>> grads;   // parameter gradients (fp32, reference shapes), accumulated like torch .grad
+  DevBuf wgrad_ws[MAX_LANES]; // per-slab partial weight gradients of dd_wgrad.hip (one workspace per concurrent lane)
+  // parameter gradients (fp32, reference shapes), accumulated like torch .grad in set 0; sets 1.. are the scratch of the concurrent lanes of
+  // dd_denoise_backward (added into set 0 and cleared at the join)
+  std::map<std::string, std::unique_ptr<DevBuf>> grads[MAX_LANES];
   std::map<std::tuple<int, int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision, lane) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
   bool neck_committed = false;            // hahineck.* folded + packed (DD_VARIANT_SWIN with the Swin-L pyramid only)
@@ -1326,7 +1328,7 @@ namespace {
 // The loop on B images (a whole call, or one lane of it: images img0 .. img0 + B - 1 of a batch of whole_B whose tensors start at the
 // pointers given -- already offset to the lane's first image) on stream s.
 int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
-                 int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0, int whole_B) {
+                 int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0, int whole_B, int64_t ticket) {
   int rc = DD_OK;
   const bool timed = h->timing && lane == 0 && B == whole_B;      // lanes: the caller brackets fork .. join
   Plan* pl = nullptr;
@@ -1420,7 +1422,7 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
   // x_0 = c1*x + c2*relu(gn4(y4)) of the last step, written NCHW
   DD_HIP(launch_final(x_last, static_cast<const float*>(pl->slot(pl->y4, T - 1)), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
                       h->L[3].beta.as<float>(), pl->c1c2.as<float>(), T - 1, 0, x_0, B, lat_h, lat_w, s));
-  if (keep) { pl->traj_ticket = ++h->traj_serial; pl->traj_weights = h->weights_serial; }
+  if (keep) { pl->traj_ticket = ticket; pl->traj_weights = h->weights_serial; }       // one ticket per dd_denoise call, shared by its lanes
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   return DD_OK;
 }
@@ -1442,13 +1444,14 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   // Option "streams" = S > 1: the images of a batch are independent (GroupNorm is per sample), so the batch runs as S concurrent
   // sub-batches, lane 0 on the caller's stream and the others on streams of the handle, forked and joined with events on the caller's
   // stream.  Each lane has its own plan (activation buffers, hipGraph); the workgroups of one lane's kernels fill the tail of the
-  // other's and hide its kernel boundaries.  Not for the naive path, the per-launch timing mode, or a forward that keeps its
-  // activations for the backward (one plan must hold the whole batch).
+  // other's and hide its kernel boundaries.  Not for the naive path or the per-launch timing mode.  A training forward
+  // ("keep_trajectory") keeps every lane's states and activations in that lane's plan under ONE ticket; dd_denoise_backward splits alike.
   int S = h->n_streams;
   if (S > B) S = B;
   if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
-  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->keep_traj || h->prof_buf) S = 1;
-  if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B);
+  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->prof_buf) S = 1;
+  const int64_t ticket = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? ++h->traj_serial : 0;
+  if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket);
   for (int l = 1; l < S; ++l) {
     if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
     if (!h->lane_done[l]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
@@ -1466,7 +1469,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
     hipStream_t ls = l == 0 ? s : h->lane_stream[l];
     if (l > 0) DD_HIP(hipStreamWaitEvent(ls, h->lane_fork, 0));
     rc = denoise_lane(h, x_T + img0 * n_x, cond ? cond + img0 * n_c : nullptr, x_0 + img0 * n_x, n, lat_h, lat_w, cond_h, cond_w, T, precision,
-                      ls, l, img0, B);
+                      ls, l, img0, B, ticket);
     if (l > 0) {                                           // join even after an error: the caller's stream must not run ahead of a lane
       (void)hipEventRecord(h->lane_done[l], ls);
       (void)hipStreamWaitEvent(s, h->lane_done[l], 0);
@@ -1563,14 +1566,15 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
 
 namespace {
 
-float* grad_buf(dd_handle_t h, const std::string& name, size_t numel, hipStream_t s, hipError_t* err) {
-  auto it = h->grads.find(name);
-  if (it == h->grads.end()) {
+float* grad_buf(dd_handle_t h, const std::string& name, size_t numel, hipStream_t s, hipError_t* err, int lane = 0) {
+  auto& set = h->grads[lane];
+  auto it = set.find(name);
+  if (it == set.end()) {
     std::unique_ptr<DevBuf> b(new DevBuf());
     *err = b->alloc(numel * 4);
     if (*err != hipSuccess) return nullptr;
     *err = hipMemsetAsync(b->p, 0, numel * 4, s);
-    it = h->grads.emplace(name, std::move(b)).first;
+    it = set.emplace(name, std::move(b)).first;
   }
   return it->second->as<float>();
 }
@@ -1580,14 +1584,14 @@ float* grad_buf(dd_handle_t h, const std::string& name, size_t numel, hipStream_
 int dd_zero_grad(dd_handle_t h, void* stream) {
   if (!h) return DD_ERR_INVALID_ARG;
   DD_HIP(hipSetDevice(h->device));
-  for (auto& kv : h->grads) DD_HIP(hipMemsetAsync(kv.second->p, 0, kv.second->bytes, reinterpret_cast<hipStream_t>(stream)));
+  for (auto& kv : h->grads[0]) DD_HIP(hipMemsetAsync(kv.second->p, 0, kv.second->bytes, reinterpret_cast<hipStream_t>(stream)));
   return DD_OK;
 }
 
 int dd_get_grad(dd_handle_t h, const char* name, float* dst, int64_t numel, void* stream) {
   if (!h || !name || !dst) return h ? h->fail(DD_ERR_INVALID_ARG, "dd_get_grad: null argument") : DD_ERR_INVALID_ARG;
-  auto it = h->grads.find(name);
-  if (it == h->grads.end()) return h->fail(DD_ERR_STATE, std::string("dd_get_grad: no gradient accumulated for '") + name + "'");
+  auto it = h->grads[0].find(name);
+  if (it == h->grads[0].end()) return h->fail(DD_ERR_STATE, std::string("dd_get_grad: no gradient accumulated for '") + name + "'");
   if ((size_t)numel * 4 != it->second->bytes)
     return h->fail(DD_ERR_INVALID_ARG, std::string("dd_get_grad: '") + name + "' has " + std::to_string(it->second->bytes / 4) + " elements");
   DD_HIP(hipSetDevice(h->device));
@@ -1618,7 +1622,7 @@ int ensure_bwd_buffers(dd_handle_t h, Plan* pl) {
 // (fp32 NHWC16).  Recomputes the forward pass (GroupNorm sums in stat slot 0), accumulates the parameter gradients into
 // h->grads, writes (or accumulates) dLoss/dcond as NCHW fp32 into grad_cond when that is not NULL.
 int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, int t_base, int t_bstride, float* grad_cond,
-             int accumulate_cond, hipStream_t s, const Plan* kept = nullptr, int kstep = 0) {
+             int accumulate_cond, hipStream_t s, const Plan* kept = nullptr, int kstep = 0, int lane = 0) {
   // kept != NULL: the forward pass of this step is NOT recomputed -- its raw conv outputs and GroupNorm sums are read from slot `kstep`
   // of the forward plan that kept them (PlanKey::keep == 2; same shape and element kinds as `pl`)
   const Plan* src = kept ? kept : pl;
@@ -1675,9 +1679,9 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
     const ActView yv{ybuf[l], ek_y, lay, C, HW}, gav{pl->gA.p, (l == 3) ? (int)EK_F32 : ek_g, lay, C, HW}, gyv{pl->gY.p, ek_g, lay, C, HW};
     const float* gamma = h->L[l].gamma.as<float>();
     const float* beta = h->L[l].beta.as<float>();
-    float* dgam = grad_buf(h, std::string(kGnNames[l]) + ".weight", C, s, &e); DD_HIP(e);
-    float* dbet = grad_buf(h, std::string(kGnNames[l]) + ".bias", C, s, &e); DD_HIP(e);
-    float* dbias = grad_buf(h, std::string(kConvNames[l]) + ".bias", C, s, &e); DD_HIP(e);
+    float* dgam = grad_buf(h, std::string(kGnNames[l]) + ".weight", C, s, &e, lane); DD_HIP(e);
+    float* dbet = grad_buf(h, std::string(kGnNames[l]) + ".bias", C, s, &e, lane); DD_HIP(e);
+    float* dbias = grad_buf(h, std::string(kConvNames[l]) + ".bias", C, s, &e, lane); DD_HIP(e);
     // 16-bit channel-blocked tensors (layers 0..2 of the fused bf16 / f16 modes): vectorised kernels, one pass for all sums
     const bool vec = !naive && ek != EK_F32 && l < 3;
     if (vec) {
@@ -1686,7 +1690,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       DD_HIP(launch_gn_bwd_apply_blocked(pl->gA.p, ybuf[l], ek, yk, st(l), gamma, beta, pl->dgb.as<double>(), pl->gY.p, nullptr,
                                          nullptr, nullptr, nullptr, 0, 0, B, C, HW, s));
       float* demb = nullptr;
-      if (l == 1) { demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e); }
+      if (l == 1) { demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e, lane); DD_HIP(e); }
       DD_HIP(launch_gn_param_grad4(pl->dgb.as<double>(), st(l), gamma, dgam, dbet, dbias, demb, tv, t_base, t_bstride, B, C, HW, s));
     } else {
       DD_HIP(hipMemsetAsync(pl->dgb.p, 0, (size_t)B * C * 2 * sizeof(double), s));
@@ -1695,12 +1699,12 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
       DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
     }
-    float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e); DD_HIP(e);
+    float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e, lane); DD_HIP(e);
     const ActView inv{inbuf[l], ek_g, lay, CI, HW};
     if (!naive && ek != EK_F32 && !h->naive_wgrad) {
       const size_t need = wgrad_workspace_bytes(C, CI, B, lat_h, lat_w);
-      if (h->wgrad_ws.bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws.alloc(need)); }
-      DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, h->wgrad_ws.as<float>(), ek, C, CI, B, lat_h, lat_w, s));
+      if (h->wgrad_ws[lane].bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws[lane].alloc(need)); }
+      DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, h->wgrad_ws[lane].as<float>(), ek, C, CI, B, lat_h, lat_w, s));
     } else {
       DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));     // fp32 operands: the unfused kernel (parity modes)
     }
@@ -1725,14 +1729,14 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       void* gbuf[3] = {pl->gA.p, pl->gY.p, pl->gA.p};      // gradient w.r.t. sf -> sa -> u
       for (int i = 0; i < 2; ++i) {
         const ActView gout{gbuf[i], ek, 1, COND_C, HW}, fv{fin[i], ek, 1, COND_C, HW};
-        float* db = grad_buf(h, std::string(fuse[i]) + ".bias", COND_C, s, &e); DD_HIP(e);
-        float* dwf = grad_buf(h, std::string(fuse[i]) + ".weight", (size_t)COND_C * COND_C * 9, s, &e); DD_HIP(e);
+        float* db = grad_buf(h, std::string(fuse[i]) + ".bias", COND_C, s, &e, lane); DD_HIP(e);
+        float* dwf = grad_buf(h, std::string(fuse[i]) + ".weight", (size_t)COND_C * COND_C * 9, s, &e, lane); DD_HIP(e);
         if (ek != EK_F32) DD_HIP(launch_channel_sum_blocked(gbuf[i], ek, db, B, COND_C, HW, s));
         else DD_HIP(launch_channel_sum(gout, db, nullptr, 0, 0, B, s));
         if (ek != EK_F32 && !h->naive_wgrad) {
           const size_t need = wgrad_workspace_bytes(COND_C, COND_C, B, lat_h, lat_w);
-          if (h->wgrad_ws.bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws.alloc(need)); }
-          DD_HIP(launch_wgrad_mfma(gbuf[i], fin[i], dwf, h->wgrad_ws.as<float>(), ek, COND_C, COND_C, B, lat_h, lat_w, s));
+          if (h->wgrad_ws[lane].bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws[lane].alloc(need)); }
+          DD_HIP(launch_wgrad_mfma(gbuf[i], fin[i], dwf, h->wgrad_ws[lane].as<float>(), ek, COND_C, COND_C, B, lat_h, lat_w, s));
         } else {
           DD_HIP(launch_naive_wgrad(gout, fv, dwf, B, lat_h, lat_w, s));
         }
@@ -1755,7 +1759,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
         else DD_HIP(launch_view_to_nchw(gf, grad_cond, B, accumulate_cond, s));
       }
       if (naive || ek == EK_F32) {     // (16-bit modes: the layer-1 reduction pass below also sums g_f per channel)
-        float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e); DD_HIP(e);
+        float* demb = grad_buf(h, "model.time_embedding.weight", (size_t)EMB_ROWS * COND_C, s, &e, lane); DD_HIP(e);
         DD_HIP(launch_channel_sum(gf, demb, tv, t_base, t_bstride, B, s));
       }
     }
@@ -1799,18 +1803,16 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   return DD_OK;
 }
 
-int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
-                        int B, int lat_h, int lat_w, int cond_h, int cond_w, int T, int precision, void* stream) {
-  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
-  if (rc) return rc;
-  if (!x_T || !grad_x0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: null pointer");
-  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: num_inference_steps must be in [1, num_train_timesteps]");
-  rc = check_bwd(h, precision, "dd_denoise_backward");
-  if (rc) return rc;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  DD_HIP(hipSetDevice(h->device));
+}  // extern "C"
+
+namespace {
+// The loop backward on B images (a whole call or one lane of it, see denoise_lane); parameter gradients go to gradient set `lane`.
+int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
+                          int B, int lat_h, int lat_w, int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0,
+                          int whole_B, int64_t ticket, bool* reused) {
+  int rc = DD_OK;
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, 0}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, 0, 0, lane}, &pl);
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1819,21 +1821,20 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   // The states entering each step: kept by the forward call (option "keep_trajectory" + the ticket passed through "use_trajectory": same
   // shape, same parameters, nothing run on that plan since), else regenerated here by running the forward loop again.
   const Plan* kept = nullptr;
-  for (int lvl = 2; lvl >= 1 && !kept && h->use_traj != 0 && !naive; --lvl) {
-    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), lvl});
-    if (it != h->plans.end() && it->second->traj_ticket == h->use_traj && it->second->traj_weights == h->weights_serial) kept = it->second.get();
+  for (int lvl = 2; lvl >= 1 && !kept && ticket != 0 && !naive; --lvl) {
+    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), lvl, lane});
+    if (it != h->plans.end() && it->second->traj_ticket == ticket && it->second->traj_weights == h->weights_serial) kept = it->second.get();
   }
   const Plan* kept_act = (kept && kept->key.keep == 2 && kept->ek == pl->ek) ? kept : nullptr;      // activations too: no recompute
-  h->use_traj = 0;
+  *reused = kept != nullptr;
   const size_t need = (size_t)(kept ? 1 : T + 1) * n16 * 4;
   if (pl->xstash.bytes < need) DD_HIP(pl->xstash.alloc(need));
   float* Xown = pl->xstash.as<float>();
   const float* X = kept ? kept->xstash.as<float>() : Xown;      // X[k] = state entering step k (k < T)
   float* G = kept ? Xown : Xown + (size_t)T * n16;              // running dLoss/dx
   const long long* ts = pl->tsteps.as<long long>();
-  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
+  rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s, img0, whole_B);
   if (rc) return rc;
-  if (kept) h->n_traj_reuse++;
   // ---- forward loop again, keeping every intermediate state (16 channels: T x 6.8 MB per KITTI image) ----
   if (!kept) DD_HIP(launch_nchw_to_nhwc(x_T, Xown, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   if (!kept) DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
@@ -1857,11 +1858,74 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   DD_HIP(launch_nchw_to_nhwc(grad_x0, G, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   for (int k = T - 1; k >= 0; --k) {
     DD_HIP(launch_bwd_chain(G, pl->gA.as<float>(), pl->c1c2.as<float>(), k, 0, (long long)n16, s));          // gA = c2_k G
-    rc = bwd_core(h, pl, X + (size_t)k * n16, ts, k, 0, grad_cond, k < T - 1 ? 1 : 0, s, kept_act, k);
+    rc = bwd_core(h, pl, X + (size_t)k * n16, ts, k, 0, grad_cond, k < T - 1 ? 1 : 0, s, kept_act, k, lane);
     if (rc) return rc;
     DD_HIP(launch_bwd_chain(G, pl->gA.as<float>(), pl->c1c2.as<float>(), k, 1, (long long)n16, s));          // G = c1_k G + gA
   }
   if (grad_xT) DD_HIP(launch_nhwc_to_nchw_f32(G, EK_F32, grad_xT, B, LATENT_C, lat_h, lat_w, 0, s));
+  return DD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
+                        int B, int lat_h, int lat_w, int cond_h, int cond_w, int T, int precision, void* stream) {
+  int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, true);
+  if (rc) return rc;
+  if (!x_T || !grad_x0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: null pointer");
+  if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_backward: num_inference_steps must be in [1, num_train_timesteps]");
+  rc = check_bwd(h, precision, "dd_denoise_backward");
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DD_HIP(hipSetDevice(h->device));
+  const int64_t ticket = h->use_traj;
+  h->use_traj = 0;
+  // Option "streams": the images' backward passes are independent except for the parameter gradients -- every lane accumulates into its
+  // own gradient set and weight-gradient workspace, the sets of lanes 1.. are added into set 0 (what dd_get_grad reads) after the join.
+  int S = h->n_streams;
+  if (S > B) S = B;
+  if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
+  if (precision == DD_PREC_NAIVE_FP32 || h->debug_sync) S = 1;
+  bool reused = false;
+  if (S <= 1) {
+    rc = denoise_backward_lane(h, x_T, cond, grad_x0, grad_xT, grad_cond, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, &reused);
+    if (rc == DD_OK && reused) h->n_traj_reuse++;
+    return rc;
+  }
+  for (int l = 1; l < S; ++l) {
+    if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    if (!h->lane_done[l]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
+  }
+  if (!h->lane_fork) DD_HIP(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
+  DD_HIP(hipEventRecord(h->lane_fork, s));
+  const size_t n_x = (size_t)LATENT_C * lat_h * lat_w, n_c = (size_t)COND_C * cond_h * cond_w;
+  int img0 = 0;
+  bool all_reused = true;
+  for (int l = 0; l < S; ++l) {
+    const int n = B / S + (l < B % S ? 1 : 0);
+    hipStream_t ls = l == 0 ? s : h->lane_stream[l];
+    if (l > 0) DD_HIP(hipStreamWaitEvent(ls, h->lane_fork, 0));
+    rc = denoise_backward_lane(h, x_T + img0 * n_x, cond ? cond + img0 * n_c : nullptr, grad_x0 + img0 * n_x, grad_xT ? grad_xT + img0 * n_x : nullptr,
+                               grad_cond ? grad_cond + img0 * n_c : nullptr, n, lat_h, lat_w, cond_h, cond_w, T, precision, ls, l, img0, B, ticket, &reused);
+    all_reused = all_reused && reused;
+    if (l > 0) {
+      (void)hipEventRecord(h->lane_done[l], ls);
+      (void)hipStreamWaitEvent(s, h->lane_done[l], 0);
+    }
+    if (rc) return rc;
+    img0 += n;
+  }
+  // after the join, on the caller's stream: set 0 += set l, set l = 0
+  for (int l = 1; l < S; ++l)
+    for (auto& kv : h->grads[l]) {
+      hipError_t e = hipSuccess;
+      float* dst = grad_buf(h, kv.first, kv.second->bytes / 4, s, &e, 0); DD_HIP(e);
+      DD_HIP(launch_add_inplace(dst, kv.second->as<float>(), (long long)(kv.second->bytes / 4), s));
+      DD_HIP(hipMemsetAsync(kv.second->p, 0, kv.second->bytes, s));
+    }
+  if (all_reused) h->n_traj_reuse++;
+  h->n_lane_calls++;
   return DD_OK;
 }
 

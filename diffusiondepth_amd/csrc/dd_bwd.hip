@@ -635,6 +635,17 @@ hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int
   return hipGetLastError();
 }
 
+// dst += src (parameter-gradient sets of the concurrent backward lanes, dd_api.cpp)
+__global__ void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+hipError_t launch_add_inplace(float* dst, const float* src, long long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, src, n);
+  return hipGetLastError();
+}
+
 // dgamma_c += sum_b dgb[b][c][1],  dbeta_c += sum_b dgb[b][c][0]
 __global__ void gn_param_grad_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;

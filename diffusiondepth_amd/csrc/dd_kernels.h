@@ -155,6 +155,7 @@ hipError_t launch_channel_sum_blocked(const void* v, int ek, float* out, int B, 
 // adjoint of the align_corners bilinear upsample: blocked 2-byte (h, w) gradient -> NCHW fp32 (ch, cw) gradient
 hipError_t launch_upsample_adjoint(const void* g, int ek, float* dst, int B, int C, int ch, int cw, int h, int w, int accumulate, hipStream_t s, bool tiled = true);
 hipError_t launch_channel_sum(const ActView& v, float* out, const long long* rows, int t_base, int t_bstride, int B, hipStream_t s);
+hipError_t launch_add_inplace(float* dst, const float* src, long long n, hipStream_t s);
 hipError_t launch_gn_param_grad(const double* dgb, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
 hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oihw, int B, int h, int w, hipStream_t s);
 // MFMA weight gradient (dd_wgrad.hip), bf16 / f16 operands in the activation layouts, fp32 atomics into dw [CO][CI][3][3]

@@ -211,6 +211,42 @@ def test_loop_backward_on_the_states_the_forward_kept(U, cases, prec):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("variant,prec", [("res", "bf16"), ("res", "fp32"), ("swin", "bf16")])
+def test_training_pair_as_concurrent_lanes_equals_one_stream(U, cases, variant, prec):
+    """dd_set_option("streams", 2) in training: the state-keeping forward and the backward run the batch as two concurrent sub-batches on
+    separate HIP streams (per-lane plans, kept activations, gradient sets and weight-gradient workspaces; the sets are summed at the join).
+    Per-image results (x_0, grad_xT, grad_cond) are bit-identical to one stream; the parameter gradients are sums over the batch in another
+    order.  Three images on two lanes (2 + 1)."""
+    import diffusiondepth_amd as dda
+    be = dda.HipDenoiser(variant=variant)
+    be.load_state_dict(synth.make_state_dict(7240, variant))
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    B, h, w, T = 3, 24, 72, 3
+    inp = synth.make_inputs(31, B, h, w, (12, 36)) if variant == "swin" else synth.make_inputs(31, B, h, w)
+    x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+    g = U.cu(np.random.RandomState(2).standard_normal(inp["x_T"].shape).astype(np.float32))
+    names = list(be.param_shapes())
+    res = {}
+    try:
+        for S in (1, 2):
+            be.set_option("streams", S)
+            for rep in range(2):                       # second pass: replayed lane graphs, reused buffers
+                n0, r0 = be.counter("lane_calls"), be.counter("trajectory_reuses")
+                out = be.denoise(x, cond, T, prec, keep_trajectory=True)
+                be.zero_grad()
+                gx, gc = be.denoise_backward(x, cond, g, T, prec, need_grad_xT=True, trajectory_ticket=be.last_trajectory_ticket)
+                assert be.counter("trajectory_reuses") == r0 + 1 and be.counter("lane_calls") == n0 + (2 if S > 1 else 0)
+            res[S] = [out, gx, gc] + [be.grad(n) for n in names]
+    finally:
+        be.set_option("streams", 1)
+    for k in range(3):
+        assert torch.equal(res[2][k], res[1][k]), ("x0", "grad_xT", "grad_cond")[k]
+    bad = {n: _rel(a.cpu().numpy(), b.cpu().numpy()) for n, a, b in zip(names, res[2][3:], res[1][3:])}
+    bad = {n: e for n, e in bad.items() if e > 2e-5}
+    assert not bad, bad
+    be.close()
+
+
 def test_loop_backward_t1_equals_single_call(U, cases):
     """T = 1: x_0 = c1 x_T + c2 eps(x_T, t = 0)  ->  the loop backward is one denoiser VJP scaled by c2 plus c1 * g."""
     import diffusiondepth_amd as dda

@@ -427,8 +427,8 @@ def test_16bit_backward_close_to_the_fp32_backward(on_host, variant, hw, cond_hw
 def test_concurrent_lanes_return_the_single_stream_result(on_host, variant, cond_hw, precs, lanes):
     """dd_set_option("streams", S): dd_denoise runs a batch as S concurrent sub-batches (own plans, buffers and graphs per lane; fork / join
     by events on the caller's stream).  Same bytes as one stream -- the images are independent -- with an explicit condition tensor (each
-    lane converts its slice; Swin: upsamples it), uneven split (3 images on 2 lanes), replayed lane graphs; the trajectory-keeping training
-    forward stays on one stream.  (The lanes' slices of a condition map left by dd_condition: tests/test_gpu_fpn.py.)"""
+    lane converts its slice; Swin: upsamples it), uneven split (3 images on 2 lanes), replayed lane graphs; then the training pair
+    (state-keeping forward + backward) as lanes.  (The lanes' slices of a condition map left by dd_condition: tests/test_gpu_fpn.py.)"""
     be = on_host(CPU, variant)
     be.load_state_dict(synth.make_state_dict(7240, variant))
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
@@ -445,6 +445,24 @@ def test_concurrent_lanes_return_the_single_stream_result(on_host, variant, cond
             assert be.counter("lane_calls") == n0 + 1
             assert torch.equal(got, want), (prec, S)
         assert torch.equal(be.denoise(x, cond, T, prec), want)               # second call: the lanes' graphs replay
-        n0 = be.counter("lane_calls")
-        assert torch.equal(be.denoise(x, cond, T, prec, keep_trajectory=True), want) and be.counter("lane_calls") == n0
     be.set_option("streams", 1)
+    if variant != "res":
+        return
+    # training: forward that keeps its states / activations + backward, as lanes vs on one stream.  Every lane keeps its images in its own
+    # plan under ONE ticket, the backward splits alike, parameter gradients are summed over the lanes' gradient sets at the join.
+    prec = precs[0]
+    g = torch.from_numpy(np.random.RandomState(7).standard_normal(inp["x_T"].shape).astype(np.float32))
+    names = ["model.pred.3.weight", "model.noise_embedding.3.weight", "model.pred.1.weight", "model.pred.0.bias", "model.time_embedding.weight"]
+    res = {}
+    for S in (1, 2):
+        be.set_option("streams", S)
+        n0, r0 = be.counter("lane_calls"), be.counter("trajectory_reuses")
+        out = be.denoise(x, cond, 2, prec, keep_trajectory=True)
+        be.zero_grad()
+        gx, gc = be.denoise_backward(x, cond, g, 2, prec, need_grad_xT=True, trajectory_ticket=be.last_trajectory_ticket)
+        assert be.counter("trajectory_reuses") == r0 + 1 and be.counter("lane_calls") == n0 + (2 if S > 1 else 0)
+        res[S] = [out, gx, gc] + [be.grad(n) for n in names]
+    be.set_option("streams", 1)
+    assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1]) and torch.equal(res[2][2], res[1][2])     # per-image results
+    for a, b_ in zip(res[2][3:], res[1][3:]):                                                                                # sums over the batch: order
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max())
