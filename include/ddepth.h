@@ -211,6 +211,7 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
  * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent, the result is bit-identical;
+ * dd_denoise_backward splits the same way, with one parameter-gradient set per lane summed into the caller-visible one at the join;
  * default 1), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
  * "keep_activations_mb" (budget of the per-step activation slots kept by a "keep_trajectory" forward, default 65536). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
