@@ -2,6 +2,7 @@
 """Timing ablation of the v2 conv kernels (results are WRONG under ablation; timing only).
 Prints per-layer average launch time (us) for a set of ablation masks."""
 import os, sys, json
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import diffusiondepth_amd as dda

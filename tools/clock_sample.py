@@ -2,6 +2,7 @@
 """Samples sclk / socket power (rocm-smi) while the DDIM loop runs back to back: is the chip clock- or power-limited under
 the MFMA kernels?   python tools/clock_sample.py [precision] [batch]"""
 import os, re, subprocess, sys, threading, time
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import diffusiondepth_amd as dda

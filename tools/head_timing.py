@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end head timing on the GPU: PyTorch-ROCm FPN (condition aggregation) vs the HIP hot path."""
 import os, sys, time
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import diffusiondepth_amd as dda

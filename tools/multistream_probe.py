@@ -4,6 +4,7 @@
 activation buffers are per handle).  Prints maps/s of one B-image loop vs S concurrent (B/S)-image loops.
     python tools/multistream_probe.py [B] [precision]"""
 import os, sys, time
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # the lanes here are the probe's own handles / streams
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import diffusiondepth_amd as dda
@@ -22,7 +23,7 @@ def make():
     return be
 
 
-def bench(S, n=12):
+def bench(S, n=12, stagger_us=0.0):
     hs = [make() for _ in range(S)]
     ss = [torch.cuda.Stream() for _ in range(S)]
     per = B // S
@@ -37,6 +38,10 @@ def bench(S, n=12):
     for _ in range(3):
         once()
     torch.cuda.synchronize()
+    if stagger_us > 0:          # streams 1.. start late by i * stagger_us; nothing re-aligns them before the final synchronize
+        for i in range(1, S):
+            with torch.cuda.stream(ss[i]):
+                torch.cuda._sleep(int(i * stagger_us * 100))       # wall-clock counter: 100 MHz
     t0 = time.perf_counter()
     for _ in range(n):
         once()
@@ -52,3 +57,8 @@ for S in [s for s in (1, 2, 4, 8) if B % s == 0 and s <= B]:
         ref = out
     err = float((out - ref).abs().max() / ref.abs().max())
     print(f"B={B} {prec}: {S} stream(s) x {B // S} image(s): {dt * 1e3:.3f} ms per {B} maps = {B / dt:.1f} maps/s   (max rel diff vs one stream {err:.1e})", flush=True)
+
+if len(sys.argv) > 3:
+    for st in [float(v) for v in sys.argv[3].split(",")]:
+        dt, _ = bench(2, n=24, stagger_us=st)
+        print(f"B={B} {prec}: 2 streams, second one starts {st:.0f} us late: {dt * 1e3:.3f} ms per {B} maps = {B / dt:.1f} maps/s", flush=True)

@@ -9,6 +9,7 @@ the eager loop and summarises: phase durations, workgroup lifetime, concurrency 
     python tools/phase_prof.py run [layers] [B] [prec]    (on the GPU box; layers e.g. 2,9,1,4)
 """
 import os, subprocess, sys
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 VARIANT = os.path.join(ROOT, "build_variants", "libddepth_hip_prof.so")
 

@@ -3,6 +3,7 @@
 ~1.5 s and sample sclk / socket power -> ms per loop, average clock, average power, joules per loop.
     DDEPTH_LIBRARY=build_variants/lib_abl.so python tools/power_ablate.py [precision] [batch] [mask,mask,...]"""
 import os, re, subprocess, sys, threading, time
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 import diffusiondepth_amd as dda

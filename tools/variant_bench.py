@@ -2,6 +2,7 @@
 """One library variant (DDEPTH_LIBRARY): quick parity against the fp64 oracle on ragged shapes, then loop / per-layer times at KITTI size.
     DDEPTH_LIBRARY=build_variants/libddepth_x.so python tools/variant_bench.py [B ...]"""
 import os, sys, json
+os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import diffusiondepth_amd as dda
