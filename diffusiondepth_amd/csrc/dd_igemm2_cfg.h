@@ -29,6 +29,18 @@
 #ifndef DD_C3_2_RD1
 #define DD_C3_2_RD1 1      // 16x32 conv3 tiles: raw patch one chunk ahead only (registers: two workgroups per CU need <= 128 VGPRs beside the accumulators)
 #endif
+// Swin fuse convs (256 -> 256, layers 5 / 6) in the 2-byte kinds: 0 = 32-channel chunks, one tap per stage (16 MFMAs per wave between
+// barriers); 1 [default since round 2: convB -4.6 %, convA -5 % with the two options below] = 16-channel chunks, three taps per stage
+// (24 MFMAs between barriers, 46 KB of LDS)
+#ifndef DD_SWIN_TG3
+#define DD_SWIN_TG3 1
+#endif
+#ifndef DD_SWIN_FD2
+#define DD_SWIN_FD2 1      // convA with DD_SWIN_TG3: two-deep fragment registers (the 32-channel-chunk prologue left no room for them)
+#endif
+#ifndef DD_SWIN_RD2
+#define DD_SWIN_RD2 1      // convB with DD_SWIN_TG3: raw patch two chunks ahead
+#endif
 #ifndef DD_CONV2_DUAL
 #define DD_CONV2_DUAL 1
 #endif
@@ -94,9 +106,10 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
   static constexpr bool C3SHAPE = (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);
   static constexpr int C3 = (C3SHAPE && ESZ == 2) ? DD_C3 : 0;
-  static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0) ? 16 : (64 / ESZ);
+  static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2;
+  static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0 || SWIN3) ? 16 : (64 / ESZ);
   static constexpr int TG = (LAYER == 1 || LAYER == 20 || C3 != 0) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
-                          : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
+                          : SWIN3 ? 3 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = IS_NECK ? 64 : (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
@@ -140,8 +153,8 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
   // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
   // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
-  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
-  static constexpr int FRAG_DEPTH = (LAYER == 5) ? 1 : DD_FRAG_DEPTH;
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22 || (LAYER == 6 && SWIN3 && DD_SWIN_RD2)) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
+  static constexpr int FRAG_DEPTH = (LAYER == 5 && !(SWIN3 && DD_SWIN_FD2)) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
   static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS
