@@ -17,7 +17,7 @@ echo "== C4 train-dp res B=4"; timeout 400 python bench.py --mode train-dp --var
 echo "== N=1 under the launcher (RCCL process group: init, barrier, all-reduce of the timing)"; timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --no-train-extra --no-nlspn-extra --no-head-extra --no-latency-b1 > gpurun_out/bench_launcher_n1.log 2>&1; echo "rc=$?"; tail -n 1 gpurun_out/bench_launcher_n1.log | cut -c1-300
 echo "== C5 swin f16 T=50 B=1 (+NLSPN extra)"; timeout 600 python bench.py --variant swin --precision f16 --T 50 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra > gpurun_out/bench_c5_swin_f16_t50_b1.log 2>&1; tail -n 1 gpurun_out/bench_c5_swin_f16_t50_b1.log | cut -c1-400
 echo "== rocprof"
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_bf16" -o bench --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-train-extra --no-latency-b1 --no-nlspn-extra --no-head-extra > "$OLDPWD/gpurun_out/rocprof_bf16.log" 2>&1); echo "rocprof rc=$?"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_bf16" -o bench --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 1 --no-cpu-baseline --no-train-extra --no-latency-b1 --no-streams-extra --no-nlspn-extra --no-head-extra > "$OLDPWD/gpurun_out/rocprof_bf16.log" 2>&1); echo "rocprof rc=$?"
 for f in $(find gpurun_out/prof_bf16 -name "*kernel_stats.csv" | head -1); do head -n 12 "$f" | cut -c1-200; done
 find gpurun_out/prof_bf16 -name "*kernel_trace.csv" -delete
 echo "== pmc"; bash tools/gpu/pmc.sh > gpurun_out/pmc.log 2>&1; tail -n 30 gpurun_out/pmc.log
