@@ -378,7 +378,7 @@ def main():
     be.set_option("hoist_cond", args.hoist)
     be.set_option("bf16_storage", 1 if args.bf16_storage else 0)
     be.set_option("streams", args.streams)
-    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and args.precision == "bf16" and not args.bf16_storage))
+    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision == "f16")))
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)

@@ -205,8 +205,8 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * Time of the last dd_denoise graph launch measured with hipEvents recorded on `stream` around
  * the graph (0 if timing is off).  dd_set_option("timing", 1) enables it; other options:
  * "graph" (1 = hipGraph replay [default], 0 = eager launches), "debug_sync" (1 = sync + check
- * after every launch), "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 [default] = the
- * condition map is re-added in conv3's prologue every step), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
+ * after every launch), "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 = the
+ * condition map is re-added in conv3's prologue every step; -1 [default] = hoisted in the bf16 and f16 modes of the Res variant), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked

@@ -326,7 +326,8 @@ def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     sd = synth.make_state_dict(7240)
     be.load_state_dict(sd)
     be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
-    T, prec = 2, ("fp32" if FULL else "f16")       # modes without the hoisted condition term: kept and regenerated states are the same bytes
+    T, prec = 2, ("fp32" if FULL else "f16")
+    be.set_option("hoist_cond", 0)                 # without the hoisted condition term the kept and the regenerated states are the same bytes
     inp, inp2 = synth.make_inputs(5, 1, 6, 33), synth.make_inputs(6, 1, 6, 33)
     x, cond, x2 = torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["cond"]), torch.from_numpy(inp2["x_T"])
     g = torch.from_numpy(np.random.RandomState(3).standard_normal(inp["x_T"].shape).astype(np.float32))
