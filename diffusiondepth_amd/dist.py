@@ -351,6 +351,8 @@ class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
     """BatchNorm over the global batch in .train() under an initialised process group of more than one rank; plain batch_norm otherwise
     (eval mode, a single process).  Same parameters / buffers / state-dict keys as nn.BatchNorm{1,2,3}d."""
 
+    force_sync = False      # tests: take the exchanging path with a single rank too (exercises the collectives on a one-GPU box)
+
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, process_group=None):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.process_group = process_group
@@ -361,7 +363,7 @@ class SyncBatchNorm(torch.nn.modules.batchnorm._BatchNorm):
 
     def forward(self, x):
         self._check_input_dim(x)
-        sync = self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
+        sync = self.training and dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.process_group) > 1 or self.force_sync)
         if not sync:
             return super().forward(x)
         momentum = 0.0 if self.momentum is None else self.momentum
