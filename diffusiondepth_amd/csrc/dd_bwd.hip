@@ -362,25 +362,39 @@ hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, in
 // Parameter gradients of one layer from the per (b, c) sums [B][C][4] of gn_bwd_reduce_blocked_kernel:
 //   dbeta_c += sum_b s0,  dgamma_c += sum_b s1,  dbias_c += sum_b sum_p g_y = sum_b (A_c s0 + HW P_g + Q_g s2)   (g_y as above),
 //   demb[t_b][c] += s3 (only when demb != NULL).
+// One workgroup per GroupNorm group, one thread per channel of it: the gamma-weighted group sums S1, S2 of every image are reduced across the
+// group's threads in LDS (each thread used to re-read all C/4 channels' sums per image: 32 us of dependent loads for a kernel that moves 16 KB).
 __global__ void gn_param_grad4_kernel(const double* __restrict__ sums, const double* __restrict__ stats, const float* __restrict__ gamma,
                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias, float* __restrict__ demb,
                                       const long long* __restrict__ tvec, int t_base, int t_bstride, int B, int C, long long HW) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const int CG = C / GN_GROUPS, grp = c / CG;
+  __shared__ double s_part[2][64];
+  __shared__ double s_tot[2];
+  const int CG = C / GN_GROUPS, grp = blockIdx.x, tid = threadIdx.x;      // blockDim.x == CG <= 64
+  const int c = grp * CG + tid;
+  const double g = (double)gamma[c];
   double sb = 0.0, sg = 0.0, sbias = 0.0;
   for (int b = 0; b < B; ++b) {
     const double* sc = sums + ((size_t)b * C + c) * 4;
-    sb += sc[0]; sg += sc[1];
+    const double s0 = sc[0], s1c = sc[1], s2c = sc[2], s3c = sc[3];
+    s_part[0][tid] = g * s0;
+    s_part[1][tid] = g * s1c;
+    __syncthreads();
+    if (tid < 2) {
+      double t = 0.0;
+      for (int k = 0; k < CG; ++k) t += s_part[tid][k];      // channel order: the sums of the previous kernel, bit for bit
+      s_tot[tid] = t;
+    }
+    __syncthreads();
+    const double s1 = s_tot[0], s2 = s_tot[1];
     float mean, rstd;
     group_moments(stats, b, grp, (double)HW * CG, mean, rstd);
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = grp * CG; k < (grp + 1) * CG; ++k) { s1 += (double)gamma[k] * sums[((size_t)b * C + k) * 4]; s2 += (double)gamma[k] * sums[((size_t)b * C + k) * 4 + 1]; }
     const double inv_n = 1.0 / ((double)HW * CG);
     const double qg = -(double)rstd * rstd * s2 * inv_n;
     const double pg = -(double)rstd * s1 * inv_n - (double)mean * qg;
-    sbias += (double)gamma[c] * rstd * sc[0] + (double)HW * pg + qg * sc[2];
-    if (demb) atomicAdd(demb + (size_t)clamp_t(tvec[t_base + b * t_bstride]) * C + c, (float)sc[3]);
+    sb += s0; sg += s1c;
+    sbias += g * rstd * s0 + (double)HW * pg + qg * s2c;
+    if (demb) atomicAdd(demb + (size_t)clamp_t(tvec[t_base + b * t_bstride]) * C + c, (float)s3c);
+    __syncthreads();                                          // s_part / s_tot are rewritten for the next image
   }
   dbeta[c] += (float)sb;
   dgamma[c] += (float)sg;
@@ -388,7 +402,8 @@ __global__ void gn_param_grad4_kernel(const double* __restrict__ sums, const dou
 }
 hipError_t launch_gn_param_grad4(const double* sums_bc4, const double* stats, const float* gamma, float* dgamma, float* dbeta, float* dbias,
                                  float* demb, const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s) {
-  hipLaunchKernelGGL(gn_param_grad4_kernel, dim3((C + 63) / 64), dim3(64), 0, s, sums_bc4, stats, gamma, dgamma, dbeta, dbias, demb, tvec,
+  if (C % GN_GROUPS != 0 || C / GN_GROUPS > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_param_grad4_kernel, dim3(GN_GROUPS), dim3(C / GN_GROUPS), 0, s, sums_bc4, stats, gamma, dgamma, dbeta, dbias, demb, tvec,
                      t_base, t_bstride, B, C, HW);
   return hipGetLastError();
 }
