@@ -394,6 +394,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   if (abl & 1024) return;
   // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
   auto mfma_block = [&](int chunk, int tg) {
+#if DD_SETPRIO && !defined(DD_HOST_EMULATION)
+    __builtin_amdgcn_s_setprio(DD_SETPRIO);      // the wave inside its MFMA block wins issue arbitration against the co-resident workgroup's staging wave
+#endif
     const int s = sbase + chunk * C::NTG + tg;
     const int poff = (chunk & (C::NPB - 1)) * C::PATCH_BYTES;
     const int woff = (s & (C::NWB - 1)) * C::W_BYTES;
@@ -451,6 +454,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
       }
     }
+#if DD_SETPRIO && !defined(DD_HOST_EMULATION)
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   constexpr int NRAW = NIT * NLD * ((C::PRO == PRO_GN || C::PRO == PRO_RAW) ? 1 : 2);   // raw-patch loads per load_raw()

@@ -35,6 +35,10 @@
 #ifndef DD_SWIN_TG3
 #define DD_SWIN_TG3 1
 #endif
+// s_setprio level of a wave while it is inside a stage's MFMA block (0 = off)
+#ifndef DD_SETPRIO
+#define DD_SETPRIO 0
+#endif
 #ifndef DD_SWIN_FD2
 #define DD_SWIN_FD2 1      // convA with DD_SWIN_TG3: two-deep fragment registers (the 32-channel-chunk prologue left no room for them)
 #endif
