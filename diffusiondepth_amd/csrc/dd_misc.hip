@@ -35,12 +35,29 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restri
   const int tid = threadIdx.x;
   const int px = tid & 63, cs = tid >> 6;
   const float* s = src + ((size_t)b * C) * HW;
+  if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    // 16-B loads along the pixels of a channel plane: four independent loads per thread in flight (the scalar form below has 16 x 4 B)
+    const int q = tid & 15, crow = tid >> 4;          // 16 quads of pixels x 16 channels per pass, 4 passes
+    float4 v4[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = cc * 16 + crow;
+      v4[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + 4 * q < HW && c0 + c < C) v4[cc] = *reinterpret_cast<const float4*>(s + (size_t)(c0 + c) * HW + p0 + 4 * q);   // HW % 4 == 0: a quad is inside or outside
+    }
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = cc * 16 + crow;
+      tile[4 * q + 0][c] = v4[cc].x; tile[4 * q + 1][c] = v4[cc].y; tile[4 * q + 2][c] = v4[cc].z; tile[4 * q + 3][c] = v4[cc].w;
+    }
+  } else {
 #pragma unroll 4
   for (int cc = 0; cc < 16; ++cc) {
     const int c = cc * 4 + cs;
     float v = 0.f;
     if (p0 + px < HW && c0 + c < C) v = s[(size_t)(c0 + c) * HW + p0 + px];
     tile[px][c] = v;
+  }
   }
   __syncthreads();
   const int opx = tid >> 2, part = tid & 3;           // 4 threads per pixel, 16 channels each
