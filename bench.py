@@ -127,16 +127,20 @@ def head_extra(dev, B, H, W, precision, T, variant="res"):
     fp = [torch.from_numpy(f).to(dev) for f in synth.make_backbone_features(1, B, H // 2 if swin else H, W // 2 if swin else W, in_channels=chans)]
     gt = torch.from_numpy(synth.make_gt_depth(2, B, H, W)).to(dev)
 
-    def timed(n=5):
+    def timed(n=7):
+        # median of per-forward times: one host-side pause (a 25-ms stall between two library calls was traced in a 5-forward average:
+        # profiles/r02_run29_lanes_head_trace.md) must not pass for the forward's cost
+        ts = []
         with torch.no_grad():
             for _ in range(2):
                 head(fp, gt, gt > 0, gt_depth_map=gt)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
             for _ in range(n):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
                 head(fp, gt, gt > 0, gt_depth_map=gt)
-            torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / n * 1e3
+                torch.cuda.synchronize(dev)
+                ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
     t_ref = timed()
     head.loss_noise_device = "device"
     t_dev = timed()

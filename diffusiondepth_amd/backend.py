@@ -143,9 +143,8 @@ class HipDenoiser:
         self._cond_token = None      # (tensor, version, precision id) of the map the last condition() call returned
         # DDEPTH_STREAMS=S: dd_denoise / dd_denoise_backward run a batch of B >= 2 as S concurrent sub-batches on separate HIP streams
         # (dd_set_option "streams": +6..13 % throughput on MI355X in a process with one handle, per-image results bit-identical, the whole
-        # GPU suite passes with it).  Opt-in: one configuration is erratic -- the head's eval forward with its ddim_loss call took 8.6 ms in
-        # some processes and 12.9-14.8 ms in others with two lanes (9.0-9.5 on one stream; tools/lanes_head_probe.py) -- so it is a knob to
-        # turn on where it was measured (bench.py --mode train-dp does), not a default.
+        # GPU suite passes with it).  Opt-in (bench.py --mode train-dp turns it on); an apparent instability of the head forward under it was
+        # a host-side pause in a short average (profiles/r02_run29_lanes_head_trace.md).
         self.n_streams = max(1, int(os.environ.get("DDEPTH_STREAMS", "1") or 1))
         if self.n_streams > 1:
             self.set_option("streams", self.n_streams)

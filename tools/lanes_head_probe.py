@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """bench.py's default run once showed the head forward (second handle, two lanes) at 14.8 instead of 9.2 ms after the bench's own handle
-had run lanes, a B=1 plan and a training pass.  Replays that order and prints the head backend's counters per configuration."""
+had run lanes, a B=1 plan and a training pass.  Replays that order and prints per-forward times and the head backend's counters.  Finding
+(profiles/r02_run29_lanes_head_trace.md): ONE forward of the five stalls ~25 ms on the host between two library calls; the others take 8.5 ms."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ["DDEPTH_STREAMS"] = sys.argv[1] if len(sys.argv) > 1 else "2"
@@ -46,12 +47,13 @@ def timed(n=5):
         torch.cuda.synchronize(dev)
         hb = head._bound.backend
         c0 = {k: hb.counter(k) for k in ("graph_launches", "eager_loops", "plans", "lane_calls")}
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(n):
+            t0 = time.perf_counter()
             head(fp, gt, gt > 0, gt_depth_map=gt)
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / n * 1e3
-        return dt, {k: hb.counter(k) - v for k, v in c0.items()}
+            torch.cuda.synchronize(dev)
+            ts.append(round((time.perf_counter() - t0) * 1e3, 2))
+        return f"mean {sum(ts) / n:.2f} ms, per forward {ts}", {k: hb.counter(k) - v for k, v in c0.items()}
 
 
 print(f"DDEPTH_STREAMS={os.environ['DDEPTH_STREAMS']} after [{pre}]:", flush=True)
