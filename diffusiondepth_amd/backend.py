@@ -142,10 +142,11 @@ class HipDenoiser:
         self._have_neck = False
         self._cond_token = None      # (tensor, version, precision id) of the map the last condition() call returned
         # DDEPTH_STREAMS=S: dd_denoise / dd_denoise_backward run a batch of B >= 2 as S concurrent sub-batches on separate HIP streams
-        # (dd_set_option "streams": +6..13 % throughput on MI355X in a process with one handle, per-image results bit-identical, the whole
-        # GPU suite passes with it).  Opt-in (bench.py --mode train-dp turns it on); an apparent instability of the head forward under it was
-        # a host-side pause in a short average (profiles/r02_run29_lanes_head_trace.md).
-        self.n_streams = max(1, int(os.environ.get("DDEPTH_STREAMS", "1") or 1))
+        # (dd_set_option "streams": +6..13 % throughput on MI355X, per-image results bit-identical).  The C library's default is 1; this
+        # binding's is 2 (the whole GPU suite passes either way; DDEPTH_STREAMS=1 turns it off); bench.py pins 1 for its headline line,
+        # whose roofline object is defined per launch on one stream.  (An apparent instability of the head forward under it was a host-side
+        # pause in a short average: profiles/r02_run29_lanes_head_trace.md.)
+        self.n_streams = max(1, int(os.environ.get("DDEPTH_STREAMS", "2") or 2))
         if self.n_streams > 1:
             self.set_option("streams", self.n_streams)
 
