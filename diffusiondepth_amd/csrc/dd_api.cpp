@@ -151,16 +151,23 @@ struct FpnWork {
 
 }  // namespace
 
-// The HAHI neck's convolutions (reference src/model/necks/hahi.py:60-97; attention off): kernel layer 30 + 4 * kind + level.
-struct NeckConv { int layer; std::string name; int cout, cin, ks; };
-static std::vector<NeckConv> neck_convs() {
+// The HAHI neck's convolutions (reference src/model/necks/hahi.py:60-97; attention off): kernel layer base + 4 * kind + level, base 30 for
+// the Swin-L pyramid (192 << level channels), 54 for MPViT-small (128 | 216 | 288 | 288; the kernels carry 216 as 224 channels).
+// cout / cin = the reference tensors' sizes; C = real channels of the level, Ck = channels the kernels carry.
+struct NeckConv { int layer; std::string name; int cout, cin, ks, level, kind, C, Ck; };
+static const int NECK_C_MPVIT[4] = {128, 216, 288, 288};
+inline int neck_c(int pyr, int level) { return pyr == PYR_MPVIT ? NECK_C_MPVIT[level] : (192 << level); }
+inline int neck_ck(int pyr, int level) { return pyr == PYR_MPVIT ? FPN_CIN_MPVIT_PAD[level] : (192 << level); }
+inline int neck_base(int pyr) { return pyr == PYR_MPVIT ? 54 : 30; }
+static std::vector<NeckConv> neck_convs(int pyr) {
   std::vector<NeckConv> v;
+  const int base = neck_base(pyr);
   for (int i = 0; i < 4; ++i) {
-    const int C = 192 << i;
+    const int C = neck_c(pyr, i), Ck = neck_ck(pyr, i);
     const std::string si = std::to_string(i), sj = std::to_string(i - 1);
-    v.push_back({30 + i, "hahineck.lateral_convs." + si, C, C, 1});
-    v.push_back({34 + i, i == 0 ? std::string("hahineck.conv_proj.0") : "hahineck.trans_proj." + sj, 512, C, 1});
-    v.push_back({38 + i, i == 0 ? std::string("hahineck.conv_fusion.0") : "hahineck.trans_fusion." + sj, C, C + 512, 3});
+    v.push_back({base + i, "hahineck.lateral_convs." + si, C, C, 1, i, 0, C, Ck});
+    v.push_back({base + 4 + i, i == 0 ? std::string("hahineck.conv_proj.0") : "hahineck.trans_proj." + sj, 512, C, 1, i, 1, C, Ck});
+    v.push_back({base + 8 + i, i == 0 ? std::string("hahineck.conv_fusion.0") : "hahineck.trans_fusion." + sj, C, C + 512, 3, i, 2, C, Ck});
   }
   return v;
 }
@@ -214,7 +221,7 @@ struct dd_handle_s {
   std::map<std::tuple<int, int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision, lane) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
   bool neck_committed = false;            // hahineck.* folded + packed (DD_VARIANT_SWIN with the Swin-L pyramid only)
-  DevBuf neck_w[12][NUM_EK], neck_b[12];  // index = kernel layer - 30
+  DevBuf neck_w[12][NUM_EK], neck_b[12];  // index = kernel layer - 30 (Swin-L pyramid) / - 54 (MPViT-small): 4 * kind + level
   int64_t n_neck_launches = 0;
   bool fpn_committed = false;
   int fpn_pyramid = PYR_DEFAULT;  // PYR_MPVIT once MPViT-sized lateral weights were set (DD_VARIANT_SWIN only)
@@ -230,7 +237,7 @@ struct dd_handle_s {
   bool ev_valid = false;
   hipStream_t cap_stream = nullptr;   // capture-only stream (torch's default stream is the NULL stream, which cannot capture)
   int64_t n_graph_launches = 0, n_eager_loops = 0, n_capture_failures = 0;
-  static constexpr int N_LAYER_SLOTS = 48;   // kernel layer ids run up to 41 (see dd_igemm2_cfg.h)
+  static constexpr int N_LAYER_SLOTS = 72;   // kernel layer ids run up to 65 (see dd_igemm2_cfg.h)
   double layer_ms[N_LAYER_SLOTS] = {0};     // index = kernel layer id - 1 (1..4 Res, 5..7 Swin fuse, 8..9 hoisted conv3, 10..18 / 24..26 condition FPN, 20..23 dgrad)
   int64_t layer_cnt[N_LAYER_SLOTS] = {0};
   std::vector<std::tuple<int, hipEvent_t, hipEvent_t>> pending_ev;
@@ -305,10 +312,10 @@ std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
       for (const char* b : bn) v.push_back({pre + ".1." + b, COND_C});
     }
   }
-  if (variant == DD_VARIANT_SWIN && pyr == PYR_DEFAULT) {
+  if (variant == DD_VARIANT_SWIN) {
     // HAHI neck (optional 4th group): ConvModule = bias-free conv + BatchNorm + ReLU
     const char* bn[4] = {"weight", "bias", "running_mean", "running_var"};
-    for (const NeckConv& c : neck_convs()) {
+    for (const NeckConv& c : neck_convs(pyr)) {
       v.push_back({c.name + ".conv.weight", (int64_t)c.cout * c.cin * c.ks * c.ks});
       for (const char* b : bn) v.push_back({c.name + ".bn." + b, c.cout});
     }
@@ -712,10 +719,23 @@ int dd_set_weight(dd_handle_t h, const char* name, const float* data, int64_t nu
         const int pyr = numel == (int64_t)COND_C * FPN_CIN_MPVIT[i] * 9 ? PYR_MPVIT : PYR_DEFAULT;
         if (pyr != h->fpn_pyramid) {
           for (int j = 0; j < FPN_LEVELS; ++j) h->host_w.erase("conv_lateral." + std::to_string(j) + ".0.weight");   // other pyramid's
+          for (const NeckConv& c : neck_convs(h->fpn_pyramid)) h->host_w.erase(c.name + ".conv.weight");
           h->fpn_pyramid = pyr;
           h->fpn_committed = false;
+          h->neck_committed = false;
         }
       }
+    // ... or in the neck's first lateral convolution, whichever arrives first (the heads register the neck in front of the FPN)
+    if (nm == "hahineck.lateral_convs.0.conv.weight") {
+      const int pyr = numel == (int64_t)NECK_C_MPVIT[0] * NECK_C_MPVIT[0] ? PYR_MPVIT : PYR_DEFAULT;
+      if (pyr != h->fpn_pyramid) {
+        for (int j = 0; j < FPN_LEVELS; ++j) h->host_w.erase("conv_lateral." + std::to_string(j) + ".0.weight");
+        for (const NeckConv& c : neck_convs(h->fpn_pyramid)) h->host_w.erase(c.name + ".conv.weight");
+        h->fpn_pyramid = pyr;
+        h->fpn_committed = false;
+        h->neck_committed = false;
+      }
+    }
   }
   for (const auto& ws : required_weights(h->variant, h->fpn_pyramid)) {
     if (ws.name == name) {
@@ -1018,24 +1038,34 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   }
   if (do_neck) {
     // ---- HAHI neck: fold eval-mode BatchNorm into the bias-free convolutions (scale into the weights, shift = bias), pack ----
-    for (const NeckConv& c : neck_convs()) {
+    // The kernels' channel counts can exceed the reference's (MPViT level 1: 216 carried as 224): the folded weights are laid into
+    // [cout_k][cin_k] with zeros in the padding; a fusion convolution reads the concatenation [lateral (Ck) | projection (512)] (level 0:
+    // [projection | lateral]), so its reference input channel ci >= C of the lateral part's successor moves up by Ck - C.
+    for (const NeckConv& c : neck_convs(h->fpn_pyramid)) {
       const auto &g = h->host_w[c.name + ".bn.weight"], &b = h->host_w[c.name + ".bn.bias"], &m = h->host_w[c.name + ".bn.running_mean"],
                  &v = h->host_w[c.name + ".bn.running_var"];
       const std::vector<float>& w0 = h->host_w[c.name + ".conv.weight"];
-      const size_t per = (size_t)c.cin * c.ks * c.ks;
-      std::vector<float> w(w0.size()), sh(c.cout);
+      const PackGeom pg = conv_pack_geom2(c.layer, EK_F32);
+      const int kk = c.ks * c.ks, cin_k = pg.cin, cout_k = pg.cout;
+      std::vector<float> w((size_t)cout_k * cin_k * kk, 0.f), sh((size_t)pg.cout_pad, 0.f);
       for (int co = 0; co < c.cout; ++co) {
         const double sc = (double)g[co] / std::sqrt((double)v[co] + (double)BN_EPS);
         sh[co] = (float)((double)b[co] - (double)m[co] * sc);
-        for (size_t k = 0; k < per; ++k) w[co * per + k] = (float)((double)w0[co * per + k] * sc);
+        for (int ci = 0; ci < c.cin; ++ci) {
+          int cik = ci;
+          if (c.kind == 2 && c.level > 0 && ci >= c.C) cik = ci - c.C + c.Ck;          // [lateral | projection]: the projection part starts at Ck
+          for (int k = 0; k < kk; ++k)
+            w[((size_t)co * cin_k + cik) * kk + k] = (float)((double)w0[((size_t)co * c.cin + ci) * kk + k] * sc);
+        }
       }
+      const int slot = c.layer - neck_base(h->fpn_pyramid);
       for (int ek = 0; ek < NUM_EK; ++ek) {
         std::vector<uint8_t> packed;
         pack_conv_weights(w.data(), conv_pack_geom2(c.layer, ek), ek, true, packed);
-        int rc = upload(h, h->neck_w[c.layer - 30][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        int rc = upload(h, h->neck_w[slot][ek], packed.data(), packed.size(), s); if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
-      int rc = upload(h, h->neck_b[c.layer - 30], sh.data(), sh.size() * 4, s); if (rc) return rc;
+      int rc = upload(h, h->neck_b[slot], sh.data(), sh.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
     }
     h->neck_committed = true;
@@ -1196,7 +1226,7 @@ int dd_neck_condition(dd_handle_t h, const float* const* feats, const int* feat_
                       float* cond_out, int precision, void* stream) {
   if (!h) return DD_ERR_INVALID_ARG;
   if (!h->neck_committed) return h->fail(DD_ERR_STATE, "hahineck.* weights not committed (dd_set_weight for the lateral / projection / fusion convolutions, "
-                                                       "dd_commit_weights; DD_VARIANT_SWIN with the Swin-L pyramid only)");
+                                                       "dd_commit_weights; DD_VARIANT_SWIN)");
   return condition_impl(h, feats, feat_h, feat_w, n_levels, B, cond_out, precision, stream, true);
 }
 
@@ -1204,8 +1234,8 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
                           float* cond_out, int precision, void* stream, bool with_neck) {
   if (!h) return DD_ERR_INVALID_ARG;
   if (!h->fpn_committed) return h->fail(DD_ERR_STATE, "conv_lateral.* / conv_up.* weights not committed (dd_set_weight, dd_commit_weights)");
-  if (with_neck && (h->variant != DD_VARIANT_SWIN || h->fpn_pyramid != PYR_DEFAULT))
-    return h->fail(DD_ERR_UNSUPPORTED, "dd_neck_condition: the HAHI neck kernels are built for the Swin-L pyramid (192/384/768/1536)");
+  if (with_neck && h->variant != DD_VARIANT_SWIN)
+    return h->fail(DD_ERR_UNSUPPORTED, "dd_neck_condition: the HAHI neck kernels are built for the Swin-L (192/384/768/1536) and MPViT-small (128/216/288/288) pyramids of DD_VARIANT_SWIN");
   if (n_levels != FPN_LEVELS || !feats || !feat_h || !feat_w) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: expects 4 pyramid levels");
   if (precision < DD_PREC_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16 or f16");
   if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
@@ -1232,8 +1262,8 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
       const size_t px = (size_t)B * feat_h[i] * feat_w[i];
       DD_HIP(fw->fin[i].alloc(px * fpn_cin_pad(h->variant, h->fpn_pyramid)[i] * es));
       if (with_neck) {
-        DD_HIP(fw->nk_cat[i].alloc(px * ((192 << i) + 512) * es));
-        DD_HIP(fw->nk_out[i].alloc(px * (192 << i) * es));
+        DD_HIP(fw->nk_cat[i].alloc(px * (neck_ck(h->fpn_pyramid, i) + 512) * es));
+        DD_HIP(fw->nk_out[i].alloc(px * neck_ck(h->fpn_pyramid, i) * es));
         fw->neck = true;
       }
       if (i > 0) {
@@ -1279,7 +1309,8 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
     if (with_neck) {
       // HAHI neck of level i (reference hahi.py:170-173,196-197,226-272; attention off): l = lateral(x); e = proj(l);
       // out = fusion(cat) with cat = [e | l] at level 0 (hahi.py:249: cat([fusion_res_conv, feat_conv])) and [l | e] above (:262)
-      const int C = 192 << i, CT = C + 512, l_off = (i == 0) ? 512 : 0, e_off = (i == 0) ? 0 : C;
+      const int C = neck_ck(h->fpn_pyramid, i), CT = C + 512, l_off = (i == 0) ? 512 : 0, e_off = (i == 0) ? 0 : C;
+      const int nb = neck_base(h->fpn_pyramid);
       ConvParams q{};
       q.B = B; q.h = hh; q.w = ww;
       q.tiles_x = (ww + 31) / 32;
@@ -1287,15 +1318,15 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
       q.in = fw->fin[i].p; q.in_cstride = C; q.in_coff = 0;
       q.out = fw->nk_cat[i].p; q.out_cstride = CT; q.out_coff = l_off;
       q.wpack = h->neck_w[i][ok].p; q.bias = h->neck_b[i].as<float>();
-      DD_HIP(launch(30 + i, q));
+      DD_HIP(launch(nb + i, q));
       q.in = fw->nk_cat[i].p; q.in_cstride = CT; q.in_coff = l_off;
       q.out = fw->nk_cat[i].p; q.out_cstride = CT; q.out_coff = e_off;
       q.wpack = h->neck_w[4 + i][ok].p; q.bias = h->neck_b[4 + i].as<float>();
-      DD_HIP(launch(34 + i, q));
+      DD_HIP(launch(nb + 4 + i, q));
       q.in = fw->nk_cat[i].p; q.in_cstride = CT; q.in_coff = 0;
       q.out = fw->nk_out[i].p; q.out_cstride = C; q.out_coff = 0;
       q.wpack = h->neck_w[8 + i][ok].p; q.bias = h->neck_b[8 + i].as<float>();
-      DD_HIP(launch(38 + i, q));
+      DD_HIP(launch(nb + 8 + i, q));
       h->n_neck_launches += 3;
       lat_in = fw->nk_out[i].p;
     }

@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           reinterpret_cast<float4*>(p.out)[((((size_t)e_tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane] =
               make_float4(v[0], v[1], v[2], v[3]);
         } else if constexpr (C::OUT_ESZ == 4) {
-          if (pvalid) {
+          if (pvalid && (C::COUT_PAD == C::COUT || co < C::COUT)) {      // (padding couts of a rounded-up tile are never stored)
             if constexpr (C::SCATTER) {
               const int par = co >> 8, cc = co & (COND_C - 1);
               *reinterpret_cast<float4*>(reinterpret_cast<char*>(p.out) + ((size_t)e_b * 4 * h * w * COND_C +
@@ -625,8 +625,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         for (int k = 0; k < 2; ++k) {
           const auto rx = __builtin_amdgcn_permlane32_swap(pk[2 * k].x, pk[2 * k + 1].x, false, false);
           const auto ry = __builtin_amdgcn_permlane32_swap(pk[2 * k].y, pk[2 * k + 1].y, false, false);
-          if (pvalid) {
-            const int co = n0 + n * 32 + 16 * k + 8 * g;
+          const int co = n0 + n * 32 + 16 * k + 8 * g;
+          if (pvalid && (C::COUT_PAD == C::COUT || co < C::COUT)) {
             if constexpr (C::SCATTER) {
               const int par = co >> 8, cc = co & (COND_C - 1);
               *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.out) + ((size_t)e_b * 4 * h * w * COND_C +
@@ -737,6 +737,18 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 39: return launch_one2<EK, 39>(p, s);
     case 40: return launch_one2<EK, 40>(p, s);
     case 41: return launch_one2<EK, 41>(p, s);
+    case 54: return launch_one2<EK, 54>(p, s);
+    case 55: return launch_one2<EK, 55>(p, s);
+    case 56: return launch_one2<EK, 56>(p, s);
+    case 57: return launch_one2<EK, 57>(p, s);
+    case 58: return launch_one2<EK, 58>(p, s);
+    case 59: return launch_one2<EK, 59>(p, s);
+    case 60: return launch_one2<EK, 60>(p, s);
+    case 61: return launch_one2<EK, 61>(p, s);
+    case 62: return launch_one2<EK, 62>(p, s);
+    case 63: return launch_one2<EK, 63>(p, s);
+    case 64: return launch_one2<EK, 64>(p, s);
+    case 65: return launch_one2<EK, 65>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -808,6 +820,18 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 39: return geom2_of<EK, 39>();
     case 40: return geom2_of<EK, 40>();
     case 41: return geom2_of<EK, 41>();
+    case 54: return geom2_of<EK, 54>();
+    case 55: return geom2_of<EK, 55>();
+    case 56: return geom2_of<EK, 56>();
+    case 57: return geom2_of<EK, 57>();
+    case 58: return geom2_of<EK, 58>();
+    case 59: return geom2_of<EK, 59>();
+    case 60: return geom2_of<EK, 60>();
+    case 61: return geom2_of<EK, 61>();
+    case 62: return geom2_of<EK, 62>();
+    case 63: return geom2_of<EK, 63>();
+    case 64: return geom2_of<EK, 64>();
+    case 65: return geom2_of<EK, 65>();
     default: return geom2_of<EK, 23>();
   }
 }

@@ -91,10 +91,15 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   //   38 + i = conv_fusion / trans_fusion[i-1]: 3x3 (C_i + 512) -> C_i on the channel concatenation
   // all + ReLU, raw inputs.  The concatenation is free in the channel-blocked layout: the two 1x1 convs write their couts at a channel
   // offset of ONE buffer (ConvParams::out_coff / out_cstride), the projection reads the lateral result from it (in_coff / in_cstride).
-  static constexpr bool IS_NECK = (LAYER >= 30 && LAYER <= 41);
-  static constexpr int NECK_LVL = IS_NECK ? (LAYER - 30) % 4 : 0;
-  static constexpr int NECK_KIND = IS_NECK ? (LAYER - 30) / 4 : -1;      // 0 lateral, 1 projection, 2 fusion
-  static constexpr int NECK_C = 192 << NECK_LVL;
+  //   54..65 = the same twelve convolutions for the MPViT-small pyramid (reference ...res_mpvit_HAHI.py:32,51-53: 128 | 216 | 288 | 288,
+  //   embedding 512): 216 is carried as 224 channels (zero channels / zero weights, as in dd_condition), couts round up to whole 64-cout
+  //   workgroup tiles (224 -> 256, 288 -> 320: the padding couts are computed on zero weights and never stored)
+  static constexpr bool NECK_MP = (LAYER >= 54 && LAYER <= 65);
+  static constexpr bool IS_NECK = (LAYER >= 30 && LAYER <= 41) || NECK_MP;
+  static constexpr int NECK_BASE = NECK_MP ? 54 : 30;
+  static constexpr int NECK_LVL = IS_NECK ? (LAYER - NECK_BASE) % 4 : 0;
+  static constexpr int NECK_KIND = IS_NECK ? (LAYER - NECK_BASE) / 4 : -1;      // 0 lateral, 1 projection, 2 fusion
+  static constexpr int NECK_C = NECK_MP ? (NECK_LVL == 0 ? 128 : NECK_LVL == 1 ? 224 : 288) : (192 << NECK_LVL);
   static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18) || (LAYER >= 24 && LAYER <= 26);
   static constexpr bool IS_DGRAD = (LAYER >= 20 && LAYER <= 23);
   static constexpr bool IS_UP = (LAYER == 14);
@@ -107,7 +112,7 @@ template <int EKM_, int LAYER_> struct Cfg2 {
                             : (LAYER == 1 || LAYER == 3 || LAYER >= 7) ? HID_C : (LAYER == 4) ? LATENT_C : COND_C;
   static constexpr bool RELU_OUT = IS_LAT || IS_UP || IS_NECK;   // epilogue: relu(acc + bias)
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
-  static constexpr int COUT_PAD = (COUT < 32) ? 32 : COUT;
+  static constexpr int COUT_PAD = (COUT < 32) ? 32 : IS_NECK ? ((COUT + 63) / 64) * 64 : COUT;
   static constexpr bool C3SHAPE = (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);
   static constexpr int C3 = (C3SHAPE && ESZ == 2) ? DD_C3 : 0;
   static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2;

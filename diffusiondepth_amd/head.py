@@ -98,9 +98,9 @@ class DDIMDepthEstimate_Res(nn.Module):
         if self._hip_fpn:
             bound.register("conv_lateral.", self.conv_lateral)
             bound.register("conv_up.", self.conv_up)
-        # the HAHI neck's convolutions run in the library too (dd_neck_condition) at the Swin-L widths; other pyramids (MPViT) keep the
-        # PyTorch neck in front of the library's FPN
-        self._hip_neck = self._hip_fpn and self._HAHI and list(in_channels) == [192, 384, 768, 1536]
+        # the HAHI neck's convolutions run in the library too (dd_neck_condition) for the two pyramids its kernels are built for (Swin-L,
+        # MPViT-small); any other widths keep the PyTorch neck in front of the library's FPN
+        self._hip_neck = self._hip_fpn and self._HAHI and list(in_channels) in ([192, 384, 768, 1536], [128, 216, 288, 288])
         if self._hip_neck:
             bound.register("hahineck.", self.hahineck)
 

@@ -121,7 +121,8 @@ int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, co
  * every ConvModule = bias-free conv + eval-mode BatchNorm + ReLU (folded at dd_commit_weights) -- then dd_condition's FPN on the neck's
  * outputs.  Parameters: the keys "hahineck.{lateral_convs.i, conv_proj.0, trans_proj.j, conv_fusion.0, trans_fusion.j}.{conv.weight,
  * bn.weight, bn.bias, bn.running_mean, bn.running_var}" form a fourth optional group of dd_set_weight (the neck's attention / embedding
- * parameters are never executed by the reference and are not part of it).  DD_VARIANT_SWIN with the Swin-L pyramid (192/384/768/1536).
+ * parameters are never executed by the reference and are not part of it).  DD_VARIANT_SWIN with the Swin-L pyramid (192/384/768/1536) or the
+ * MPViT-small one (128/216/288/288; which one shows in the sizes of the weights set).
  * Same arguments and result hand-over as dd_condition; feats are the RAW backbone maps. */
 int dd_neck_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
                       float* cond_out, int precision, void* stream);

@@ -75,6 +75,21 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
         e_c = float((c_hip - c_torch).abs().max())
         U.record("mpvit_fpn_hip_vs_torch", cond_maxabs=e_c, cond_max=float(c_torch.abs().max()))
         assert e_c < 1e-4 * max(1.0, float(c_torch.abs().max()))
+        # ... and the neck itself in the library for these widths too (layers 54..65: 216 carried as 224 channels with a gap in the fusion
+        # convolution's input, couts rounded up to 64-cout tiles and not stored): the forward above already ran it
+        assert head._hip_neck and head._bound.backend.counter("neck_launches") >= 12
+        with torch.no_grad():
+            c_lib = head.aggregate_condition(fp, neck_in_library=True)
+        e_n = float((c_lib - c_torch).abs().max())
+        U.record("mpvit_neck_hip_vs_torch", cond_maxabs=e_n, cond_max=float(c_torch.abs().max()))
+        assert e_n < 1e-4 * max(1.0, float(c_torch.abs().max()))
+        errs = {}
+        for prec in ("bf16", "f16"):
+            hb = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
+                                         loss_cfgs=[], precision=prec).eval(), sd)
+            errs[prec] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
+        U.record(case + "_16bit", depth_rmse_bf16=errs["bf16"], depth_rmse_f16=errs["f16"], pred_max=float(g["pred"].max()))
+        assert errs["bf16"] < 0.1 and errs["f16"] < 0.02
     if case == "head_swin_hahi":
         # the neck's 1x1 / 3x3 convolutions ran in the library (dd_neck_condition), not in MIOpen: 3 launches per
         # pyramid level per forward -- and they equal the PyTorch neck + library FPN on the same features
