@@ -339,7 +339,9 @@ class HipDenoiser:
                      "dd_denoise_trace")
         return states
 
-    def denoise_once(self, x_t, t, cond, precision="fp32"):
+    def denoise_once(self, x_t, t, cond, precision="fp32", keep_trajectory=False):
+        """One epsilon-network evaluation.  ``keep_trajectory=True`` (training forward): ``self.last_trajectory_ticket`` names the
+        activations this call leaves in the library; passed to ``denoise_once_backward`` it saves that call its forward recompute."""
         torch = _torch()
         x_t = _check_tensor(x_t, "x_t", dtype=torch.float32)
         cond = _check_tensor(cond, "cond", dtype=torch.float32)
@@ -349,10 +351,19 @@ class HipDenoiser:
             t = t.expand(B)
         t = _check_tensor(t, "t", (B,), torch.int64)
         out = torch.empty_like(x_t)
-        with torch.cuda.device(self.device):
-            self._ck(self._lib.dd_denoise_once(self._h, x_t.data_ptr(), t.data_ptr(), self._cond_arg(cond, precision), out.data_ptr(),
-                                               B, h, w, cond.shape[2], cond.shape[3], precision_id(precision),
-                                               _stream_ptr(self.device)), "dd_denoise_once")
+        self.last_trajectory_ticket = 0
+        if keep_trajectory:
+            self.set_option("keep_trajectory", 1)
+        try:
+            with torch.cuda.device(self.device):
+                self._ck(self._lib.dd_denoise_once(self._h, x_t.data_ptr(), t.data_ptr(), self._cond_arg(cond, precision), out.data_ptr(),
+                                                   B, h, w, cond.shape[2], cond.shape[3], precision_id(precision),
+                                                   _stream_ptr(self.device)), "dd_denoise_once")
+            if keep_trajectory and precision != "naive_fp32":
+                self.last_trajectory_ticket = self.counter("trajectory_ticket")
+        finally:
+            if keep_trajectory:
+                self.set_option("keep_trajectory", 0)
         return out
 
     # -- training: backward of one denoiser call ---------------------------------------------------
@@ -379,7 +390,8 @@ class HipDenoiser:
             d.update(self.SWIN_PARAM_SHAPES)
         return d
 
-    def denoise_once_backward(self, x_t, t, cond, grad_eps, precision="naive_fp32", need_grad_x=True, need_grad_cond=True):
+    def denoise_once_backward(self, x_t, t, cond, grad_eps, precision="naive_fp32", need_grad_x=True, need_grad_cond=True,
+                              trajectory_ticket=0):
         """VJP of one ScheduledCNNRefine.forward (what autograd computes for ``self.model(...)`` in the reference's
         training step): returns (grad_x, grad_cond); parameter gradients accumulate in the handle (``grads()``)."""
         torch = _torch()
@@ -393,6 +405,8 @@ class HipDenoiser:
         t = _check_tensor(t, "t", (B,), torch.int64)
         gx = torch.empty_like(x_t) if need_grad_x else None
         gc = torch.empty_like(cond) if need_grad_cond else None
+        if trajectory_ticket:
+            self.set_option("use_trajectory", int(trajectory_ticket))      # the forward call's activations instead of a recompute
         with torch.cuda.device(self.device):
             self._ck(self._lib.dd_denoise_once_backward(
                 self._h, x_t.data_ptr(), t.data_ptr(), cond.data_ptr(), grad_eps.data_ptr(),

@@ -1594,6 +1594,10 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
                         h->L[3].beta.as<float>(), pl->c1c2.as<float>(), 0, 1, eps, B, lat_h, lat_w, s));
   }
   h->last_once_plan = pl;
+  // "keep_trajectory": the raw conv outputs and GroupNorm sums this call leaves in the plan are what dd_denoise_once_backward would
+  // recompute; a ticket lets it read them instead (same validity rules as for the loop)
+  pl->traj_ticket = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? ++h->traj_serial : 0;
+  pl->traj_weights = h->weights_serial;
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   return DD_OK;
 }
@@ -1830,7 +1834,17 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
   if (rc) return rc;
   DD_HIP(launch_nchw_to_nhwc(grad_eps, pl->gA.p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
-  rc = bwd_core(h, pl, pl->x[0].as<float>(), reinterpret_cast<const long long*>(t), 0, 1, grad_cond, 0, s);
+  // the forward call's activations, if it kept them for us (option "use_trajectory" = its ticket): no recompute
+  const int64_t ticket = h->use_traj;
+  h->use_traj = 0;
+  const Plan* kept = nullptr;
+  if (ticket != 0 && precision != DD_PREC_NAIVE_FP32) {
+    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision)});
+    if (it != h->plans.end() && it->second->traj_ticket == ticket && it->second->traj_weights == h->weights_serial && it->second->ek == pl->ek)
+      kept = it->second.get();
+  }
+  if (kept) h->n_traj_reuse++;
+  rc = bwd_core(h, pl, pl->x[0].as<float>(), reinterpret_cast<const long long*>(t), 0, 1, grad_cond, 0, s, kept, 0);
   if (rc) return rc;
   if (grad_x) DD_HIP(launch_nhwc_to_nchw_f32(pl->gA.p, EK_F32, grad_x, B, LATENT_C, lat_h, lat_w, 0, s));
   h->last_once_plan = pl;

@@ -184,7 +184,9 @@ class _DenoiseOnceFn(torch.autograd.Function):
     def forward(ctx, be, precision, x, t, cond, *params):
         ctx.be, ctx.precision = be, precision
         ctx.save_for_backward(x, t, cond)
-        return be.denoise_once(x, t, cond, precision)
+        out = be.denoise_once(x, t, cond, precision, keep_trajectory=True)          # the backward reads this call's activations
+        ctx.ticket = be.last_trajectory_ticket
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -192,7 +194,8 @@ class _DenoiseOnceFn(torch.autograd.Function):
         be = ctx.be
         be.zero_grad()
         gx, gc = be.denoise_once_backward(x, t, cond, g.contiguous().float(), ctx.precision,
-                                          need_grad_x=ctx.needs_input_grad[2], need_grad_cond=ctx.needs_input_grad[4])
+                                          need_grad_x=ctx.needs_input_grad[2], need_grad_cond=ctx.needs_input_grad[4],
+                                          trajectory_ticket=ctx.ticket)
         grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_param_order(be.variant))]
         return (None, None, gx, None, gc, *grads)
 

@@ -164,7 +164,8 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
  * Parameter gradients ACCUMULATE inside the handle (like Tensor.grad) under the state-dict names of dd_set_weight
  * ("model.pred.0.weight", "model.time_embedding.weight", ...) in the reference's own shapes; dd_get_grad copies one to a
  * caller DEVICE buffer, dd_zero_grad clears all.  The forward pass is recomputed internally (no stash from
- * dd_denoise_once is needed).  Both variants (DD_VARIANT_SWIN: grad_cond has the condition map's own size (B,256,cond_h,cond_w),
+ * dd_denoise_once is needed; with one -- dd_set_option "keep_trajectory" around the forward call, its "trajectory_ticket" passed through
+ * "use_trajectory" in front of this call, see dd_denoise_backward -- the forward's activations are read instead).  Both variants (DD_VARIANT_SWIN: grad_cond has the condition map's own size (B,256,cond_h,cond_w),
  * the fuse convs' gradients are "model.upsample_fuse.conv{A,B}.conv.{weight,bias}"; no naive_fp32 path).  precision: naive_fp32 = unfused fp32 kernels (cross-check); fp32 / bf16 / f16 =
  * data gradients on the fused convolution kernels (transposed, flipped weights), weight gradients on the matrix cores
  * (bf16 / f16; the fp32 mode keeps the unfused weight-gradient kernel), GroupNorm backward fused into two passes per layer. */

@@ -360,10 +360,25 @@ def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     be.set_option("keep_activations_mb", 65536)
     be.denoise(x, cond, T, prec, keep_trajectory=True)
     tk3 = be.last_trajectory_ticket
+    # the single call (ddim_loss): the forward's activations stay in its plan; its backward with the ticket recomputes nothing
+    t = torch.tensor([400])
+    def once(ticket):
+        be.zero_grad()
+        gx1, gc1 = be.denoise_once_backward(x, t, cond, g, prec, trajectory_ticket=ticket)
+        return [gx1, gc1] + [be.grad(n) for n in names]
+    eps0 = be.denoise_once(x, t, cond, prec)
+    want1 = once(0)
+    n_re = be.counter("trajectory_reuses")
+    eps1 = be.denoise_once(x, t, cond, prec, keep_trajectory=True)
+    tk1 = be.last_trajectory_ticket
+    assert tk1 > 0 and torch.equal(eps1, eps0)
+    assert same(once(tk1), want1) and be.counter("trajectory_reuses") == n_re + 1
+    be.denoise_once(x2, t, cond, prec, keep_trajectory=True)                             # overwritten by another call: the old ticket is refused
+    assert same(once(tk1), want1) and be.counter("trajectory_reuses") == n_re + 1
     bumped = {"model.pred.4.weight": sd["model.pred.4.weight"] * 1.5}                   # the last GroupNorm's gamma
     be.load_state_dict(bumped)                                                          # parameters changed after the forward
     got = backward(tk3)
-    assert be.counter("trajectory_reuses") == 2
+    assert be.counter("trajectory_reuses") == 3
     assert not same(got, want)                                                          # ... and the gradient is the new parameters' one
 
 
