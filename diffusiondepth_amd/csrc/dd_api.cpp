@@ -210,6 +210,7 @@ struct dd_handle_s {
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   int64_t n_lane_calls = 0;
+  int active_lanes = 1;       // lanes of the dd_denoise_backward call in progress (the weight-gradient kernels size their slab count by it)
   bool adjoint_tiled = true;  // Swin backward: tiled separable kernel for the adjoint of the condition upsampling (0 = the one-thread-per-piece kernel, A/B check)
   int64_t traj_serial = 0, use_traj = 0, weights_serial = 0, n_traj_reuse = 0;
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
@@ -1742,7 +1743,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
     if (!naive && ek != EK_F32 && !h->naive_wgrad) {
       const size_t need = wgrad_workspace_bytes(C, CI, B, lat_h, lat_w);
       if (h->wgrad_ws[lane].bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws[lane].alloc(need)); }
-      DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, h->wgrad_ws[lane].as<float>(), ek, C, CI, B, lat_h, lat_w, s));
+      DD_HIP(launch_wgrad_mfma(pl->gY.p, inbuf[l], dw, h->wgrad_ws[lane].as<float>(), ek, C, CI, B, lat_h, lat_w, s, h->active_lanes));
     } else {
       DD_HIP(launch_naive_wgrad(gyv, inv, dw, B, lat_h, lat_w, s));     // fp32 operands: the unfused kernel (parity modes)
     }
@@ -1774,7 +1775,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
         if (ek != EK_F32 && !h->naive_wgrad) {
           const size_t need = wgrad_workspace_bytes(COND_C, COND_C, B, lat_h, lat_w);
           if (h->wgrad_ws[lane].bytes < need) { DD_HIP(hipStreamSynchronize(s)); DD_HIP(h->wgrad_ws[lane].alloc(need)); }
-          DD_HIP(launch_wgrad_mfma(gbuf[i], fin[i], dwf, h->wgrad_ws[lane].as<float>(), ek, COND_C, COND_C, B, lat_h, lat_w, s));
+          DD_HIP(launch_wgrad_mfma(gbuf[i], fin[i], dwf, h->wgrad_ws[lane].as<float>(), ek, COND_C, COND_C, B, lat_h, lat_w, s, h->active_lanes));
         } else {
           DD_HIP(launch_naive_wgrad(gout, fv, dwf, B, lat_h, lat_w, s));
         }
@@ -1950,6 +1951,7 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   const size_t n_x = (size_t)LATENT_C * lat_h * lat_w, n_c = (size_t)COND_C * cond_h * cond_w;
   int img0 = 0;
   bool all_reused = true;
+  h->active_lanes = S;
   for (int l = 0; l < S; ++l) {
     const int n = B / S + (l < B % S ? 1 : 0);
     hipStream_t ls = l == 0 ? s : h->lane_stream[l];
@@ -1961,9 +1963,10 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
       (void)hipEventRecord(h->lane_done[l], ls);
       (void)hipStreamWaitEvent(s, h->lane_done[l], 0);
     }
-    if (rc) return rc;
+    if (rc) { h->active_lanes = 1; return rc; }
     img0 += n;
   }
+  h->active_lanes = 1;
   // after the join, on the caller's stream: set 0 += set l, set l = 0
   for (int l = 1; l < S; ++l)
     for (auto& kv : h->grads[l]) {

@@ -160,7 +160,8 @@ hipError_t launch_gn_param_grad(const double* dgb, float* dgamma, float* dbeta, 
 hipError_t launch_naive_wgrad(const ActView& gy, const ActView& a, float* dw_oihw, int B, int h, int w, hipStream_t s);
 // MFMA weight gradient (dd_wgrad.hip), bf16 / f16 operands in the activation layouts, fp32 atomics into dw [CO][CI][3][3]
 size_t wgrad_workspace_bytes(int CO, int CI, int B, int h, int w);     // per-slab partial sums
-hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, float* workspace, int ek, int CO, int CI, int B, int h, int w, hipStream_t s);
+hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, float* workspace, int ek, int CO, int CI, int B, int h, int w, hipStream_t s,
+                             int share = 1);      // share = concurrent callers splitting the GPU (lanes): fewer partial-sum slabs each
 // chain rule of x_{k+1} = c1_k x_k + c2_k eps: mode 0: ga = c2_k * g;  mode 1: g = c1_k * g + ga   (c1c2 = [T][2] device table)
 hipError_t launch_bwd_chain(float* g, float* ga, const float* c1c2, int k, int mode, long long n, hipStream_t s);
 hipError_t launch_view_copy(const ActView& src, const ActView& dst, int B, hipStream_t s);

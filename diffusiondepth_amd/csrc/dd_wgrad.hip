@@ -206,25 +206,27 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 
 // second generation (dd_wgrad2.hip): channel counts that are multiples of 64
 bool wgrad2_supports(int CO, int CI);
-int wgrad2_slabs(int CO, int CI, int n_tiles);
-hipError_t launch_wgrad2(const void* gy, const void* a, float* workspace, int ek, int CO, int CI, int B, int h, int w, int* slabs_out, hipStream_t s);
+int wgrad2_slabs(int CO, int CI, int n_tiles, int share);
+hipError_t launch_wgrad2(const void* gy, const void* a, float* workspace, int ek, int CO, int CI, int B, int h, int w, int* slabs_out, hipStream_t s,
+                         int share);
 
 size_t wgrad_workspace_bytes(int CO, int CI, int B, int h, int w) {
   const int types = ((CO + 63) / 64) * ((CI + 31) / 32);
   const int n_tiles = B * ((w + 31) / 32) * ((h + 7) / 8);
-  if (wgrad2_supports(CO, CI)) return (size_t)wgrad2_slabs(CO, CI, n_tiles) * 9 * CO * CI * sizeof(float);
+  if (wgrad2_supports(CO, CI)) return (size_t)wgrad2_slabs(CO, CI, n_tiles, 1) * 9 * CO * CI * sizeof(float);
   int slabs = (512 + types - 1) / types;
   if (slabs > n_tiles) slabs = n_tiles;
   return (size_t)slabs * 9 * CO * CI * sizeof(float);
 }
 
-hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, float* workspace, int ek, int CO, int CI, int B, int h, int w, hipStream_t s) {
+hipError_t launch_wgrad_mfma(const void* gy, const void* a, float* dw_oihw, float* workspace, int ek, int CO, int CI, int B, int h, int w, hipStream_t s,
+                             int share) {
   if (ek != EK_BF16 && ek != EK_F16) return hipErrorInvalidValue;
   if (CO % 8 != 0 || CI % 8 != 0) return hipErrorInvalidValue;
   if ((long long)B * h * w * (CO > CI ? CO : CI) >= (1LL << 32)) return hipErrorInvalidValue;      // 32-bit element offsets inside the kernel
   if (wgrad2_supports(CO, CI)) {
     int slabs2 = 0;
-    hipError_t e = launch_wgrad2(gy, a, workspace, ek, CO, CI, B, h, w, &slabs2, s);
+    hipError_t e = launch_wgrad2(gy, a, workspace, ek, CO, CI, B, h, w, &slabs2, s, share);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((9 * CO * CI + 255) / 256), dim3(256), 0, s, workspace, dw_oihw, slabs2, CO, CI);
     return hipGetLastError();

@@ -140,18 +140,20 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad2_kernel(WgradParams p) {
 
 bool wgrad2_supports(int CO, int CI) { return CO % 64 == 0 && CI % 64 == 0; }
 
-int wgrad2_slabs(int CO, int CI, int n_tiles) {
+int wgrad2_slabs(int CO, int CI, int n_tiles, int share) {
   const int types = (CO / 64) * (CI / 64);
-  int slabs = (256 + types - 1) / types;                  // one 12-wave workgroup per CU over all types
+  const int cus = 256 / (share < 1 ? 1 : share);          // `share` concurrent callers (lanes of dd_denoise_backward) split the CUs: fewer slabs
+  int slabs = (cus + types - 1) / types;                  // each, i.e. the same partial-sum traffic for the reduction as one caller alone
   if (slabs > n_tiles) slabs = n_tiles;
   return slabs < 1 ? 1 : slabs;
 }
 
-hipError_t launch_wgrad2(const void* gy, const void* a, float* workspace, int ek, int CO, int CI, int B, int h, int w, int* slabs_out, hipStream_t s) {
+hipError_t launch_wgrad2(const void* gy, const void* a, float* workspace, int ek, int CO, int CI, int B, int h, int w, int* slabs_out, hipStream_t s,
+                         int share) {
   WgradParams p{};
   p.gy = gy; p.a = a; p.part = workspace; p.CO = CO; p.CI = CI; p.B = B; p.h = h; p.w = w;
   p.tiles_x = (w + 31) / 32; p.tiles_y = (h + 7) / 8;
-  p.slabs = wgrad2_slabs(CO, CI, B * p.tiles_x * p.tiles_y);
+  p.slabs = wgrad2_slabs(CO, CI, B * p.tiles_x * p.tiles_y, share);
   *slabs_out = p.slabs;
   static bool attr_set[2] = {false, false};
   const int idx = ek == EK_BF16 ? 0 : 1;
