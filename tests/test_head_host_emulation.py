@@ -484,3 +484,28 @@ def test_concurrent_lanes_return_the_single_stream_result(on_host, variant, cond
     assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1]) and torch.equal(res[2][2], res[1][2])     # per-image results
     for a, b_ in zip(res[2][3:], res[1][3:]):                                                                                # sums over the batch: order
         assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max())
+
+
+@pytest.mark.parametrize("cls,chans", [("DDIMDepthEstimate_MPVIT_ADDHAHI", (128, 216, 288, 288))] + ([("DDIMDepthEstimate_Swin_ADDHAHI", (192, 384, 768, 1536))] if FULL else []),
+                         ids=["mpvit"] + (["swin"] if FULL else []))
+def test_neck_in_the_library_equals_the_pytorch_neck(on_host, monkeypatch, cls, chans):
+    """dd_neck_condition (the HAHI neck's twelve convolutions + the FPN, all in the library) against the PyTorch neck feeding the library's
+    FPN, fp32 kernels, on a small odd-sized pyramid.  MPViT widths: 216 channels carried as 224 (zero weights, a gap in the fusion
+    convolution's input channels), couts rounded up to whole 64-cout workgroup tiles whose padding is never stored."""
+    sd = synth.make_state_dict(7240, "swin")
+    sd.update({k: v for k, v in synth.make_fpn_state_dict(7241, in_channels=chans).items() if not k.startswith("convup_fp")})
+    sd.update(synth.make_hahi_state_dict(7242, chans))
+    head = getattr(dda, cls)(in_channels=list(chans), inference_steps=2, num_train_timesteps=1000, depth_feature_dim=16, loss_cfgs=[],
+                             precision="fp32", neck_autocast=False).eval()
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    monkeypatch.setattr(type(head), "_on_hip", staticmethod(lambda tensors: True))
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(3, 1, 36, 52, in_channels=chans)]      # 9x13, 5x7, 3x4, 2x2: both pool size fixes
+    assert head._hip_neck
+    with torch.no_grad():
+        c_lib = head.aggregate_condition(fp, neck_in_library=True)
+        n0 = head._bound.backend.counter("neck_launches")
+        c_ref = head.aggregate_condition([f.float() for f in head.hahineck(fp)])
+    assert n0 == 12 and head._bound.backend.counter("neck_launches") == 12
+    assert c_lib.shape == c_ref.shape == (1, 256, fp[0].shape[2], fp[0].shape[3])
+    assert float((c_lib - c_ref).abs().max()) <= 1e-4 * max(1.0, float(c_ref.abs().max()))
