@@ -306,7 +306,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=sorted(PEAK_TFLOPS))
+    ap.add_argument("--precision", default=None, choices=sorted(PEAK_TFLOPS),
+                    help="default: bf16; f16 for the inference line of --variant swin (BASELINE config 5 names fp16, and the Swin denoiser's "
+                         "bf16 mode is OUT of the depth tolerance: RMSE 3.4e-3 at KITTI size against 4.3e-4 in f16 -- it is the training mode)")
     ap.add_argument("--batch", type=int, default=4,
                     help="depth maps per GPU per step (throughput setting; 4 = the per-GPU batch of BASELINE config 4). "
                          "The B=1 latency of the reference's test() setting is reported alongside as `latency_b1`.")
@@ -333,6 +335,8 @@ def main():
     args = ap.parse_args()
     if args.streams is None:
         args.streams = 2 if args.mode == "train-dp" else 1
+    if args.precision is None:
+        args.precision = "f16" if (args.variant == "swin" and args.mode != "train-dp") else "bf16"
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # invoked plainly: this process becomes the launcher of N ranks (each re-enters main() with WORLD_SIZE set)

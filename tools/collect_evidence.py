@@ -5,7 +5,7 @@ import os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-logs = ["bench_c3_bf16_b4", "bench_c3_bf16_b1", "bench_c3_bf16_b16", "bench_c3_f16_b4", "bench_c3_fp32_b4", "bench_c2_nyu_bf16_b4", "bench_swin_bf16_b4",
+logs = ["bench_c3_bf16_b4", "bench_c3_bf16_b1", "bench_c3_bf16_b16", "bench_c3_f16_b4", "bench_c3_fp32_b4", "bench_c2_nyu_bf16_b4", "bench_swin_bf16_b4", "bench_swin_f16_b4",
         "bench_c5_swin_f16_t50_b1", "bench_launcher_n1", "train_dp_swin_b4", "train_dp_res_b4"]
 for n in logs:
     src = os.path.join(G, n + ".log")

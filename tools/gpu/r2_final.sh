@@ -11,7 +11,8 @@ echo "== bench C3 B=16";      timeout 300 python bench.py --steps 5 --warmup 2 -
 echo "== bench C3 f16";       timeout 300 python bench.py --steps 10 --warmup 2 --precision f16 --no-train-extra --no-nlspn-extra --no-head-extra > gpurun_out/bench_c3_f16_b4.log 2>&1; tail -n 1 gpurun_out/bench_c3_f16_b4.log | cut -c1-400
 echo "== bench C3 fp32";      timeout 300 python bench.py --steps 3 --warmup 1 --precision fp32 --no-train-extra --no-nlspn-extra --no-head-extra --no-latency-b1 > gpurun_out/bench_c3_fp32_b4.log 2>&1; tail -n 1 gpurun_out/bench_c3_fp32_b4.log | cut -c1-400
 echo "== bench C2 NYU";       timeout 300 python bench.py --steps 20 --warmup 3 --size nyu --no-train-extra --no-nlspn-extra > gpurun_out/bench_c2_nyu_bf16_b4.log 2>&1; tail -n 1 gpurun_out/bench_c2_nyu_bf16_b4.log | cut -c1-400
-echo "== bench C4-shape swin bf16 T=20"; timeout 300 python bench.py --steps 5 --warmup 2 --variant swin --no-cpu-baseline --no-train-extra --no-nlspn-extra > gpurun_out/bench_swin_bf16_b4.log 2>&1; tail -n 1 gpurun_out/bench_swin_bf16_b4.log | cut -c1-400
+echo "== bench C4-shape swin bf16 T=20 (the training precision; out of the depth tolerance for inference)"; timeout 300 python bench.py --steps 5 --warmup 2 --variant swin --precision bf16 --no-cpu-baseline --no-train-extra --no-nlspn-extra > gpurun_out/bench_swin_bf16_b4.log 2>&1; tail -n 1 gpurun_out/bench_swin_bf16_b4.log | cut -c1-400
+echo "== bench swin f16 T=20 (in tolerance: with the CPU baseline and the parity gate)"; timeout 400 python bench.py --steps 5 --warmup 2 --variant swin --precision f16 --no-train-extra --no-nlspn-extra --no-head-extra > gpurun_out/bench_swin_f16_b4.log 2>&1; echo "rc=$?"; tail -n 1 gpurun_out/bench_swin_f16_b4.log | cut -c1-400
 echo "== C4 train-dp swin B=4"; timeout 400 python bench.py --mode train-dp --variant swin --batch 4 --steps 3 --warmup 1 > gpurun_out/train_dp_swin_b4.log 2>&1; tail -n 1 gpurun_out/train_dp_swin_b4.log | cut -c1-400
 echo "== C4 train-dp res B=4"; timeout 400 python bench.py --mode train-dp --variant res --batch 4 --steps 3 --warmup 1 > gpurun_out/train_dp_res_b4.log 2>&1; tail -n 1 gpurun_out/train_dp_res_b4.log | cut -c1-400
 echo "== N=1 under the launcher (RCCL process group: init, barrier, all-reduce of the timing)"; timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --no-train-extra --no-nlspn-extra --no-head-extra --no-latency-b1 > gpurun_out/bench_launcher_n1.log 2>&1; echo "rc=$?"; tail -n 1 gpurun_out/bench_launcher_n1.log | cut -c1-300
