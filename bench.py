@@ -47,8 +47,25 @@ LAYERS = {"res": (1, 2, 9, 4), "res_nohoist": (1, 2, 3, 4), "swin": (1, 2, 5, 6,
 # algorithmic HBM bytes per latent pixel per launch with 2-byte activations (fp32 mode doubles the
 # activation terms, the fp32 state / y4 terms of conv1 / conv4 are approximated the same way)
 ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640, 9: 896}     # 9: y2 512 + conv3(cond) fp32 256 + y3 128
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "fp32": 157.3, "naive_fp32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
-DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "fp32": "f32", "naive_fp32": "f32"}
+# MI355X_MICROARCH.md dense MFMA peaks.  f16x3 (split f16, DD_PREC_F16X3): every algorithmic multiply-add costs three f16 MFMA
+# multiply-adds (Whi.Phi + Whi.Plo + Wlo.Phi), so its ceiling in ALGORITHMIC FLOP/s is a third of the f16 peak
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "fp32": 157.3, "naive_fp32": 157.3}
+DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "f16x3": "f16x3 (f16 hi+lo operand pairs, fp32 tensors)", "fp32": "f32", "naive_fp32": "f32"}
+STORE_BYTES = {"bf16": 1, "f16": 1, "f16x3": 2, "fp32": 2, "naive_fp32": 2}      # multiples of the 2-byte activation terms of ALGO_BYTES_PER_PIXEL
+FAR_LOG_SCALE = 1.8      # decoder shifted to KITTI's depth range: every depth times e^1.8 (~0.5 .. 80 m); synth.make_state_dict(decoder_log_scale=)
+
+
+def lib_source_sha():
+    """sha256 over the library's sources (csrc + include): what profiles/pmc_traffic.json is stamped with (tools/pmc_traffic.py) so that a PMC
+    figure taken on other kernels is not reported for these"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for d in (os.path.join(ROOT, "diffusiondepth_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hip", ".cpp")):
+                hsh.update(f.encode())
+                hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
 
 
 def nlspn_extra(dev, B, H, W, T=18):
@@ -324,9 +341,12 @@ def main():
                     help="conv3(cond)+conv3(E[t]) out of the loop: -1 = the library default (on in the bf16 mode), 0 / 1 = forced (A/B switch)")
     ap.add_argument("--bf16-storage", action="store_true", help="A/B: all-bf16 tensors in --precision bf16 (default: f16 storage / thin layers)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train-dp"])
-    ap.add_argument("--streams", type=int, default=None, help="concurrent sub-batches inside dd_denoise / dd_denoise_backward (option 'streams'); default: 1 for "
-                    "the inference line (its roofline object is defined per launch on one stream), 2 for --mode train-dp")
-    ap.add_argument("--no-streams-extra", action="store_true", help="skip the two-stream timing of the same step")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent sub-batches inside dd_denoise / dd_denoise_backward (option 'streams'); default 2 = the "
+                    "binding's own default (DDEPTH_STREAMS): the timed configuration is the shipped one.  The per-kernel `roofline` object is taken "
+                    "in a separate one-stream pass (per-launch durations are not defined under concurrency); the loop-level fraction "
+                    "(`roofline.step_frac_of_peak` = flops_per_map x maps/s / peak) is the figure that survives concurrency")
+    ap.add_argument("--no-streams-extra", action="store_true", help="skip the one-stream timing of the same step")
+    ap.add_argument("--no-abs-extra", action="store_true", help="skip the far-range / abs-clean (f16x3) parity + throughput extras")
     ap.add_argument("--no-sync-bn", action="store_true", help="train-dp with N > 1: keep per-rank BatchNorm statistics (default: synchronised, as the reference)")
     ap.add_argument("--dist-selftest", action="store_true", help="multi-rank plumbing only, no hot path (any backend)")
     ap.add_argument("--no-parity-gate", action="store_true", help="do not fail when the timed precision misses the depth-RMSE tolerance")
@@ -334,7 +354,7 @@ def main():
                     help="res: ScheduledCNNRefine of the ResNet heads; swin: UpSample_add variant, stride-4 condition map")
     args = ap.parse_args()
     if args.streams is None:
-        args.streams = 2 if args.mode == "train-dp" else 1
+        args.streams = 2
     if args.precision is None:
         args.precision = "f16" if (args.variant == "swin" and args.mode != "train-dp") else "bf16"
 
@@ -390,7 +410,7 @@ def main():
     be.set_option("hoist_cond", args.hoist)
     be.set_option("bf16_storage", 1 if args.bf16_storage else 0)
     be.set_option("streams", args.streams)
-    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision == "f16")))
+    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision in ("f16", "f16x3"))))
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
@@ -423,10 +443,19 @@ def main():
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     gc.enable()
+    ranks_seen, maps_done = 1, B * args.steps
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # rank census over RCCL: every rank marks its own slot and reports the maps it really processed
+        seen = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+        seen[rank] = 1
+        seen[world] = B * args.steps
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks_seen, maps_done = int((seen[:world] > 0).sum()), int(seen[world])
+        if ranks_seen != world:
+            raise SystemExit(f"rank census: {ranks_seen} of {world} ranks answered")
     assert torch.isfinite(depth).all()
 
     # ---- loop-only time of one graph replay (hipEvents on the launch stream), median of 5 ------------
@@ -440,9 +469,10 @@ def main():
 
     # ---- the same step with the batch split over two concurrent HIP streams (dd_set_option "streams"; results bit-identical) ----
     lanes = None
-    if rank == 0 and world == 1 and B >= 2 and args.streams == 1 and args.precision != "naive_fp32" and not args.no_streams_extra:
+    if rank == 0 and world == 1 and B >= 2 and args.precision != "naive_fp32" and not args.no_streams_extra:
         ref_x0 = x0.clone()
-        be.set_option("streams", 2)
+        other = 1 if args.streams != 1 else 2
+        be.set_option("streams", other)
         for _ in range(2):
             step()
         torch.cuda.synchronize(dev)
@@ -451,12 +481,11 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         el2 = time.perf_counter() - t1
-        lanes = {"what": f"the same step with dd_set_option('streams', 2): the {B} images as two concurrent sub-batches on separate HIP streams "
-                         "(own plans and hipGraphs per lane, fork / join by events); not the default: per-launch durations (roofline object) are "
-                         "defined on one stream",
-                 "maps_per_s": round(B * args.steps / el2, 2), "ms_per_step": round(el2 / args.steps * 1e3, 4),
-                 "bit_identical_to_one_stream": bool(torch.equal(x0, ref_x0))}
-        be.set_option("streams", 1)
+        lanes = {"what": f"the same step with dd_set_option('streams', {other}) instead of {args.streams}: streams = S runs the {B} images as S concurrent sub-batches on "
+                         "separate HIP streams (own plans and hipGraphs per lane, fork / join by events)",
+                 "streams": other, "maps_per_s": round(B * args.steps / el2, 2), "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                 "bit_identical_to_the_timed_configuration": bool(torch.equal(x0, ref_x0))}
+        be.set_option("streams", args.streams)
         step()
 
     # ---- B = 1 latency (the reference's test() feeds one image at a time, README.md:249) ----------------
@@ -476,43 +505,69 @@ def main():
         ms1 = (time.perf_counter() - t1) / n1 * 1e3
         lat = {"ms_per_map": round(ms1, 4), "maps_per_s": round(1e3 / ms1, 2)}
 
-    # ---- per-kernel roofline: eager pass with an event pair around every conv launch ------------------
-    roof = None
-    if args.precision != "naive_fp32":
+    # ---- per-kernel roofline: eager ONE-STREAM pass with an event pair around every conv launch (the library runs the per-launch timing
+    #      mode on one stream whatever "streams" says: a launch's duration is not a property of the kernel under concurrency) ------------
+    def kernel_roofline(xb, cb, nb, loop_ms_b):
         be.set_option("layer_timing", 1)
+        ob = torch.empty_like(xb)
         for _ in range(2):
-            be.denoise(x_T, cond, T, args.precision, out=x0)
+            be.denoise(xb, cb, T, args.precision, out=ob)
         torch.cuda.synchronize(dev)
         per_layer = {l: be.layer_ms(l) for l in layer_set}
         be.set_option("layer_timing", 0)
         dom = max(per_layer, key=lambda l: per_layer[l][0])
         tot_ms, cnt = per_layer[dom]
         cin, cout = LAYER_DIMS[dom]
-        flops = 2.0 * 9 * cin * cout * B * h * w
+        flops = 2.0 * 9 * cin * cout * nb * h * w
         avg_s = tot_ms / max(cnt, 1) * 1e-3
         achieved = flops / avg_s / 1e12
         peak = PEAK_TFLOPS[args.precision]
-        # HBM traffic of that kernel from the committed PMC passes (tools/pmc_traffic.py), if they were taken on this config
-        traffic = None
+        # HBM traffic of that kernel from the committed PMC passes (tools/pmc_traffic.py) -- only if they were taken on THESE sources
+        # (stamp = sha256 of csrc + include) and on this configuration; otherwise null, with the reason
+        traffic, traffic_note = None, "no PMC pass for this configuration"
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            want = f"--precision {args.precision} --batch {B} --size {args.size} --variant {args.variant}"
-            if pt.get("bench_args", "").strip() == want:
-                # kernel names carry the element kind / mode: 0 fp32, 1 bf16, 2 f16, 3 = the default bf16 mode (dd_kernels.h EK_BF16M)
-                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,)}[args.precision]:
+            want = f"--precision {args.precision} --batch {nb} --size {args.size} --variant {args.variant}"
+            if pt.get("bench_args", "").strip() != want:
+                traffic_note = f"profiles/pmc_traffic.json was taken with '{pt.get('bench_args', '')}'"
+            elif pt.get("lib_source_sha") != lib_source_sha():
+                traffic_note = f"profiles/pmc_traffic.json is stale: taken on library sources {pt.get('lib_source_sha')}, these are {lib_source_sha()}"
+            else:
+                # kernel names carry the element kind / mode: 0 fp32, 1 bf16, 2 f16, 3 = the default bf16 mode, 4 = split f16 (dd_kernels.h)
+                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,), "f16x3": (4,)}[args.precision]:
                     if f"layer{dom}_ek{ekid}" in pt["kernels"]:
                         traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
+                        traffic_note = f"rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/pmc_traffic.json, sources {pt.get('lib_source_sha')}, {pt.get('taken', '')})"
                         break
-        except Exception:
-            traffic = None
-        roof = {"bound": "mfma", "kernel": f"conv_igemm2_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
-                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/pmc_traffic.json)",
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL.get(dom, 0) * ({"bf16": 1, "f16": 1, "fp32": 2}[args.precision]) * B * h * w,
-                "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops,
+        except Exception as e:  # noqa: BLE001
+            traffic_note = f"profiles/pmc_traffic.json unreadable: {type(e).__name__}"
+        return {"bound": "mfma", "kernel": f"conv_igemm2_kernel<layer {dom}: conv3x3 {cin}->{cout}>", "achieved": round(achieved, 2),
+                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch", "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL.get(dom, 0) * STORE_BYTES[args.precision] * nb * h * w,
+                "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops, "batch": nb, "streams_in_this_pass": 1,
                 "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
-                "loop_ms_graph": round(loop_ms, 4),
-                "loop_frac_of_peak": round(B * T * h * w * FPS / (loop_ms * 1e-3) / 1e12 / peak, 4) if loop_ms > 0 else None}
+                "per_layer_frac_of_peak": {str(l): round(2.0 * 9 * LAYER_DIMS[l][0] * LAYER_DIMS[l][1] * nb * h * w /
+                                                         (per_layer[l][0] / max(per_layer[l][1], 1) * 1e-3) / 1e12 / peak, 4) for l in per_layer},
+                "loop_ms_graph": round(loop_ms_b, 4),
+                "loop_frac_of_peak": round(nb * T * h * w * FPS / (loop_ms_b * 1e-3) / 1e12 / peak, 4) if loop_ms_b > 0 else None}
+
+    roof = roof1 = None
+    if args.precision != "naive_fp32":
+        roof = kernel_roofline(x_T, cond, B, loop_ms)
+        # the headline's own fraction: whole step (encoder + loop + decoder) as timed above, all streams -- survives concurrency
+        roof["step_frac_of_peak"] = round(B * T * h * w * FPS * args.steps / elapsed / 1e12 / PEAK_TFLOPS[args.precision], 4)
+        roof["streams_in_the_timed_step"] = args.streams
+        if B != 1 and not args.no_latency_b1:
+            # SURVEY.md 8(d) names C3 at B = 1: the same objects for one map
+            be.set_option("timing", 1)
+            l1 = []
+            for _ in range(5):
+                be.denoise(x1, c1_, T, args.precision, out=o1)
+                l1.append(be.last_loop_ms())
+            be.set_option("timing", 0)
+            roof1 = kernel_roofline(x1, c1_, 1, sorted(l1)[2])
+            roof1["step_frac_of_peak"] = round(T * h * w * FPS / (lat["ms_per_map"] * 1e-3) / 1e12 / PEAK_TFLOPS[args.precision], 4)
 
     # ---- CPU baseline: torch-CPU port of the reference path, ONE map, this host's cores -----------
     cpu = None
@@ -534,6 +589,47 @@ def main():
         dg = depth[:1].cpu() if rank == 0 else None
         cpu["gpu_vs_cpu_depth_rmse"] = float(torch.sqrt(torch.mean((dg - d_cpu) ** 2)))
         cpu["gpu_vs_cpu_depth_maxabs"] = float((dg - d_cpu).abs().max())
+        rel = float(torch.sqrt(torch.mean(((dg - d_cpu) / d_cpu.clamp_min(1e-6)) ** 2)))
+        cpu["depth_range_m"] = [round(float(d_cpu.min()), 3), round(float(d_cpu.max()), 3)]
+        cpu["gpu_vs_cpu_depth_rel_rmse"] = rel
+        # the decoder ends in exp(-z): a 16-bit mode's depth error is RELATIVE, so its absolute RMSE grows with the depths decoded.  With
+        # these untrained weights (the loop amplifies the latent to |x_0| ~ 5e2) the 1e-3 absolute RMSE of the north star holds up to:
+        cpu["abs_rmse_1e3_holds_to_rms_depth_m"] = round(1e-3 / max(rel, 1e-12), 2)
+        if not args.no_abs_extra and args.variant == "res":
+            # the SAME latents decoded at KITTI's depth range (decoder bias shifted: every depth x e^1.8), and the abs-clean mode beside
+            # the timed one: split f16 (f16x3) -- throughput of the same step and its max-abs error, near and far range
+            sd_far = synth.make_state_dict(7240, args.variant, decoder_log_scale=FAR_LOG_SCALE)
+            bf = dda.HipDenoiser(dev, args.variant)
+            bf.load_state_dict({k: v for k, v in sd_far.items() if k.startswith("depth_transform.")})
+            with torch.no_grad():
+                d_cpu_far = P.decode(P.to_torch_sd(sd_far), lat_cpu)
+            dg_far = bf.decode(x0[:1]).cpu()
+            cpu["far_range"] = {"what": f"the same latents decoded with the decoder shifted to KITTI's depth range (every depth x e^{FAR_LOG_SCALE})",
+                                "depth_range_m": [round(float(d_cpu_far.min()), 3), round(float(d_cpu_far.max()), 3)],
+                                "gpu_vs_cpu_depth_rmse": float(torch.sqrt(torch.mean((dg_far - d_cpu_far) ** 2))),
+                                "gpu_vs_cpu_depth_maxabs": float((dg_far - d_cpu_far).abs().max()),
+                                "gpu_vs_cpu_depth_rel_rmse": float(torch.sqrt(torch.mean(((dg_far - d_cpu_far) / d_cpu_far.clamp_min(1e-6)) ** 2)))}
+            if args.precision != "f16x3":
+                xs = torch.empty_like(x_T)
+                for _ in range(2):
+                    be.encode(gt); be.denoise(x_T, cond, T, "f16x3", out=xs); ds = be.decode(xs)
+                torch.cuda.synchronize(dev)
+                ns = max(3, args.steps // 4)
+                t3 = time.perf_counter()
+                for _ in range(ns):
+                    be.encode(gt); be.denoise(x_T, cond, T, "f16x3", out=xs); ds = be.decode(xs)
+                torch.cuda.synchronize(dev)
+                el3 = time.perf_counter() - t3
+                ds1, ds_far = ds[:1].cpu(), bf.decode(xs[:1]).cpu()
+                cpu["abs_clean_mode"] = {
+                    "what": "the same step in the split-f16 mode (precision f16x3: f16 hi+lo operand pairs, three MFMAs per product, fp32 tensors): "
+                            "the mode that holds the north star's 1e-3 ABSOLUTE depth tolerance over the whole depth range",
+                    "maps_per_s": round(B * ns / el3, 2), "ms_per_step": round(el3 / ns * 1e3, 3),
+                    "frac_of_f16x3_peak": round(B * T * h * w * FPS * ns / el3 / 1e12 / PEAK_TFLOPS["f16x3"], 4),
+                    "gpu_vs_cpu_depth_maxabs": float((ds1 - d_cpu).abs().max()), "gpu_vs_cpu_depth_rmse": float(torch.sqrt(torch.mean((ds1 - d_cpu) ** 2))),
+                    "far_range_depth_maxabs": float((ds_far - d_cpu_far).abs().max()),
+                    "far_range_depth_rmse": float(torch.sqrt(torch.mean((ds_far - d_cpu_far) ** 2)))}
+            bf.close()
 
     # ---- training extra: one T-step loop forward + backward (dd_denoise + dd_denoise_backward) ----
     train = None
@@ -575,7 +671,7 @@ def main():
             headx = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        maps = B * args.steps * world
+        maps = maps_done                       # summed over the ranks by the census all-reduce
         n_world = dist.get_world_size() if dist is not None else 1
         out = {
             "metric": f"depth-maps/sec ({T}-step DDIM, {args.size.upper()} {H}x{W} {args.precision}, B={B} maps per GPU per step)",
@@ -585,15 +681,18 @@ def main():
             "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
+                       "ranks_seen": ranks_seen, "streams": args.streams,
                        "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant},
-            "roofline": roof, "cpu_baseline": cpu, "latency_b1": lat, "two_streams": lanes, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
+            "roofline": roof, "roofline_b1": roof1, "cpu_baseline": cpu, "latency_b1": lat, "other_stream_count": lanes, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
         }
         print(json.dumps(out), flush=True)
         # parity gate of the TIMED configuration (north star: depth RMSE within 1e-3 of the reference): a fast number out of tolerance
         # is not a result.  fp32 additionally holds the 1e-3 abs reading.
         if cpu is not None and not args.no_parity_gate:
             rmse, mx = cpu["gpu_vs_cpu_depth_rmse"], cpu["gpu_vs_cpu_depth_maxabs"]
-            if rmse > 1e-3 or (args.precision in ("fp32", "naive_fp32") and mx > 1e-3):
+            if args.precision in ("fp32", "naive_fp32", "f16x3") and "far_range" in cpu:
+                mx = max(mx, cpu["far_range"]["gpu_vs_cpu_depth_maxabs"])        # the abs-clean modes hold 1e-3 abs at KITTI's depth range too
+            if rmse > 1e-3 or (args.precision in ("fp32", "naive_fp32", "f16x3") and mx > 1e-3):
                 print(f"[bench] PARITY GATE FAILED: {args.precision} depth RMSE {rmse:.3e} (max abs {mx:.3e}) vs the CPU reference path exceeds 1e-3",
                       file=sys.stderr, flush=True)
                 if dist is not None:

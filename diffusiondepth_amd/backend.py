@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libddepth_hip.so"
 _lib = None
 
-PRECISIONS = {"naive_fp32": 0, "fp32": 1, "bf16": 2, "f16": 3, "fp16": 3}
+# "f16x3": split f16 (DD_PREC_F16X3, include/ddepth.h) -- the abs-1e-3-on-depth inference mode (forward only)
+PRECISIONS = {"naive_fp32": 0, "fp32": 1, "bf16": 2, "f16": 3, "fp16": 3, "f16x3": 4, "split_f16": 4}
 VARIANTS = {"res": 0, "swin": 1}
 
 # every symbol include/ddepth.h declares (checked by tests/test_abi.py)

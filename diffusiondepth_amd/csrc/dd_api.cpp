@@ -50,7 +50,11 @@ inline uint16_t host_f32_to_f16(float f) {
   return u;
 }
 
-constexpr int NUM_EK = 3;
+constexpr int NUM_EK = 3;     // weight images every convolution has: fp32, bf16, f16 (index = element kind)
+constexpr int NUM_WIMG = 4;   // ... the denoiser's forward convolutions have a fourth: the split-f16 image of the mode EK_F16S (index WIMG_SPLIT)
+constexpr int WIMG_SPLIT = 3;
+inline int wimg_kind(int slot) { return slot == WIMG_SPLIT ? (int)EK_F16S : slot; }     // image slot -> kind handed to the packers / conv_pack_geom2
+inline int wimg_slot(int kind) { return kind == EK_F16S ? WIMG_SPLIT : kind; }
 // precision -> element kind / mode of the fused kernels.  DD_PREC_BF16 is the mode EK_BF16M (bf16 operands on the large convolutions, f16
 // storage and thin layers: dd_kernels.h) unless the handle option "bf16_storage" = 1 selects all-bf16 tensors (A/B and error budget).
 inline int ek_of_precision(int prec, bool bf16_pure) {
@@ -58,10 +62,11 @@ inline int ek_of_precision(int prec, bool bf16_pure) {
     case DD_PREC_FP32: return EK_F32;
     case DD_PREC_BF16: return bf16_pure ? EK_BF16 : EK_BF16M;
     case DD_PREC_F16: return EK_F16;
+    case DD_PREC_F16X3: return EK_F16S;
     default: return -1;
   }
 }
-inline size_t ek_size(int ek) { return ek == EK_F32 ? 4 : 2; }
+inline size_t ek_size(int ek) { return (ek == EK_F32 || ek == EK_F16S) ? 4 : 2; }     // bytes per STORED element (EK_F16S stores fp32)
 inline int thin_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek; }      // conv1 / conv4 / once-per-image conv3(cond): kernels and weights
 
 constexpr int FPN_LEVELS = 4;
@@ -84,7 +89,7 @@ inline int fpn_lat_layer(int variant, int pyr, int level) {      // kernel layer
 
 struct ConvLayer {                  // one Conv3x3 + its following GroupNorm
   int cin = 0, cout = 0;
-  DevBuf wpack2[NUM_EK];            // packed for the fused kernels (pre-swizzled for LDS-DMA)
+  DevBuf wpack2[NUM_WIMG];          // packed for the fused kernels (pre-swizzled for LDS-DMA)
   DevBuf bias;                      // [cout padded to 32]
   DevBuf w_oihw;                    // naive path
   DevBuf wpackT[NUM_EK];            // fused backward: W' packed for the dgrad layer (23 - conv index) of dd_igemm2.hip
@@ -328,8 +333,10 @@ std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
 //   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT; ks x ks taps)
 void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
   const int ks = g.ks, n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = ks * ks / g.tg;
-  const size_t n_el = (size_t)n_tiles * n_chunks * n_tg * g.tg * g.nt * g.ck;
-  const size_t esz = ek_size(ek);
+  const int planes = g.planes > 1 ? 2 : 1;       // split f16 (EK_F16S): every stage block is [hi plane | lo plane] of f16 elements
+  const size_t n_el = (size_t)n_tiles * n_chunks * n_tg * g.tg * g.nt * g.ck * planes;
+  const size_t esz = planes == 2 ? 2 : ek_size(ek);
+  const size_t plane_el = (size_t)g.tg * g.nt * g.ck;
   out.assign(n_el * esz, 0);
   for (int nt = 0; nt < n_tiles; ++nt)
     for (int ch = 0; ch < n_chunks; ++ch)
@@ -337,7 +344,7 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
         for (int t = 0; t < g.tg; ++t) {
           const int tap = tg * g.tg + t, dy = tap / ks, dx = tap % ks;
           const int rowb = g.ck * (int)esz, ppp = rowb / 16, rpb = 256 / rowb, epp = 16 / (int)esz;
-          const size_t blk0 = (((size_t)(nt * n_chunks + ch) * n_tg + tg) * g.tg + 0) * (size_t)g.nt * g.ck;
+          const size_t blk0 = (((size_t)(nt * n_chunks + ch) * n_tg + tg) * g.tg + 0) * (size_t)g.nt * g.ck * planes;
           for (int n = 0; n < g.nt; ++n)
             for (int k = 0; k < g.ck; ++k) {
               const int co = nt * g.nt + n, ci = ch * g.ck + k;
@@ -347,7 +354,14 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
               const int piece_sw = swizzle ? (piece ^ ((row / rpb) & (ppp - 1))) : piece;
               const size_t idx = blk0 + (size_t)row * g.ck + (size_t)piece_sw * epp + within;
               const float v = (co < g.cout) ? w_oihw[(((size_t)co * g.cin + ci) * ks + dy) * ks + dx] : 0.f;
-              if (ek == EK_F32) std::memcpy(&out[idx * 4], &v, 4);
+              if (planes == 2) {
+                // hi = f16(w * SPLIT_WSCALE), lo = f16(w * SPLIT_WSCALE - hi): the same arithmetic as pack_weights_kernel (dd_misc.hip)
+                const float vs = v * SPLIT_WSCALE;
+                const _Float16 hi = (_Float16)vs;
+                const _Float16 lo = (_Float16)(vs - (float)hi);
+                std::memcpy(&out[idx * 2], &hi, 2);
+                std::memcpy(&out[(idx + plane_el) * 2], &lo, 2);
+              } else if (ek == EK_F32) std::memcpy(&out[idx * 4], &v, 4);
               else {
                 const uint16_t u = (ek == EK_BF16) ? host_f32_to_bf16(v) : host_f32_to_f16(v);
                 std::memcpy(&out[idx * 2], &u, 2);
@@ -406,7 +420,7 @@ int want_hoist(dd_handle_t h, int precision) {
   if (h->variant != DD_VARIANT_RES || precision == DD_PREC_NAIVE_FP32) return 0;
   if (h->hoist_cond >= 0) return h->hoist_cond;
   const int ek = ek_of_precision(precision, h->bf16_pure);
-  return (ek == EK_BF16M || ek == EK_F16) ? 1 : 0;
+  return (ek == EK_BF16M || ek == EK_F16 || ek == EK_F16S) ? 1 : 0;
 }
 
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
@@ -494,7 +508,8 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   // the loop's timesteps are the plan's own schedule: pass the value, not the address (clamped as clamp_t does on the device)
   if (tvec == pl->tsteps.as<long long>() && t_bstride == 0 && t_base >= 0 && t_base < (int)pl->tsteps_host.size())
     p.t_known = clamp_t(pl->tsteps_host[t_base]);
-  const int ek = pl->ek, ok = opnd_kind(ek), tk = thin_kind(ek);    // mode; operand kind of the large convolutions; kind of conv1 / conv4
+  const int ek = pl->ek, tk = thin_kind(ek);    // mode; kind of conv1 / conv4
+  const int wk = ek == EK_F16S ? WIMG_SPLIT : opnd_kind(ek);    // weight image of the large convolutions (their operand kind; the split image in the split mode)
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
@@ -516,33 +531,33 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   void *sa_ = pl->slot(pl->sa, step), *sf_ = pl->slot(pl->sf, step);
   const float* y4_prev = static_cast<const float*>(pl->slot(pl->y4, step > 0 ? step - 1 : 0));     // read by the fused update of step - 1
   // conv1: state (+ fused DDIM update of the previous step) -> y1
-  p.in = x_in; p.wpack = h->L[0].wpack2[tk].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
+  p.in = x_in; p.wpack = h->L[0].wpack2[wimg_slot(tk)].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
   p.stats_out = pl->stat_ptr(step, 0);
   p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
   p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
   p.y4 = y4_prev; p.xout = x_out; p.c1c2 = pl->c1c2.as<float>(); p.step = apply_update ? step : 0;
   DD_HIP(timed_launch(1, p));
   // conv2: relu(gn1(y1)) -> y2
-  p.in = y1_; p.wpack = h->L[1].wpack2[ok].p; p.bias = h->L[1].bias.as<float>(); p.out = y2_;
+  p.in = y1_; p.wpack = h->L[1].wpack2[wk].p; p.bias = h->L[1].bias.as<float>(); p.out = y2_;
   p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
   p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
   DD_HIP(timed_launch(2, p));
   if (h->variant == DD_VARIANT_SWIN) {
     // upsample_fuse: convB(convA(relu(gn2(y2)) + up(cond) + E[t]))  then pred.0 on the raw result
-    p.in = y2_; p.wpack = h->LA.wpack2[ok].p; p.bias = h->LA.bias.as<float>(); p.out = sa_;
+    p.in = y2_; p.wpack = h->LA.wpack2[wk].p; p.bias = h->LA.bias.as<float>(); p.out = sa_;
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
     p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
     p.cond = pl->cond_ptr(); p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
     DD_HIP(timed_launch(5, p));
-    p.in = sa_; p.wpack = h->LB.wpack2[ok].p; p.bias = h->LB.bias.as<float>(); p.out = sf_;
+    p.in = sa_; p.wpack = h->LB.wpack2[wk].p; p.bias = h->LB.bias.as<float>(); p.out = sf_;
     p.stats_in = nullptr;
     DD_HIP(timed_launch(6, p));
-    p.in = sf_; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
+    p.in = sf_; p.wpack = h->L[2].wpack2[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
     p.stats_out = pl->stat_ptr(step, 2);
     DD_HIP(timed_launch(7, p));
   } else {
   // conv3: relu(gn2(y2)) + cond + E[t] -> y3   (hoisted form: conv3(relu(gn2(y2))) + [conv3(cond) + conv3(E[t])])
-  p.in = y2_; p.wpack = h->L[2].wpack2[ok].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
+  p.in = y2_; p.wpack = h->L[2].wpack2[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
   p.stats_out = pl->stat_ptr(step, 2); p.stats_in = pl->stat_ptr(step, 1);
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond_ptr(); p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
@@ -550,7 +565,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
-  p.in = y3_; p.wpack = h->L[3].wpack2[tk].p; p.bias = h->L[3].bias.as<float>(); p.out = y4_;
+  p.in = y3_; p.wpack = h->L[3].wpack2[wimg_slot(tk)].p; p.bias = h->L[3].bias.as<float>(); p.out = y4_;
   p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
   p.gn_gamma = h->L[2].gamma.as<float>(); p.gn_beta = h->L[2].beta.as<float>();
   DD_HIP(timed_launch(4, p));
@@ -592,7 +607,7 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   p.tiles_x = (k.w + 31) / 32;
   p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
   p.ablate = 0;
-  p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[thin_kind(pl->ek)].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
+  p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[wimg_slot(thin_kind(pl->ek))].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
   DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
   return DD_OK;
 }
@@ -802,10 +817,12 @@ int ensure_bytes(dd_handle_t h, DevBuf& dst, size_t bytes) {
 // One convolution's weights from a device fp32 OIHW tensor into every layout the forward / backward kernels read -- the device twin of the
 // host loops in dd_commit_weights (same geometries, same buffers), all on stream `s`.
 int pack_conv_layer_device(dd_handle_t h, ConvLayer& L, const float* w, int fwd_layer, int dgrad_layer, bool with_naive, hipStream_t s) {
-  for (int ek = 0; ek < NUM_EK; ++ek) {
+  for (int wi = 0; wi < NUM_WIMG; ++wi) {
+    const int ek = wimg_kind(wi);
     const PackGeom g2 = conv_pack_geom2(fwd_layer, ek);
-    int rc = ensure_bytes(h, L.wpack2[ek], pack_weights_bytes(g2, ek)); if (rc) return rc;
-    DD_HIP(launch_pack_weights(w, L.wpack2[ek].p, g2, ek, true, false, s));
+    int rc = ensure_bytes(h, L.wpack2[wi], pack_weights_bytes(g2, ek)); if (rc) return rc;
+    DD_HIP(launch_pack_weights(w, L.wpack2[wi].p, g2, ek, true, false, s));
+    if (wi == WIMG_SPLIT) continue;           // the split-f16 mode is forward only
     const PackGeom gt = conv_pack_geom2(dgrad_layer, ek);
     rc = ensure_bytes(h, L.wpackT[ek], pack_weights_bytes(gt, ek)); if (rc) return rc;
     DD_HIP(launch_pack_weights(w, L.wpackT[ek].p, gt, ek, true, true, s));
@@ -908,10 +925,10 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     L.cin = cins[l]; L.cout = couts[l];
     const std::vector<float>& w = h->host_w[std::string(conv_names[l]) + ".weight"];
     const std::vector<float>& b = h->host_w[std::string(conv_names[l]) + ".bias"];
-    for (int ek = 0; ek < NUM_EK; ++ek) {
+    for (int wi = 0; wi < NUM_WIMG; ++wi) {
       std::vector<uint8_t> packed;
-      pack_conv_weights(w.data(), conv_pack_geom2(l + 1, ek), ek, true, packed);
-      int rc = upload(h, L.wpack2[ek], packed.data(), packed.size(), s);
+      pack_conv_weights(w.data(), conv_pack_geom2(l + 1, wimg_kind(wi)), wimg_kind(wi), true, packed);
+      int rc = upload(h, L.wpack2[wi], packed.data(), packed.size(), s);
       if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));     // `packed` is a temporary
     }
@@ -948,10 +965,10 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       L.cin = COND_C; L.cout = COND_C;
       const std::vector<float>& w = h->host_w[std::string(names[i]) + ".weight"];
       const std::vector<float>& b = h->host_w[std::string(names[i]) + ".bias"];
-      for (int ek = 0; ek < NUM_EK; ++ek) {
+      for (int wi = 0; wi < NUM_WIMG; ++wi) {
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(5 + i, ek), ek, true, packed);
-        int rc = upload(h, L.wpack2[ek], packed.data(), packed.size(), s);
+        pack_conv_weights(w.data(), conv_pack_geom2(5 + i, wimg_kind(wi)), wimg_kind(wi), true, packed);
+        int rc = upload(h, L.wpack2[wi], packed.data(), packed.size(), s);
         if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
@@ -1238,7 +1255,7 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   if (with_neck && h->variant != DD_VARIANT_SWIN)
     return h->fail(DD_ERR_UNSUPPORTED, "dd_neck_condition: the HAHI neck kernels are built for the Swin-L (192/384/768/1536) and MPViT-small (128/216/288/288) pyramids of DD_VARIANT_SWIN");
   if (n_levels != FPN_LEVELS || !feats || !feat_h || !feat_w) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: expects 4 pyramid levels");
-  if (precision < DD_PREC_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16 or f16");
+  if (precision < DD_PREC_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16, f16 or f16x3");
   if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
   for (int i = 0; i < FPN_LEVELS; ++i) {
     if (!feats[i] || feat_h[i] <= 0 || feat_w[i] <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: null feature pointer or non-positive size");
@@ -1246,7 +1263,8 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
-  const int ek = ek_of_precision(precision, h->bf16_pure);      // EK_BF16M: inner tensors bf16, the result (level-0 lateral conv) f16
+  int ek = ek_of_precision(precision, h->bf16_pure);      // EK_BF16M: inner tensors bf16, the result (level-0 lateral conv) f16
+  if (ek == EK_F16S) ek = EK_F32;       // split-f16 mode: the once-per-image pyramid runs on the fp32 kernels (its result is an fp32 map either way)
   const int ok = opnd_kind(ek), sk = store_kind(ek);
   const size_t es = ek_size(ek);
   // workspace for this pyramid shape
@@ -1471,7 +1489,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (rc) return rc;
   if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1523,7 +1541,7 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
   if (rc) return rc;
   if (!x_T || !states) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: num_inference_steps must be in [1, num_train_timesteps]");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: unknown precision");
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1571,7 +1589,7 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, false);
   if (rc) return rc;
   if (!x_t || !t || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1810,7 +1828,9 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
 int check_bwd(dd_handle_t h, int precision, const char* who) {
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_SWIN has no unfused path (use fp32 / bf16 / f16)");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
+  if (precision == DD_PREC_F16X3)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16X3 (split f16) is a forward-only parity mode; train in fp32 / bf16 / f16");
   return DD_OK;
 }
 
@@ -2063,6 +2083,7 @@ int dd_debug_weights_digest(dd_handle_t h, uint64_t* digest) {
       hipError_t e = eat(L.wpack2[ek]); if (e != hipSuccess) return e;
       e = eat(L.wpackT[ek]); if (e != hipSuccess) return e;
     }
+    { hipError_t e = eat(L.wpack2[WIMG_SPLIT]); if (e != hipSuccess) return e; }
     const DevBuf* rest[5] = {&L.bias, &L.w_oihw, &L.wT_oihw, &L.gamma, &L.beta};
     for (const DevBuf* b : rest) { hipError_t e = eat(*b); if (e != hipSuccess) return e; }
     return hipSuccess;

@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
       for (int q = 0; q < NLD; ++q) raw[slot][u][q] = *reinterpret_cast<const uint4*>(in_b + goff + q * 16);
       if constexpr (C::PRO == PRO_GN_ADD) {
-        aux[u][0] = *reinterpret_cast<const uint4*>(cond_b + goff);
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) aux[u][q] = *reinterpret_cast<const uint4*>(cond_b + goff + q * 16);
       } else if constexpr (C::PRO == PRO_X) {
         if (have_norm) {
 #pragma unroll
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   };
   auto transform_item = [&](int chunk, int pbuf_off, int u, int slot) {
     if (!((m_valid >> u) & 1u)) return;
-    if constexpr (C::PRO == PRO_RAW) {
+    if constexpr (C::PRO == PRO_RAW && !C::SPLIT) {
       // no normalisation between the producer and this convolution: the stored elements are the operands
       *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = ((m_inside >> u) & 1u) ? raw[slot][u][0] : make_uint4(0u, 0u, 0u, 0u);
       return;
@@ -243,6 +244,27 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           for (int q = 0; q < NLD; ++q)
             *reinterpret_cast<float4*>(xout_b + goff + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
         }
+        if constexpr (C::SPLIT) {
+#pragma unroll
+          for (int i = 0; i < EPP; ++i) v[i] *= SPLIT_PSCALE;
+        }
+      } else if constexpr (C::SPLIT) {
+        // fp32 tensors in HBM: the piece's 8 channels are two 16-byte loads; the table already carries SPLIT_PSCALE
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+          const uint32_t yw[4] = {raw[slot][u][q].x, raw[slot][u][q].y, raw[slot][u][q].z, raw[slot][u][q].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float y = __builtin_bit_cast(float, yw[i]);
+            if constexpr (C::PRO == PRO_RAW) v[q * 4 + i] = y * SPLIT_PSCALE;
+            else v[q * 4 + i] = fmaxf(fmaf(ta[q * 4 + i], y, tb[q * 4 + i]), 0.f);
+          }
+          if constexpr (C::PRO == PRO_GN_ADD) {
+            const uint32_t cw[4] = {aux[u][q].x, aux[u][q].y, aux[u][q].z, aux[u][q].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[q * 4 + i] = fmaf(__builtin_bit_cast(float, cw[i]), SPLIT_PSCALE, v[q * 4 + i] + te[q * 4 + i]);
+          }
+        }
       } else {
         if constexpr (C::PRO == PRO_GN && EK != EK_F32) {
           *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = affine_relu_pack<C::IN_K, EK>(raw[slot][u][0], ta, tb);
@@ -262,7 +284,18 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
       for (int i = 0; i < EPP; ++i) v[i] = 0.f;       // zero padding applies AFTER the normalisation
     }
-    *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = Piece<EK>::pack(v);
+    if constexpr (C::SPLIT) {
+      // operand pair: hi = f16(v), lo = f16(v - hi); the two planes of the patch buffer
+      const uint4 hi = Piece<EK_F16>::pack(v);
+      float vh[EPP];
+      Piece<EK_F16>::unpack(hi, vh);
+#pragma unroll
+      for (int i = 0; i < EPP; ++i) vh[i] = v[i] - vh[i];
+      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = hi;
+      *reinterpret_cast<uint4*>(smem + pbuf_off + C::PATCH_PLANE + lds_off[u]) = Piece<EK_F16>::pack(vh);
+    } else {
+      *reinterpret_cast<uint4*>(smem + pbuf_off + lds_off[u]) = Piece<EK>::pack(v);
+    }
   };
   auto transform_write = [&](int chunk, int pbuf_off, int slot) {
     load_table_slice(chunk);
@@ -338,10 +371,17 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       for (int q = 0; q < 4; ++q) {
         float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (C::ADD_C) {
-          // layer 8 stored conv3(cond) in accumulator-fragment order: every load is one contiguous KiB per wave
+          // layer 8 stored conv3(cond) in accumulator-fragment order: every load is one contiguous KiB (f16: half a KiB) per wave
           (void)pv;
-          cv = reinterpret_cast<const float4*>(p.cadd)[((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane];
+          const size_t fi = ((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane;
+          if constexpr (C::CADD16) {
+            const uint2 h2 = reinterpret_cast<const uint2*>(p.cadd)[fi];
+            cv = make_float4(f16_to_f32(h2.x & 0xFFFFu), f16_to_f32(h2.x >> 16), f16_to_f32(h2.y & 0xFFFFu), f16_to_f32(h2.y >> 16));
+          } else {
+            cv = reinterpret_cast<const float4*>(p.cadd)[fi];
+          }
         }
+        if constexpr (C::SPLIT && C::ADD_C) { constexpr float IS = 1.f / SPLIT_OSCALE; cv.x *= IS; cv.y *= IS; cv.z *= IS; cv.w *= IS; }   // accumulators run at the operands' scale
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }
   }
@@ -370,9 +410,12 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       double var = gs.y * inv_cnt - mean * mean;                 // biased, as torch
       var = var > 0.0 ? var : 0.0;
       const double a = (double)my_gamma / sqrt(var + (double)GN_EPS);
-      tab_a[tid] = (float)a;
-      tab_b[tid] = (float)((double)my_beta - mean * a);
-      if constexpr (C::PRO == PRO_GN_ADD) tab_e[tid] = my_emb;
+      // split f16: the patch is carried times SPLIT_PSCALE (exact power of two; relu commutes with it).  conv1 scales behind the DDIM
+      // update instead: its table also produces the state that is written back
+      constexpr float TS = (C::SPLIT && C::PRO != PRO_X) ? SPLIT_PSCALE : 1.f;
+      tab_a[tid] = (float)a * TS;
+      tab_b[tid] = (float)((double)my_beta - mean * a) * TS;
+      if constexpr (C::PRO == PRO_GN_ADD) tab_e[tid] = my_emb * TS;
     }
     if constexpr (C::ADD_C) {
 #pragma unroll
@@ -408,8 +451,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       // are issued between the MFMAs of group g, into the other half of a two-deep register buffer, so a wave's MFMA
       // stream does not wait for LDS latency inside a stage (only the first group of a stage is exposed).
       constexpr int NG = C::TG * NKQ;          // fragment groups per stage
-      constexpr int NF = C::WM + C::WN;        // fragments (ds_read_b128) per group
-      constexpr int NM = C::WM * C::WN * ((EK == EK_F32) ? 4 : 1);   // MFMA instructions per group
+      constexpr int NF = C::NPL * (C::WM + C::WN);        // fragments (ds_read_b128) per group; split f16: [pixel hi | pixel lo | weight hi | weight lo]
+      constexpr int NM = C::WM * C::WN * ((EK == EK_F32) ? 4 : C::SPLIT ? 3 : 1);   // MFMA instructions per group
       constexpr int FD = C::FRAG_DEPTH;        // register buffers: FD-1 groups of ds_reads are in flight ahead of the MFMAs
       uint4 fr[FD][NF];
       auto load_group = [&](int gi, uint4 (&f)[NF]) {
@@ -419,8 +462,16 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         const int pa = colt[dx][kq] + poff + dy * (PW * ROWB);
 #pragma unroll
         for (int m = 0; m < C::WM; ++m) f[m] = *reinterpret_cast<const uint4*>(smem + pa + m * (PW * ROWB));
+        if constexpr (C::SPLIT) {
 #pragma unroll
-        for (int n = 0; n < C::WN; ++n) f[C::WM + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + (t * C::NT + n * 32) * ROWB);
+          for (int m = 0; m < C::WM; ++m) f[C::WM + m] = *reinterpret_cast<const uint4*>(smem + pa + C::PATCH_PLANE + m * (PW * ROWB));
+        }
+#pragma unroll
+        for (int n = 0; n < C::WN; ++n) f[C::NPL * C::WM + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + (t * C::NT + n * 32) * ROWB);
+        if constexpr (C::SPLIT) {
+#pragma unroll
+          for (int n = 0; n < C::WN; ++n) f[2 * C::WM + C::WN + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + C::W_PLANE + (t * C::NT + n * 32) * ROWB);
+        }
       };
       if constexpr (FD > 1) {
 #pragma unroll
@@ -435,10 +486,27 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         } else {
           load_group(gi, fr[0]);
         }
+        if constexpr (C::SPLIT) {
+          // W.P = Whi.Phi + Whi.Plo + Wlo.Phi (the product kind outermost: consecutive MFMAs hit different accumulators)
+          constexpr int PH_ = 0, PL_ = C::WM, WH_ = 2 * C::WM, WL_ = 2 * C::WM + C::WN;
+#pragma unroll
+          for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+            for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][WH_ + n], fr[gi % FD][PH_ + m]);
+#pragma unroll
+          for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+            for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][WH_ + n], fr[gi % FD][PL_ + m]);
+#pragma unroll
+          for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+            for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][WL_ + n], fr[gi % FD][PH_ + m]);
+        } else {
 #pragma unroll
         for (int n = 0; n < C::WN; ++n)
 #pragma unroll
           for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][C::WM + n], fr[gi % FD][m]);
+        }
         if constexpr (FD == 1) {
         } else if (pre) {
           // one ds_read behind each of the first NF MFMAs, the rest of the MFMAs after them
@@ -568,8 +636,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             }
           }
         }
-        float v[4] = {acc[n][m][q * 4 + 0] + bv.x, acc[n][m][q * 4 + 1] + bv.y,
-                      acc[n][m][q * 4 + 2] + bv.z, acc[n][m][q * 4 + 3] + bv.w};
+        float v[4];
+        if constexpr (C::SPLIT) {      // accumulators carry SPLIT_WSCALE * SPLIT_PSCALE: one exact power-of-two multiply, fused with the bias add
+          v[0] = fmaf(acc[n][m][q * 4 + 0], SPLIT_OSCALE, bv.x); v[1] = fmaf(acc[n][m][q * 4 + 1], SPLIT_OSCALE, bv.y);
+          v[2] = fmaf(acc[n][m][q * 4 + 2], SPLIT_OSCALE, bv.z); v[3] = fmaf(acc[n][m][q * 4 + 3], SPLIT_OSCALE, bv.w);
+        } else {
+          v[0] = acc[n][m][q * 4 + 0] + bv.x; v[1] = acc[n][m][q * 4 + 1] + bv.y;
+          v[2] = acc[n][m][q * 4 + 2] + bv.z; v[3] = acc[n][m][q * 4 + 3] + bv.w;
+        }
         if constexpr (C::RELU_OUT) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -602,8 +676,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
         if constexpr (C::LAYER == 8) {
           // hoisted condition term: fp32, accumulator-fragment order [tile][wave][n][m][q][lane] (read back by layer 9 only)
-          reinterpret_cast<float4*>(p.out)[((((size_t)e_tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane] =
-              make_float4(v[0], v[1], v[2], v[3]);
+          const size_t fi = ((((size_t)e_tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane;
+          if constexpr (C::CADD16) reinterpret_cast<uint2*>(p.out)[fi] = make_uint2(pack2<EK_F16>(v[0], v[1]), pack2<EK_F16>(v[2], v[3]));
+          else reinterpret_cast<float4*>(p.out)[fi] = make_float4(v[0], v[1], v[2], v[3]);
         } else if constexpr (C::OUT_ESZ == 4) {
           if (pvalid && (C::COUT_PAD == C::COUT || co < C::COUT)) {      // (padding couts of a rounded-up tile are never stored)
             if constexpr (C::SCATTER) {
@@ -768,8 +843,24 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     default: return launch_layer2<EK_BF16>(layer, p, s);
   }
 }
+// EK_F16S (split f16): the denoiser's layers only
+static hipError_t launch_layer2_split(int layer, const ConvParams& p, hipStream_t s) {
+  switch (layer) {
+    case 1: return launch_one2<EK_F16S, 1>(p, s);
+    case 2: return launch_one2<EK_F16S, 2>(p, s);
+    case 3: return launch_one2<EK_F16S, 3>(p, s);
+    case 4: return launch_one2<EK_F16S, 4>(p, s);
+    case 5: return launch_one2<EK_F16S, 5>(p, s);
+    case 6: return launch_one2<EK_F16S, 6>(p, s);
+    case 7: return launch_one2<EK_F16S, 7>(p, s);
+    case 8: return launch_one2<EK_F16S, 8>(p, s);
+    case 9: return launch_one2<EK_F16S, 9>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s) {
   switch (ek) {
+    case EK_F16S: return launch_layer2_split(layer, p, s);
     case EK_F32: return launch_layer2<EK_F32>(layer, p, s);
     case EK_BF16: return launch_layer2<EK_BF16>(layer, p, s);
     case EK_F16: return launch_layer2<EK_F16>(layer, p, s);
@@ -780,7 +871,7 @@ hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_
 
 template <int EK, int LAYER> static PackGeom geom2_of() {
   using C = Cfg2<EK, LAYER>;
-  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH, C::KS};
+  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH, C::KS, C::NPL};
 }
 template <int EK> static PackGeom geom2_layer(int layer) {
   switch (layer) {
@@ -835,8 +926,22 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     default: return geom2_of<EK, 23>();
   }
 }
+static PackGeom geom2_layer_split(int layer) {
+  switch (layer) {
+    case 1: return geom2_of<EK_F16S, 1>();
+    case 2: return geom2_of<EK_F16S, 2>();
+    case 3: return geom2_of<EK_F16S, 3>();
+    case 4: return geom2_of<EK_F16S, 4>();
+    case 5: return geom2_of<EK_F16S, 5>();
+    case 6: return geom2_of<EK_F16S, 6>();
+    case 7: return geom2_of<EK_F16S, 7>();
+    case 8: return geom2_of<EK_F16S, 8>();
+    default: return geom2_of<EK_F16S, 9>();
+  }
+}
 PackGeom conv_pack_geom2(int layer, int ek) {
   switch (ek) {
+    case EK_F16S: return geom2_layer_split(layer);
     case EK_F32: return geom2_layer<EK_F32>(layer);
     case EK_BF16: case EK_BF16M: return geom2_layer<EK_BF16>(layer);     // 2-byte kinds share one geometry
     default: return geom2_layer<EK_F16>(layer);

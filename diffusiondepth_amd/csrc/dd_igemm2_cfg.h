@@ -52,6 +52,12 @@
 #ifndef DD_T_KNOWN
 #define DD_T_KNOWN 1
 #endif
+// hoisted condition term conv3(cond) (layer 8 -> layer 9) in the 2-byte modes: 1 = stored as f16 quads (8 bytes per lane and register quad:
+// 128 instead of 256 bytes per pixel and step in conv3's prologue; it is added to accumulators whose result is stored as f16 anyway),
+// 0 = fp32.  The fp32 and split-f16 modes always keep fp32.
+#ifndef DD_CADD_F16
+#define DD_CADD_F16 0
+#endif
 // per-workgroup phase timestamps (ConvParams::prof); compiled in by tools/phase_prof.py only
 #ifndef DD_PHASE_PROF
 #define DD_PHASE_PROF 0
@@ -65,11 +71,17 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   // of them (conv2, conv3, Swin pred.0, the level-0 lateral conv of the condition FPN); the launcher sends every other layer to its
   // plain f16 (conv1, conv4, once-per-image conv3(cond)) or bf16 (Swin convB, inner FPN layers, data gradients) instantiation.
   static constexpr bool MX = EKM_ == EK_BF16M;
-  static constexpr int EK = MX ? (int)EK_BF16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
+  // EKM_ == EK_F16S (split f16, DD_PREC_F16X3; dd_kernels.h): tensors in HBM are fp32 (the fp32 mode's layouts), the LDS patch and the
+  // packed weights carry TWO f16 planes (hi, lo) and every (weight, pixel) fragment pair costs three MFMAs.  Instantiated for the
+  // denoiser's layers 1..9 only; one tiling for all of them: 16-channel chunks, 3 taps per stage (conv1: 9), 64-cout workgroup tiles.
+  static constexpr bool SPLIT = EKM_ == EK_F16S;
+  static constexpr int NPL = SPLIT ? 2 : 1;                    // operand planes in LDS / in a packed weight stage
+  static constexpr int EK = MX ? (int)EK_BF16 : SPLIT ? (int)EK_F16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
   static constexpr int LAYER = LAYER_;
-  static constexpr int IN_K = (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)
-  static constexpr int OUT_K = (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
+  static constexpr int IN_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)
+  static constexpr int OUT_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
   static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
+  static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 9), "EK_F16S is instantiated for the denoiser's layers only");
   static constexpr int ESZ = ElemSize<EK>::V;
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
   //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
@@ -114,15 +126,16 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : IS_NECK ? ((COUT + 63) / 64) * 64 : COUT;
   static constexpr bool C3SHAPE = (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);
-  static constexpr int C3 = (C3SHAPE && ESZ == 2) ? DD_C3 : 0;
-  static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2;
-  static constexpr int CK = (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0 || SWIN3) ? 16 : (64 / ESZ);
-  static constexpr int TG = (LAYER == 1 || LAYER == 20 || C3 != 0) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
+  static constexpr int C3 = (C3SHAPE && ESZ == 2 && !SPLIT) ? DD_C3 : 0;
+  static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2 && !SPLIT;
+  static constexpr int CK = SPLIT ? 16 : (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0 || SWIN3) ? 16 : (64 / ESZ);
+  static constexpr int TG = SPLIT ? (LAYER == 1 ? 9 : 3) : (LAYER == 1 || LAYER == 20 || C3 != 0) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
                           : SWIN3 ? 3 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
-  static constexpr int NT = IS_NECK ? 64 : (COUT >= COND_C) ? 128 : COUT_PAD;
-  static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
+  static constexpr int NT = (IS_NECK || (SPLIT && COUT >= 64)) ? 64 : (COUT >= COND_C) ? 128 : COUT_PAD;
+  static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL && !SPLIT) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
+  static constexpr bool CADD16 = DD_CADD_F16 && ESZ == 2 && !SPLIT && (LAYER == 8 || LAYER == 9);   // the hoisted term travels as f16
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
@@ -132,8 +145,8 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;
   static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
-  static constexpr int IN_ESZ = (LAYER == 1) ? 4 : ESZ;
-  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8 || LAYER == 23) ? 4 : ESZ;
+  static constexpr int IN_ESZ = (LAYER == 1 || SPLIT) ? 4 : ESZ;
+  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8 || LAYER == 23 || SPLIT) ? 4 : ESZ;
   static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
   static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
   static constexpr int PPP = ROWB / 16;
@@ -145,8 +158,10 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr int NTG = NTAPS / TG;
   static constexpr int NSTAGE = NCHUNK * NTG;
   static constexpr int NPB = (NCHUNK > 1) ? 2 : 1;       // patch buffers
-  static constexpr int PATCH_BYTES = PH * PW * ROWB;
-  static constexpr int W_BYTES = TG * NT * ROWB;
+  static constexpr int PATCH_PLANE = PH * PW * ROWB;      // one operand plane of a patch buffer (split f16: hi plane, then lo plane)
+  static constexpr int PATCH_BYTES = NPL * PATCH_PLANE;
+  static constexpr int W_PLANE = TG * NT * ROWB;          // one operand plane of a weight stage
+  static constexpr int W_BYTES = NPL * W_PLANE;
   static constexpr int NWB = (NSTAGE > 1) ? 2 : 1;       // weight ring slots
   static constexpr int W_OFF = NPB * PATCH_BYTES;        // LDS byte offset of the weight ring
   static constexpr int CTAB = (PRO == PRO_RAW) ? 0 : (LAYER == 1) ? LATENT_C : CIN;   // channels of the prologue GroupNorm table
@@ -162,8 +177,8 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
   // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
   // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
-  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && (LAYER == 9 || LAYER == 7 || LAYER == 22 || (LAYER == 6 && SWIN3 && DD_SWIN_RD2)) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
-  static constexpr int FRAG_DEPTH = (LAYER == 5 && !(SWIN3 && DD_SWIN_FD2)) ? 1 : DD_FRAG_DEPTH;
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && !SPLIT && (LAYER == 9 || LAYER == 7 || LAYER == 22 || (LAYER == 6 && SWIN3 && DD_SWIN_RD2)) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
+  static constexpr int FRAG_DEPTH = (LAYER == 5 && !SPLIT && !(SWIN3 && DD_SWIN_FD2)) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
   static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS

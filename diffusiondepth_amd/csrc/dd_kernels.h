@@ -34,9 +34,18 @@ constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2
 // condition map are STORED as f16 (same bytes, 11-bit mantissa; GroupNorm bounds their range), and the two thin layers conv1 / conv4
 // (16 <-> 64 channels, 6 % of the FLOPs) and the once-per-image conv3(cond) run as f16 kernels.  Why: DESIGN.md section 4 (the error
 // budget of tools/bf16_error_budget.py: pure bf16 sits at 1.2e-3 depth RMSE, above the 1e-3 tolerance; this mode at ~0.4x of it).
-enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3 };
-__host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : ek; }    // MFMA operands of the large convolutions / gradients
-__host__ __device__ constexpr int store_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek; }    // y1 / y2 / y3 / condition map in HBM
+// EK_F16S is the second MODE: "split f16" (DD_PREC_F16X3) -- every tensor between kernels is fp32 (the layouts of the fp32 mode), every MFMA
+// operand is carried as an f16 PAIR hi + lo (hi = f16(v), lo = f16(v - hi): ~22 mantissa bits) and a product W.P is contracted as
+// Whi.Phi + Whi.Plo + Wlo.Phi on v_mfma_f32_32x32x16_f16 (three MFMAs; the dropped Wlo.Plo term is 2^-22 relative), fp32 accumulation.
+// Operands are pre-scaled by exact powers of two (weights x SPLIT_WSCALE at pack time, patch x SPLIT_PSCALE in the prologue) so that the
+// lo halves of ordinary values stay in f16's normal range, and the epilogue multiplies the accumulators by the exact inverse.  It is the
+// abs-1e-3-on-depth mode at ~1/3 of the 16-bit MFMA rate (5x the fp32-operand MFMA rate): DESIGN.md section 4.
+enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3, EK_F16S = 4 };
+__host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : ek == EK_F16S ? (int)EK_F16 : ek; }    // MFMA operands of the large convolutions / gradients
+__host__ __device__ constexpr int store_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek == EK_F16S ? (int)EK_F32 : ek; }    // y1 / y2 / y3 / condition map in HBM
+constexpr float SPLIT_WSCALE = 256.f;     // 2^8: default-initialised 3x3 weights (|w| <= 1/sqrt(9 Cin) ~ 0.02..0.08) land at ~5..20, their lo halves at ~2^-9
+constexpr float SPLIT_PSCALE = 16.f;      // 2^4: post-GroupNorm activations / the state x; overflow only beyond |v| = 4094
+constexpr float SPLIT_OSCALE = 1.f / (SPLIT_WSCALE * SPLIT_PSCALE);   // 2^-12, exact
 
 enum Prologue : int {
   PRO_X = 0,       // conv1: input = DDIM-updated state (c1*x + c2*relu(gn4(y4))), also written back
@@ -85,7 +94,8 @@ struct ConvParams {
 // ---- fused implicit-GEMM path (dd_igemm2.hip) ------------------------------------------------
 // layer ids: see dd_igemm2_cfg.h; ek: element kind.  Weights are packed with the LDS swizzle pre-applied
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
-struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks; };   // th = output tile height (tile width is 32), ks = kernel size
+struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks, planes; };   // th = output tile height (tile width is 32), ks = kernel size,
+                                                                            // planes = 2: split f16 image, every stage block = [hi | lo]
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
 PackGeom conv_pack_geom2(int layer, int ek);
 

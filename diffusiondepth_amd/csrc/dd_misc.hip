@@ -751,9 +751,13 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
   const int esz = ek == EK_F32 ? 4 : 2;
   const int rowb = g.ck * esz, ppp = rowb / 16, rpb = 256 / rowb, epp = 16 / esz;
   // idx = ((((nt * n_chunks + ch) * n_tg + tg) * g.tg) * g.nt * g.ck)  +  row * g.ck + piece_sw * epp + within,  row = t * g.nt + n
-  const long long blk = (long long)g.tg * g.nt * g.ck;
+  // split f16 (g.planes == 2): a stage block is [hi plane | lo plane], each laid out as above
+  const long long plane = (long long)g.tg * g.nt * g.ck;
+  const long long blk = plane * (g.planes > 1 ? 2 : 1);
   const long long outer = idx / blk;
-  const int inner = (int)(idx - outer * blk);
+  int inner = (int)(idx - outer * blk);
+  const bool lo_plane = inner >= plane;
+  if (lo_plane) inner -= (int)plane;
   const int tg = (int)(outer % n_tg);
   const int ch = (int)((outer / n_tg) % n_chunks);
   const int nt = (int)(outer / ((long long)n_tg * n_chunks));
@@ -766,12 +770,17 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
   float v = 0.f;
   if (co < g.cout)
     v = transposed ? src[((size_t)ci * g.cout + co) * kk + (kk - 1 - tap)] : src[((size_t)co * g.cin + ci) * kk + tap];
-  if (ek == EK_F32) reinterpret_cast<float*>(dst)[idx] = v;
+  if (g.planes > 1) {
+    // hi = f16(w * SPLIT_WSCALE), lo = f16(w * SPLIT_WSCALE - hi): the arithmetic of the host packer (pack_conv_weights in dd_api.cpp)
+    const float vs = v * SPLIT_WSCALE;
+    const uint32_t hi = f32_to_f16(vs);
+    reinterpret_cast<uint16_t*>(dst)[idx] = (uint16_t)(lo_plane ? f32_to_f16(vs - f16_to_f32(hi)) : hi);
+  } else if (ek == EK_F32) reinterpret_cast<float*>(dst)[idx] = v;
   else reinterpret_cast<uint16_t*>(dst)[idx] = (uint16_t)(ek == EK_BF16 ? f32_to_bf16(v) : f32_to_f16(v));
 }
 
 size_t pack_weights_bytes(const PackGeom& g, int ek) {
-  return (size_t)(g.cout_pad / g.nt) * (g.cin / g.ck) * (size_t)(g.ks * g.ks) * g.nt * g.ck * (ek == EK_F32 ? 4 : 2);
+  return (size_t)(g.cout_pad / g.nt) * (g.cin / g.ck) * (size_t)(g.ks * g.ks) * g.nt * g.ck * (ek == EK_F32 ? 4 : 2) * (g.planes > 1 ? 2 : 1);
 }
 
 hipError_t launch_pack_weights(const float* src, void* dst, const PackGeom& g, int ek, bool swizzle, bool transposed, hipStream_t s) {

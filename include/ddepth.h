@@ -54,7 +54,11 @@ typedef enum dd_precision {
   DD_PREC_NAIVE_FP32 = 0,  /* unfused one-thread-per-output fp32 kernels: on-device cross-check      */
   DD_PREC_FP32 = 1,        /* fused implicit-GEMM on v_mfma_f32_32x32x2_f32, fp32 activations (parity gate) */
   DD_PREC_BF16 = 2,        /* fused implicit-GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations (headline)  */
-  DD_PREC_F16 = 3          /* same kernels on v_mfma_f32_32x32x16_f16 (11-bit mantissa, same rate)          */
+  DD_PREC_F16 = 3,         /* same kernels on v_mfma_f32_32x32x16_f16 (11-bit mantissa, same rate)          */
+  DD_PREC_F16X3 = 4        /* split f16: every MFMA operand an f16 pair hi + lo (~22 mantissa bits), three MFMAs per product
+                              (Whi.Phi + Whi.Plo + Wlo.Phi), fp32 tensors and accumulation -- the mode that meets the
+                              1e-3 ABSOLUTE depth tolerance over the whole depth range at ~1/3 of the 16-bit rate;
+                              forward only (dd_denoise / dd_denoise_trace / dd_denoise_once / dd_condition)   */
 } dd_precision;
 
 /* ---- lifetime ---------------------------------------------------------------------------------

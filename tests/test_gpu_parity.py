@@ -5,12 +5,18 @@
   (4) size-independent properties (batch consistency, graph == eager, run-to-run determinism).
 
 Tolerances (stated per north-star: <= 1e-3 abs on predicted depth; depth RMSE within 1e-3 of the reference):
-  fp32 modes (naive_fp32, fp32): latent within 2e-5 * max|x_0| (fp32 round-off class), decoded depth within 1e-3 ABS (max over pixels).
-  bf16 / f16 modes: 16-bit operands cannot hold 1e-3 abs on every pixel of a depth map that reaches 13 m (the decoder ends in exp(-z));
-  they are gated on the north star's RMSE reading, ASSERTED at the full NYU and KITTI sizes of BASELINE.json (configs 2 / 3):
-  depth RMSE <= 1e-3, plus a max-abs regression bound (bf16 2e-2, f16 5e-3).  "bf16" is the library's default bf16 mode (bf16 MFMA
-  operands on the large convolutions, f16 storage / thin layers); the all-bf16 variant (option bf16_storage=1)
-  is measured beside it and only recorded -- it sits at ~1.2e-3, which is why it is not the default.
+  fp32 modes (naive_fp32, fp32) and the split-f16 mode f16x3 (f16 operand pairs, three MFMAs per product, fp32 tensors): latent within
+  2e-5 * max|x_0| (fp32 round-off class), decoded depth within 1e-3 ABS (max over pixels) on EVERY case -- including the far-range
+  golden (depths to 159 m) and the full KITTI size with the decoder shifted to the KITTI depth range (0..80 m).
+  bf16 / f16 modes: the decoder ends in exp(-z), so their depth error is RELATIVE (a fixed error in z): measured relative depth RMSE
+  4.1e-4 .. 5.8e-4 (bf16 mode) / 1.3e-4 .. 1.9e-4 (f16).  An absolute 1e-3 therefore holds only up to an RMS depth of ~2.4 m (bf16) / ~7 m (f16) with
+  these untrained weights, whose loop amplifies the latent to |x_0| ~ 5e2 (a trained denoiser does not; no checkpoint is available
+  offline).  Gates: (a) the north star's RMSE reading, depth RMSE <= 1e-3, ASSERTED at the full NYU and KITTI sizes on the near-range
+  weight set (depths <= 13 m) plus a max-abs regression bound (bf16 2e-2, f16 5e-3); (b) relative depth RMSE bounds, asserted on every
+  case incl. the far range (DEPTH_REL_RMSE_TOL), so that the 16-bit modes cannot drift unnoticed where (a) does not hold.  The depth range
+  over which (a) holds is recorded (`abs_rmse_1e3_holds_to_rms_depth_m`) and printed by bench.py.  "bf16" is the library's default bf16
+  mode (bf16 MFMA operands on the large convolutions, f16 storage / thin layers); the all-bf16 variant (option
+  bf16_storage=1) is measured beside it and only recorded -- it sits at ~1.2e-3, which is why it is not the default.
 """
 import numpy as np
 import pytest
@@ -20,11 +26,22 @@ from diffusiondepth_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16": 1.5e-3, "bf16": 1e-2}   # x max|x_0|  (measured: 1e-6, 1e-6, 5e-4, 4e-3)
-EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}      # abs on eps (values O(1..4); measured 1e-5, 1e-5, 5e-3, 4e-2)
-ALL_PREC = ["naive_fp32", "fp32", "bf16", "f16"]
+LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16x3": 2e-5, "f16": 1.5e-3, "bf16": 1e-2}   # x max|x_0|  (measured: 1e-6, 1e-6, 1e-6, 5e-4, 4e-3)
+EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16x3": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}      # abs on eps (values O(1..4); measured 1e-5, 1e-5, 1e-5, 5e-3, 4e-2)
+ALL_PREC = ["naive_fp32", "fp32", "f16x3", "bf16", "f16"]
+ABS_PREC = ("naive_fp32", "fp32", "f16x3")                                      # the modes held to 1e-3 ABS on every pixel of the depth map
 DEPTH_RMSE_TOL = 1e-3                                                           # north star, asserted for every precision at full size
-DEPTH_MAXABS_TOL = {"fp32": 1e-3, "bf16": 2e-2, "f16": 5e-3}                    # fp32: the north star's abs reading; 16-bit: regression bounds
+DEPTH_MAXABS_TOL = {"fp32": 1e-3, "f16x3": 1e-3, "bf16": 2e-2, "f16": 5e-3}     # fp32 / f16x3: the north star's abs reading; 16-bit: regression bounds
+DEPTH_REL_RMSE_TOL = {"bf16": 1.2e-3, "f16": 4e-4}                              # rms of (d - d_ref) / d_ref, every case incl. far range: 2x the worst measured (5.8e-4 / 1.9e-4 on loop_res_far)
+
+
+def rel_rmse(d, dref):
+    r = (np.asarray(d, np.float64) - np.asarray(dref, np.float64)) / np.maximum(np.asarray(dref, np.float64), 1e-6)
+    return float(np.sqrt((r * r).mean()))
+
+
+def rms_depth(dref):
+    return float(np.sqrt((np.asarray(dref, np.float64) ** 2).mean()))
 
 
 @pytest.fixture(scope="module")
@@ -94,7 +111,7 @@ def test_single_denoiser_call_vs_reference(U, golden, cases, prec):
     eb, es = U.maxabs(eps_b, g["eps_batch_t"]), U.maxabs(eps_s, g["eps_scalar_t"])
     U.record("denoise_once", prec=prec, eps_batch_maxabs=eb, eps_scalar_maxabs=es, eps_rms=U.rms(eps_b, g["eps_batch_t"]), **layer_err)
     assert eps_b.min() >= 0.0
-    assert layer_err["y1"] < (1e-5 if "fp32" in prec else 2e-2)
+    assert layer_err["y1"] < (1e-5 if prec in ABS_PREC else 2e-2)
     assert eb < EPS_TOL[prec] and es < EPS_TOL[prec], (eb, es)
 
 
@@ -113,15 +130,19 @@ def test_ddim_loop_vs_reference_golden(U, golden, cases, name, prec):
         e = U.maxabs(x0, ref)
         de = U.maxabs(depth, dref)
         drel = float((np.abs(depth - dref) / np.maximum(dref, 1e-2)).max())
+        rr = rel_rmse(depth, dref)
         U.record("loop", case=name, prec=prec, T=T, latent_maxabs=e, latent_scale=scale, latent_rms=U.rms(x0, ref),
-                 depth_maxabs=de, depth_rmse=U.rms(depth, dref), depth_maxrel=drel, depth_max=float(dref.max()))
+                 depth_maxabs=de, depth_rmse=U.rms(depth, dref), depth_maxrel=drel, depth_max=float(dref.max()),
+                 depth_rel_rmse=rr, depth_rms=rms_depth(dref))
         assert np.isfinite(x0).all()
         assert e < LATENT_TOL[prec] * scale, (e, scale)
-        if "fp32" in prec:
-            assert de < 1e-3, de                       # the north-star tolerance on predicted depth
+        if prec in ABS_PREC:
+            assert de < 1e-3, de                       # the north-star tolerance on predicted depth, near AND far range (159 m)
+        else:
+            assert rr < DEPTH_REL_RMSE_TOL[prec], (name, prec, rr)      # 16-bit modes: the error is relative; absolute 1e-3 only at short range
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16"])
 def test_ragged_sizes_and_batch_vs_oracle(U, prec):
     """Tile edges: sizes that are not multiples of the 8x32 tile, 1-pixel-wide, taller than wide, B=3."""
     from oracle import ddim_oracle as O
@@ -233,16 +254,32 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
     ref = ref.numpy()
     scale = float(np.abs(ref).max())
     x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
-    for prec in ("fp32", "bf16", "f16"):
+    # the same loop result decoded at KITTI's depth range: the decoder's last bias shifted by -FAR_LOG_SCALE multiplies every depth by
+    # e^1.8 (~0.5 .. 80 m); only the decoder differs, so the latent reference is shared
+    FAR_LOG_SCALE = 1.8
+    cfar = {"wseed": 7240, "decoder_log_scale": FAR_LOG_SCALE}
+    be_far, sd_far = U.backend_for(cfar), U.sd_for(cfar)
+    dref_far = P.decode(P.to_torch_sd(sd_far), torch.from_numpy(ref)).numpy()
+    for prec in ("fp32", "f16x3", "bf16", "f16"):
         x0 = be.denoise(x, cond, 20, prec)
         d = be.decode(x0).cpu().numpy()
+        d_far = be_far.decode(x0).cpu().numpy()
         x0 = x0.cpu().numpy()
         e, de = U.maxabs(x0, ref), U.maxabs(d, dref)
+        rr = rel_rmse(d, dref)
         U.record("full_size", size=size, prec=prec, latent_maxabs=e, latent_scale=scale, latent_rms=U.rms(x0, ref),
-                 depth_maxabs=de, depth_rmse=U.rms(d, dref), depth_max=float(dref.max()), cpu_port_seconds=cpu_s)
-        assert e < LATENT_TOL[prec] * scale * (2.5 if prec == "fp32" else 1.0), (prec, e, scale)   # port itself is fp32
+                 depth_maxabs=de, depth_rmse=U.rms(d, dref), depth_max=float(dref.max()), cpu_port_seconds=cpu_s,
+                 depth_rel_rmse=rr, depth_rms=rms_depth(dref), abs_rmse_1e3_holds_to_rms_depth_m=1e-3 / max(rr, 1e-12),
+                 far_depth_max=float(dref_far.max()), far_depth_rms=rms_depth(dref_far), far_depth_rmse=U.rms(d_far, dref_far),
+                 far_depth_maxabs=U.maxabs(d_far, dref_far), far_depth_rel_rmse=rel_rmse(d_far, dref_far))
+        assert e < LATENT_TOL[prec] * scale * (2.5 if prec in ABS_PREC else 1.0), (prec, e, scale)   # port itself is fp32
         assert U.rms(d, dref) <= DEPTH_RMSE_TOL, (size, prec, U.rms(d, dref))
         assert de <= DEPTH_MAXABS_TOL[prec], (size, prec, de)
+        if prec in ABS_PREC:
+            # the abs-clean modes keep 1e-3 on every pixel at KITTI's depth range too
+            assert dref_far.max() > 40.0 and U.maxabs(d_far, dref_far) <= 1e-3, (size, prec, U.maxabs(d_far, dref_far))   # NYU 52 m, KITTI 69 m
+        else:
+            assert rel_rmse(d_far, dref_far) < DEPTH_REL_RMSE_TOL[prec], (size, prec, rel_rmse(d_far, dref_far))
     # the all-bf16 variant beside the default bf16 mode: recorded, not gated (it is the reason the default stores f16)
     import diffusiondepth_amd as dda
     pure = dda.HipDenoiser()
@@ -256,7 +293,7 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
 
 
 # ---- Swin / MPViT variant of the denoiser: UpSample_add fuse, stride-4 condition map ----
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16", "f16"])
 def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):
     c, g = cases["denoise_swin"], golden("denoise_swin")
     be = U.backend_for(c)
@@ -279,7 +316,7 @@ def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):
     assert eps_b.min() >= 0.0
     assert eb < EPS_TOL[prec] and es < EPS_TOL[prec], (eb, es)
     assert e < LATENT_TOL[prec] * scale, (e, scale)
-    if prec == "fp32":
+    if prec in ABS_PREC:
         assert de < 1e-3
     # depth gates of the Swin denoiser: f16 is its inference mode inside the tolerance (BASELINE config 5 names fp16); bf16, with two more
     # 256 -> 256 convolutions on bf16 operands per step, is NOT (2.6e-3 here, 3.4e-3 at KITTI size: DESIGN.md section 4) -- it is the
@@ -318,7 +355,7 @@ def test_conv3_without_hoisting_the_condition_term(U, golden, cases):
     try:
         for hoist in (0, 1):
             be.set_option("hoist_cond", hoist)
-            for prec in ("fp32", "bf16"):
+            for prec in ("fp32", "bf16", "f16x3"):
                 x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), 20, prec).cpu().numpy()
                 ref = g["x0_T20"]
                 e, scale = U.maxabs(x0, ref), float(np.abs(ref).max())

@@ -89,7 +89,15 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
                                          loss_cfgs=[], precision=prec).eval(), sd)
             errs[prec] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
         U.record(case + "_16bit", depth_rmse_bf16=errs["bf16"], depth_rmse_f16=errs["f16"], pred_max=float(g["pred"].max()))
-        assert errs["bf16"] < 0.1 and errs["f16"] < 0.02
+        # bounds = 2x the measured values (2.7e-3 / 4.0e-4): f16 is inside the 1e-3 RMSE tolerance, bf16 -- this denoiser's TRAINING precision --
+        # is not and is held here only against drift
+        assert errs["bf16"] < 6e-3 and errs["f16"] < 1e-3
+        # the abs-clean inference mode of the same head (split f16: neck / FPN on the fp32 kernels, loop on f16 pairs): 1e-3 abs on every pixel
+        hs = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
+                                     loss_cfgs=[], precision="f16x3").eval(), sd)
+        e_split = U.maxabs(_run(hs, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
+        U.record(case + "_f16x3", pred_maxabs=e_split)
+        assert e_split < 1e-3
     if case == "head_swin_hahi":
         # the neck's 1x1 / 3x3 convolutions ran in the library (dd_neck_condition), not in MIOpen: 3 launches per
         # pyramid level per forward -- and they equal the PyTorch neck + library FPN on the same features
@@ -114,7 +122,15 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
                                          loss_cfgs=[], precision=prec).eval(), sd)
             errs[prec] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
         U.record(case + "_16bit", depth_rmse_bf16=errs["bf16"], depth_rmse_f16=errs["f16"], pred_max=float(g["pred"].max()))
-        assert errs["bf16"] < 0.1 and errs["f16"] < 0.02
+        # bounds = 2x the measured values (2.7e-3 / 4.0e-4): f16 is inside the 1e-3 RMSE tolerance, bf16 -- this denoiser's TRAINING precision --
+        # is not and is held here only against drift
+        assert errs["bf16"] < 6e-3 and errs["f16"] < 1e-3
+        # the abs-clean inference mode of the same head (split f16: neck / FPN on the fp32 kernels, loop on f16 pairs): 1e-3 abs on every pixel
+        hs = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
+                                     loss_cfgs=[], precision="f16x3").eval(), sd)
+        e_split = U.maxabs(_run(hs, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
+        U.record(case + "_f16x3", pred_maxabs=e_split)
+        assert e_split < 1e-3
 
 
 def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):

@@ -41,6 +41,9 @@ def rnd(x, dt):
         return x
     if dt == "bf16x2":
         return split2(x)
+    if dt == "f16x2":          # hi + lo f16 pair (the split-f16 mode's operands: ~22 mantissa bits)
+        hi = x.to(torch.float16).float()
+        return hi + (x - hi).to(torch.float16).float()
     return x.to(dt).float()
 
 
@@ -106,7 +109,7 @@ def parse_plan(spec):
             continue
         srcs, dt = part.split(":")
         for s in (SOURCES if srcs == "all" else srcs.split("+")):     # plus the pseudo-source "hoistc"
-            R[s] = dt if dt == "bf16x2" else DT[dt]
+            R[s] = dt if dt in ("bf16x2", "f16x2") else DT[dt]
     return name, R
 
 
@@ -118,6 +121,7 @@ def main():
     ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--seeds", type=int, default=2)
     ap.add_argument("--plan", action="append", default=[], help="name=src+src:dtype/src:dtype[/sr]; src 'all' = every source")
+    ap.add_argument("--log-scale", type=float, default=0.0, help="synth.make_state_dict(decoder_log_scale=...): depths times e^s")
     ap.add_argument("--sweep", action="store_true", help="each source alone and all-but-one, in bf16")
     a = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 8)
@@ -128,7 +132,7 @@ def main():
         plans += [(f"all but {s}", {q: torch.bfloat16 for q in SOURCES if q != s}) for s in SOURCES]
     rows = {}
     for sidx in range(a.seeds):
-        sd = P.to_torch_sd(synth.make_state_dict(7240 + sidx))
+        sd = P.to_torch_sd(synth.make_state_dict(7240 + sidx, decoder_log_scale=a.log_scale))
         inp = synth.make_inputs(100 + sidx, a.B, a.h, a.w)
         ref = P.decode(sd, P.ddim_loop(sd, inp["x_T"], inp["cond"], a.T))
         for name, R in plans:
