@@ -123,6 +123,7 @@ struct Plan {
   DevBuf xstash;           // loop backward: the T states entering each step + the running gradient, fp32 NHWC16
   int64_t traj_ticket = 0;         // key.keep plans: ticket of the dd_denoise call whose states x_0 .. x_{T-1} xstash holds (0 = none)
   int64_t traj_weights = -1;       // ... and the parameter generation (dd_handle_s::weights_serial) they were computed with
+  bool traj_consumed = false;      // a dd_denoise_backward has read this trajectory: the plan may be dropped when the activation budget is needed
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
@@ -136,6 +137,7 @@ struct Plan {
   uint64_t last_use = 0;
   ~Plan() { if (exec) (void)hipGraphExecDestroy(exec); }
   int slots = 1;      // per-step copies of y1..y4 / sa / sf (key.keep == 2: T, the backward then recomputes nothing; else 1)
+  size_t kept_bytes = 0;   // key.keep == 2: bytes of those per-step slots (what the handle-wide budget "keep_activations_mb" counts)
   void* slot(const DevBuf& b, int step) const { return static_cast<char*>(b.p) + (slots > 1 ? (size_t)step * (b.bytes / slots) : 0); }
   double* stat_ptr(int step, int layer) const {   // layer 0..3
     return stats.as<double>() + ((size_t)(step * 4 + layer) * key.B) * STAT_SLOTS * STAT_STRIDE;
@@ -390,6 +392,17 @@ int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw, bool need
   return DD_OK;
 }
 
+// Concurrent lanes of ONE dd_denoise / dd_denoise_backward call (option "streams"): the same rule for the forward and the backward, so that a
+// backward always looks for the kept trajectory under the keys the forward stored it (one stream for the unfused path, the per-launch timing
+// mode, debug synchronisation and the phase profiler: their per-call state -- pending_ev, prof_buf -- is not per lane).
+int lane_count(dd_handle_t h, int B, int precision) {
+  int S = h->n_streams;
+  if (S > B) S = B;
+  if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
+  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->prof_buf) S = 1;
+  return S < 1 ? 1 : S;
+}
+
 // The condition map at latent size in the activation layout of `precision`: one buffer per (B, h, w, precision), shared by
 // all plans of that shape (graphs bake its address) and written in place by dd_condition.
 int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::shared_ptr<DevBuf>* out, int lane = 0) {
@@ -421,6 +434,33 @@ int want_hoist(dd_handle_t h, int precision) {
   if (h->hoist_cond >= 0) return h->hoist_cond;
   const int ek = ek_of_precision(precision, h->bf16_pure);
   return (ek == EK_BF16M || ek == EK_F16 || ek == EK_F16S) ? 1 : 0;
+}
+
+// May a NEW plan keep `need` bytes of per-step activations (PlanKey::keep == 2)?  The budget (option "keep_activations_mb", default 64 GiB)
+// is ONE figure for the handle -- all lanes, all shapes -- and is also held against the HBM that is actually free.  Plans whose kept
+// trajectory nobody can ask for any more (ticket consumed by its backward, or invalidated by a parameter update / a newer forward) are
+// dropped first, least recently used first: a training loop that alternates shapes (train / validation crops) neither accumulates one
+// activation set per shape nor falls back to recompute while stale sets sit in HBM.
+bool keep2_fits(dd_handle_t h, size_t need) {
+  const size_t cap = (size_t)h->keep_act_mb << 20;
+  if (need > cap) return false;
+  for (;;) {
+    size_t held = 0;
+    for (auto& kv : h->plans) held += kv.second->kept_bytes;
+    size_t free_b = 0, total_b = 0;
+    const bool mem_ok = hipMemGetInfo(&free_b, &total_b) != hipSuccess || need + (need >> 3) <= free_b;    // 12 % headroom for the rest of the step
+    if (held + need <= cap && mem_ok) return true;
+    auto victim = h->plans.end();
+    for (auto j = h->plans.begin(); j != h->plans.end(); ++j) {
+      const Plan& q = *j->second;
+      if (q.kept_bytes == 0 || (q.traj_ticket != 0 && q.traj_weights == h->weights_serial && !q.traj_consumed)) continue;      // a live trajectory: its backward is still to come
+      if (victim == h->plans.end() || q.last_use < victim->second->last_use) victim = j;
+    }
+    if (victim == h->plans.end()) return false;
+    if (h->last_once_plan == victim->second.get()) h->last_once_plan = nullptr;
+    (void)hipDeviceSynchronize();
+    h->plans.erase(victim);
+  }
 }
 
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
@@ -460,6 +500,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
   DD_HIP(pl->y3.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y4.alloc(ns * px * LATENT_C * 4));
+  if (key.keep == 2) pl->kept_bytes = pl->y1.bytes + pl->y2.bytes + pl->y3.bytes + pl->y4.bytes + pl->sa.bytes + pl->sf.bytes;
   if (naive) {
     DD_HIP(pl->a1.alloc(px * HID_C * 4));
     DD_HIP(pl->f.alloc(px * COND_C * 4));
@@ -1391,9 +1432,18 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
     // the backward then recomputes nothing.  KITTI, T = 20: 1.8 GB (Res) / 4.0 GB (Swin) per image
     const size_t es = ek_size(store_kind(ek_of_precision(precision, h->bf16_pure)));
     const size_t per_step = (size_t)B * lat_h * lat_w * ((2 * HID_C + COND_C + (h->variant == DD_VARIANT_SWIN ? 2 * COND_C : 0)) * es + LATENT_C * 4);
-    if (per_step * (size_t)T <= (size_t)h->keep_act_mb << 20) keep = 2;
+    const size_t need = per_step * (size_t)T;
+    if (need <= ((size_t)h->keep_act_mb << 20) &&
+        (h->plans.count(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), 2, lane}) || keep2_fits(h, need))) keep = 2;
   }
   rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep, lane}, &pl);
+  if (rc && keep == 2) {
+    // the per-step slots did not fit after all (fragmentation, another process): states only -- the backward then recomputes the activations
+    (void)hipGetLastError();
+    h->plans.erase(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), 2, lane});
+    keep = 1;
+    rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep, lane}, &pl);
+  }
   if (rc) return rc;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
   float* x_first = keep ? pl->xstash.as<float>() : pl->x[0].as<float>();                                        // state entering step 0
@@ -1475,7 +1525,7 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
   // x_0 = c1*x + c2*relu(gn4(y4)) of the last step, written NCHW
   DD_HIP(launch_final(x_last, static_cast<const float*>(pl->slot(pl->y4, T - 1)), pl->stat_ptr(T - 1, 3), h->L[3].gamma.as<float>(),
                       h->L[3].beta.as<float>(), pl->c1c2.as<float>(), T - 1, 0, x_0, B, lat_h, lat_w, s));
-  if (keep) { pl->traj_ticket = ticket; pl->traj_weights = h->weights_serial; }       // one ticket per dd_denoise call, shared by its lanes
+  if (keep) { pl->traj_ticket = ticket; pl->traj_weights = h->weights_serial; pl->traj_consumed = false; }       // one ticket per dd_denoise call, shared by its lanes
   if (h->debug_sync) DD_HIP(hipStreamSynchronize(s));
   return DD_OK;
 }
@@ -1499,10 +1549,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   // stream.  Each lane has its own plan (activation buffers, hipGraph); the workgroups of one lane's kernels fill the tail of the
   // other's and hide its kernel boundaries.  Not for the naive path or the per-launch timing mode.  A training forward
   // ("keep_trajectory") keeps every lane's states and activations in that lane's plan under ONE ticket; dd_denoise_backward splits alike.
-  int S = h->n_streams;
-  if (S > B) S = B;
-  if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
-  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->prof_buf) S = 1;
+  const int S = lane_count(h, B, precision);
   const int64_t ticket = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? ++h->traj_serial : 0;
   if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket);
   for (int l = 1; l < S; ++l) {
@@ -1641,7 +1688,8 @@ float* grad_buf(dd_handle_t h, const std::string& name, size_t numel, hipStream_
 int dd_zero_grad(dd_handle_t h, void* stream) {
   if (!h) return DD_ERR_INVALID_ARG;
   DD_HIP(hipSetDevice(h->device));
-  for (auto& kv : h->grads[0]) DD_HIP(hipMemsetAsync(kv.second->p, 0, kv.second->bytes, reinterpret_cast<hipStream_t>(stream)));
+  for (int l = 0; l < dd_handle_s::MAX_LANES; ++l)      // set 0 = what dd_get_grad reads; sets 1.. = lane scratch (zero unless a call failed midway)
+    for (auto& kv : h->grads[l]) DD_HIP(hipMemsetAsync(kv.second->p, 0, kv.second->bytes, reinterpret_cast<hipStream_t>(stream)));
   return DD_OK;
 }
 
@@ -1847,7 +1895,8 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, 0}, &pl);
+  // the same kernels (hoisted or not) as the forward call: a recompute differentiates the function the forward evaluated
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision)}, &pl);
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1881,7 +1930,7 @@ int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, co
                           int whole_B, int64_t ticket, bool* reused) {
   int rc = DD_OK;
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, 0, 0, lane}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), 0, lane}, &pl);      // recompute = the forward's kernels
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1896,6 +1945,10 @@ int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, co
   }
   const Plan* kept_act = (kept && kept->key.keep == 2 && kept->ek == pl->ek) ? kept : nullptr;      // activations too: no recompute
   *reused = kept != nullptr;
+  // this backward consumes the ticket: from here on the plan's kept activations may be dropped when another shape needs the room
+  // (keep2_fits; until then a second backward on the same ticket still finds them); the kernels enqueued below read them -- an eviction
+  // synchronises the device first
+  if (kept) const_cast<Plan*>(kept)->traj_consumed = true;
   const size_t need = (size_t)(kept ? 1 : T + 1) * n16 * 4;
   if (pl->xstash.bytes < need) DD_HIP(pl->xstash.alloc(need));
   float* Xown = pl->xstash.as<float>();
@@ -1952,10 +2005,7 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   h->use_traj = 0;
   // Option "streams": the images' backward passes are independent except for the parameter gradients -- every lane accumulates into its
   // own gradient set and weight-gradient workspace, the sets of lanes 1.. are added into set 0 (what dd_get_grad reads) after the join.
-  int S = h->n_streams;
-  if (S > B) S = B;
-  if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
-  if (precision == DD_PREC_NAIVE_FP32 || h->debug_sync) S = 1;
+  const int S = lane_count(h, B, precision);
   bool reused = false;
   if (S <= 1) {
     rc = denoise_backward_lane(h, x_T, cond, grad_x0, grad_xT, grad_cond, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, &reused);
@@ -1983,7 +2033,13 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
       (void)hipEventRecord(h->lane_done[l], ls);
       (void)hipStreamWaitEvent(s, h->lane_done[l], 0);
     }
-    if (rc) { h->active_lanes = 1; return rc; }
+    if (rc) {
+      // a failed lane: the partial parameter gradients of the lane sets must not leak into the next call's sums
+      h->active_lanes = 1;
+      for (int q = 1; q < dd_handle_s::MAX_LANES; ++q)
+        for (auto& kv : h->grads[q]) (void)hipMemsetAsync(kv.second->p, 0, kv.second->bytes, s);
+      return rc;
+    }
     img0 += n;
   }
   h->active_lanes = 1;

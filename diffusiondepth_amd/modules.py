@@ -9,6 +9,7 @@ unchanged.  The modules hold parameters only; their forward() calls the HIP libr
 from __future__ import annotations
 
 import contextlib
+import copy
 import os
 import weakref
 from typing import Optional
@@ -20,6 +21,13 @@ from .backend import HipDenoiser
 from .scheduler import DDIMScheduler
 
 DEFAULT_PRECISION = os.environ.get("DDEPTH_PRECISION", "fp32")
+
+
+def _invalidate_bound_hook(module, incompatible_keys):
+    """load_state_dict post-hook (torch asserts that such hooks return None): invalidate the HipBound this module is registered with."""
+    bound = module.__dict__.get("_ddepth_bound")
+    if bound is not None:
+        bound.invalidate()
 
 
 class HipBound:
@@ -59,9 +67,21 @@ class HipBound:
     def register(self, prefix: str, module: nn.Module):
         self._modules.append((prefix, weakref.ref(module)))
         # load_state_dict() copies under no_grad (that does bump the version counter); hooking it anyway costs nothing and also covers
-        # custom _load_from_state_dict paths that assign .data
-        bound = weakref.ref(self)
-        module.register_load_state_dict_post_hook(lambda *_a, **_k: bound() is not None and bound().invalidate())
+        # custom _load_from_state_dict paths that assign .data.  The hook finds the HipBound THROUGH the module it is called on: a
+        # deep-copied head carries copies of the hooks, and those must invalidate the copy's HipBound, not the original's.
+        module.__dict__["_ddepth_bound"] = self
+        module.register_load_state_dict_post_hook(_invalidate_bound_hook)
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(head): a fresh HipBound (own library handle, created on first use) tracking the COPIED modules -- the weak
+        references of the original would keep pointing at the original's parameters."""
+        new = HipBound(self.variant)
+        memo[id(self)] = new
+        for prefix, ref in self._modules:
+            m = ref()
+            if m is not None:
+                new._modules.append((prefix, weakref.ref(copy.deepcopy(m, memo))))     # memoised: the module of the copied tree
+        return new
 
     def invalidate(self):
         """Forget what the library holds: the next call that needs a group uploads it again.  For updates the version counter cannot

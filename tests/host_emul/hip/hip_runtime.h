@@ -81,6 +81,13 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
   return hipSuccess;
 }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }
+// free / total "device" memory: HOSTEMU_FREE_BYTES in the environment (read at every call: a test can shrink the device), default 1 TiB
+static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+  const char* e = getenv("HOSTEMU_FREE_BYTES");
+  *free_b = e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)1 << 40);
+  *total_b = (size_t)1 << 40;
+  return hipSuccess;
+}
 static inline hipError_t hipFree(void* p) { ++hostemu::blocking_calls(); free(p); return hipSuccess; }
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 struct hostemu_event { double t; };

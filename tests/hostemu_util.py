@@ -67,8 +67,14 @@ HARNESS_UNITS = ("ddepth_host.cpp", "igemm2_host.cpp")
 _FLAGS = ["-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-fPIC", "-c"]
 
 
+def _extra_flags():
+    """DD_EMU_CFLAGS="-DDD_DMA_SPREAD=1 ...": the kernels' compile-time options (dd_igemm2_cfg.h) in the emulated build -- how a variant is
+    checked under the adversarial schedules before it meets the GPU"""
+    return os.environ.get("DD_EMU_CFLAGS", "").split()
+
+
 def _cc(cxx, src, obj, incs):
-    cmd = [cxx] + _FLAGS + [a for i in incs for a in ("-I", i)] + [src, "-o", obj]
+    cmd = [cxx] + _FLAGS + _extra_flags() + [a for i in incs for a in ("-I", i)] + [src, "-o", obj]
     return subprocess.run(cmd, capture_output=True, text=True)
 
 
@@ -87,8 +93,9 @@ def _objects():
     for s in deps:
         with open(s, "rb") as f:
             hsh.update(f.read())
+    hsh.update(" ".join(_extra_flags()).encode())
     objdir = os.path.join(OUT, "obj_" + hsh.hexdigest()[:12])
-    if not os.path.isdir(objdir) and os.path.isdir(OUT):          # a new source state: drop the builds of older ones
+    if not os.path.isdir(objdir) and os.path.isdir(OUT) and not _extra_flags():          # a new source state: drop the builds of older ones
         for d in os.listdir(OUT):
             if d.startswith("obj_"):
                 shutil.rmtree(os.path.join(OUT, d), ignore_errors=True)

@@ -28,6 +28,13 @@ from diffusiondepth_amd import synth
 pytestmark = pytest.mark.gpu
 
 TOL = {"naive_fp32": 1e-4, "fp32": 1e-4, "f16": 6e-2, "bf16": 2e-1}
+# K-step SGD trajectory, bf16 mode against fp32 (test_bf16_training_tracks_the_fp32_trajectory_over_sgd_steps): bounds = 2x measured
+# (measured, profiles/r03_run2_parity_report.jsonl: loss 1.9e-3 / 7.1e-3, step-0 gradients 0.060 / 0.091 worst tensor (the first conv's weight;
+#  most tensors 0.01-0.03), accumulated parameter change 0.062 / 0.199 worst tensor, cosine 0.998 / 0.980)
+SGD_LOSS_REL = {"res": 4e-3, "swin": 1.5e-2}
+SGD_GRAD0_REL = {"res": 0.12, "swin": 0.18}
+SGD_DELTA_REL = {"res": 0.125, "swin": 0.40}
+SGD_COS_MIN = {"res": 0.996, "swin": 0.96}
 PRECS = ["naive_fp32", "fp32", "bf16", "f16"]
 
 
@@ -182,9 +189,9 @@ def test_loop_backward_matches_reference_autograd_golden(U, golden, cases, prec)
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_loop_backward_on_the_states_the_forward_kept(U, cases, prec):
     """Training path of modules._DenoiseLoopFn: dd_denoise(keep_trajectory) + dd_denoise_backward(use_trajectory = its ticket) skips the
-    second forward loop.  fp32: same numbers as the regenerating path (same kernels, same states).  bf16 mode: the kept states are the ones
-    of the timed forward (conv3's condition term hoisted), the regenerated ones come from the un-hoisted kernels -- they differ by 16-bit
-    rounding, the gradients accordingly (relative L2, recorded)."""
+    second forward loop.  Same numbers as the regenerating path in every precision: since round 3 the backward's recompute runs the
+    kernels the forward ran (conv3's condition term hoisted in the 16-bit modes: ADVICE r2), so kept and regenerated states / activations
+    are the same bytes and both paths differentiate the same function."""
     c = cases["loop_bwd_res"]
     be = U.backend_for(c)
     inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
@@ -218,14 +225,71 @@ def test_loop_backward_on_the_states_the_forward_kept(U, cases, prec):
     assert np.array_equal(once[True][0], once[False][0])
     errs1 = {k: _rel(a, b, prec) for k, a, b in zip(["eps", "grad_x", "grad_cond"] + names, once[True], once[False])}
     U.record("once_bwd_kept_vs_recomputed", prec=prec, **{k.replace("model.", ""): v for k, v in errs1.items()})
-    # (bf16: the hoisted forward's activations vs the un-hoisted recompute differ by rounding, i.e. by some ReLU masks; dE[t] is a per-channel
-    #  sum over all pixels of a signed gradient, where those flips do not average out: measured 0.11 on this case, the rest below 0.08)
-    assert not {k: v for k, v in errs1.items() if v > (5e-3 if prec == "fp32" else 2.5e-1 if k == "model.time_embedding.weight" else 1e-1)}
+    assert not {k: v for k, v in errs1.items() if v > 1e-5}, errs1          # measured 0.0 in both precisions: the same kernels on the same bytes
     errs = {k: _rel(a, b, prec) for k, a, b in zip(["x0", "grad_xT", "grad_cond"] + names, kept, regen)}
     U.record("loop_bwd_kept_vs_regenerated", prec=prec, **{k.replace("model.", ""): v for k, v in errs.items()})
-    tol = 5e-3 if prec == "fp32" else 1e-1        # fp32: statistics atomics order -> 1e-7 on a state -> at worst one ReLU mask bit (see the golden test above)
+    tol = 1e-5        # (measured 0.0; it used to be "statistics atomics order -> 1e-7 on a state -> at worst one ReLU mask bit" when the recompute ran other kernels)
     bad = {k: v for k, v in errs.items() if v > tol}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("variant", ["res", "swin"])
+def test_bf16_training_tracks_the_fp32_trajectory_over_sgd_steps(U, variant):
+    """VERDICT r2 weak #7 / ADVICE r2: the 16-bit training mode against fp32 -- not one gradient under a loose relative-L2 gate, but K = 5
+    SGD steps: loss trajectory and the accumulated parameter change.  Both runs go through the library's own training path (forward that
+    KEEPS its states / activations + dd_denoise_backward / dd_denoise_once_backward on the ticket, as modules._DenoiseLoopFn /
+    _DenoiseOnceFn do); the fp32 run is the reference trajectory: its gradients equal the reference's autograd to 2e-6
+    (test_backward_matches_reference_autograd_golden, test_autograd_through_head_modules_matches_torch_port).
+    loss = mse(eps(x_q, t), noise) + <g, x_0(T=2 loop)> / numel, plain SGD on every denoiser parameter.
+    Also: the step-0 gradients of the bf16 KEPT path against the fp32 ones, per tensor (relative L2 bound) -- the gate ADVICE r2 asked for."""
+    import diffusiondepth_amd as dda
+    K, T, lr = 5, 2, 0.05
+    B, h, w = 2, 24, 40
+    cond_hw = (12, 20) if variant == "swin" else None
+    inp = synth.make_inputs(41, B, h, w, cond_hw)
+    x, cond, noise, t = U.cu(inp["x_T"]), U.cu(inp["cond"]), U.cu(inp["noise"]), U.cu(inp["timesteps"])
+    g = U.cu(np.random.RandomState(7).standard_normal(inp["x_T"].shape).astype(np.float32)) / float(inp["x_T"].size)
+    sd0 = {k: v for k, v in synth.make_state_dict(7246, variant).items()}
+
+    def run(prec):
+        be = dda.HipDenoiser(variant=variant)
+        sd = {k: torch.from_numpy(v.copy()).cuda() for k, v in sd0.items()}
+        be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+        names = list(be.param_shapes())
+        losses, grads0 = [], None
+        for k in range(K):
+            be.load_state_dict(sd)
+            be.zero_grad()
+            x0 = be.denoise(x, cond, T, prec, keep_trajectory=True)
+            be.denoise_backward(x, cond, g, T, prec, need_grad_xT=False, trajectory_ticket=be.last_trajectory_ticket)
+            eps = be.denoise_once(x, t, cond, prec, keep_trajectory=True)
+            ge = (2.0 / eps.numel()) * (eps - noise)
+            be.denoise_once_backward(x, t, cond, ge.contiguous(), prec, trajectory_ticket=be.last_trajectory_ticket)
+            losses.append(float(((eps - noise) ** 2).mean()) + float((g * x0).sum()))
+            gr = {n: be.grad(n).clone() for n in names}
+            if k == 0:
+                grads0 = {n: v.cpu().numpy() for n, v in gr.items()}
+            for n in names:
+                sd[n] = sd[n] - lr * gr[n].reshape(sd[n].shape)
+        out = {n: (sd[n].cpu().numpy() - sd0[n]) for n in names}
+        be.close()
+        return losses, grads0, out
+
+    l32, g32, d32 = run("fp32")
+    l16, g16, d16 = run("bf16")
+    assert l32[-1] < l32[0]                                                   # the steps do descend
+    loss_rel = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(l16, l32))
+    g_rel = {n: _rel(g16[n], g32[n], "bf16") for n in g32}
+    d_rel = {n: _rel(d16[n], d32[n], "bf16") for n in d32}
+    cos = {n: float((d16[n].astype(np.float64) * d32[n]).sum() / max(1e-30, np.linalg.norm(d16[n].astype(np.float64)) * np.linalg.norm(d32[n].astype(np.float64)))) for n in d32}
+    U.record("sgd_trajectory", variant=variant, loss_fp32=l32, loss_bf16=l16, loss_rel_max=loss_rel,
+             grad0_rel_max=max(g_rel.values()), grad0_rel_worst=max(g_rel, key=g_rel.get), delta_rel_max=max(d_rel.values()),
+             delta_rel_worst=max(d_rel, key=d_rel.get), delta_cos_min=min(cos.values()),
+             grad0_rel={k.replace("model.", ""): round(v, 4) for k, v in g_rel.items()})
+    assert loss_rel < SGD_LOSS_REL[variant], (loss_rel, l16, l32)
+    assert not {n: v for n, v in g_rel.items() if v > SGD_GRAD0_REL[variant]}, g_rel
+    assert not {n: v for n, v in d_rel.items() if v > SGD_DELTA_REL[variant]}, d_rel
+    assert min(cos.values()) > SGD_COS_MIN[variant], cos
 
 
 @pytest.mark.parametrize("variant,prec", [("res", "bf16"), ("res", "fp32"), ("swin", "bf16")])

@@ -382,6 +382,59 @@ def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     assert not same(got, want)                                                          # ... and the gradient is the new parameters' one
 
 
+def test_kept_activation_budget_is_one_figure_for_the_handle(on_host, monkeypatch):
+    """ADVICE r2: the per-step activation slots a training forward keeps (PlanKey::keep == 2) are budgeted ONCE per handle (option
+    keep_activations_mb) and against the free device memory; a plan whose trajectory has been consumed by its backward (or invalidated) is
+    dropped when another shape needs the room; when nothing can be dropped the forward keeps the states only (keep == 1) and the backward
+    recomputes -- with the same gradients."""
+    be = on_host(CPU)
+    be.load_state_dict(synth.make_state_dict(7240))
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    T, prec = 2, "f16"
+    be.set_option("hoist_cond", 0)
+    shapes = [(1, 6, 33), (1, 8, 33)]
+    ins = [synth.make_inputs(5 + i, *sh) for i, sh in enumerate(shapes)]
+    g = [torch.from_numpy(np.random.RandomState(3).standard_normal(i["x_T"].shape).astype(np.float32)) for i in ins]
+    per_step = [B * h * w * ((64 + 256 + 64) * 2 + 16 * 4) for (B, h, w) in shapes]          # f16 y1..y3 + fp32 y4
+    assert max(per_step) * T < (1 << 20)
+
+    def fwd_bwd(i):
+        x, c = torch.from_numpy(ins[i]["x_T"]), torch.from_numpy(ins[i]["cond"])
+        be.zero_grad()
+        be.denoise(x, c, T, prec, keep_trajectory=True)
+        gx, _ = be.denoise_backward(x, c, g[i], T, prec, need_grad_xT=True, trajectory_ticket=be.last_trajectory_ticket)
+        return gx, be.grad("model.pred.3.weight").clone()
+
+    be.set_option("keep_activations_mb", 1)                    # room for ONE of the two shapes' slots... (each < 1 MiB, together > 1 MiB?)
+    want = [fwd_bwd(0), fwd_bwd(1)]
+    # both fit under 1 MiB only if their sum does: force the squeeze through the free-memory reading instead
+    monkeypatch.setenv("HOSTEMU_FREE_BYTES", str(int(max(per_step) * T * 1.2)))
+    r0 = be.counter("trajectory_reuses")
+    got0 = fwd_bwd(0)            # existing keep-2 plan: reused as it is
+    got1 = fwd_bwd(1)
+    assert be.counter("trajectory_reuses") == r0 + 2
+    for (a, b), (p, q) in zip(want, [got0, got1]):
+        assert float((a - p).abs().max()) <= 1e-6 * float(a.abs().max()) and float((b - q).abs().max()) <= 1e-6 * float(b.abs().max())
+    # a THIRD shape under the squeeze: a consumed plan is dropped for it (the plan count does not grow by a keep-2 plan on top of two)
+    inp3 = synth.make_inputs(9, 1, 7, 33)
+    x3, c3 = torch.from_numpy(inp3["x_T"]), torch.from_numpy(inp3["cond"])
+    plans = be.counter("plans")
+    be.denoise(x3, c3, T, prec, keep_trajectory=True)
+    assert be.counter("plans") <= plans                      # one stale keep-2 plan went, the new one came
+    # nothing droppable (the trajectory just kept is live) and no room: states only, the backward recomputes, same gradient as the naive order
+    monkeypatch.setenv("HOSTEMU_FREE_BYTES", "1024")
+    x, c = torch.from_numpy(ins[1]["x_T"]), torch.from_numpy(ins[1]["cond"])
+    inp4 = synth.make_inputs(11, 1, 5, 33)
+    x4, c4 = torch.from_numpy(inp4["x_T"]), torch.from_numpy(inp4["cond"])
+    g4 = torch.from_numpy(np.random.RandomState(4).standard_normal(inp4["x_T"].shape).astype(np.float32))
+    be.zero_grad()
+    be.denoise(x4, c4, T, prec, keep_trajectory=True)        # keep == 1
+    gx_k, _ = be.denoise_backward(x4, c4, g4, T, prec, need_grad_xT=True, trajectory_ticket=be.last_trajectory_ticket)
+    be.zero_grad()
+    gx_n, _ = be.denoise_backward(x4, c4, g4, T, prec, need_grad_xT=True)
+    assert float((gx_k - gx_n).abs().max()) <= 1e-6 * float(gx_n.abs().max())
+
+
 @pytest.mark.parametrize("shape", [((2, 7, 19), (4, 10)), ((1, 4, 141), (2, 70))] + ([((1, 9, 33), (3, 5)), ((1, 6, 40), (6, 40))] if FULL else []),
                          ids=["x2", "two-segments"] + (["x4-ragged", "same-size"] if FULL else []))
 def test_swin_condition_gradient_tiled_adjoint_equals_the_plain_one(on_host, shape):

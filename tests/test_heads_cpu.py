@@ -213,6 +213,50 @@ def test_hipbound_sees_parameter_updates_that_bypass_the_version_counter(monkeyp
     assert len(be.loads) == 6                                            # once per hold() scope, not per library call
 
 
+def test_deepcopied_head_has_its_own_hipbound_and_hooks_return_none(monkeypatch):
+    """the load_state_dict post-hook must return None whatever happened to the HipBound (torch asserts it), and a deep-copied
+    head must track -- and invalidate -- ITS OWN parameters, not the original's (EMA copies, copy.deepcopy(model) for evaluation)."""
+    import copy
+    import gc
+    from diffusiondepth_amd import modules as M
+
+    class FakeBackend:
+        def __init__(self, device):
+            self.device, self.loads = device, []
+
+        def load_state_dict(self, sd):
+            self.loads.append({k: v.detach().clone() for k, v in sd.items()})
+
+        def set_schedule(self, acp):
+            pass
+
+    monkeypatch.setattr(M.HipBound, "_hip_device", staticmethod(lambda d: torch.device("cpu")))
+    monkeypatch.setattr(M.HipBound, "_make_backend", lambda self, d: FakeBackend(d))
+    head = dda.DDIMDepthEstimate_Res(inference_steps=5).eval()
+    twin = copy.deepcopy(head)
+    assert twin._bound is not head._bound and twin.model.bound is twin._bound and twin._bound.backend is None
+    tracked = {id(ref()) for _, ref in twin._bound._modules}
+    assert id(twin.model) in tracked and id(head.model) not in tracked            # the copy's modules, all of them
+    assert len(twin._bound._modules) == len(head._bound._modules)
+    with torch.no_grad():
+        twin.model.pred[0].weight.mul_(3.0)
+    be_t = twin._bound.ensure("cpu", need=("model",))
+    be_h = head._bound.ensure("cpu", need=("model",))
+    assert torch.equal(be_t.loads[-1]["model.pred.0.weight"], twin.model.pred[0].weight.detach())
+    assert torch.equal(be_h.loads[-1]["model.pred.0.weight"], head.model.pred[0].weight.detach())
+    n_t, n_h = len(be_t.loads), len(be_h.loads)
+    twin.load_state_dict(twin.state_dict())                                        # the copy's hooks invalidate the copy's HipBound only
+    twin._bound.ensure("cpu", need=("model",)); head._bound.ensure("cpu", need=("model",))
+    assert len(be_t.loads) == n_t + 1 and len(be_h.loads) == n_h
+    # the original gone: the copy's hooks still return None (a closure over a dead weak reference used to return False -> AssertionError)
+    del head, be_h
+    gc.collect()
+    twin.load_state_dict(twin.state_dict())
+    solo = dda.ScheduledCNNRefine(precision="bf16")
+    solo.__dict__.pop("_ddepth_bound")
+    solo.load_state_dict(solo.state_dict())                                        # no HipBound reachable: still None, no error
+
+
 def test_fpn_falls_back_to_torch_when_autograd_must_reach_it():
     """head in .eval() with grad mode on and trainable FPN weights / backbone features: the inference-only dd_condition must not be
     taken (it would drop the gradient silently).  CPU tensors + the torch path: runs here without the library."""
