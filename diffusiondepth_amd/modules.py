@@ -16,6 +16,7 @@ from typing import Optional
 
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 from .backend import HipDenoiser
 from .scheduler import DDIMScheduler
@@ -281,6 +282,8 @@ class ScheduledCNNRefine(nn.Module):
     def forward(self, noisy_image, t, *args):
         """forward(noisy_image, t, feat, blur_depth, sparse_depth, sparse_mask) -> eps (…res.py:324-344)."""
         feat = args[0]
+        if not noisy_image.is_cuda:
+            return self._eager_forward(noisy_image, t, feat)
         be = self.bound.ensure(noisy_image.device, need=("model",))
         t = torch.as_tensor(t, device=noisy_image.device)
         if _wants_grad(self, noisy_image, feat):
@@ -290,6 +293,28 @@ class ScheduledCNNRefine(nn.Module):
             return _DenoiseOnceFn.apply(be, self.precision, noisy_image.float().contiguous(), tt.contiguous(), feat.float().contiguous(),
                                         *_ordered_params(self))
         return be.denoise_once(noisy_image.float(), t, feat.float(), self.precision)
+
+
+def _eager_upsample_add(fuse, x, concat_with):
+    """UpSample_add.forward (reference …swin_addHAHI.py:331-333) on the parameter container above."""
+    up_x = F.interpolate(x, size=[concat_with.size(2), concat_with.size(3)], mode="bilinear", align_corners=True)
+    return fuse.convB.conv(fuse.convA.conv(up_x + concat_with))
+
+
+def _scheduled_cnn_refine_eager(self, noisy_image, t, feat):
+    """The module's own Conv2d / GroupNorm / Embedding children evaluated by PyTorch (reference …res.py:324-344, …swin_addHAHI.py:364-382):
+    what runs for tensors that are NOT on a HIP device -- BASELINE.json configs[0], "plumbing, no GPU".  It is the product's own module
+    tree in eager mode, never the test oracle, and it is never taken for tensors on a HIP device (there the library is the only path)."""
+    t = torch.as_tensor(t, device=noisy_image.device).long()
+    feat = feat + self.time_embedding(t)[..., None, None]
+    if self.variant == "swin":
+        feat = _eager_upsample_add(self.upsample_fuse, feat, self.noise_embedding(noisy_image))
+    else:
+        feat = feat + self.noise_embedding(noisy_image)
+    return self.pred(feat)
+
+
+ScheduledCNNRefine._eager_forward = _scheduled_cnn_refine_eager
 
 
 class CNNDDIMPipiline:
@@ -308,6 +333,8 @@ class CNNDDIMPipiline:
         image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
         self.scheduler.set_timesteps(num_inference_steps)
         why_not = self.scheduler.hip_supported(eta)
+        if why_not is None and not image.is_cuda:
+            why_not = "tensors are not on a HIP device: eager PyTorch stepping (model + scheduler.step), as the reference"
         if why_not is None:
             be = self.model.bound.ensure(image.device, self.scheduler, need=("model",))
             if _wants_grad(self.model, image, input_args[0]):
@@ -334,7 +361,7 @@ class CNNDDIMPipilineVis(CNNDDIMPipiline):
         image_shape = (batch_size, *shape)
         image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
         self.scheduler.set_timesteps(num_inference_steps)
-        if self.scheduler.hip_supported(eta) is None and not _wants_grad(self.model, image, input_args[0]):
+        if self.scheduler.hip_supported(eta) is None and image.is_cuda and not _wants_grad(self.model, image, input_args[0]):
             be = self.model.bound.ensure(image.device, self.scheduler, need=("model",))
             states = be.denoise_trace(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
             image_list = list(states.unbind(0))
@@ -379,7 +406,8 @@ class DeepDepthTransformWithUpsampling(nn.Module):
         self.bound.register("depth_transform.", self)
 
     def _torch_path(self, x) -> bool:
-        return self.training or (torch.is_grad_enabled() and x.requires_grad)
+        # (tensors that are not on a HIP device: the same torch modules in eager mode -- BASELINE configs[0], "plumbing, no GPU")
+        return self.training or (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda
 
     def t(self, depth):
         if self._torch_path(depth):

@@ -257,6 +257,77 @@ def test_deepcopied_head_has_its_own_hipbound_and_hooks_return_none(monkeypatch)
     solo.load_state_dict(solo.state_dict())                                        # no HipBound reachable: still None, no error
 
 
+def _with_draws(inp, fn):
+    """Run fn() with the reference's RNG draws injected (x_T, then the DDIM-loss noise; randint -> the timesteps)."""
+    draws = [torch.from_numpy(inp["x_T"]), torch.from_numpy(inp["noise"])]
+    real_randn, real_randint = torch.randn, torch.randint
+    torch.randn = lambda *a, **k: draws.pop(0)
+    torch.randint = lambda *a, **k: torch.from_numpy(inp["timesteps"])
+    try:
+        with torch.no_grad():
+            return fn()
+    finally:
+        torch.randn, torch.randint = real_randn, real_randint
+
+
+def test_cpu_tensors_run_the_modules_own_eager_forward_vs_reference_golden(golden, cases):
+    """SURVEY 8(b) / BASELINE configs[0] ("on CPU PyTorch, plumbing, no GPU"): tensors that are not on a HIP device run the product's OWN
+    module tree in eager PyTorch (modules.ScheduledCNNRefine._eager_forward, scheduler.step, the torch codec / FPN) -- never the oracle, and
+    never for HIP tensors.  The whole Res head forward on CPU against the golden minted from the reference's head class (the vectors the GPU
+    test holds the library to): 13 keys, prediction within 1e-3 abs, DDIM loss."""
+    c, g = cases["head_res"], golden("head_res")
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    head = dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=c["T"], num_train_timesteps=1000,
+                                     depth_feature_dim=16, loss_cfgs=[], precision="fp32").eval()
+    missing, unexpected = head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing)
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+    out = _with_draws(inp, lambda: head(fp, gt, gt > 0, gt_depth_map=gt, return_loss=False))
+    assert set(out) == set(c["output_keys"])
+    assert head._bound.backend is None                                        # no library handle was ever made for the CPU tensors
+    assert np.abs(out["pred_init"].numpy() - g["pred_init"]).max() < 2e-5
+    assert np.abs(out["pred"].numpy() - g["pred"]).max() < 1e-3               # north star: <= 1e-3 abs on predicted depth
+    assert abs(float(out["ddim_loss"]) - float(g["ddim_loss"][0])) < 1e-4 * max(1.0, abs(float(g["ddim_loss"][0])))
+
+
+def test_plumbing_configuration_on_cpu_through_the_model_facade():
+    """BASELINE.json configs[0]: ResNet-18 backbone + 64x64 latent, 5-step DDIM, batch 1, CPU -- forward(sample) -> dict of the model facade
+    (reference src/model/diffusion_dcbase_model.py:186-224) with nothing patched and no library, against the fp64 oracle on the same
+    condition map and x_T; and the Swin denoiser's eager forward against the oracle's."""
+    from diffusiondepth_amd import model as MD
+    from oracle import ddim_oracle as O
+    torch.manual_seed(7240)
+    net = MD.Diffusion_DCbase_Model(MD.default_args(backbone_name="mmbev_res18", inference_steps=5, precision="fp32")).eval()
+    rs = np.random.RandomState(5)
+    rgb = torch.from_numpy(rs.standard_normal((1, 3, 128, 128)).astype(np.float32))
+    gt = torch.from_numpy(synth.make_gt_depth(6, 1, 128, 128))
+    inp = synth.make_inputs(7, 1, 64, 64)
+    out = _with_draws(inp, lambda: net({"rgb": rgb, "gt": gt, "dep": gt, "depth_map": gt, "depth_mask": gt > 0}))
+    assert out["pred"].shape == (1, 1, 128, 128) and out["pred_init"].shape == (1, 16, 64, 64)
+    head = net.depth_head
+    with torch.no_grad():
+        cond = head.aggregate_condition(net.depth_backbone(rgb)).numpy()
+    sd = {k: v.numpy() for k, v in head.state_dict().items()}
+    want = O.decode(sd, O.ddim_loop(sd, inp["x_T"], cond, 5))
+    got = out["pred"].numpy()
+    assert float(np.abs(got - want).max()) < 1e-3 * max(1.0, float(np.abs(want).max()))
+    assert head._bound.backend is None
+    # Swin / MPViT denoiser (UpSample_add fuse, stride-4 condition map) in eager mode against the oracle's restatement
+    sds = synth.make_state_dict(7245, "swin")
+    m = dda.ScheduledCNNRefine(variant="swin", precision="fp32").eval()
+    m.load_state_dict({k[len("model."):]: torch.from_numpy(v) for k, v in sds.items() if k.startswith("model.")})
+    i2 = synth.make_inputs(9, 2, 10, 18, (5, 9))
+    with torch.no_grad():
+        eps = m(torch.from_numpy(i2["x_T"]), torch.from_numpy(i2["timesteps"]), torch.from_numpy(i2["cond"]), None, None, None).numpy()
+    ref = O.denoiser_forward(sds, i2["x_T"], i2["timesteps"], i2["cond"], "swin")
+    assert float(np.abs(eps - ref).max()) < 5e-5
+
+
 def test_fpn_falls_back_to_torch_when_autograd_must_reach_it():
     """head in .eval() with grad mode on and trainable FPN weights / backbone features: the inference-only dd_condition must not be
     taken (it would drop the gradient silently).  CPU tensors + the torch path: runs here without the library."""
