@@ -46,7 +46,7 @@ LAYER_DIMS = {1: (16, 64), 2: (64, 256), 3: (256, 64), 4: (64, 16), 5: (256, 256
 LAYERS = {"res": (1, 2, 9, 4), "res_nohoist": (1, 2, 3, 4), "swin": (1, 2, 5, 6, 7, 4)}
 # algorithmic HBM bytes per latent pixel per launch with 2-byte activations (fp32 mode doubles the
 # activation terms, the fp32 state / y4 terms of conv1 / conv4 are approximated the same way)
-ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640, 9: 896}     # 9: y2 512 + conv3(cond) fp32 256 + y3 128
+ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640, 9: 768}     # 9: y2 512 + conv3(cond) f16 128 + y3 128 (the split / fp32 modes keep the term in fp32)
 # MI355X_MICROARCH.md dense MFMA peaks.  f16x3 (split f16, DD_PREC_F16X3): every algorithmic multiply-add costs three f16 MFMA
 # multiply-adds (Whi.Phi + Whi.Plo + Wlo.Phi), so its ceiling in ALGORITHMIC FLOP/s is a third of the f16 peak
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "fp32": 157.3, "naive_fp32": 157.3}

@@ -26,9 +26,24 @@ def per_kernel(d, counter):
     return out
 
 
+def lib_source_sha():
+    """the stamp bench.py compares (bench.lib_source_sha): sha256 over csrc + include"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hsh = hashlib.sha256()
+    for d in (os.path.join(root, "diffusiondepth_amd", "csrc"), os.path.join(root, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".h", ".hip", ".cpp")):
+                hsh.update(f.encode())
+                hsh.update(open(os.path.join(d, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"bench_args": sys.argv[3] if len(sys.argv) > 3 else "", "note": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction), write = WRITE_SIZE KiB * 1024",
+import time
+out = {"bench_args": sys.argv[3] if len(sys.argv) > 3 else "", "lib_source_sha": lib_source_sha(), "taken": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
+       "note": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction), write = WRITE_SIZE KiB * 1024",
        "kernels": {k: {"fetch_bytes": fetch[k] * 1024 * 2, "write_bytes": write.get(k, 0.0) * 1024,
                        "hbm_bytes": fetch[k] * 1024 * 2 + write.get(k, 0.0) * 1024} for k in sorted(fetch)}}
 print(json.dumps(out, indent=1))
