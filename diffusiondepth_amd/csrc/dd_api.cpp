@@ -333,6 +333,7 @@ std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
 
 // Packed layout consumed by conv_igemm_kernel:
 //   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT; ks x ks taps)
+bool split_overflow = false;      // set by pack_conv_weights when a weight does not fit the split-f16 image; dd_commit_weights turns it into an error
 void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
   const int ks = g.ks, n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = ks * ks / g.tg;
   const int planes = g.planes > 1 ? 2 : 1;       // split f16 (EK_F16S): every stage block is [hi plane | lo plane] of f16 elements
@@ -359,6 +360,7 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
               if (planes == 2) {
                 // hi = f16(w * SPLIT_WSCALE), lo = f16(w * SPLIT_WSCALE - hi): the same arithmetic as pack_weights_kernel (dd_misc.hip)
                 const float vs = v * SPLIT_WSCALE;
+                if (!(std::fabs(vs) < 60000.f)) split_overflow = true;       // |w| >= 234: beyond f16 after scaling (reported by the caller)
                 const _Float16 hi = (_Float16)vs;
                 const _Float16 lo = (_Float16)(vs - (float)hi);
                 std::memcpy(&out[idx * 2], &hi, 2);
@@ -1027,6 +1029,10 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
         DD_HIP(hipStreamSynchronize(s));
       }
     }
+  }
+  if (do_model && split_overflow) {
+    split_overflow = false;
+    return h->fail(DD_ERR_INVALID_ARG, "dd_commit_weights: a convolution weight of magnitude >= 234 does not fit the split-f16 image (DD_PREC_F16X3 scales weights by 256 into f16)");
   }
   if (do_model) {
     const std::vector<float>& e = h->host_w["model.time_embedding.weight"];

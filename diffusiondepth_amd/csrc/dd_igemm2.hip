@@ -246,19 +246,16 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           for (int q = 0; q < NLD; ++q)
             *reinterpret_cast<float4*>(xout_b + goff + q * 16) = make_float4(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
         }
-        if constexpr (C::SPLIT) {
-#pragma unroll
-          for (int i = 0; i < EPP; ++i) v[i] *= SPLIT_PSCALE;
-        }
       } else if constexpr (C::SPLIT) {
-        // fp32 tensors in HBM: the piece's 8 channels are two 16-byte loads; the table already carries SPLIT_PSCALE
+        // fp32 tensors in HBM: the piece's 8 channels are two 16-byte loads; the GroupNorm table already carries SPLIT_PSCALE, raw inputs
+        // (no bound on their range) stay unscaled
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
           const uint32_t yw[4] = {raw[slot][u][q].x, raw[slot][u][q].y, raw[slot][u][q].z, raw[slot][u][q].w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float y = __builtin_bit_cast(float, yw[i]);
-            if constexpr (C::PRO == PRO_RAW) v[q * 4 + i] = y * SPLIT_PSCALE;
+            if constexpr (C::PRO == PRO_RAW) v[q * 4 + i] = y;
             else v[q * 4 + i] = fmaxf(fmaf(ta[q * 4 + i], y, tb[q * 4 + i]), 0.f);
           }
           if constexpr (C::PRO == PRO_GN_ADD) {
@@ -383,7 +380,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             cv = reinterpret_cast<const float4*>(p.cadd)[fi];
           }
         }
-        if constexpr (C::SPLIT && C::ADD_C) { constexpr float IS = 1.f / SPLIT_OSCALE; cv.x *= IS; cv.y *= IS; cv.z *= IS; cv.w *= IS; }   // accumulators run at the operands' scale
+        if constexpr (C::SPLIT && C::ADD_C) { constexpr float IS = 1.f / split_oscale(C::PRO); cv.x *= IS; cv.y *= IS; cv.z *= IS; cv.w *= IS; }   // accumulators run at the operands' scale
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }
   }
@@ -412,9 +409,9 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       double var = gs.y * inv_cnt - mean * mean;                 // biased, as torch
       var = var > 0.0 ? var : 0.0;
       const double a = (double)my_gamma / sqrt(var + (double)GN_EPS);
-      // split f16: the patch is carried times SPLIT_PSCALE (exact power of two; relu commutes with it).  conv1 scales behind the DDIM
-      // update instead: its table also produces the state that is written back
-      constexpr float TS = (C::SPLIT && C::PRO != PRO_X) ? SPLIT_PSCALE : 1.f;
+      // split f16: behind a GroupNorm the patch is carried times SPLIT_PSCALE (exact power of two; relu commutes with it); conv1's table
+      // produces the state that is written back and its input has no bound: unscaled (dd_kernels.h)
+      constexpr float TS = C::SPLIT ? split_pscale(C::PRO) : 1.f;
       tab_a[tid] = (float)a * TS;
       tab_b[tid] = (float)((double)my_beta - mean * a) * TS;
       if constexpr (C::PRO == PRO_GN_ADD) tab_e[tid] = my_emb * TS;
@@ -653,9 +650,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           }
         }
         float v[4];
-        if constexpr (C::SPLIT) {      // accumulators carry SPLIT_WSCALE * SPLIT_PSCALE: one exact power-of-two multiply, fused with the bias add
-          v[0] = fmaf(acc[n][m][q * 4 + 0], SPLIT_OSCALE, bv.x); v[1] = fmaf(acc[n][m][q * 4 + 1], SPLIT_OSCALE, bv.y);
-          v[2] = fmaf(acc[n][m][q * 4 + 2], SPLIT_OSCALE, bv.z); v[3] = fmaf(acc[n][m][q * 4 + 3], SPLIT_OSCALE, bv.w);
+        if constexpr (C::SPLIT) {      // accumulators carry the operands' scales: one exact power-of-two multiply, fused with the bias add
+          constexpr float OS = split_oscale(C::PRO);
+          v[0] = fmaf(acc[n][m][q * 4 + 0], OS, bv.x); v[1] = fmaf(acc[n][m][q * 4 + 1], OS, bv.y);
+          v[2] = fmaf(acc[n][m][q * 4 + 2], OS, bv.z); v[3] = fmaf(acc[n][m][q * 4 + 3], OS, bv.w);
         } else {
           v[0] = acc[n][m][q * 4 + 0] + bv.x; v[1] = acc[n][m][q * 4 + 1] + bv.y;
           v[2] = acc[n][m][q * 4 + 2] + bv.z; v[3] = acc[n][m][q * 4 + 3] + bv.w;

@@ -37,15 +37,19 @@ constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2
 // EK_F16S is the second MODE: "split f16" (DD_PREC_F16X3) -- every tensor between kernels is fp32 (the layouts of the fp32 mode), every MFMA
 // operand is carried as an f16 PAIR hi + lo (hi = f16(v), lo = f16(v - hi): ~22 mantissa bits) and a product W.P is contracted as
 // Whi.Phi + Whi.Plo + Wlo.Phi on v_mfma_f32_32x32x16_f16 (three MFMAs; the dropped Wlo.Plo term is 2^-22 relative), fp32 accumulation.
-// Operands are pre-scaled by exact powers of two (weights x SPLIT_WSCALE at pack time, patch x SPLIT_PSCALE in the prologue) so that the
-// lo halves of ordinary values stay in f16's normal range, and the epilogue multiplies the accumulators by the exact inverse.  It is the
+// Operands are pre-scaled by exact powers of two (weights x SPLIT_WSCALE at pack time; the patch x SPLIT_PSCALE in the prologues that sit
+// behind a GroupNorm, whose output is bounded -- the unbounded inputs, the state x of conv1 and the raw tensors the Swin convB / pred.0 read,
+// are carried unscaled: f16 overflows only beyond |v| = 65504) so that the lo halves of ordinary values stay in f16's normal range, and the
+// epilogue multiplies the accumulators by the exact inverse.  (gfx950's f16 MFMA honours subnormal inputs -- tools/micro/f16_denorm_probe.hip,
+// profiles/r03_run1_f16_denorm_probe.txt -- so the scaling buys bits for small values, it is not needed for correctness.)  It is the
 // abs-1e-3-on-depth mode at ~1/3 of the 16-bit MFMA rate (5x the fp32-operand MFMA rate): DESIGN.md section 4.
 enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3, EK_F16S = 4 };
 __host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : ek == EK_F16S ? (int)EK_F16 : ek; }    // MFMA operands of the large convolutions / gradients
 __host__ __device__ constexpr int store_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek == EK_F16S ? (int)EK_F32 : ek; }    // y1 / y2 / y3 / condition map in HBM
 constexpr float SPLIT_WSCALE = 256.f;     // 2^8: default-initialised 3x3 weights (|w| <= 1/sqrt(9 Cin) ~ 0.02..0.08) land at ~5..20, their lo halves at ~2^-9
-constexpr float SPLIT_PSCALE = 16.f;      // 2^4: post-GroupNorm activations / the state x; overflow only beyond |v| = 4094
-constexpr float SPLIT_OSCALE = 1.f / (SPLIT_WSCALE * SPLIT_PSCALE);   // 2^-12, exact
+constexpr float SPLIT_PSCALE = 16.f;      // 2^4: activations behind a GroupNorm + ReLU (+ condition map + E[t]); overflow only beyond |v| = 4094
+__host__ __device__ constexpr float split_pscale(int pro) { return (pro == 1 /* PRO_GN */ || pro == 2 /* PRO_GN_ADD */) ? SPLIT_PSCALE : 1.f; }
+__host__ __device__ constexpr float split_oscale(int pro) { return 1.f / (SPLIT_WSCALE * split_pscale(pro)); }     // exact powers of two
 
 enum Prologue : int {
   PRO_X = 0,       // conv1: input = DDIM-updated state (c1*x + c2*relu(gn4(y4))), also written back
