@@ -214,6 +214,8 @@ struct dd_handle_s {
   bool keep_traj = false;
   int64_t keep_act_mb = 65536;
   int n_streams = 1;          // option "streams": concurrent sub-batches of dd_denoise (1 = off)
+  int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
+  bool thin_stream = true;    // option "thin_stream": conv4 as the persistent streaming kernel (dd_thin.hip); 0 = the general kernel (A/B switch)
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   int64_t n_lane_calls = 0;
@@ -553,10 +555,14 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     p.t_known = clamp_t(pl->tsteps_host[t_base]);
   const int ek = pl->ek, tk = thin_kind(ek);    // mode; kind of conv1 / conv4
   const int wk = ek == EK_F16S ? WIMG_SPLIT : opnd_kind(ek);    // weight image of the large convolutions (their operand kind; the split image in the split mode)
+  // conv4 runs as the persistent streaming kernel of dd_thin.hip in the 2-byte modes (option "thin_stream", default on; the phase profiler
+  // instruments the general kernel)
+  const bool stream4 = h->thin_stream && (tk == EK_F16 || tk == EK_BF16) && !h->prof_buf && k.B <= h->thin_slots;
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
       q.tiles_y = (k.h + conv_pack_geom2(layer, ek).th - 1) / conv_pack_geom2(layer, ek).th;
+      if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
       return launch_conv_igemm2(layer, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
@@ -1237,6 +1243,18 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "adjoint_tiled") h->adjoint_tiled = value != 0;
   else if (k == "streams") h->n_streams = value < 1 ? 1 : (int)value;
   else if (k == "keep_activations_mb") h->keep_act_mb = value < 0 ? 0 : value;
+  else if (k == "thin_slots") {
+    if (value < 1 || value > 4096) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_slots must be in [1, 4096]");
+    if (h->thin_slots != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
+    h->thin_slots = (int)value;
+  }
+  else if (k == "thin_stream") {
+    if (h->thin_stream != (value != 0)) {          // the kernel choice is baked into captured graphs
+      DD_HIP(hipDeviceSynchronize());
+      h->plans.clear(); h->last_once_plan = nullptr;
+    }
+    h->thin_stream = value != 0;
+  }
   else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
   else if (k == "phase_prof_layer") h->prof_layer = (int)value;
   else if (k == "layer_timing") {

@@ -15,6 +15,7 @@
 #define DD_WAIT_VM_LGKM0(n) hostemu::wait_vm(n)
 #define DD_WAIT_LGKM0() ((void)0)
 #define DD_VMEM_LOADS_ISSUED(n) hostemu::vmem_loads_issued(n)
+#define DD_GLOBAL_STORE16_UNTRACKED(ptr, v) (*reinterpret_cast<float4*>(ptr) = (v))
 typedef hostemu::tr16_v2u dd_u32x2_t;
 #define DD_LDS_READ_TR16(smem, byte_off) hostemu::lds_read_tr16((smem) + (byte_off))
 
@@ -37,6 +38,17 @@ typedef hostemu::tr16_v2u dd_u32x2_t;
 #define DD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define DD_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
 #define DD_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// A 16-byte global store the compiler does NOT see (inline asm).  hipcc keeps ONE vmcnt for loads and stores; once a store is pending beside
+// loads it can no longer count ("counter out of order") and waits vmcnt(0) for the next load it needs -- which drains every prefetched load
+// of a software pipeline.  Hidden from it, the store only makes its counted waits for loads more conservative (the hardware counter is
+// higher than it assumes); the data is in memory by the end of the kernel like any other store.
+typedef __attribute__((ext_vector_type(4))) float dd_f32x4_t;
+#define DD_GLOBAL_STORE16_UNTRACKED(ptr, v)                                                                                     \
+  do {                                                                                                                          \
+    const float4 f4_ = (v);                                                                                                     \
+    const dd_f32x4_t v_ = {f4_.x, f4_.y, f4_.z, f4_.w};                                                                         \
+    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v_) : "memory");                                            \
+  } while (0)
 // bookkeeping for the host model only: n ordinary global loads were just issued by this wave (they count in vmcnt)
 #define DD_VMEM_LOADS_ISSUED(n) ((void)0)
 // ds_read_b64_tr_b16: the lane's 8-byte-aligned LDS address -> 4 x 16 bit, transposed inside each group of 16 lanes (see dd_wgrad2.hip)

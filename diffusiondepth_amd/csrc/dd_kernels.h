@@ -90,6 +90,7 @@ struct ConvParams {
   int in_cstride, in_coff, out_cstride, out_coff;
   unsigned long long* prof; // -DDD_PHASE_PROF=1 builds only (tools/phase_prof.py): 8 x u64 per workgroup: wall-clock (100 MHz) at kernel entry,
                             // GroupNorm table done, first patch + weights in LDS, main loop done, stores issued, exit; [6] = HW_ID, [7] = XCC_ID
+  int persist_slots;        // persistent kernels (dd_thin.hip): resident workgroup slots to fill (0 = 512: two per CU on the 256 CUs)
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
                             // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
                             // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier
@@ -98,9 +99,18 @@ struct ConvParams {
 // ---- fused implicit-GEMM path (dd_igemm2.hip) ------------------------------------------------
 // layer ids: see dd_igemm2_cfg.h; ek: element kind.  Weights are packed with the LDS swizzle pre-applied
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
+// workgroups of a persistent launch (dd_thin.hip): B x n with n workgroups per image, at most `slots` in all
+inline int persist_grid(int B, int tiles_per_img, int slots) {
+  int n = slots / (B > 0 ? B : 1);
+  if (n < 1) n = 1;
+  if (n > tiles_per_img) n = tiles_per_img;
+  return B * n;
+}
 struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks, planes; };   // th = output tile height (tile width is 32), ks = kernel size,
                                                                             // planes = 2: split f16 image, every stage block = [hi | lo]
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
+// conv4 (64 -> 16) as a persistent streaming kernel (dd_thin.hip): same ConvParams and packed weights as layer 4; ek = EK_F16 / EK_BF16
+hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s);
 PackGeom conv_pack_geom2(int layer, int ek);
 
 // ---- weights into kernel layout on the device (dd_misc.hip): the packed image of pack_conv_weights() in dd_api.cpp, bit for bit ----

@@ -179,6 +179,30 @@ def test_res_loop_with_the_hoisted_condition_term(lib):
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("prec,B,slots", [("f16", 2, 4), ("bf16", 1, 2), ("f16", 3, 5)])
+def test_streaming_conv4_walks_several_tiles_per_workgroup(lib, prec, B, slots):
+    """dd_thin.hip: conv4 as a persistent streaming kernel -- B x n workgroups, each walking the tiles j, j + n, ... of ONE image with the
+    weights resident in LDS and a rolling register prefetch of the next tile's four channel chunks.  17 x 70 latent = 3 x 3 tiles per image
+    (ragged right / bottom edges): with `slots` resident slots a workgroup walks 3 to 9 tiles (uneven counts, a last workgroup with fewer).
+    Against the oracle, against the general kernel (option thin_stream = 0: same packed weights, same accumulation order per output), and
+    bit-identical across the adversarial wave orders."""
+    be, inp, ref, T = _loop_case(lib, B=B, h=17, w=70)
+    be.set_option("thin_stream", 0)
+    classic = be.denoise(inp["x_T"], inp["cond"], T, prec)
+    be.set_option("thin_stream", 1)
+    be.set_option("thin_slots", slots)
+    outs = []
+    for order, late in ((0, 0), (1, 1)):
+        be.timing(order=order, dma_late=late)
+        outs.append(be.denoise(inp["x_T"], inp["cond"], T, prec))
+    be.set_option("thin_slots", 512)
+    one_tile_each = be.denoise(inp["x_T"], inp["cond"], T, prec)
+    assert np.array_equal(outs[0], outs[1])
+    assert maxabs(outs[0], ref) < LATENT_TOL[prec] * np.abs(ref).max()
+    # (16-bit rounding class, not closer: the next GroupNorm's partial sums are taken in another order)
+    assert maxabs(outs[0], classic) < LATENT_TOL[prec] * np.abs(ref).max() and maxabs(one_tile_each, classic) < LATENT_TOL[prec] * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("late,prec", [(0, "f16"), (1, "f16"), (1, "f16x3")])
 def test_swin_loop_vs_oracle(lib, late, prec):
     be, inp, ref, T = _loop_case(lib, "swin", cond_hw=(3, 9), h=5, w=17, T=1)
