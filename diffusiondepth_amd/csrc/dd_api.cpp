@@ -215,7 +215,7 @@ struct dd_handle_s {
   int64_t keep_act_mb = 65536;
   int n_streams = 1;          // option "streams": concurrent sub-batches of dd_denoise (1 = off)
   int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
-  bool thin_stream = true;    // option "thin_stream": conv4 as the persistent streaming kernel (dd_thin.hip); 0 = the general kernel (A/B switch)
+  int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   int64_t n_lane_calls = 0;
@@ -1249,11 +1249,12 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->thin_slots = (int)value;
   }
   else if (k == "thin_stream") {
-    if (h->thin_stream != (value != 0)) {          // the kernel choice is baked into captured graphs
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_stream must be 0 or 1");
+    if (h->thin_stream != (int)value) {          // the kernel choice is baked into captured graphs
       DD_HIP(hipDeviceSynchronize());
       h->plans.clear(); h->last_once_plan = nullptr;
     }
-    h->thin_stream = value != 0;
+    h->thin_stream = (int)value;
   }
   else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
   else if (k == "phase_prof_layer") h->prof_layer = (int)value;

@@ -1,5 +1,6 @@
 // dd_thin.hip -- conv4 of the denoiser (64 -> 16, `model.pred.3`; reference src/model/head/ddim_depth_estimate_res.py:319-321) as a PERSISTENT
-// STREAMING kernel.
+// STREAMING kernel.  (conv1 -- 16 -> 64 with the fused DDIM update -- was built the same way in round 3 and measured: 40.3 -> 38.8 us at
+// B=4, 70.9 -> 66.2 at B=8, 15.8 -> 17.3 at B=1; not kept: profiles/r03_run2_variants.md.)
 //
 // conv4 carries 3 % of the step's FLOPs and is bound by memory: 192 algorithmic bytes per latent pixel (y3 in, y4 out) against 18 kFLOP.  As an
 // instance of the general convolution kernel (dd_igemm2.hip, one workgroup per tile) it ran at 0.27-0.29 of the HBM rate: a workgroup's life

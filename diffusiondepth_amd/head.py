@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import modules as _modules
 from .modules import CNNDDIMPipiline, CNNDDIMPipilineVis, DeepDepthTransformWithUpsampling, HipBound, ScheduledCNNRefine
 from .necks import HAHIHeteroNeck
 from .scheduler import DDIMScheduler
@@ -186,7 +187,7 @@ class DDIMDepthEstimate_Res(nn.Module):
         timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bs,), device=gt_depth.device).long()
         # the loop output is not detached in the reference: when it carries gradient, q_sample stays a torch op so that
         # autograd reaches the loop through it; otherwise dd_add_noise (HIP tensors; CPU tensors: the scheduler's torch mirror)
-        keep_graph = (torch.is_grad_enabled() and blur_depth_t.requires_grad) or not blur_depth_t.is_cuda
+        keep_graph = (torch.is_grad_enabled() and blur_depth_t.requires_grad) or not _modules._on_hip_device(blur_depth_t)
         be = None if keep_graph else self._bound.ensure(blur_depth_t.device, self.scheduler, need=())        # q_sample needs the schedule only
         noisy_images = self.scheduler.add_noise(blur_depth_t, noise, timesteps, backend=None if keep_graph else be)
         noise_pred = self.model(noisy_images, timesteps, *refine_module_inputs)

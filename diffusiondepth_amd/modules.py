@@ -24,6 +24,13 @@ from .scheduler import DDIMScheduler
 DEFAULT_PRECISION = os.environ.get("DDEPTH_PRECISION", "fp32")
 
 
+def _on_hip_device(t) -> bool:
+    """Does this tensor take the library?  Tensors on a HIP device: always (the library is their only path).  Anything else runs the modules'
+    own torch children in eager mode (BASELINE configs[0]).  One predicate for every dispatch point (the host-emulation tests patch it to
+    drive the emulated library with CPU tensors)."""
+    return t.is_cuda
+
+
 def _invalidate_bound_hook(module, incompatible_keys):
     """load_state_dict post-hook (torch asserts that such hooks return None): invalidate the HipBound this module is registered with."""
     bound = module.__dict__.get("_ddepth_bound")
@@ -282,7 +289,7 @@ class ScheduledCNNRefine(nn.Module):
     def forward(self, noisy_image, t, *args):
         """forward(noisy_image, t, feat, blur_depth, sparse_depth, sparse_mask) -> eps (…res.py:324-344)."""
         feat = args[0]
-        if not noisy_image.is_cuda:
+        if not _on_hip_device(noisy_image):
             return self._eager_forward(noisy_image, t, feat)
         be = self.bound.ensure(noisy_image.device, need=("model",))
         t = torch.as_tensor(t, device=noisy_image.device)
@@ -333,7 +340,7 @@ class CNNDDIMPipiline:
         image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
         self.scheduler.set_timesteps(num_inference_steps)
         why_not = self.scheduler.hip_supported(eta)
-        if why_not is None and not image.is_cuda:
+        if why_not is None and not _on_hip_device(image):
             why_not = "tensors are not on a HIP device: eager PyTorch stepping (model + scheduler.step), as the reference"
         if why_not is None:
             be = self.model.bound.ensure(image.device, self.scheduler, need=("model",))
@@ -361,7 +368,7 @@ class CNNDDIMPipilineVis(CNNDDIMPipiline):
         image_shape = (batch_size, *shape)
         image = x_T if x_T is not None else torch.randn(image_shape, generator=generator, device=device, dtype=dtype)
         self.scheduler.set_timesteps(num_inference_steps)
-        if self.scheduler.hip_supported(eta) is None and image.is_cuda and not _wants_grad(self.model, image, input_args[0]):
+        if self.scheduler.hip_supported(eta) is None and _on_hip_device(image) and not _wants_grad(self.model, image, input_args[0]):
             be = self.model.bound.ensure(image.device, self.scheduler, need=("model",))
             states = be.denoise_trace(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
             image_list = list(states.unbind(0))
@@ -407,7 +414,7 @@ class DeepDepthTransformWithUpsampling(nn.Module):
 
     def _torch_path(self, x) -> bool:
         # (tensors that are not on a HIP device: the same torch modules in eager mode -- BASELINE configs[0], "plumbing, no GPU")
-        return self.training or (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda
+        return self.training or (torch.is_grad_enabled() and x.requires_grad) or not _on_hip_device(x)
 
     def t(self, depth):
         if self._torch_path(depth):

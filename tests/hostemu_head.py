@@ -47,6 +47,7 @@ def install(lib, setattr_fn):
         be._cond_token = None
         made.append(be)
         return be
+    setattr_fn(M_, "_on_hip_device", lambda t: True)      # CPU tensors take the (emulated) library, not the eager torch path
     setattr_fn(M_.HipBound, "_hip_device", staticmethod(lambda device: CPU))
     setattr_fn(M_.HipBound, "_make_backend", lambda self, device: make(device, self.variant))
     return make, made

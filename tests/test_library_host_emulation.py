@@ -179,7 +179,7 @@ def test_res_loop_with_the_hoisted_condition_term(lib):
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("prec,B,slots", [("f16", 2, 4), ("bf16", 1, 2), ("f16", 3, 5)])
+@pytest.mark.parametrize("prec,B,slots", [("bf16", 1, 2), ("f16", 2, 3)])
 def test_streaming_conv4_walks_several_tiles_per_workgroup(lib, prec, B, slots):
     """dd_thin.hip: conv4 as a persistent streaming kernel -- B x n workgroups, each walking the tiles j, j + n, ... of ONE image with the
     weights resident in LDS and a rolling register prefetch of the next tile's four channel chunks.  17 x 70 latent = 3 x 3 tiles per image
