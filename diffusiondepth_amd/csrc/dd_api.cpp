@@ -335,8 +335,9 @@ std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
 
 // Packed layout consumed by conv_igemm_kernel:
 //   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT; ks x ks taps)
-bool split_overflow = false;      // set by pack_conv_weights when a weight does not fit the split-f16 image; dd_commit_weights turns it into an error
-void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
+// returns false when a weight does not fit the split-f16 image (|w| x SPLIT_WSCALE beyond f16): dd_commit_weights turns that into an error
+bool pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
+  bool fits = true;
   const int ks = g.ks, n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = ks * ks / g.tg;
   const int planes = g.planes > 1 ? 2 : 1;       // split f16 (EK_F16S): every stage block is [hi plane | lo plane] of f16 elements
   const size_t n_el = (size_t)n_tiles * n_chunks * n_tg * g.tg * g.nt * g.ck * planes;
@@ -362,7 +363,7 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
               if (planes == 2) {
                 // hi = f16(w * SPLIT_WSCALE), lo = f16(w * SPLIT_WSCALE - hi): the same arithmetic as pack_weights_kernel (dd_misc.hip)
                 const float vs = v * SPLIT_WSCALE;
-                if (!(std::fabs(vs) < 60000.f)) split_overflow = true;       // |w| >= 234: beyond f16 after scaling (reported by the caller)
+                if (!(std::fabs(vs) < 60000.f)) fits = false;       // |w| >= 234: beyond f16 after scaling (reported by the caller)
                 const _Float16 hi = (_Float16)vs;
                 const _Float16 lo = (_Float16)(vs - (float)hi);
                 std::memcpy(&out[idx * 2], &hi, 2);
@@ -374,6 +375,7 @@ void pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
               }
             }
         }
+  return fits;
 }
 
 int upload(dd_handle_t h, DevBuf& dst, const void* src, size_t bytes, hipStream_t s) {
@@ -966,6 +968,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       int rc = pull_device_weights_to_host(h, s); if (rc) return rc;            // mixed update: newest values to the host, host route
     }
   }
+  bool split_fits = true;       // every forward weight fits the split-f16 image (checked while packing, reported once the group is through)
   const char* conv_names[4] = {"model.noise_embedding.0", "model.noise_embedding.3", "model.pred.0", "model.pred.3"};
   const char* gn_names[4] = {"model.noise_embedding.1", "model.noise_embedding.4", "model.pred.1", "model.pred.4"};
   const int cins[4] = {LATENT_C, HID_C, COND_C, HID_C}, couts[4] = {HID_C, COND_C, HID_C, LATENT_C};
@@ -976,7 +979,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     const std::vector<float>& b = h->host_w[std::string(conv_names[l]) + ".bias"];
     for (int wi = 0; wi < NUM_WIMG; ++wi) {
       std::vector<uint8_t> packed;
-      pack_conv_weights(w.data(), conv_pack_geom2(l + 1, wimg_kind(wi)), wimg_kind(wi), true, packed);
+      if (!pack_conv_weights(w.data(), conv_pack_geom2(l + 1, wimg_kind(wi)), wimg_kind(wi), true, packed)) split_fits = false;
       int rc = upload(h, L.wpack2[wi], packed.data(), packed.size(), s);
       if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));     // `packed` is a temporary
@@ -1016,7 +1019,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       const std::vector<float>& b = h->host_w[std::string(names[i]) + ".bias"];
       for (int wi = 0; wi < NUM_WIMG; ++wi) {
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(5 + i, wimg_kind(wi)), wimg_kind(wi), true, packed);
+        if (!pack_conv_weights(w.data(), conv_pack_geom2(5 + i, wimg_kind(wi)), wimg_kind(wi), true, packed)) split_fits = false;
         int rc = upload(h, L.wpack2[wi], packed.data(), packed.size(), s);
         if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
@@ -1036,8 +1039,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
     }
   }
-  if (do_model && split_overflow) {
-    split_overflow = false;
+  if (do_model && !split_fits) {
     return h->fail(DD_ERR_INVALID_ARG, "dd_commit_weights: a convolution weight of magnitude >= 234 does not fit the split-f16 image (DD_PREC_F16X3 scales weights by 256 into f16)");
   }
   if (do_model) {

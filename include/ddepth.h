@@ -219,7 +219,11 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent, the result is bit-identical;
  * dd_denoise_backward splits the same way, with one parameter-gradient set per lane summed into the caller-visible one at the join;
  * default 1), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
- * "keep_activations_mb" (budget of the per-step activation slots kept by a "keep_trajectory" forward, default 65536). */
+ * "keep_activations_mb" (budget of the per-step activation slots kept by "keep_trajectory" forwards, default 65536: ONE figure for the
+ * handle -- all lanes and shapes -- also held against the free device memory; stale sets are dropped first, and a forward that cannot
+ * keep its activations keeps the states only), "thin_stream" (1 [default] = conv4 runs as the persistent streaming kernel of
+ * csrc/dd_thin.hip in the 16-bit modes, 0 = as an instance of the general kernel: A/B switch), "thin_slots" (workgroups of that kernel,
+ * default 512 = two per CU), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches", "trajectory_ticket" (ticket of the

@@ -136,6 +136,19 @@ def test_split_f16_mode_meets_the_absolute_depth_tolerance_at_far_range(lib, gol
     assert dref.max() > 100.0 and maxabs(be.decode(x0), dref) < 1e-3
 
 
+def test_split_f16_image_refuses_weights_it_cannot_hold(lib):
+    """The split-f16 image carries weights times 2^8 in f16: a convolution weight of magnitude >= 234 cannot be represented and is refused at
+    commit (loudly, for the whole group) instead of turning into inf in one precision mode."""
+    be = EmuDenoiser(lib, "res")
+    sd = synth.make_state_dict(7240)
+    sd["model.pred.0.weight"] = sd["model.pred.0.weight"].copy()
+    sd["model.pred.0.weight"][3, 5, 1, 1] = 300.0
+    with pytest.raises(RuntimeError, match="split-f16"):
+        be.load_state_dict(sd)
+    be.load_state_dict(synth.make_state_dict(7240))          # a good set afterwards commits
+    be.close()
+
+
 # ---- the loop against the oracle, every kernel family and option ----------------------------------------------------------------------------------
 LOOP = dict(B=1, h=9, w=33, T=2)
 
