@@ -186,6 +186,17 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def rank_census(dist, world, rank, dev, maps_done):
+    """Every rank marks its own slot and reports the units it really processed; one SUM all-reduce over the job's process group (RCCL on
+    the GPU, gloo in the CPU self-test).  -> (ranks that answered, units summed over the ranks).  The real line and --dist-selftest share it."""
+    seen = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+    seen[rank] = 1
+    seen[world] = int(maps_done)
+    if dist is not None and world > 1:
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    return int((seen[:world] > 0).sum()), int(seen[world])
+
+
 def dist_selftest(args, world, rank, local_rank):
     """The multi-rank plumbing of this file without the hot path: process group, barrier-bracketed timed region, MAX over ranks,
     rank census.  Runs on any backend (gloo on a CPU-only host: tests/test_bench_dist_cpu.py)."""
@@ -199,8 +210,6 @@ def dist_selftest(args, world, rank, local_rank):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    seen = torch.zeros(world, dtype=torch.int64, device=dev)
-    seen[rank] = 1
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -211,10 +220,10 @@ def dist_selftest(args, world, rank, local_rank):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    ranks_seen, units = rank_census(dist if world > 1 else None, world, rank, dev, args.steps * (rank + 1))
     if rank == 0:
         n = dist.get_world_size() if world > 1 else 1
-        print(json.dumps({"dist_selftest": True, "n_gpus": n, "requested_gpus": args.gpus, "ranks_seen": int(seen.sum()),
+        print(json.dumps({"dist_selftest": True, "n_gpus": n, "requested_gpus": args.gpus, "ranks_seen": ranks_seen, "units_summed": units,
                           "backend": (dist.get_backend() if world > 1 else None), "steps": args.steps,
                           "ms_per_step": round(float(el.item()) / max(args.steps, 1) * 1e3, 4)}), flush=True)
     if world > 1:
@@ -449,11 +458,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # rank census over RCCL: every rank marks its own slot and reports the maps it really processed
-        seen = torch.zeros(world + 1, dtype=torch.int64, device=dev)
-        seen[rank] = 1
-        seen[world] = B * args.steps
-        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
-        ranks_seen, maps_done = int((seen[:world] > 0).sum()), int(seen[world])
+        ranks_seen, maps_done = rank_census(dist, world, rank, dev, B * args.steps)
         if ranks_seen != world:
             raise SystemExit(f"rank census: {ranks_seen} of {world} ranks answered")
     assert torch.isfinite(depth).all()

@@ -25,6 +25,7 @@ def test_plain_invocation_spawns_the_ranks_itself():
     assert len(lines) == 1, r.stdout                                   # rank 0 prints ONE line
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["requested_gpus"] == 2 and d["backend"] == "gloo"
+    assert d["units_summed"] == 3 * 1 + 3 * 2                           # the census the real N > 1 line uses (bench.rank_census): units summed over ranks
     assert d["ms_per_step"] >= 2.0                                      # MAX over ranks: rank 1 sleeps 2 ms per step, rank 0 only 1 ms
     assert "starting 2 ranks" in r.stderr
 
