@@ -355,6 +355,7 @@ def main():
                     "in a separate one-stream pass (per-launch durations are not defined under concurrency); the loop-level fraction "
                     "(`roofline.step_frac_of_peak` = flops_per_map x maps/s / peak) is the figure that survives concurrency")
     ap.add_argument("--no-streams-extra", action="store_true", help="skip the one-stream timing of the same step")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="dd_set_option on the timed handle (A/B switches: thin_stream=0, thin_slots=256, ...)")
     ap.add_argument("--no-abs-extra", action="store_true", help="skip the far-range / abs-clean (f16x3) parity + throughput extras")
     ap.add_argument("--no-sync-bn", action="store_true", help="train-dp with N > 1: keep per-rank BatchNorm statistics (default: synchronised, as the reference)")
     ap.add_argument("--dist-selftest", action="store_true", help="multi-rank plumbing only, no hot path (any backend)")
@@ -419,6 +420,9 @@ def main():
     be.set_option("hoist_cond", args.hoist)
     be.set_option("bf16_storage", 1 if args.bf16_storage else 0)
     be.set_option("streams", args.streams)
+    for kv in args.set:
+        k_, v_ = kv.split("=", 1)
+        be.set_option(k_, int(v_))
     hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision in ("f16", "f16x3"))))
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
@@ -686,7 +690,7 @@ def main():
             "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
                                    f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
-                       "ranks_seen": ranks_seen, "streams": args.streams,
+                       "ranks_seen": ranks_seen, "streams": args.streams, "options": args.set,
                        "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant},
             "roofline": roof, "roofline_b1": roof1, "cpu_baseline": cpu, "latency_b1": lat, "other_stream_count": lanes, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
         }

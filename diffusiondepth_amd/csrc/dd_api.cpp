@@ -215,6 +215,7 @@ struct dd_handle_s {
   int64_t keep_act_mb = 65536;
   int n_streams = 1;          // option "streams": concurrent sub-batches of dd_denoise (1 = off)
   int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
+  int big_tiles = -1;         // option "big_tiles": hoisted conv3 pair on 16x32 tiles: -1 = when the 8x32 tiles exceed the 512 resident slots, 0 / 1 = forced
   int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
@@ -469,6 +470,19 @@ bool keep2_fits(dd_handle_t h, size_t need) {
   }
 }
 
+// The hoisted conv3 pair of a plan runs on 16x32-pixel tiles (kernel ids BIG_CONV3C / BIG_CONV3H, dd_kernels.h) when its 8x32 tiles would not
+// fit the chip's resident workgroup slots at once; a function of the plan key only, so that the once-per-image kernel, the loop kernel, the
+// buffer of the hoisted term and every backward recompute agree.  Option "big_tiles": -1 = this rule, 0 / 1 = forced (A/B, tests).
+bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
+  if (!key.hoist || key.prec == DD_PREC_NAIVE_FP32) return false;
+  const int ek = ek_of_precision(key.prec, h->bf16_pure);
+  if (ek == EK_F32 || ek == EK_F16S) return false;
+  if (h->big_tiles >= 0) return h->big_tiles != 0;
+  return (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > 512;
+}
+inline int conv3c_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3C : 8; }
+inline int conv3h_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3H : 9; }
+
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   auto it = h->plans.find(key);
   if (it != h->plans.end()) { it->second->last_use = ++h->tick; *out = it->second.get(); return DD_OK; }
@@ -499,7 +513,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   if (swin) { DD_HIP(pl->sa.alloc(ns * px * COND_C * es)); DD_HIP(pl->sf.alloc(ns * px * COND_C * es)); }
   if (key.hoist)   // conv3(cond) in accumulator-fragment order: whole (th x 32)-pixel tiles
   {
-    const int th = conv_pack_geom2(9, pl->ek).th;
+    const int th = conv_pack_geom2(conv3h_kid(h, key), pl->ek).th;
     DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
@@ -561,11 +575,12 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   // instruments the general kernel)
   const bool stream4 = h->thin_stream && (tk == EK_F16 || tk == EK_BF16) && !h->prof_buf && k.B <= h->thin_slots;
   auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
+    const int kid = layer == 9 ? conv3h_kid(h, k) : layer;            // kernel id; times are booked under `layer`
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
-      q.tiles_y = (k.h + conv_pack_geom2(layer, ek).th - 1) / conv_pack_geom2(layer, ek).th;
+      q.tiles_y = (k.h + conv_pack_geom2(kid, ek).th - 1) / conv_pack_geom2(kid, ek).th;
       if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
-      return launch_conv_igemm2(layer, ek, q, s);
+      return launch_conv_igemm2(kid, ek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
     hipEvent_t a, b;
@@ -656,10 +671,11 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   ConvParams p{};
   p.B = k.B; p.h = k.h; p.w = k.w;
   p.tiles_x = (k.w + 31) / 32;
-  p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
+  const int kid = conv3c_kid(h, k);
+  p.tiles_y = (k.h + conv_pack_geom2(kid, pl->ek).th - 1) / conv_pack_geom2(kid, pl->ek).th;
   p.ablate = 0;
   p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[wimg_slot(thin_kind(pl->ek))].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
-  DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
+  DD_HIP(launch_conv_igemm2(kid, pl->ek, p, s));
   return DD_OK;
 }
 
@@ -1245,6 +1261,11 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "adjoint_tiled") h->adjoint_tiled = value != 0;
   else if (k == "streams") h->n_streams = value < 1 ? 1 : (int)value;
   else if (k == "keep_activations_mb") h->keep_act_mb = value < 0 ? 0 : value;
+  else if (k == "big_tiles") {
+    if (value < -1 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: big_tiles must be -1 (automatic), 0 or 1");
+    if (h->big_tiles != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // tile shape is baked into buffers and graphs
+    h->big_tiles = (int)value;
+  }
   else if (k == "thin_slots") {
     if (value < 1 || value > 4096) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_slots must be in [1, 4096]");
     if (h->thin_slots != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }

@@ -826,6 +826,8 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 39: return launch_one2<EK, 39>(p, s);
     case 40: return launch_one2<EK, 40>(p, s);
     case 41: return launch_one2<EK, 41>(p, s);
+    case BIG_CONV3C: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3C>(p, s); else return hipErrorInvalidValue;
+    case BIG_CONV3H: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3H>(p, s); else return hipErrorInvalidValue;
     case 54: return launch_one2<EK, 54>(p, s);
     case 55: return launch_one2<EK, 55>(p, s);
     case 56: return launch_one2<EK, 56>(p, s);
@@ -851,6 +853,8 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     case 5: return launch_one2<EK_BF16M, 5>(p, s);
     case 7: return launch_one2<EK_BF16M, 7>(p, s);
     case 9: return launch_one2<EK_BF16M, 9>(p, s);
+    case BIG_CONV3C: return launch_one2<EK_F16, BIG_CONV3C>(p, s);          // (the once-per-image conv3(cond) is an f16 kernel in this mode)
+    case BIG_CONV3H: return launch_one2<EK_BF16M, BIG_CONV3H>(p, s);
     case 10: return launch_one2<EK_BF16M, 10>(p, s);
     case 15: return launch_one2<EK_BF16M, 15>(p, s);
     case 24: return launch_one2<EK_BF16M, 24>(p, s);
@@ -925,6 +929,8 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 39: return geom2_of<EK, 39>();
     case 40: return geom2_of<EK, 40>();
     case 41: return geom2_of<EK, 41>();
+    case BIG_CONV3C: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3C>(); else return geom2_of<EK, 8>();      // same packed image as layers 8 / 9, th = 16
+    case BIG_CONV3H: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3H>(); else return geom2_of<EK, 9>();
     case 54: return geom2_of<EK, 54>();
     case 55: return geom2_of<EK, 55>();
     case 56: return geom2_of<EK, 56>();

@@ -20,6 +20,8 @@
 //   0 = 8x32 pixels, 32-channel chunks, 3 taps per stage (24 MFMAs per wave between barriers)
 //   1 = 8x32 pixels, 16-channel chunks, 9 taps per stage (36 MFMAs per wave between barriers)
 //   2 = 16x32 pixels, 4 waves x (128 pixels x 64 couts), 16-channel chunks, 9 taps per stage (72 MFMAs between barriers, 0.75 LDS reads per MFMA)
+// Round 3: tiling 2 is ALSO instantiated beside the default as the kernel ids BIG_CONV3C / BIG_CONV3H (layers 8 / 9) and picked per launch when
+// the tiles do not fit the chip at once -- under the two concurrent lanes it is worth +1.8 % at B=4 and +4 % at B=8 (profiles/r03_run2_variants.md).
 #ifndef DD_C3
 #define DD_C3 1
 #endif
@@ -83,7 +85,10 @@
 
 namespace dd {
 
-template <int EKM_, int LAYER_> struct Cfg2 {
+template <int EKM_, int LAYER_ID_> struct Cfg2 {
+  // kernel ids BIG_CONV3C / BIG_CONV3H (dd_kernels.h) = layers 8 / 9 on 16x32-pixel tiles
+  static constexpr bool BIG = LAYER_ID_ == BIG_CONV3C || LAYER_ID_ == BIG_CONV3H;
+  static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : LAYER_ID_ == BIG_CONV3H ? 9 : LAYER_ID_;
   // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands
   // are instantiated here -- conv2 / conv3 / hoisted conv3 / Swin convA (f16 in, bf16 operands), the producers of f16 tensors in front
   // of them (conv2, conv3, Swin pred.0, the level-0 lateral conv of the condition FPN); the launcher sends every other layer to its
@@ -144,7 +149,8 @@ template <int EKM_, int LAYER_> struct Cfg2 {
   static constexpr bool SCATTER = IS_UP;                         // epilogue: cout block -> output parity of a 2x upsampled tensor
   static constexpr int COUT_PAD = (COUT < 32) ? 32 : IS_NECK ? ((COUT + 63) / 64) * 64 : COUT;
   static constexpr bool C3SHAPE = (LAYER == 3 || LAYER == 7 || LAYER == 8 || LAYER == 9);
-  static constexpr int C3 = (C3SHAPE && ESZ == 2 && !SPLIT) ? DD_C3 : 0;
+  static constexpr int C3 = (C3SHAPE && ESZ == 2 && !SPLIT) ? (BIG ? 2 : DD_C3) : 0;
+  static_assert(!BIG || (ESZ == 2 && !SPLIT), "big-tile forms: 2-byte kinds only");
   static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2 && !SPLIT;
   static constexpr bool C4K16 = DD_C4_CK16 && LAYER == 4 && ESZ == 2 && !SPLIT;
   static constexpr int CK = (SPLIT || C4K16) ? 16 : (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0 || SWIN3) ? 16 : (64 / ESZ);

@@ -99,6 +99,11 @@ struct ConvParams {
 // ---- fused implicit-GEMM path (dd_igemm2.hip) ------------------------------------------------
 // layer ids: see dd_igemm2_cfg.h; ek: element kind.  Weights are packed with the LDS swizzle pre-applied
 // (16-B piece j of block row r is stored at j ^ ((r / (256/rowbytes)) & (rowbytes/16 - 1))).
+// Kernel ids of the BIG-TILE forms of the hoisted conv3 pair (dd_igemm2_cfg.h): layer 8 (conv3(cond), once per image) and layer 9 (conv3 in
+// the loop) on 16x32-pixel tiles -- four waves of 128 pixels x 64 couts each, 0.75 instead of 1.0 LDS fragment reads per MFMA, half the
+// weight stream per pixel -- chosen per launch when there are more 8x32 tiles than resident workgroup slots (the two must agree: layer 8
+// leaves its result in the accumulator-fragment order of layer 9's tiles).  Same packed weights as layers 8 / 9.
+constexpr int BIG_CONV3C = 48, BIG_CONV3H = 49;
 // workgroups of a persistent launch (dd_thin.hip): B x n with n workgroups per image, at most `slots` in all
 inline int persist_grid(int B, int tiles_per_img, int slots) {
   int n = slots / (B > 0 ? B : 1);
