@@ -14,10 +14,18 @@ def per_kernel(d, counter):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d+), (\d+)>", row.get("Kernel_Name", ""))
-            if not m:
-                continue
-            rows[f"layer{m.group(2)}_ek{m.group(1)}"].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
+            name = row.get("Kernel_Name", "")
+            m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d+), (\d+)>", name)
+            if m:
+                # kernel ids 48 / 49 are layers 8 / 9 on 16x32 tiles (dd_kernels.h): booked under the layer they implement
+                layer = {48: 8, 49: 9}.get(int(m.group(2)), int(m.group(2)))
+                key = f"layer{layer}_ek{m.group(1)}"
+            else:
+                m = re.search(r"conv4_stream_kernel<(\d+)>", name)      # dd_thin.hip: conv4 as the persistent streaming kernel
+                if not m:
+                    continue
+                key = f"layer4_ek{m.group(1)}"
+            rows[key].append((int(row["Grid_Size"]), float(row["Counter_Value"])))
     out = {}
     for k, v in rows.items():
         g = max(x[0] for x in v)
