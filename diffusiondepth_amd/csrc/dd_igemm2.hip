@@ -435,9 +435,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   DD_PROF_MARK(2);
   if (abl & 1024) return;
   // ---- the MFMAs of stage (chunk, tg): TG taps x NKQ k-steps x (WM x WN) tiles out of LDS ------------------
-  // s_next >= 0 / raw_chunk >= 0 (C::DMA_SPREAD only): the next stage's weight DMA and the raw patch loads of chunk raw_chunk are issued
-  // from inside this block, between its tap groups
-  auto mfma_block = [&](int chunk, int tg, int s_next, int raw_chunk, int raw_slot) {
+  auto mfma_block = [&](int chunk, int tg) {
 #if DD_SETPRIO && !defined(DD_HOST_EMULATION)
     __builtin_amdgcn_s_setprio(DD_SETPRIO);      // the wave inside its MFMA block wins issue arbitration against the co-resident workgroup's staging wave
 #endif
@@ -521,14 +519,6 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         } else {
           __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
         }
-        if constexpr (C::DMA_SPREAD) {
-          static_assert(!C::DMA_SPREAD || NG > NWPIECE, "one DMA piece behind each of the first tap groups, the raw loads behind the next");
-          if (gi < NWPIECE) { if (s_next >= 0) issue_weight_piece(s_next, gi); }
-          else if (gi == NWPIECE) {
-            asm volatile("" ::: "memory");         // the raw loads stay behind the DMA in issue order (counted vmcnt at the end of the stage)
-            if (raw_chunk >= 0) load_raw(raw_chunk, raw_slot);
-          }
-        }
       }
     }
 #if DD_SETPRIO && !defined(DD_HOST_EMULATION)
@@ -546,13 +536,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const int s = sbase + chunk * C::NTG + tg;
     const bool want_w = s + 1 < C::NSTAGE * C::SPW && !(abl & 4);
     const bool want_raw = C::NCHUNK > 1 && tg == 0 && chunk + RD < C::NCHUNK && !(abl & 2);
-    if constexpr (!C::DMA_SPREAD) {
-      if (want_w) issue_weights(s + 1);
-      asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
-      if (want_raw) load_raw(chunk + RD, par);
-    }
+    if (want_w) issue_weights(s + 1);
+    asm volatile("" ::: "memory");         // keep the DMA ahead of the raw loads in issue order (counted vmcnt below)
+    if (want_raw) load_raw(chunk + RD, par);
     DD_PROF_LOOP_ADD(3);
-    if (!(abl & 8)) mfma_block(chunk, tg, (C::DMA_SPREAD && want_w) ? s + 1 : -1, (C::DMA_SPREAD && want_raw) ? chunk + RD : -1, par);
+    if (!(abl & 8)) mfma_block(chunk, tg);
     DD_PROF_LOOP_ADD(0);
     if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, (par + 1) % RD);

@@ -2,6 +2,8 @@
 // Variants that were measured slower on MI355X and removed in round 2 (profiles/r01_run30_power_and_variants.md,
 // profiles/r02_run1_ddimloss_and_winograd.md): wave-specialised staging waves, a 16x32 / 8-wave / 9-taps-per-stage conv3 tile with
 // and without ping-pong halves, persistent conv1 / conv4 workgroups, in-loop interleaving of the prologue, Winograd F(2x2,3x3).
+// Round 3 (profiles/r03_run2_variants.md): the next stage's weight DMA issued between the tap groups of the MFMA block, conv1 at eight
+// waves per SIMD, eight-wave "latency variants" of conv2 / conv3, a persistent conv3.
 #pragma once
 #include "dd_elem.h"
 
@@ -60,23 +62,10 @@
 #ifndef DD_CADD_F16
 #define DD_CADD_F16 1      // measured (round 3, one box): conv3 155 -> 138 us at KITTI B=4, 46.5 -> 44.9 at B=1; loop 7.30 -> 7.03 ms
 #endif
-// conv3-shaped layers with nine taps per stage: 1 = the next stage's weight DMA is issued piece by piece BETWEEN the tap groups of the running
-// stage's MFMA block (one 1-KiB LDS-DMA instruction per wave behind each of the first groups, the next-but-one chunk's raw patch loads
-// behind them) instead of as one burst in front of it -- a wave that waits for room in the memory pipeline's queue then waits beside
-// running MFMAs; 0 = burst at the start of the stage.  Measured (round 3): conv3 138 -> 147 us at B=4 (the asm DMA statements between the tap
-// groups split hipcc's scheduling regions: the ds_read / MFMA interleave of the block suffers more than the burst cost): off
-#ifndef DD_DMA_SPREAD
-#define DD_DMA_SPREAD 0
-#endif
 // conv4 (64 -> 16) in the 2-byte kinds: 1 = 16-channel chunks, nine taps per stage (four chunks, double-buffered 11-KB patches, 40 KB of LDS:
 // three to four workgroups per CU instead of two, the next chunk's loads fly under the current chunk's MFMAs); 0 = one 64-channel patch
 #ifndef DD_C4_CK16
 #define DD_C4_CK16 1       // measured (round 3): conv4 36.7 -> 34.3 us at KITTI B=4, neutral at B=1
-#endif
-// conv1 / conv4 (eight-wave workgroups, latency-bound): 1 = ask for 8 waves per SIMD (<= 64 VGPRs) so that four workgroups share a CU.
-// Measured (round 3): conv1 spills 25 registers at 64 VGPRs and gets SLOWER (39.9 -> 56.5 us at B=4): off
-#ifndef DD_THIN_OCC8
-#define DD_THIN_OCC8 0
 #endif
 // per-workgroup phase timestamps (ConvParams::prof); compiled in by tools/phase_prof.py only
 #ifndef DD_PHASE_PROF
@@ -160,7 +149,6 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL && !SPLIT) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
-  static constexpr bool DMA_SPREAD = DD_DMA_SPREAD && C3 == 1;
   static constexpr bool CADD16 = DD_CADD_F16 && ESZ == 2 && !SPLIT && (LAYER == 8 || LAYER == 9);   // the hoisted term travels as f16
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
@@ -207,8 +195,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int FRAG_DEPTH = (LAYER == 5 && !SPLIT && !(SWIN3 && DD_SWIN_FD2)) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
-  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((DD_THIN_OCC8 && (LAYER == 1 || LAYER == 4) && !SPLIT && SMEM_BYTES <= 40 * 1024) ? 8 : (SMEM_BYTES <= 80 * 1024) ? 4 : 2)
-                                                         : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS
+  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS
   static_assert(CIN % CK == 0 && NTAPS % TG == 0 && COUT_PAD % NT == 0, "tiling");
   static_assert(PATCH_BYTES % 16 == 0 && W_BYTES % 1024 == 0, "LDS carve / DMA granularity");
   static_assert(WAVES <= 8 && (COUT_PAD / NT) % SPW == 0 && (SPW == 1 || NCHUNK == 1), "scratch size; splits per workgroup");
