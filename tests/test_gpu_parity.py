@@ -292,6 +292,43 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
     pure.close()
 
 
+def test_big_tile_and_lane_paths_agree_with_the_single_image_path_at_kitti_size(U):
+    """At KITTI size a batch takes other kernels than one image: two concurrent lanes (option streams), and -- 836 tiles per two-image lane
+    against 512 resident slots -- the hoisted conv3 pair on 16x32 tiles (kernel ids 48 / 49), conv4's streaming workgroups walking several
+    tiles each.  Every image of a batch of 3 must equal its solo run (8x32 tiles, one tile per streaming workgroup) within the precision's
+    bound (bf16: the 16-bit rounding class -- other GroupNorm partial-sum order; fp32 and f16x3 do not have the big tiles: round-off), and
+    the forced settings must agree with the automatic ones."""
+    c = {"wseed": 7240}
+    be = U.backend_for(c)
+    h, w, T = 176, 608, 4
+    inp = synth.make_inputs(91, 3, h, w)
+    x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+    for prec in ("bf16", "fp32"):
+        batch = be.denoise(x, cond, T, prec).cpu().numpy()
+        scale = float(np.abs(batch).max())
+        for i in range(3):
+            solo = be.denoise(x[i:i + 1].contiguous(), cond[i:i + 1].contiguous(), T, prec).cpu().numpy()
+            e = U.maxabs(batch[i:i + 1], solo)
+            U.record("batch_vs_solo_kitti", prec=prec, image=i, maxabs=e, scale=scale)
+            assert e < (LATENT_TOL[prec] if prec == "bf16" else 2e-6) * scale, (prec, i, e, scale)
+    try:
+        be.set_option("big_tiles", 0)
+        small = be.denoise(x, cond, T, "bf16").cpu().numpy()
+        be.set_option("big_tiles", 1)
+        big = be.denoise(x, cond, T, "bf16").cpu().numpy()
+    finally:
+        be.set_option("big_tiles", -1)
+    auto = be.denoise(x, cond, T, "bf16").cpu().numpy()
+    s = float(np.abs(auto).max())
+    assert U.maxabs(small, big) < LATENT_TOL["bf16"] * s
+    # the automatic rule is per plan, i.e. per lane: lane 0 carries two images (836 tiles: 16x32), lane 1 one image (418 tiles: 8x32)
+    lanes = min(getattr(be, "n_streams", 1), 3)
+    if lanes == 2:
+        assert np.array_equal(auto[:2], big[:2]) and np.array_equal(auto[2:], small[2:])
+    elif lanes == 1:
+        assert np.array_equal(auto, big)
+
+
 # ---- Swin / MPViT variant of the denoiser (SURVEY.md 8a row a3): UpSample_add fuse, stride-4 condition map ----
 @pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16", "f16"])
 def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):
