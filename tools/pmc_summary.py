@@ -33,7 +33,7 @@ def main(dirs):
                     cnt[k][c] += 1
         print("==", d)
         for k in sorted(acc, key=lambda k: -sum(cnt[k].values())):
-            if "conv_igemm" not in k:
+            if "conv_igemm" not in k and "conv4_stream" not in k:
                 continue
             parts = [f"{c}={acc[k][c] / max(cnt[k][c], 1):.4g}" for c in sorted(acc[k])]
             n = max(cnt[k].values())
