@@ -126,6 +126,8 @@ struct Plan {
   bool traj_consumed = false;      // a dd_denoise_backward has read this trajectory: the plan may be dropped when the activation budget is needed
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
+  DevBuf ttab, tt_scratch;   // Swin variant, hoisted form: E[t] border tables of the T loop steps [T][SWIN_TT_ROWS][64] (swin_ttab, dd_misc.hip) ...
+  int64_t ttab_weights = -1; // ... and the parameter generation they were computed from
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
@@ -436,10 +438,19 @@ int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::share
 // conv3's condition term out of the loop?  (Res variant, fused modes; option "hoist_cond": -1 = in the 16-bit modes whose tensors are
 // stored in f16 -- the default bf16 mode and the f16 mode: faster AND closer to the fp32 path, the condition term reaching the accumulators
 // in fp32 (f16 mode at KITTI size: 533 vs 502 maps/s, depth RMSE 1.54e-4 vs 1.74e-4); the fp32 parity mode keeps the reference's order of sums)
-int want_hoist(dd_handle_t h, int precision) {
-  if (h->variant != DD_VARIANT_RES || precision == DD_PREC_NAIVE_FP32) return 0;
-  if (h->hoist_cond >= 0) return h->hoist_cond;
+// Swin variant (SWIN_CONVA_H / SWIN_PRED_H, dd_kernels.h): the whole step-invariant part of pred.0(convB(convA(.))) -- condition map and
+// time embedding through three convolutions -- in the plans of the loop that keep nothing for a backward (T > 0, keep == 0): the weight
+// gradients of convB / pred.0 need the un-split activations, so training plans and the single-call plans (per-sample timesteps) run the
+// reference's order.  -1 = in the 2-byte modes; 1 also in the fp32 mode; never in the split-f16 mode (no such kernels).
+int want_hoist(dd_handle_t h, int precision, int T = 1, int keep = 0) {
+  if (precision == DD_PREC_NAIVE_FP32) return 0;
   const int ek = ek_of_precision(precision, h->bf16_pure);
+  if (h->variant == DD_VARIANT_SWIN) {
+    if (T <= 0 || keep != 0 || ek == EK_F16S || h->hoist_cond == 0) return 0;
+    return (h->hoist_cond == 1 || ek != EK_F32) ? 1 : 0;
+  }
+  if (h->variant != DD_VARIANT_RES) return 0;
+  if (h->hoist_cond >= 0) return h->hoist_cond;
   return (ek == EK_BF16M || ek == EK_F16 || ek == EK_F16S) ? 1 : 0;
 }
 
@@ -474,7 +485,7 @@ bool keep2_fits(dd_handle_t h, size_t need) {
 // fit the chip's resident workgroup slots at once; a function of the plan key only, so that the once-per-image kernel, the loop kernel, the
 // buffer of the hoisted term and every backward recompute agree.  Option "big_tiles": -1 = this rule, 0 / 1 = forced (A/B, tests).
 bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
-  if (!key.hoist || key.prec == DD_PREC_NAIVE_FP32) return false;
+  if (!key.hoist || key.prec == DD_PREC_NAIVE_FP32 || h->variant != DD_VARIANT_RES) return false;
   const int ek = ek_of_precision(key.prec, h->bf16_pure);
   if (ek == EK_F32 || ek == EK_F16S) return false;
   if (h->big_tiles >= 0) return h->big_tiles != 0;
@@ -515,6 +526,12 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   {
     const int th = conv_pack_geom2(conv3h_kid(h, key), pl->ek).th;
     DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
+  }
+  if (key.hoist && swin) {
+    const int T1 = key.T > 0 ? key.T : 1;
+    const int RH = key.h < SWIN_TT_AX ? key.h : SWIN_TT_AX, RW = key.w < SWIN_TT_AX ? key.w : SWIN_TT_AX;
+    DD_HIP(pl->ttab.alloc((size_t)T1 * SWIN_TT_ROWS * HID_C * 4));
+    DD_HIP(pl->tt_scratch.alloc((size_t)T1 * RH * RW * (2 * COND_C + HID_C) * 4));
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
@@ -574,8 +591,8 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   // conv4 runs as the persistent streaming kernel of dd_thin.hip in the 2-byte modes (option "thin_stream", default on; the phase profiler
   // instruments the general kernel)
   const bool stream4 = h->thin_stream && (tk == EK_F16 || tk == EK_BF16) && !h->prof_buf && k.B <= h->thin_slots;
-  auto timed_launch = [&](int layer, const ConvParams& cp) -> hipError_t {
-    const int kid = layer == 9 ? conv3h_kid(h, k) : layer;            // kernel id; times are booked under `layer`
+  auto timed_launch = [&](int layer, const ConvParams& cp, int kid_as = -1) -> hipError_t {
+    const int kid = kid_as >= 0 ? kid_as : layer == 9 ? conv3h_kid(h, k) : layer;            // kernel id; times are booked under `layer`
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
       q.tiles_y = (k.h + conv_pack_geom2(kid, ek).th - 1) / conv_pack_geom2(kid, ek).th;
@@ -608,7 +625,21 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.stats_out = pl->stat_ptr(step, 1); p.stats_in = pl->stat_ptr(step, 0);
   p.gn_gamma = h->L[0].gamma.as<float>(); p.gn_beta = h->L[0].beta.as<float>();
   DD_HIP(timed_launch(2, p));
-  if (h->variant == DD_VARIANT_SWIN) {
+  if (h->variant == DD_VARIANT_SWIN && k.hoist) {
+    // hoisted form: pred.0(convB(convA(relu(gn2(y2))))) without the fuse convs' biases; the accumulators of pred.0 start at the per-image
+    // term of enqueue_swin_hoist and its epilogue adds this step's E[t] rows
+    p.in = y2_; p.wpack = h->LA.wpack2[wk].p; p.bias = h->zero_bias.as<float>(); p.out = sa_;
+    p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
+    p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
+    DD_HIP(timed_launch(5, p, SWIN_CONVA_H));
+    p.in = sa_; p.wpack = h->LB.wpack2[wk].p; p.out = sf_;
+    p.stats_in = nullptr;
+    DD_HIP(timed_launch(6, p));
+    p.in = sf_; p.wpack = h->L[2].wpack2[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
+    p.stats_out = pl->stat_ptr(step, 2);
+    p.cadd = pl->ccond.as<float>(); p.ttab = pl->ttab.as<float>() + (size_t)step * SWIN_TT_ROWS * HID_C;
+    DD_HIP(timed_launch(7, p, SWIN_PRED_H));
+  } else if (h->variant == DD_VARIANT_SWIN) {
     // upsample_fuse: convB(convA(relu(gn2(y2)) + up(cond) + E[t]))  then pred.0 on the raw result
     p.in = y2_; p.wpack = h->LA.wpack2[wk].p; p.bias = h->LA.bias.as<float>(); p.out = sa_;
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
@@ -679,6 +710,32 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   return DD_OK;
 }
 
+// Swin variant, hoisted form: the per-image term pred.0(convB(convA(up(feat)) + a) + b) without pred.0's bias, left in the accumulator-fragment
+// order of pred.0's tiles (layer 8), and -- once per plan and parameter generation -- the E[t] tables of the loop's steps.  The upsampled
+// condition map is in the plan's buffer; Plan::sa / sf are free until the loop starts.
+int enqueue_swin_hoist(dd_handle_t h, Plan* pl, hipStream_t s) {
+  const PlanKey& k = pl->key;
+  if (pl->ttab_weights != h->weights_serial) {
+    if (!h->LA.w_oihw.p || !h->LB.w_oihw.p || !h->L[2].w_oihw.p) return h->fail(DD_ERR_STATE, "hoisted Swin form: the fp32 weights of the fuse convolutions are not on the device");
+    DD_HIP(launch_swin_ttab(h->LA.w_oihw.as<float>(), h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->emb.as<float>(),
+                            pl->tsteps.as<long long>(), k.T, k.h, k.w, pl->tt_scratch.as<float>(), pl->ttab.as<float>(), s));
+    pl->ttab_weights = h->weights_serial;
+  }
+  const int tk = thin_kind(pl->ek);           // once per image: f16 kernels in the bf16 mode, as the Res variant's conv3(cond)
+  ConvParams p{};
+  p.B = k.B; p.h = k.h; p.w = k.w;
+  p.tiles_x = (k.w + 31) / 32;
+  p.tiles_y = (k.h + conv_pack_geom2(6, tk).th - 1) / conv_pack_geom2(6, tk).th;
+  p.in = pl->cond_ptr(); p.wpack = h->LA.wpack2[wimg_slot(tk)].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
+  DD_HIP(launch_conv_igemm2(6, tk, p, s));
+  p.in = pl->sa.p; p.wpack = h->LB.wpack2[wimg_slot(tk)].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
+  DD_HIP(launch_conv_igemm2(6, tk, p, s));
+  p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
+  p.in = pl->sf.p; p.wpack = h->L[2].wpack2[wimg_slot(tk)].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
+  DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
+  return DD_OK;
+}
+
 // Bring the condition map into the plan's (shared) buffer: convert the caller's NCHW fp32 tensor, or -- cond == NULL --
 // check that dd_condition left its result there.
 // A lane (img0 > 0 or B < whole_B) is handed its images of the caller's tensor by the caller; of dd_condition's result it takes its slice.
@@ -704,7 +761,7 @@ int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h
     if (!whole)     // this lane's images inside the whole batch's condition map (per-image contiguous in the activation layout)
       pl->cond_alias = static_cast<const char*>(h->fpn_cond->p) + (size_t)img0 * lat_h * lat_w * COND_C * ek_size(store_kind(pl->ek));
   }
-  if (pl->key.hoist) { int rc = enqueue_cond_conv(h, pl, s); if (rc) return rc; }
+  if (pl->key.hoist) { int rc = h->variant == DD_VARIANT_SWIN ? enqueue_swin_hoist(h, pl, s) : enqueue_cond_conv(h, pl, s); if (rc) return rc; }
   return DD_OK;
 }
 
@@ -929,7 +986,7 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s) {
     for (int i = 0; i < 2; ++i) {
       ConvLayer& L = *Ls[i];
       L.cin = COND_C; L.cout = COND_C;
-      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, false, s); if (rc) return rc;
+      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, true, s); if (rc) return rc;      // (fp32 OIHW copy: the hoisted form's E[t] tables)
       rc = copy_small(L.bias, std::string(names[i]) + ".bias", 0); if (rc) return rc;
     }
   }
@@ -1041,6 +1098,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
         DD_HIP(hipStreamSynchronize(s));
       }
       int rc = upload(h, L.bias, b.data(), b.size() * 4, s); if (rc) return rc;
+      rc = upload(h, L.w_oihw, w.data(), w.size() * 4, s); if (rc) return rc;       // fp32 OIHW: the hoisted form's E[t] tables (swin_ttab)
       DD_HIP(hipStreamSynchronize(s));
       // backward: data gradient of a 256->256 conv = the convB kernel (layer 6: raw input, no norm) on W^T flipped
       std::vector<float> wt(w.size());
@@ -1482,15 +1540,15 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
     const size_t per_step = (size_t)B * lat_h * lat_w * ((2 * HID_C + COND_C + (h->variant == DD_VARIANT_SWIN ? 2 * COND_C : 0)) * es + LATENT_C * 4);
     const size_t need = per_step * (size_t)T;
     if (need <= ((size_t)h->keep_act_mb << 20) &&
-        (h->plans.count(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), 2, lane}) || keep2_fits(h, need))) keep = 2;
+        (h->plans.count(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 2), 2, lane}) || keep2_fits(h, need))) keep = 2;
   }
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep, lane}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, keep), keep, lane}, &pl);
   if (rc && keep == 2) {
     // the per-step slots did not fit after all (fragmentation, another process): states only -- the backward then recomputes the activations
     (void)hipGetLastError();
-    h->plans.erase(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), 2, lane});
+    h->plans.erase(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 2), 2, lane});
     keep = 1;
-    rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), keep, lane}, &pl);
+    rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, keep), keep, lane}, &pl);
   }
   if (rc) return rc;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
@@ -1642,7 +1700,7 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision)}, &pl);    // the kernels dd_denoise runs: same bits
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 0)}, &pl);    // the kernels dd_denoise runs: same bits
   if (rc) return rc;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
@@ -1690,7 +1748,7 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision)}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision, 0, 0)}, &pl);
   if (rc) return rc;
   const long long* tv = reinterpret_cast<const long long*>(t);
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
@@ -1944,7 +2002,7 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
   // the same kernels (hoisted or not) as the forward call: a recompute differentiates the function the forward evaluated
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision)}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision, 0, 0)}, &pl);
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1957,7 +2015,7 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
   h->use_traj = 0;
   const Plan* kept = nullptr;
   if (ticket != 0 && precision != DD_PREC_NAIVE_FP32) {
-    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision)});
+    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, 0, precision, want_hoist(h, precision, 0, 0)});
     if (it != h->plans.end() && it->second->traj_ticket == ticket && it->second->traj_weights == h->weights_serial && it->second->ek == pl->ek)
       kept = it->second.get();
   }
@@ -1978,7 +2036,7 @@ int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, co
                           int whole_B, int64_t ticket, bool* reused) {
   int rc = DD_OK;
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), 0, lane}, &pl);      // recompute = the forward's kernels
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 1), 0, lane}, &pl);      // recompute = the kernels of the forward that kept the trajectory
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -1988,7 +2046,7 @@ int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, co
   // shape, same parameters, nothing run on that plan since), else regenerated here by running the forward loop again.
   const Plan* kept = nullptr;
   for (int lvl = 2; lvl >= 1 && !kept && ticket != 0 && !naive; --lvl) {
-    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision), lvl, lane});
+    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, lvl), lvl, lane});
     if (it != h->plans.end() && it->second->traj_ticket == ticket && it->second->traj_weights == h->weights_serial) kept = it->second.get();
   }
   const Plan* kept_act = (kept && kept->key.keep == 2 && kept->ek == pl->ek) ? kept : nullptr;      // activations too: no recompute

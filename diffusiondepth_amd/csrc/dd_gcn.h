@@ -14,6 +14,7 @@
 #define DD_WAIT_VM(n) hostemu::wait_vm(n)
 #define DD_WAIT_VM_LGKM0(n) hostemu::wait_vm(n)
 #define DD_WAIT_LGKM0() ((void)0)
+#define DD_SCHED_FENCE() ((void)0)
 #define DD_VMEM_LOADS_ISSUED(n) hostemu::vmem_loads_issued(n)
 #define DD_GLOBAL_STORE16_UNTRACKED(ptr, v) (*reinterpret_cast<float4*>(ptr) = (v))
 typedef hostemu::tr16_v2u dd_u32x2_t;
@@ -38,6 +39,8 @@ typedef hostemu::tr16_v2u dd_u32x2_t;
 #define DD_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #define DD_WAIT_VM_LGKM0(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
 #define DD_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// nothing is scheduled across this point: keeps a burst of independent loads in front of the first code that waits for one of them
+#define DD_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // A 16-byte global store the compiler does NOT see (inline asm).  hipcc keeps ONE vmcnt for loads and stores; once a store is pending beside
 // loads it can no longer count ("counter out of order") and waits vmcnt(0) for the next load it needs -- which drains every prefetched load
 // of a software pipeline.  Hidden from it, the store only makes its counted waits for loads more conservative (the hardware counter is

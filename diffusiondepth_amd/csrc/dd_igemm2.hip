@@ -304,8 +304,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 
   // ---- kick off every independent load at once: weights of stage 0 (LDS-DMA), the GroupNorm partial sums
   //      of the producing layer, this thread's gamma/beta/embedding entries, the raw patch of chunk 0 ------
+  // Loads only, in the order they are needed, and nothing that waits in between (VMEM returns in issue order: a wait for a late small
+  // load is a wait for every large one in front of it): small table inputs, then the patch, then the accumulators' start values.
   issue_weights(0);
-  if (tid < C::NT * C::SPW) tab_bias[tid] = p.bias[n0 + tid];     // visible after the first barrier below
+  float my_bias = p.bias[n0 + (tid < C::NT * C::SPW ? tid : 0)];     // into tab_bias behind the loads below
+  if constexpr (C::ADD_T) my_bias += p.ttab[tid < HID_C ? tid : 0];        // hoisted Swin form: + the E[t] term of the reference border class
   // hoisted condition term: this thread's entries of the E[t] tap-sum row.  Only the LOADS are issued here (into registers): the LDS
   // image is written behind the GroupNorm butterfly and read in the epilogue, so the timestep -> etab row -> LDS dependency does
   // not sit in front of the partial-sum / patch / accumulator loads (it cost ~4 us of every workgroup: profiles/r02_run3_phase_profile.md)
@@ -327,19 +330,23 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const double* st = p.stats_in + (size_t)b * STAT_SLOTS * STAT_STRIDE + (lane >> 1) * STAT_STRIDE + (lane & 1) * 4;
     sv0 = *reinterpret_cast<const double2*>(st);
     sv1 = *reinterpret_cast<const double2*>(st + 2);
-    if (tid < C::CTAB) {
-      my_gamma = p.gn_gamma[tid];
-      my_beta = p.gn_beta[tid];
+    {
+      // unconditional (clamped) so that no branch ties a wait to the load: threads past CTAB never use what they read
+      const int ct = (C::CTAB > 0 && tid < C::CTAB) ? tid : 0;
+      my_gamma = p.gn_gamma[ct];
+      my_beta = p.gn_beta[ct];
       if constexpr (C::PRO == PRO_GN_ADD) {
         const long long t = (DD_T_KNOWN && p.t_known >= 0) ? p.t_known : clamp_t(p.tvec[p.t_base + b * p.t_bstride]);
-        my_emb = p.emb[(size_t)t * COND_C + tid];
+        my_emb = p.emb[(size_t)t * COND_C + ct];
       }
     }
     if constexpr (C::PRO == PRO_X) { c1 = p.c1c2[2 * (p.step - 1)]; c2 = p.c1c2[2 * (p.step - 1) + 1]; }
   };
   load_norm_inputs();
+  DD_SCHED_FENCE();                         // table inputs first: the butterfly below waits for them and for nothing issued after them
   load_raw(0, 0);
   if constexpr (RD == 2 && C::NCHUNK > 1) load_raw(1, 1);
+  DD_SCHED_FENCE();                         // the patch in front of the accumulators' start values
 
   // per-lane LDS addressing.  Pixel block (wave*WM + m) is tile row (wave*WM + m), lane li is tile column li,
   // so tap (dy,dx) reads patch row (wave*WM + m + dy), patch column (li + dx): everything row-dependent is an
@@ -369,7 +376,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (C::ADD_C) {
+        if constexpr (C::ADD_ACC) {
           // layer 8 stored conv3(cond) in accumulator-fragment order: every load is one contiguous KiB (f16: half a KiB) per wave
           (void)pv;
           const size_t fi = ((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane;
@@ -386,6 +393,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   }
   };
   init_acc();
+  DD_SCHED_FENCE();                         // every load above is in flight before the first wait below
+  if (tid < C::NT * C::SPW) tab_bias[tid] = my_bias;     // visible after the first barrier below
   if (abl & 512) { DD_WAIT_VM(0); if (raw[0][0][0].x == 0x12345678u && sv0.x == 1.5) p.xout[0] = my_gamma; return; }
 
   // ---- GroupNorm affine table: butterfly over the 32 slots inside each wave, then one channel per thread ----
@@ -610,6 +619,11 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   for (int m = 0; m < C::WM; ++m) {
     const int gy = e_y0 + wave * C::WM + m, gx = e_x0 + li;
     const bool pvalid = gy < h && gx < w && !(abl & 16);
+    int trow = -1;                           // ADD_T: this pixel's row of the E[t] border table (-1: the reference class, already in tab_bias)
+    if constexpr (C::ADD_T) {
+      const int rc = swin_tt_class(gy, h), cc = swin_tt_class(gx, w);
+      if (pvalid && (rc != swin_tt_ref(h) || cc != swin_tt_ref(w))) trow = 1 + rc * SWIN_TT_AX + cc;
+    }
     unsigned tapmask = 0x1FFu;               // ADD_C: taps of the 3x3 window that fall inside the image at this pixel
     if constexpr (C::ADD_C) {
       const unsigned ry = (gy >= 1 ? 1u : 0u) | 2u | (gy + 1 < h ? 4u : 0u);
@@ -635,6 +649,12 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
                 bv.x -= ev.x; bv.y -= ev.y; bv.z -= ev.z; bv.w -= ev.w;
               }
             }
+          }
+        }
+        if constexpr (C::ADD_T) {
+          if (trow >= 0) {
+            const float4 dv = *reinterpret_cast<const float4*>(p.ttab + trow * HID_C + n * 32 + 8 * q + 4 * g);
+            bv.x += dv.x; bv.y += dv.y; bv.z += dv.z; bv.w += dv.w;
           }
         }
         float v[4];
@@ -816,6 +836,8 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 41: return launch_one2<EK, 41>(p, s);
     case BIG_CONV3C: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3C>(p, s); else return hipErrorInvalidValue;
     case BIG_CONV3H: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3H>(p, s); else return hipErrorInvalidValue;
+    case SWIN_CONVA_H: return launch_one2<EK, SWIN_CONVA_H>(p, s);
+    case SWIN_PRED_H: return launch_one2<EK, SWIN_PRED_H>(p, s);
     case 54: return launch_one2<EK, 54>(p, s);
     case 55: return launch_one2<EK, 55>(p, s);
     case 56: return launch_one2<EK, 56>(p, s);
@@ -843,6 +865,8 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     case 9: return launch_one2<EK_BF16M, 9>(p, s);
     case BIG_CONV3C: return launch_one2<EK_F16, BIG_CONV3C>(p, s);          // (the once-per-image conv3(cond) is an f16 kernel in this mode)
     case BIG_CONV3H: return launch_one2<EK_BF16M, BIG_CONV3H>(p, s);
+    case SWIN_CONVA_H: return launch_one2<EK_BF16M, SWIN_CONVA_H>(p, s);
+    case SWIN_PRED_H: return launch_one2<EK_BF16M, SWIN_PRED_H>(p, s);
     case 10: return launch_one2<EK_BF16M, 10>(p, s);
     case 15: return launch_one2<EK_BF16M, 15>(p, s);
     case 24: return launch_one2<EK_BF16M, 24>(p, s);
@@ -919,6 +943,8 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 41: return geom2_of<EK, 41>();
     case BIG_CONV3C: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3C>(); else return geom2_of<EK, 8>();      // same packed image as layers 8 / 9, th = 16
     case BIG_CONV3H: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3H>(); else return geom2_of<EK, 9>();
+    case SWIN_CONVA_H: return geom2_of<EK, 5>();          // same packed images as layers 5 / 7
+    case SWIN_PRED_H: return geom2_of<EK, 7>();
     case 54: return geom2_of<EK, 54>();
     case 55: return geom2_of<EK, 55>();
     case 56: return geom2_of<EK, 56>();

@@ -77,7 +77,9 @@ namespace dd {
 template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // kernel ids BIG_CONV3C / BIG_CONV3H (dd_kernels.h) = layers 8 / 9 on 16x32-pixel tiles
   static constexpr bool BIG = LAYER_ID_ == BIG_CONV3C || LAYER_ID_ == BIG_CONV3H;
-  static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : LAYER_ID_ == BIG_CONV3H ? 9 : LAYER_ID_;
+  // kernel ids SWIN_CONVA_H / SWIN_PRED_H (dd_kernels.h) = layers 5 / 7 of the Swin denoiser with the step-invariant terms hoisted
+  static constexpr bool HOIST_A = LAYER_ID_ == SWIN_CONVA_H, ADD_T = LAYER_ID_ == SWIN_PRED_H;
+  static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : LAYER_ID_ == BIG_CONV3H ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
   // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands
   // are instantiated here -- conv2 / conv3 / hoisted conv3 / Swin convA (f16 in, bf16 operands), the producers of f16 tensors in front
   // of them (conv2, conv3, Swin pred.0, the level-0 lateral conv of the condition FPN); the launcher sends every other layer to its
@@ -94,6 +96,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int OUT_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
   static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
   static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 9), "EK_F16S is instantiated for the denoiser's layers only");
+  static_assert(!SPLIT || !(HOIST_A || ADD_T), "the hoisted Swin forms exist in the one-plane kinds only");
   static constexpr int ESZ = ElemSize<EK>::V;
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
   //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256
@@ -149,7 +152,8 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL && !SPLIT) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
-  static constexpr bool CADD16 = DD_CADD_F16 && ESZ == 2 && !SPLIT && (LAYER == 8 || LAYER == 9);   // the hoisted term travels as f16
+  static constexpr bool ADD_ACC = ADD_C || ADD_T;              // accumulators start at the hoisted per-image term (ConvParams::cadd)
+  static constexpr bool CADD16 = DD_CADD_F16 && ESZ == 2 && !SPLIT && (LAYER == 8 || LAYER == 9 || ADD_T);   // the hoisted term travels as f16
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
@@ -158,7 +162,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int THREADS = WAVES * 64;
   static constexpr int WM = (TH * TW) / (32 * WAVES);
   static constexpr int WN = NT / 32;
-  static constexpr int PRO = (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
+  static constexpr int PRO = HOIST_A ? PRO_GN : (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1 || SPLIT) ? 4 : ESZ;
   static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8 || LAYER == 23 || SPLIT) ? 4 : ESZ;
   static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
@@ -191,7 +195,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // prologue (GroupNorm + upsampled condition + embedding on 256 channels, 128 couts per wave) has no registers to spare
   // raw-patch register slots: layers whose prologue reads ONE tensor (no aux term) and has several channel chunks fetch two
   // chunks ahead -- measured on MI355X the global-load latency under load (4-5 us) exceeds one chunk of MFMA work
-  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && !SPLIT && (LAYER == 9 || LAYER == 7 || LAYER == 22 || (LAYER == 6 && SWIN3 && DD_SWIN_RD2)) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
+  static constexpr int RAW_DEPTH = (DD_RAW_DEPTH == 2 && !SPLIT && (LAYER == 9 || LAYER == 7 || LAYER == 22 || ((LAYER == 6 || HOIST_A) && SWIN3 && DD_SWIN_RD2)) && !(C3 == 2 && DD_C3_2_RD1)) ? 2 : 1;
   static constexpr int FRAG_DEPTH = (LAYER == 5 && !SPLIT && !(SWIN3 && DD_SWIN_FD2)) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)

@@ -84,6 +84,9 @@ struct ConvParams {
   // fall inside the image of etab[t][tap][cout]   (conv is linear: conv3(r + cond + E[t]) = conv3(r) + conv3(cond) + conv3(E[t]))
   const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
   const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
+  // Swin denoiser with the step-invariant part of pred.0(convB(convA(.))) hoisted (kernel id SWIN_PRED_H): this step's rows of the
+  // time-embedding table [SWIN_TT_ROWS][64] fp32 -- row 0 is added to every pixel, row 1 + 7 r + c to the pixels of border class (r, c)
+  const float* ttab;
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
   // HAHI neck layers (30..41): the input / output tensor is a channel range of a wider channel-blocked buffer (the concatenation the
   // fusion conv reads): buffer width and first channel, both multiples of 32; 0 = the tensor is the whole buffer (every other layer)
@@ -104,6 +107,20 @@ struct ConvParams {
 // weight stream per pixel -- chosen per launch when there are more 8x32 tiles than resident workgroup slots (the two must agree: layer 8
 // leaves its result in the accumulator-fragment order of layer 9's tiles).  Same packed weights as layers 8 / 9.
 constexpr int BIG_CONV3C = 48, BIG_CONV3H = 49;
+// Swin / MPViT denoiser, forward-only plans: upsample_fuse (convA, convB: no norm, no activation) and pred.0 are ONE linear map of
+// s = up(feat) + E[t] + NE(x_t) (reference ...swin_addHAHI.py:321-333,378-380), so
+//   pred.0(convB(convA(s))) = W3*WB*WA*NE(x_t)  +  [W3*(WB*(WA*up(feat) + a) + b)]  +  W3*WB*WA*(E[t] on every pixel)  + b3
+// with every convolution zero-padding its own input as the reference's does.  The bracket is computed ONCE per image (layer 6 kernel on
+// convA's and convB's weights, then layer 8: accumulator-fragment order, as the Res variant's hoisted conv3(cond)); the E[t] term is constant
+// over the image except within three pixels of its border: a table per loop step with one row per border class (swin_ttab, dd_misc.hip).
+//   SWIN_CONVA_H = convA on relu(gn2(y2)) alone (layer 5 without the condition / embedding addends, no bias)
+//   SWIN_PRED_H  = pred.0 (layer 7) whose accumulators start at the hoisted term and whose epilogue adds the table rows
+constexpr int SWIN_CONVA_H = 50, SWIN_PRED_H = 52;
+// border classes of the E[t] term along one axis of n pixels: position y < 3 -> y, y >= n - 3 -> R - (n - y), else 3, with R = min(n, 7):
+// the value at a pixel depends only on its distances (capped at 3) to the two borders, i.e. equals the value at pixel class(y) of an R-pixel axis
+constexpr int SWIN_TT_AX = 7, SWIN_TT_ROWS = 1 + SWIN_TT_AX * SWIN_TT_AX;
+__host__ __device__ inline int swin_tt_class(int y, int n) { const int R = n < SWIN_TT_AX ? n : SWIN_TT_AX; return y < 3 ? y : (y >= n - 3 ? R - (n - y) : 3); }
+__host__ __device__ inline int swin_tt_ref(int n) { return n - 1 < 3 ? n - 1 : 3; }     // the class whose value row 0 carries
 // workgroups of a persistent launch (dd_thin.hip): B x n with n workgroups per image, at most `slots` in all
 inline int persist_grid(int B, int tiles_per_img, int slots) {
   int n = slots / (B > 0 ? B : 1);
@@ -143,6 +160,10 @@ hipError_t launch_final(const float* x, const float* y4, const double* stats, co
                         const float* c1c2, int step, int mode, float* out_nchw, int B, int h, int w, hipStream_t s);
 // etab[t][tap][co] = sum_c w3[co][c][tap] * emb[t][c] (tap < 9), etab[t][9][co] = sum over taps; w3 = pred.0 weight OIHW (64,256,3,3)
 hipError_t launch_etab(const float* w3_oihw, const float* emb, float* etab, hipStream_t s);
+// Swin hoist: ttab[k][..][64] for the T loop steps (timesteps ts[k]) of an h x w image from the fp32 OIHW weights of convA, convB, pred.0 and the
+// embedding table; scratch: T * R_h * R_w * 576 floats (R = min(n, 7))
+hipError_t launch_swin_ttab(const float* wa_oihw, const float* wb_oihw, const float* w3_oihw, const float* emb, const long long* ts, int T,
+                            int h, int w, float* scratch, float* ttab, hipStream_t s);
 hipError_t launch_add_noise(const float* x0, const float* noise, const long long* t, const float* acp, int n_train,
                             float* out, int B, long long per_sample, hipStream_t s);
 struct CodecWeights {   // device pointers, BatchNorm already folded (eval mode)

@@ -455,6 +455,55 @@ hipError_t launch_etab(const float* w3_oihw, const float* emb, float* etab, hipS
 }
 
 // ------------------------------------------------------------------------------------------------
+// Swin denoiser, hoisted form (dd_kernels.h: SWIN_CONVA_H / SWIN_PRED_H): the time-embedding term pred.0(convB(convA(E[t] on every pixel)))
+// without biases.  Every convolution zero-pads its own input, so the term is constant over the image except within three pixels of the
+// border, where it depends on the pixel's distances to the borders only: it is evaluated on an R_h x R_w image (R = min(n, 7)), whose
+// pixels are the border classes (swin_tt_class), once per plan and parameter generation.  fp64 accumulation, fp32 between the stages.
+// ------------------------------------------------------------------------------------------------
+// out[k][r][c][co] = sum over the taps inside the R_h x R_w image, sum_ci w[co][ci][tap] * in[k][r+dy][c+dx][ci];  in == NULL: emb[ts[k]][ci]
+__global__ void __launch_bounds__(256) swin_tt_conv_kernel(const float* __restrict__ in, const float* __restrict__ emb, const long long* __restrict__ ts,
+                                                           const float* __restrict__ wt, float* __restrict__ out, int RH, int RW, int cin, int cout) {
+  const int pix = blockIdx.x % (RH * RW), k = blockIdx.x / (RH * RW);
+  const int r = pix / RW, c = pix - r * RW, co = threadIdx.x;
+  if (co >= cout) return;
+  double acc = 0.0;
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = r + ky - 1;
+    if (iy < 0 || iy >= RH) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = c + kx - 1;
+      if (ix < 0 || ix >= RW) continue;
+      const float* ip = in ? in + (((size_t)k * RH + iy) * RW + ix) * cin : emb + (size_t)clamp_t(ts[k]) * COND_C;
+      const float* wp = wt + (size_t)co * cin * 9 + ky * 3 + kx;
+      for (int ci = 0; ci < cin; ++ci) acc += (double)wp[(size_t)ci * 9] * (double)ip[ci];
+    }
+  }
+  out[((size_t)blockIdx.x) * cout + co] = (float)acc;
+}
+// ttab[k][0][co] = value of the reference class, ttab[k][1 + 7 r + c][co] = value of class (r, c) minus it (rows of classes the image does not have: 0)
+__global__ void __launch_bounds__(64) swin_tt_final_kernel(const float* __restrict__ timg, float* __restrict__ ttab, int RH, int RW) {
+  const int k = blockIdx.x, co = threadIdx.x;
+  const float* ti = timg + (size_t)k * RH * RW * HID_C;
+  float* tt = ttab + (size_t)k * SWIN_TT_ROWS * HID_C;
+  const float ref = ti[((size_t)swin_tt_ref(RH) * RW + swin_tt_ref(RW)) * HID_C + co];
+  tt[co] = ref;
+  for (int r = 0; r < SWIN_TT_AX; ++r)
+    for (int c = 0; c < SWIN_TT_AX; ++c)
+      tt[(size_t)(1 + r * SWIN_TT_AX + c) * HID_C + co] = (r < RH && c < RW) ? ti[((size_t)r * RW + c) * HID_C + co] - ref : 0.f;
+}
+hipError_t launch_swin_ttab(const float* wa_oihw, const float* wb_oihw, const float* w3_oihw, const float* emb, const long long* ts, int T,
+                            int h, int w, float* scratch, float* ttab, hipStream_t s) {
+  const int RH = h < SWIN_TT_AX ? h : SWIN_TT_AX, RW = w < SWIN_TT_AX ? w : SWIN_TT_AX;
+  const size_t npix = (size_t)T * RH * RW;
+  float *a_img = scratch, *b_img = a_img + npix * COND_C, *t_img = b_img + npix * COND_C;
+  hipLaunchKernelGGL(swin_tt_conv_kernel, dim3((unsigned)npix), dim3(COND_C), 0, s, (const float*)nullptr, emb, ts, wa_oihw, a_img, RH, RW, COND_C, COND_C);
+  hipLaunchKernelGGL(swin_tt_conv_kernel, dim3((unsigned)npix), dim3(COND_C), 0, s, (const float*)a_img, emb, ts, wb_oihw, b_img, RH, RW, COND_C, COND_C);
+  hipLaunchKernelGGL(swin_tt_conv_kernel, dim3((unsigned)npix), dim3(COND_C), 0, s, (const float*)b_img, emb, ts, w3_oihw, t_img, RH, RW, COND_C, HID_C);
+  hipLaunchKernelGGL(swin_tt_final_kernel, dim3((unsigned)T), dim3(HID_C), 0, s, (const float*)t_img, ttab, RH, RW);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // q_sample (reference scheduling_ddim.py:355-376): out = sqrt(abar_t)*x0 + sqrt(1-abar_t)*noise
 // ------------------------------------------------------------------------------------------------
 __global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,

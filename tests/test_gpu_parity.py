@@ -356,12 +356,13 @@ def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):
     if prec in ABS_PREC:
         assert de < 1e-3
     # depth gates of the Swin denoiser: f16 is its inference mode inside the tolerance (BASELINE config 5 names fp16); bf16, with two more
-    # 256 -> 256 convolutions on bf16 operands per step, is NOT (2.6e-3 here, 3.4e-3 at KITTI size: DESIGN.md section 4) -- it is the
-    # training precision, bounded here so that it cannot drift unnoticed
+    # 256 -> 256 convolutions on bf16 operands per step, is NOT -- 1.4e-3 here, 1.6e-3 at KITTI size with the step-invariant terms hoisted
+    # out of those operands (round 3; 2.6e-3 / 3.4e-3 before: DESIGN.md section 4) -- it is the training precision, bounded at twice the
+    # measured value so that it cannot drift unnoticed
     if prec == "f16":
         assert U.rms(depth, dref) <= DEPTH_RMSE_TOL
     if prec == "bf16":
-        assert U.rms(depth, dref) <= 1e-2
+        assert U.rms(depth, dref) <= 3e-3
 
 
 def test_swin_variant_odd_sizes_vs_oracle(U):
@@ -378,6 +379,38 @@ def test_swin_variant_odd_sizes_vs_oracle(U):
         e = U.maxabs(x0, ref)
         U.record("swin_ragged", B=B, h=h, w=w, ch=ch, cw=cw, latent_maxabs=e, latent_scale=scale)
         assert e < LATENT_TOL["fp32"] * scale, (B, h, w, e, scale)
+
+
+def test_swin_with_and_without_hoisting_the_step_invariant_terms(U, golden, cases):
+    """Swin forward-only plans take the condition map and the time embedding through pred.0(convB(convA(.))) outside the loop (kernel ids
+    SWIN_CONVA_H / SWIN_PRED_H; default in the 2-byte modes, option hoist_cond = 1 also in fp32).  Both forms against the reference's golden
+    loop and, on ragged sizes whose borders exercise every class of the E[t] table (an axis shorter than seven pixels included), the oracle."""
+    from oracle import ddim_oracle as O
+    c2, g2 = cases["loop_swin"], golden("loop_swin")
+    be = U.backend_for(c2)
+    sd = U.sd_for(c2)
+    inp = synth.make_inputs(c2["iseed"], c2["B"], c2["h"], c2["w"], c2["cond_hw"])
+    ref, dref = g2["x0_T20"], g2["depth_T20"]
+    scale = float(np.abs(ref).max())
+    rag = [(2, 5, 40, 3, 9, 3), (1, 13, 6, 5, 3, 2)]
+    rag_in = [synth.make_inputs(400 + h, B, h, w, (ch, cw)) for (B, h, w, ch, cw, T) in rag]
+    rag_ref = [O.ddim_loop(sd, i["x_T"], i["cond"], r[5], "swin") for i, r in zip(rag_in, rag)]
+    try:
+        for hoist in (0, 1):
+            be.set_option("hoist_cond", hoist)
+            for prec in ("fp32", "bf16", "f16"):
+                x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), 20, prec)
+                depth = be.decode(x0).cpu().numpy()
+                e = U.maxabs(x0.cpu().numpy(), ref)
+                er = []
+                for i, r, rr in zip(rag_in, rag, rag_ref):
+                    xr = be.denoise(U.cu(i["x_T"]), U.cu(i["cond"]), r[5], prec).cpu().numpy()
+                    er.append(U.maxabs(xr, rr) / float(np.abs(rr).max()))
+                U.record("swin_hoist_ab", hoist=hoist, prec=prec, latent_maxabs=e, latent_scale=scale, depth_rmse=U.rms(depth, dref),
+                         depth_maxabs=U.maxabs(depth, dref), ragged_rel=er)
+                assert e < LATENT_TOL[prec] * scale and max(er) < LATENT_TOL[prec], (hoist, prec, e, scale, er)
+    finally:
+        be.set_option("hoist_cond", -1)
 
 
 def test_conv3_without_hoisting_the_condition_term(U, golden, cases):

@@ -245,6 +245,27 @@ def test_swin_loop_vs_oracle(lib, late, prec):
     assert maxabs(x0, ref) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("h,w,T", [(5, 17, 2)] + ([(8, 9, 1), (3, 4, 1)] if FULL else []))
+def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
+    """Forward-only Swin plans (kernel ids SWIN_CONVA_H / SWIN_PRED_H, dd_kernels.h): pred.0(convB(convA(.))) is linear in its input, so the
+    condition map's part runs once per image and the time embedding's part is a table with one row per border class (three pixels deep: every
+    convolution zero-pads its own input).  fp32 with the hoist forced on: the decomposition itself, at fp32 rounding, against the oracle and
+    against the reference's order of operations (hoist off) -- on images smaller than seven pixels along an axis (every row / column its own
+    class) and larger (interior class); f16: the default there."""
+    be, inp, ref, _ = _loop_case(lib, "swin", cond_hw=(3, 5), h=h, w=w, T=T)
+    be.set_option("hoist_cond", 0)
+    plain = be.denoise(inp["x_T"], inp["cond"], T, "fp32")
+    be.set_option("hoist_cond", 1)
+    hoisted = be.denoise(inp["x_T"], inp["cond"], T, "fp32")
+    be.set_option("hoist_cond", -1)
+    scale = max(np.abs(ref).max(), 1.0)
+    assert maxabs(plain, ref) < LATENT_TOL["fp32"] * scale and maxabs(hoisted, ref) < LATENT_TOL["fp32"] * scale
+    assert not np.array_equal(plain, hoisted)                 # (two different orders of summation did run)
+    be.timing(order=1, dma_late=1)
+    x16 = be.denoise(inp["x_T"], inp["cond"], T, "f16")       # hoisted by default
+    assert maxabs(x16, ref) < LATENT_TOL["f16"] * scale
+
+
 @full_only
 def test_swin_single_call_vs_reference_golden(lib, golden, cases):
     c, g = cases["denoise_swin"], golden("denoise_swin")
