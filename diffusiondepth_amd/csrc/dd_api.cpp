@@ -126,6 +126,7 @@ struct Plan {
   bool traj_consumed = false;      // a dd_denoise_backward has read this trajectory: the plan may be dropped when the activation budget is needed
   DevBuf gA, gY;           // backward scratch: gradient w.r.t. a layer's activation / conv output (fp32, up to 256 channels)
   DevBuf dgb;              // backward: per (sample, channel) sums, [B][C][2] (generic kernels) or [B][C][4] (blocked kernels) doubles
+  DevBuf bcorr;              // Swin variant, hoisted 5x5 form: this step's border correction [B][swin_ring_size][64] fp32 (swin_bcorr)
   DevBuf ttab, tt_scratch;   // Swin variant, hoisted form: E[t] border tables of the T loop steps [T][SWIN_TT_ROWS][64] (swin_ttab, dd_misc.hip) ...
   int64_t ttab_weights = -1; // ... and the parameter generation they were computed from
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
@@ -195,6 +196,11 @@ struct dd_handle_s {
   ConvLayer LA, LB;            // Swin variant: upsample_fuse.convA / convB (256->256, no norm)
   DevBuf emb;
   DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
+  // Swin variant, hoisted 5x5 form (SWIN_PRED5_H, dd_kernels.h): pred.0 o convB as one kernel (fp32 OIHW and the packed images of the one-plane
+  // kinds), the tap-pair products of the border correction; built by the first hoisted plan that runs after a parameter update
+  DevBuf w5_oihw, w5pack[NUM_EK], pairp, kside;
+  int64_t w5_weights = -1;
+  int swin_w5 = 1;           // option "swin_w5": 1 = the 5x5 form, 0 = convB and pred.0 as two kernels (SWIN_PRED_H)
   DevBuf zero_bias;          // 256 zeros
   int hoist_cond = -1;       // Res variant: conv3(cond) once per image (f16 in the bf16 mode) instead of re-adding cond in conv3's prologue every
                              // step.  -1 = automatic: on in the default bf16 mode (EK_BF16M), where it carries precision (the condition
@@ -532,6 +538,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
     const int RH = key.h < SWIN_TT_AX ? key.h : SWIN_TT_AX, RW = key.w < SWIN_TT_AX ? key.w : SWIN_TT_AX;
     DD_HIP(pl->ttab.alloc((size_t)T1 * SWIN_TT_ROWS * HID_C * 4));
     DD_HIP(pl->tt_scratch.alloc((size_t)T1 * RH * RW * (2 * COND_C + HID_C) * 4));
+    if (h->swin_w5) DD_HIP(pl->bcorr.alloc((size_t)key.B * swin_ring_size(key.h, key.w) * HID_C * 4));
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
@@ -632,13 +639,21 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     p.stats_out = nullptr; p.stats_in = pl->stat_ptr(step, 1);
     p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
     DD_HIP(timed_launch(5, p, SWIN_CONVA_H));
-    p.in = sa_; p.wpack = h->LB.wpack2[wk].p; p.out = sf_;
     p.stats_in = nullptr;
-    DD_HIP(timed_launch(6, p));
-    p.in = sf_; p.wpack = h->L[2].wpack2[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
-    p.stats_out = pl->stat_ptr(step, 2);
     p.cadd = pl->ccond.as<float>(); p.ttab = pl->ttab.as<float>() + (size_t)step * SWIN_TT_ROWS * HID_C;
-    DD_HIP(timed_launch(7, p, SWIN_PRED_H));
+    if (pl->bcorr.p) {
+      // pred.0 o convB as one 5x5 convolution on convA's result; the border ring's correction first
+      DD_HIP(launch_swin_bcorr(sa_, opnd_kind(ek), h->pairp.as<float>(), h->kside.p, pl->bcorr.as<float>(), k.B, k.h, k.w, s));
+      p.in = sa_; p.wpack = h->w5pack[opnd_kind(ek)].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
+      p.stats_out = pl->stat_ptr(step, 2); p.bcorr = pl->bcorr.as<float>();
+      DD_HIP(timed_launch(7, p, SWIN_PRED5_H));
+    } else {
+      p.in = sa_; p.wpack = h->LB.wpack2[wk].p; p.out = sf_;
+      DD_HIP(timed_launch(6, p));
+      p.in = sf_; p.wpack = h->L[2].wpack2[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
+      p.stats_out = pl->stat_ptr(step, 2);
+      DD_HIP(timed_launch(7, p, SWIN_PRED_H));
+    }
   } else if (h->variant == DD_VARIANT_SWIN) {
     // upsample_fuse: convB(convA(relu(gn2(y2)) + up(cond) + E[t]))  then pred.0 on the raw result
     p.in = y2_; p.wpack = h->LA.wpack2[wk].p; p.bias = h->LA.bias.as<float>(); p.out = sa_;
@@ -710,6 +725,8 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   return DD_OK;
 }
 
+int ensure_bytes(dd_handle_t h, DevBuf& dst, size_t bytes);
+
 // Swin variant, hoisted form: the per-image term pred.0(convB(convA(up(feat)) + a) + b) without pred.0's bias, left in the accumulator-fragment
 // order of pred.0's tiles (layer 8), and -- once per plan and parameter generation -- the E[t] tables of the loop's steps.  The upsampled
 // condition map is in the plan's buffer; Plan::sa / sf are free until the loop starts.
@@ -720,6 +737,19 @@ int enqueue_swin_hoist(dd_handle_t h, Plan* pl, hipStream_t s) {
     DD_HIP(launch_swin_ttab(h->LA.w_oihw.as<float>(), h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->emb.as<float>(),
                             pl->tsteps.as<long long>(), k.T, k.h, k.w, pl->tt_scratch.as<float>(), pl->ttab.as<float>(), s));
     pl->ttab_weights = h->weights_serial;
+  }
+  if (pl->bcorr.p && h->w5_weights != h->weights_serial) {
+    // pred.0 o convB of this parameter generation: fp32 composition, then the packed images of the one-plane kinds
+    if (!h->w5_oihw.p) {
+      DD_HIP(h->w5_oihw.alloc((size_t)HID_C * COND_C * 25 * 4)); DD_HIP(h->pairp.alloc((size_t)81 * COND_C * HID_C * 4)); DD_HIP(h->kside.alloc(SWIN_KSIDE_BYTES));
+    }
+    DD_HIP(launch_swin_compose(h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->w5_oihw.as<float>(), h->pairp.as<float>(), h->kside.p, s));
+    for (int ekk = 0; ekk < NUM_EK; ++ekk) {
+      const PackGeom g5 = conv_pack_geom2(SWIN_PRED5_H, ekk);
+      int rc = ensure_bytes(h, h->w5pack[ekk], pack_weights_bytes(g5, ekk)); if (rc) return rc;
+      DD_HIP(launch_pack_weights(h->w5_oihw.as<float>(), h->w5pack[ekk].p, g5, ekk, true, false, s));
+    }
+    h->w5_weights = h->weights_serial;
   }
   const int tk = thin_kind(pl->ek);           // once per image: f16 kernels in the bf16 mode, as the Res variant's conv3(cond)
   ConvParams p{};
@@ -986,7 +1016,9 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s) {
     for (int i = 0; i < 2; ++i) {
       ConvLayer& L = *Ls[i];
       L.cin = COND_C; L.cout = COND_C;
-      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, true, s); if (rc) return rc;      // (fp32 OIHW copy: the hoisted form's E[t] tables)
+      int rc = pack_conv_layer_device(h, L, D(std::string(names[i]) + ".weight"), 5 + i, 6, false, s); if (rc) return rc;
+      rc = ensure_bytes(h, L.w_oihw, (size_t)COND_C * COND_C * 9 * 4); if (rc) return rc;      // fp32 OIHW: the hoisted form's E[t] tables / 5x5 composition
+      DD_HIP(hipMemcpyAsync(L.w_oihw.p, D(std::string(names[i]) + ".weight"), (size_t)COND_C * COND_C * 9 * 4, hipMemcpyDeviceToDevice, s));
       rc = copy_small(L.bias, std::string(names[i]) + ".bias", 0); if (rc) return rc;
     }
   }
@@ -1300,6 +1332,11 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
       h->last_once_plan = nullptr;
     }
     h->ablate = (int)value;
+  }
+  else if (k == "swin_w5") {
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: swin_w5 must be 0 or 1");
+    if (h->swin_w5 != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // buffers and graphs are laid out for it
+    h->swin_w5 = (int)value;
   }
   else if (k == "hoist_cond") {
     if (value < -1 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: hoist_cond must be -1 (automatic), 0 or 1");

@@ -352,9 +352,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // so tap (dy,dx) reads patch row (wave*WM + m + dy), patch column (li + dx): everything row-dependent is an
   // immediate or a wave-uniform scalar; only the column term (3 variants of dx) lives in VGPRs.
   const int g16 = g << 4;
-  int colt[3][NKQ];
+  constexpr int NDX = C::KS == 5 ? 5 : 3;
+  int colt[NDX][NKQ];
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx)
+  for (int dx = 0; dx < NDX; ++dx)
 #pragma unroll
     for (int kq = 0; kq < NKQ; ++kq)
       colt[dx][kq] = wave * (C::WM * PW * ROWB) + (li + dx) * ROWB + (((kq << 5) | g16) ^ swz16<RPB, PPP>(li + dx));
@@ -465,8 +466,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       uint4 fr[FD][NF];
       auto load_group = [&](int gi, uint4 (&f)[NF]) {
         const int t = gi / NKQ, kq = gi % NKQ;
-        const int dy = (C::KS == 1) ? 0 : (C::TG == 9) ? t / 3 : (C::TG == 3) ? tg : tg / 3;
-        const int dx = (C::KS == 1) ? 0 : (C::TG == 9) ? t % 3 : (C::TG == 3) ? t : tg % 3;
+        const int dy = (C::KS == 1) ? 0 : (C::TG == 9) ? t / 3 : (C::TG == 3 || C::TG == 5) ? tg : tg / 3;      // (5x5: one kernel row per stage)
+        const int dx = (C::KS == 1) ? 0 : (C::TG == 9) ? t % 3 : (C::TG == 3 || C::TG == 5) ? t : tg % 3;
         const int pa = colt[dx][kq] + poff + dy * (PW * ROWB);
 #pragma unroll
         for (int m = 0; m < C::WM; ++m) f[m] = *reinterpret_cast<const uint4*>(smem + pa + m * (PW * ROWB));
@@ -656,6 +657,13 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             const float4 dv = *reinterpret_cast<const float4*>(p.ttab + trow * HID_C + n * 32 + 8 * q + 4 * g);
             bv.x += dv.x; bv.y += dv.y; bv.z += dv.z; bv.w += dv.w;
           }
+          if constexpr (C::PRED5) {
+            // pixels on the image border: take out what the 5x5 form summed through pred.0 taps that leave the image (swin_bcorr)
+            if (pvalid && (gy == 0 || gy == h - 1 || gx == 0 || gx == w - 1)) {
+              const float4 cv = *reinterpret_cast<const float4*>(p.bcorr + ((size_t)e_b * swin_ring_size(h, w) + swin_ring_index(gy, gx, h, w)) * HID_C + n * 32 + 8 * q + 4 * g);
+              bv.x -= cv.x; bv.y -= cv.y; bv.z -= cv.z; bv.w -= cv.w;
+            }
+          }
         }
         float v[4];
         if constexpr (C::SPLIT) {      // accumulators carry the operands' scales: one exact power-of-two multiply, fused with the bias add
@@ -838,6 +846,7 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case BIG_CONV3H: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3H>(p, s); else return hipErrorInvalidValue;
     case SWIN_CONVA_H: return launch_one2<EK, SWIN_CONVA_H>(p, s);
     case SWIN_PRED_H: return launch_one2<EK, SWIN_PRED_H>(p, s);
+    case SWIN_PRED5_H: return launch_one2<EK, SWIN_PRED5_H>(p, s);
     case 54: return launch_one2<EK, 54>(p, s);
     case 55: return launch_one2<EK, 55>(p, s);
     case 56: return launch_one2<EK, 56>(p, s);
@@ -867,6 +876,7 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     case BIG_CONV3H: return launch_one2<EK_BF16M, BIG_CONV3H>(p, s);
     case SWIN_CONVA_H: return launch_one2<EK_BF16M, SWIN_CONVA_H>(p, s);
     case SWIN_PRED_H: return launch_one2<EK_BF16M, SWIN_PRED_H>(p, s);
+    case SWIN_PRED5_H: return launch_one2<EK_BF16M, SWIN_PRED5_H>(p, s);
     case 10: return launch_one2<EK_BF16M, 10>(p, s);
     case 15: return launch_one2<EK_BF16M, 15>(p, s);
     case 24: return launch_one2<EK_BF16M, 24>(p, s);
@@ -945,6 +955,7 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case BIG_CONV3H: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3H>(); else return geom2_of<EK, 9>();
     case SWIN_CONVA_H: return geom2_of<EK, 5>();          // same packed images as layers 5 / 7
     case SWIN_PRED_H: return geom2_of<EK, 7>();
+    case SWIN_PRED5_H: return geom2_of<EK, SWIN_PRED5_H>();
     case 54: return geom2_of<EK, 54>();
     case 55: return geom2_of<EK, 55>();
     case 56: return geom2_of<EK, 56>();

@@ -78,7 +78,9 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // kernel ids BIG_CONV3C / BIG_CONV3H (dd_kernels.h) = layers 8 / 9 on 16x32-pixel tiles
   static constexpr bool BIG = LAYER_ID_ == BIG_CONV3C || LAYER_ID_ == BIG_CONV3H;
   // kernel ids SWIN_CONVA_H / SWIN_PRED_H (dd_kernels.h) = layers 5 / 7 of the Swin denoiser with the step-invariant terms hoisted
-  static constexpr bool HOIST_A = LAYER_ID_ == SWIN_CONVA_H, ADD_T = LAYER_ID_ == SWIN_PRED_H;
+  // SWIN_PRED5_H = pred.0 o convB as one 5x5 convolution (layer 7's tiling with five taps per stage)
+  static constexpr bool PRED5 = LAYER_ID_ == SWIN_PRED5_H;
+  static constexpr bool HOIST_A = LAYER_ID_ == SWIN_CONVA_H, ADD_T = LAYER_ID_ == SWIN_PRED_H || PRED5;
   static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : LAYER_ID_ == BIG_CONV3H ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
   // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands
   // are instantiated here -- conv2 / conv3 / hoisted conv3 / Swin convA (f16 in, bf16 operands), the producers of f16 tensors in front
@@ -130,7 +132,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr bool IS_LAT = (LAYER >= 10 && LAYER <= 13) || (LAYER >= 15 && LAYER <= 18) || (LAYER >= 24 && LAYER <= 26);
   static constexpr bool IS_DGRAD = (LAYER >= 20 && LAYER <= 23);
   static constexpr bool IS_UP = (LAYER == 14);
-  static constexpr int KS = (IS_UP || (IS_NECK && NECK_KIND != 2)) ? 1 : 3;      // kernel size
+  static constexpr int KS = PRED5 ? 5 : (IS_UP || (IS_NECK && NECK_KIND != 2)) ? 1 : 3;      // kernel size
   static constexpr int HALO = KS / 2;
   static constexpr int NTAPS = KS * KS;
   static constexpr int CIN = IS_NECK ? (NECK_KIND == 2 ? NECK_C + 512 : NECK_C) : (LAYER == 1 || LAYER == 20) ? LATENT_C : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? HID_C : IS_LAT ? (LAYER >= 24 ? (LAYER == 24 ? 128 : LAYER == 25 ? 224 : 288) : LAYER >= 15 ? (192 << ((LAYER - 15) & 3)) : (64 << ((LAYER - 10) & 3))) : COND_C;
@@ -146,7 +148,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2 && !SPLIT;
   static constexpr bool C4K16 = DD_C4_CK16 && LAYER == 4 && ESZ == 2 && !SPLIT;
   static constexpr int CK = (SPLIT || C4K16) ? 16 : (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0 || SWIN3) ? 16 : (64 / ESZ);
-  static constexpr int TG = SPLIT ? (LAYER == 1 ? 9 : 3) : (LAYER == 1 || LAYER == 20 || C3 != 0 || C4K16) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
+  static constexpr int TG = PRED5 ? 5 : SPLIT ? (LAYER == 1 ? 9 : 3) : (LAYER == 1 || LAYER == 20 || C3 != 0 || C4K16) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
                           : SWIN3 ? 3 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = (IS_NECK || (SPLIT && COUT >= 64)) ? 64 : (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL && !SPLIT) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)
@@ -206,7 +208,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static_assert(ROWB == 32 || ROWB == 64 || ROWB == 128, "swizzle derivation");
   static_assert(TW == 32, "one 32-pixel MFMA block == one tile row (column-only swizzle, lane == column)");
   static_assert(THREADS % PPP == 0 && NIT <= 32, "per-thread piece index is constant; masks fit 32 bits");
-  static_assert(TG == 1 || TG == 3 || TG == 9, "tap decomposition");
+  static_assert(TG == 1 || TG == 3 || TG == 9 || (TG == 5 && KS == 5), "tap decomposition");
 };
 
 // LDS swizzle: 16-B piece j of a row is stored at j ^ swz(k), k = the row's COLUMN index in the patch

@@ -87,6 +87,7 @@ struct ConvParams {
   // Swin denoiser with the step-invariant part of pred.0(convB(convA(.))) hoisted (kernel id SWIN_PRED_H): this step's rows of the
   // time-embedding table [SWIN_TT_ROWS][64] fp32 -- row 0 is added to every pixel, row 1 + 7 r + c to the pixels of border class (r, c)
   const float* ttab;
+  const float* bcorr;       // SWIN_PRED5_H: [B][swin_ring_size][64] fp32, subtracted at the pixels on the image border
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
   // HAHI neck layers (30..41): the input / output tensor is a channel range of a wider channel-blocked buffer (the concatenation the
   // fusion conv reads): buffer width and first channel, both multiples of 32; 0 = the tensor is the whole buffer (every other layer)
@@ -116,6 +117,17 @@ constexpr int BIG_CONV3C = 48, BIG_CONV3H = 49;
 //   SWIN_CONVA_H = convA on relu(gn2(y2)) alone (layer 5 without the condition / embedding addends, no bias)
 //   SWIN_PRED_H  = pred.0 (layer 7) whose accumulators start at the hoisted term and whose epilogue adds the table rows
 constexpr int SWIN_CONVA_H = 50, SWIN_PRED_H = 52;
+//   SWIN_PRED5_H = pred.0 and convB as ONE 5x5 convolution 256 -> 64 on convA's result (W5[u] = sum over e + d = u of W3[e] . WB[d], built per
+//   parameter generation by swin_compose, dd_misc.hip): 0.82 instead of 1.47 MFLOP per pixel and step and no convB result in HBM.  The 5x5
+//   form also sums, at the pixels ON the image border, the terms W3[e] . convB(.)(q + e) for taps e that leave the image -- which the
+//   reference's pred.0 zero-pads away; they are computed per step from the border rows / columns of convA's result (swin_bcorr: ring
+//   buffer ConvParams::bcorr) and subtracted in the epilogue.  Accumulator start values and E[t] rows as SWIN_PRED_H.
+constexpr int SWIN_PRED5_H = 53;
+// ring buffer of the border pixels of an h x w image: top row, bottom row, left column, right column (without the corners)
+__host__ __device__ inline int swin_ring_size(int h, int w) { return 2 * w + 2 * (h > 2 ? h - 2 : 0); }
+__host__ __device__ inline int swin_ring_index(int y, int x, int h, int w) {
+  return y == 0 ? x : (y == h - 1 ? w + x : (x == 0 ? 2 * w + (y - 1) : 2 * w + (h - 2) + (y - 1)));
+}
 // border classes of the E[t] term along one axis of n pixels: position y < 3 -> y, y >= n - 3 -> R - (n - y), else 3, with R = min(n, 7):
 // the value at a pixel depends only on its distances (capped at 3) to the two borders, i.e. equals the value at pixel class(y) of an R-pixel axis
 constexpr int SWIN_TT_AX = 7, SWIN_TT_ROWS = 1 + SWIN_TT_AX * SWIN_TT_AX;
@@ -164,6 +176,13 @@ hipError_t launch_etab(const float* w3_oihw, const float* emb, float* etab, hipS
 // embedding table; scratch: T * R_h * R_w * 576 floats (R = min(n, 7))
 hipError_t launch_swin_ttab(const float* wa_oihw, const float* wb_oihw, const float* w3_oihw, const float* emb, const long long* ts, int T,
                             int h, int w, float* scratch, float* ttab, hipStream_t s);
+// Swin hoist, 5x5 form: w5 (64,256,5,5) OIHW fp32 and the tap-pair products pairp[e][d][ci][co] = sum_cm W3[co][cm][e] * WB[cm][ci][d] (81 x 256 x 64)
+// ... and kside: the four 5-tap line kernels of the border correction in MFMA fragment order, bf16 then f16 (SWIN_KSIDE_BYTES; swin_bcorr_line_kernel)
+constexpr size_t SWIN_KSIDE_BYTES = (size_t)2 * 4 * 5 * 16 * 2 * 64 * 8 * 2;
+hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float* w5_oihw, float* pairp, void* kside, hipStream_t s);
+// bcorr[b][ring(q)][co] = sum over taps e with q + e outside the image, taps d with q + e + d inside, ci: pairp[e][d][ci][co] * sa[b][q + e + d][ci]
+// (sa: convA's result in the activation layout, element kind ek)
+hipError_t launch_swin_bcorr(const void* sa, int ek, const float* pairp, const void* kside, float* bcorr, int B, int h, int w, hipStream_t s);
 hipError_t launch_add_noise(const float* x0, const float* noise, const long long* t, const float* acp, int n_train,
                             float* out, int B, long long per_sample, hipStream_t s);
 struct CodecWeights {   // device pointers, BatchNorm already folded (eval mode)

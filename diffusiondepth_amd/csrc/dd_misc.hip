@@ -504,6 +504,202 @@ hipError_t launch_swin_ttab(const float* wa_oihw, const float* wb_oihw, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// Swin hoist, 5x5 form (SWIN_PRED5_H, dd_kernels.h): pred.0(convB(a)) at pixel q = sum over taps e, d of W3[e] . WB[d] . a(q + e + d), taps e
+// restricted to q + e inside the image (pred.0 zero-pads convB's result).  The 5x5 kernel W5[u] = sum over e + d = u of W3[e] . WB[d] sums ALL
+// tap pairs; the difference -- pairs whose e leaves the image, at the pixels on the border -- is the correction of swin_bcorr_kernel.
+// ------------------------------------------------------------------------------------------------
+// w5[co][ci][u] (u = 5 (ey + dy + 2) + (ex + dx + 2)); one thread per output, fp64 accumulation
+__global__ void __launch_bounds__(256) swin_w5_kernel(const float* __restrict__ wb, const float* __restrict__ w3, float* __restrict__ w5) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HID_C * COND_C * 25) return;
+  const int u = i % 25, ci = (i / 25) % COND_C, co = i / (25 * COND_C);
+  const int uy = u / 5 - 2, ux = u % 5 - 2;
+  double acc = 0.0;
+  for (int ey = -1; ey <= 1; ++ey) {
+    const int dy = uy - ey;
+    if (dy < -1 || dy > 1) continue;
+    for (int ex = -1; ex <= 1; ++ex) {
+      const int dx = ux - ex;
+      if (dx < -1 || dx > 1) continue;
+      const float* a = w3 + (size_t)co * COND_C * 9 + (ey + 1) * 3 + (ex + 1);                       // W3[co][cm][e], cm stride 9
+      const float* b = wb + (size_t)ci * 9 + (dy + 1) * 3 + (dx + 1);                                 // WB[cm][ci][d], cm stride 256 * 9
+      for (int cm = 0; cm < COND_C; ++cm) acc += (double)a[(size_t)cm * 9] * (double)b[(size_t)cm * COND_C * 9];
+    }
+  }
+  w5[i] = (float)acc;
+}
+// pairp[e][d][ci][co] = sum_cm W3[co][cm][e] * WB[cm][ci][d]; block = (e, d, ci), thread = co
+__global__ void __launch_bounds__(64) swin_pair_kernel(const float* __restrict__ wb, const float* __restrict__ w3, float* __restrict__ pairp) {
+  const int ci = blockIdx.x % COND_C, ed = blockIdx.x / COND_C, e = ed / 9, d = ed % 9, co = threadIdx.x;
+  const float* a = w3 + (size_t)co * COND_C * 9 + e;
+  const float* b = wb + (size_t)ci * 9 + d;
+  double acc = 0.0;
+  for (int cm = 0; cm < COND_C; ++cm) acc += (double)a[(size_t)cm * 9] * (double)b[(size_t)cm * COND_C * 9];
+  pairp[((size_t)ed * COND_C + ci) * HID_C + co] = (float)acc;
+}
+hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float* w5_oihw, float* pairp, void* kside, hipStream_t s);
+// one block per border pixel (ring index) and image: thread = (cout, quarter of the 256 input channels); the 32 channels of an activation block
+// and their 32 weight rows are loaded as one batch (independent loads in flight together), four partial sums per thread, LDS reduction
+// corners != 0: only the four corner pixels (blockIdx.x = corner), only the taps e that leave the image SIDEWAYS from a row inside it, ADDED to
+// what the line kernel below left there (it covers the taps that leave through the top / bottom row)
+template <int EK>
+__global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict__ sa, const float* __restrict__ pairp, float* __restrict__ bcorr, int h, int w, int corners) {
+  __shared__ float red[4][HID_C];
+  const int b = blockIdx.y, co = threadIdx.x & (HID_C - 1), part = threadIdx.x >> 6;
+  const int r = corners ? swin_ring_index((blockIdx.x >> 1) ? h - 1 : 0, (blockIdx.x & 1) ? w - 1 : 0, h, w) : (int)blockIdx.x;
+  int y, x;      // inverse of swin_ring_index
+  if (r < w) { y = 0; x = r; }
+  else if (r < 2 * w) { y = h - 1; x = r - w; }
+  else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
+  else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (y < h && x < w && swin_ring_index(y, x, h, w) == r) {      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
+    for (int e = 0; e < 9; ++e) {
+      const int py = y + e / 3 - 1, px = x + e % 3 - 1;
+      if (py >= 0 && py < h && px >= 0 && px < w) continue;      // pred.0 tap inside the image: nothing to take out
+      if (corners && (py < 0 || py >= h)) continue;              // (the line kernel's share)
+      for (int d = 0; d < 9; ++d) {
+        const int sy = py + d / 3 - 1, sx = px + d % 3 - 1;
+        if (sy < 0 || sy >= h || sx < 0 || sx >= w) continue;    // convB tap on zero padding
+        const float* pp = pairp + ((size_t)(e * 9 + d) * COND_C) * HID_C + co;
+#pragma unroll
+        for (int k = 0; k < COND_C / ACT_CB / 4; ++k) {
+          const int cb = part * (COND_C / ACT_CB / 4) + k;
+          const size_t off = act_offset(COND_C, h, w, b, cb * ACT_CB, sy, sx);
+          float v[ACT_CB], wv[ACT_CB];
+          if constexpr (EK == EK_F32) {
+#pragma unroll
+            for (int q = 0; q < ACT_CB / 4; ++q) {
+              const float4 t = reinterpret_cast<const float4*>(static_cast<const float*>(sa) + off)[q];
+              v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < ACT_CB / 8; ++q) {
+              const uint4 t = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(sa) + off)[q];
+              const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[8 * q + 2 * i] = EK == EK_BF16 ? bf16_to_f32(u[i] & 0xFFFFu) : f16_to_f32(u[i] & 0xFFFFu);
+                v[8 * q + 2 * i + 1] = EK == EK_BF16 ? bf16_to_f32(u[i] >> 16) : f16_to_f32(u[i] >> 16);
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < ACT_CB; ++c) wv[c] = pp[(size_t)(cb * ACT_CB + c) * HID_C];
+#pragma unroll
+          for (int c = 0; c < ACT_CB; ++c) acc[c & 3] = fmaf(wv[c], v[c], acc[c & 3]);
+        }
+      }
+    }
+  }
+  red[part][co] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  __syncthreads();
+  if (part == 0) {
+    float* dst = bcorr + ((size_t)b * swin_ring_size(h, w) + r) * HID_C + co;
+    const float v = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+    *dst = corners ? *dst + v : v;
+  }
+}
+
+// The same correction for the 2-byte kinds as four LINE convolutions on the matrix cores.  At a pixel of the top row every pred.0 tap of kernel row
+// -1 leaves the image, whatever its column, and convB reaches back into row 0 only: the correction is a 1x5 convolution along row 0 with
+// K_top[u] = sum over ex + dx = u of P[(-1, ex)][(+1, dx)] (zero padding at the row's ends = convB's own padding); bottom row, left and right
+// column (rows 1 .. h-2) likewise.  kside: the four 5-tap kernels in MFMA fragment order [side][u][k-step][cout half][lane] x 8 elements
+// (lane (i, g): cout 32 nt + i, channels 16 kk + 8 g ..+7), built by swin_kside_kernel per parameter generation.
+// One wave = 32 consecutive pixels of one side x 64 couts: 5 x 16 steps of (1 activation fragment from HBM/L2, 2 weight fragments, 2 MFMAs).
+template <int EK>
+__global__ void __launch_bounds__(64) swin_bcorr_line_kernel(const uint16_t* __restrict__ sa, const uint4* __restrict__ kside, float* __restrict__ bcorr, int h, int w) {
+  const int b = blockIdx.y, lane = threadIdx.x, li = lane & 31, g = lane >> 5;
+  const int nrow = (w + 31) / 32, ncol = (h - 2 + 31) / 32;
+  int side, seg = blockIdx.x;
+  if (seg < nrow) side = 0;
+  else if (seg < 2 * nrow) { side = 1; seg -= nrow; }
+  else if (seg < 2 * nrow + ncol) { side = 2; seg -= 2 * nrow; }
+  else { side = 3; seg -= 2 * nrow + ncol; }
+  const int L = side < 2 ? w : h;                         // the line: row 0 / h-1, column 0 / w-1
+  const int t = (side < 2 ? 0 : 1) + seg * 32 + li;       // this lane's pixel along it (columns: rows 1 .. h-2 only, the corners belong to the rows)
+  f32x16_t acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  const uint4* ks = kside + (size_t)side * 5 * 16 * 2 * 64 + lane;
+#pragma unroll 1
+  for (int u = 0; u < 5; ++u) {
+    const int tp = t + u - 2;
+    const bool valid = tp >= 0 && tp < L;
+    const int tc = valid ? tp : 0;
+    const int sy = side == 0 ? 0 : side == 1 ? h - 1 : tc, sx = side == 2 ? 0 : side == 3 ? w - 1 : tc;
+#pragma unroll
+    for (int kk = 0; kk < COND_C / 16; ++kk) {
+      uint4 pf = *reinterpret_cast<const uint4*>(sa + act_offset(COND_C, h, w, b, kk * 16 + g * 8, sy, sx));
+      if (!valid) pf = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) mma_step<EK>(acc[n], ks[((size_t)(u * 16 + kk) * 2 + n) * 64], pf);
+    }
+  }
+  const bool store = side < 2 ? t < w : t <= h - 2;
+  if (store) {
+    const int ridx = side == 0 ? t : side == 1 ? w + t : side == 2 ? 2 * w + (t - 1) : 2 * w + (h - 2) + (t - 1);
+    float* dst = bcorr + ((size_t)b * swin_ring_size(h, w) + ridx) * HID_C;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(dst + n * 32 + 8 * q + 4 * g) = make_float4(acc[n][q * 4], acc[n][q * 4 + 1], acc[n][q * 4 + 2], acc[n][q * 4 + 3]);
+  }
+}
+// kside[kind][side][u][kk][nt][lane][j] (16-bit elements; kind 0 = bf16, 1 = f16) from the tap-pair products: one thread per element
+__global__ void __launch_bounds__(256) swin_kside_kernel(const float* __restrict__ pairp, uint16_t* __restrict__ kside) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  constexpr int PER_KIND = 4 * 5 * 16 * 2 * 64 * 8;
+  if (i >= 2 * PER_KIND) return;
+  const int j = i & 7, lane = (i >> 3) & 63, nt = (i >> 9) & 1, kk = (i >> 10) & 15, us = (i >> 14) % 20, kind = i / PER_KIND;
+  const int u = us % 5, side = us / 5;
+  const int co = nt * 32 + (lane & 31), ci = kk * 16 + (lane >> 5) * 8 + j;
+  float v = 0.f;
+  for (int a = -1; a <= 1; ++a) {        // a: the pred.0 tap's free coordinate, c = (u - 2) - a: convB's
+    const int c = (u - 2) - a;
+    if (c < -1 || c > 1) continue;
+    int e, d;
+    if (side == 0) { e = 0 * 3 + (a + 1); d = 2 * 3 + (c + 1); }            // e = (-1, a), d = (+1, c)
+    else if (side == 1) { e = 2 * 3 + (a + 1); d = 0 * 3 + (c + 1); }       // e = (+1, a), d = (-1, c)
+    else if (side == 2) { e = (a + 1) * 3 + 0; d = (c + 1) * 3 + 2; }       // e = (a, -1), d = (c, +1)
+    else { e = (a + 1) * 3 + 2; d = (c + 1) * 3 + 0; }                      // e = (a, +1), d = (c, -1)
+    v += pairp[((size_t)(e * 9 + d) * COND_C + ci) * HID_C + co];
+  }
+  kside[i] = (uint16_t)(kind == 0 ? f32_to_bf16(v) : f32_to_f16(v));
+}
+hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float* w5_oihw, float* pairp, void* kside, hipStream_t s) {
+  hipLaunchKernelGGL(swin_w5_kernel, dim3((HID_C * COND_C * 25 + 255) / 256), dim3(256), 0, s, wb_oihw, w3_oihw, w5_oihw);
+  hipLaunchKernelGGL(swin_pair_kernel, dim3(81 * COND_C), dim3(HID_C), 0, s, wb_oihw, w3_oihw, pairp);
+  hipLaunchKernelGGL(swin_kside_kernel, dim3((unsigned)(SWIN_KSIDE_BYTES / 2 + 255) / 256), dim3(256), 0, s, (const float*)pairp, static_cast<uint16_t*>(kside));
+  return hipGetLastError();
+}
+hipError_t launch_swin_bcorr(const void* sa, int ek, const float* pairp, const void* kside, float* bcorr, int B, int h, int w, hipStream_t s) {
+  if ((ek == EK_BF16 || ek == EK_F16) && h >= 3 && w >= 3) {
+    // matrix-core line convolutions, then the corners' sideways taps
+    const dim3 grid((unsigned)(2 * ((w + 31) / 32) + 2 * ((h - 2 + 31) / 32)), (unsigned)B);
+    const uint4* ks = static_cast<const uint4*>(kside) + (ek == EK_F16 ? SWIN_KSIDE_BYTES / 32 : 0);
+    if (ek == EK_BF16) {
+      hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_BF16>, grid, dim3(64), 0, s, static_cast<const uint16_t*>(sa), ks, bcorr, h, w);
+      hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, dim3(4, (unsigned)B), dim3(256), 0, s, sa, pairp, bcorr, h, w, 1);
+    } else {
+      hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_F16>, grid, dim3(64), 0, s, static_cast<const uint16_t*>(sa), ks, bcorr, h, w);
+      hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, dim3(4, (unsigned)B), dim3(256), 0, s, sa, pairp, bcorr, h, w, 1);
+    }
+    return hipGetLastError();
+  }
+  const dim3 grid((unsigned)swin_ring_size(h, w), (unsigned)B);
+  if (ek == EK_F32) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F32>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w, 0);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w, 0);
+  else if (ek == EK_F16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w, 0);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // q_sample (reference scheduling_ddim.py:355-376): out = sqrt(abar_t)*x0 + sqrt(1-abar_t)*noise
 // ------------------------------------------------------------------------------------------------
 __global__ void add_noise_kernel(const float* __restrict__ x0, const float* __restrict__ noise,

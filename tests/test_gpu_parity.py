@@ -396,8 +396,10 @@ def test_swin_with_and_without_hoisting_the_step_invariant_terms(U, golden, case
     rag_in = [synth.make_inputs(400 + h, B, h, w, (ch, cw)) for (B, h, w, ch, cw, T) in rag]
     rag_ref = [O.ddim_loop(sd, i["x_T"], i["cond"], r[5], "swin") for i, r in zip(rag_in, rag)]
     try:
-        for hoist in (0, 1):
+        # (hoist, w5): the reference's order; hoisted with convB and pred.0 as two kernels; hoisted with pred.0 o convB as one 5x5 convolution (default)
+        for hoist, w5 in ((0, 1), (1, 0), (1, 1)):
             be.set_option("hoist_cond", hoist)
+            be.set_option("swin_w5", w5)
             for prec in ("fp32", "bf16", "f16"):
                 x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), 20, prec)
                 depth = be.decode(x0).cpu().numpy()
@@ -406,11 +408,12 @@ def test_swin_with_and_without_hoisting_the_step_invariant_terms(U, golden, case
                 for i, r, rr in zip(rag_in, rag, rag_ref):
                     xr = be.denoise(U.cu(i["x_T"]), U.cu(i["cond"]), r[5], prec).cpu().numpy()
                     er.append(U.maxabs(xr, rr) / float(np.abs(rr).max()))
-                U.record("swin_hoist_ab", hoist=hoist, prec=prec, latent_maxabs=e, latent_scale=scale, depth_rmse=U.rms(depth, dref),
+                U.record("swin_hoist_ab", hoist=hoist, w5=w5, prec=prec, latent_maxabs=e, latent_scale=scale, depth_rmse=U.rms(depth, dref),
                          depth_maxabs=U.maxabs(depth, dref), ragged_rel=er)
-                assert e < LATENT_TOL[prec] * scale and max(er) < LATENT_TOL[prec], (hoist, prec, e, scale, er)
+                assert e < LATENT_TOL[prec] * scale and max(er) < LATENT_TOL[prec], (hoist, w5, prec, e, scale, er)
     finally:
         be.set_option("hoist_cond", -1)
+        be.set_option("swin_w5", 1)
 
 
 def test_conv3_without_hoisting_the_condition_term(U, golden, cases):
