@@ -253,25 +253,28 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
     against the reference's order of operations (hoist off) -- on images smaller than seven pixels along an axis (every row / column its own
     class) and larger (interior class); f16: the default there."""
     be, inp, ref, _ = _loop_case(lib, "swin", cond_hw=(3, 5), h=h, w=w, T=T)
-    be.set_option("hoist_cond", 0)
-    plain = be.denoise(inp["x_T"], inp["cond"], T, "fp32")
+    scale = max(np.abs(ref).max(), 1.0)
     be.set_option("hoist_cond", 1)
     hoisted = be.denoise(inp["x_T"], inp["cond"], T, "fp32")            # pred.0 o convB as one 5x5 convolution + border ring correction (SWIN_PRED5_H)
-    be.set_option("swin_w5", 0)
-    chain = be.denoise(inp["x_T"], inp["cond"], T, "fp32")              # convB and pred.0 as two kernels (SWIN_PRED_H)
-    be.set_option("swin_w5", 1)
+    assert np.isfinite(hoisted).all() and maxabs(hoisted, ref) < LATENT_TOL["fp32"] * scale
+    if FULL:
+        be.set_option("swin_w5", 0)
+        chain = be.denoise(inp["x_T"], inp["cond"], T, "fp32")          # convB and pred.0 as two kernels (SWIN_PRED_H)
+        be.set_option("swin_w5", 1)
+        be.set_option("hoist_cond", 0)
+        plain = be.denoise(inp["x_T"], inp["cond"], T, "fp32")          # the reference's order
+        for got in (plain, chain):
+            assert np.isfinite(got).all() and maxabs(got, ref) < LATENT_TOL["fp32"] * scale
+        assert not np.array_equal(plain, hoisted) and not np.array_equal(chain, hoisted)     # (three different orders of summation did run)
     be.set_option("hoist_cond", -1)
-    scale = max(np.abs(ref).max(), 1.0)
-    for got in (plain, hoisted, chain):
-        assert np.isfinite(got).all() and maxabs(got, ref) < LATENT_TOL["fp32"] * scale
-    assert not np.array_equal(plain, hoisted) and not np.array_equal(chain, hoisted)     # (three different orders of summation did run)
     be.timing(order=1, dma_late=1)
     x16 = be.denoise(inp["x_T"], inp["cond"], T, "f16")       # hoisted, 5x5 form by default: border correction as line convolutions on the matrix cores
-    be.set_option("swin_w5", 0)
-    x16_chain = be.denoise(inp["x_T"], inp["cond"], T, "f16")
-    be.set_option("swin_w5", 1)
-    assert maxabs(x16, ref) < LATENT_TOL["f16"] * scale and maxabs(x16_chain, ref) < LATENT_TOL["f16"] * scale
-    assert maxabs(x16, x16_chain) < LATENT_TOL["f16"] * scale
+    assert maxabs(x16, ref) < LATENT_TOL["f16"] * scale
+    if FULL:
+        be.set_option("swin_w5", 0)
+        x16_chain = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+        be.set_option("swin_w5", 1)
+        assert maxabs(x16_chain, ref) < LATENT_TOL["f16"] * scale and maxabs(x16, x16_chain) < LATENT_TOL["f16"] * scale
 
 
 @full_only
