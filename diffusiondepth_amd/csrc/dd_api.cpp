@@ -538,7 +538,11 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
     const int RH = key.h < SWIN_TT_AX ? key.h : SWIN_TT_AX, RW = key.w < SWIN_TT_AX ? key.w : SWIN_TT_AX;
     DD_HIP(pl->ttab.alloc((size_t)T1 * SWIN_TT_ROWS * HID_C * 4));
     DD_HIP(pl->tt_scratch.alloc((size_t)T1 * RH * RW * (2 * COND_C + HID_C) * 4));
-    if (h->swin_w5) DD_HIP(pl->bcorr.alloc((size_t)key.B * swin_ring_size(key.h, key.w) * HID_C * 4));
+    if (h->swin_w5) {
+      DD_HIP(pl->bcorr.alloc((size_t)key.B * swin_ring_stride(key.h, key.w) * HID_C * 4));
+      DD_HIP(hipMemsetAsync(pl->bcorr.p, 0, pl->bcorr.bytes, nullptr));
+      DD_HIP(hipStreamSynchronize(nullptr));
+    }
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));

@@ -660,8 +660,13 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           if constexpr (C::PRED5) {
             // pixels on the image border: take out what the 5x5 form summed through pred.0 taps that leave the image (swin_bcorr)
             if (pvalid && (gy == 0 || gy == h - 1 || gx == 0 || gx == w - 1)) {
-              const float4 cv = *reinterpret_cast<const float4*>(p.bcorr + ((size_t)e_b * swin_ring_size(h, w) + swin_ring_index(gy, gx, h, w)) * HID_C + n * 32 + 8 * q + 4 * g);
+              const float* ring = p.bcorr + (size_t)e_b * swin_ring_stride(h, w) * HID_C + n * 32 + 8 * q + 4 * g;
+              const float4 cv = *reinterpret_cast<const float4*>(ring + (size_t)swin_ring_index(gy, gx, h, w) * HID_C);
               bv.x -= cv.x; bv.y -= cv.y; bv.z -= cv.z; bv.w -= cv.w;
+              if ((gy == 0 || gy == h - 1) && (gx == 0 || gx == w - 1)) {      // corner: + the taps that leave sideways
+                const float4 cc = *reinterpret_cast<const float4*>(ring + (size_t)(swin_ring_size(h, w) + (gy ? 2 : 0) + (gx ? 1 : 0)) * HID_C);
+                bv.x -= cc.x; bv.y -= cc.y; bv.z -= cc.z; bv.w -= cc.w;
+              }
             }
           }
         }

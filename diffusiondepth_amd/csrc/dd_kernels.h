@@ -87,7 +87,7 @@ struct ConvParams {
   // Swin denoiser with the step-invariant part of pred.0(convB(convA(.))) hoisted (kernel id SWIN_PRED_H): this step's rows of the
   // time-embedding table [SWIN_TT_ROWS][64] fp32 -- row 0 is added to every pixel, row 1 + 7 r + c to the pixels of border class (r, c)
   const float* ttab;
-  const float* bcorr;       // SWIN_PRED5_H: [B][swin_ring_size][64] fp32, subtracted at the pixels on the image border
+  const float* bcorr;       // SWIN_PRED5_H: [B][swin_ring_stride][64] fp32, subtracted at the pixels on the image border (corners: ring entry + corner entry)
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
   // HAHI neck layers (30..41): the input / output tensor is a channel range of a wider channel-blocked buffer (the concatenation the
   // fusion conv reads): buffer width and first channel, both multiples of 32; 0 = the tensor is the whole buffer (every other layer)
@@ -125,6 +125,7 @@ constexpr int SWIN_CONVA_H = 50, SWIN_PRED_H = 52;
 constexpr int SWIN_PRED5_H = 53;
 // ring buffer of the border pixels of an h x w image: top row, bottom row, left column, right column (without the corners)
 __host__ __device__ inline int swin_ring_size(int h, int w) { return 2 * w + 2 * (h > 2 ? h - 2 : 0); }
+__host__ __device__ inline int swin_ring_stride(int h, int w) { return swin_ring_size(h, w) + 4; }      // + one entry per corner: its sideways taps (swin_bcorr_line_kernel)
 __host__ __device__ inline int swin_ring_index(int y, int x, int h, int w) {
   return y == 0 ? x : (y == h - 1 ? w + x : (x == 0 ? 2 * w + (y - 1) : 2 * w + (h - 2) + (y - 1)));
 }

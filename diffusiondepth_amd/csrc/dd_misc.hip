@@ -540,66 +540,70 @@ __global__ void __launch_bounds__(64) swin_pair_kernel(const float* __restrict__
 hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float* w5_oihw, float* pairp, void* kside, hipStream_t s);
 // one block per border pixel (ring index) and image: thread = (cout, quarter of the 256 input channels); the 32 channels of an activation block
 // and their 32 weight rows are loaded as one batch (independent loads in flight together), four partial sums per thread, LDS reduction
-// corners != 0: only the four corner pixels (blockIdx.x = corner), only the taps e that leave the image SIDEWAYS from a row inside it, ADDED to
-// what the line kernel below left there (it covers the taps that leave through the top / bottom row)
+// The pair sum of ONE border pixel (y, x) of image b by a 256-thread block: thread = (cout, quarter of the 256 input channels); the 32 channels of
+// an activation block and their 32 weight rows are loaded as one batch, four partial sums per thread, LDS reduction; the result is returned to the
+// threads of wave 0 (thread = cout).  sideways_only: only the taps e that leave the image sideways from a row inside it (the corners' share
+// beside the line convolutions below, which cover the taps leaving through the top / bottom row).
 template <int EK>
-__global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict__ sa, const float* __restrict__ pairp, float* __restrict__ bcorr, int h, int w, int corners) {
-  __shared__ float red[4][HID_C];
-  const int b = blockIdx.y, co = threadIdx.x & (HID_C - 1), part = threadIdx.x >> 6;
-  const int r = corners ? swin_ring_index((blockIdx.x >> 1) ? h - 1 : 0, (blockIdx.x & 1) ? w - 1 : 0, h, w) : (int)blockIdx.x;
-  int y, x;      // inverse of swin_ring_index
-  if (r < w) { y = 0; x = r; }
-  else if (r < 2 * w) { y = h - 1; x = r - w; }
-  else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
-  else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
+__device__ __forceinline__ float swin_bcorr_pixel(const void* __restrict__ sa, const float* __restrict__ pairp, int b, int y, int x, int h, int w,
+                                                  bool sideways_only, float (&red)[4][HID_C]) {
+  const int co = threadIdx.x & (HID_C - 1), part = threadIdx.x >> 6;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  if (y < h && x < w && swin_ring_index(y, x, h, w) == r) {      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
-    for (int e = 0; e < 9; ++e) {
-      const int py = y + e / 3 - 1, px = x + e % 3 - 1;
-      if (py >= 0 && py < h && px >= 0 && px < w) continue;      // pred.0 tap inside the image: nothing to take out
-      if (corners && (py < 0 || py >= h)) continue;              // (the line kernel's share)
-      for (int d = 0; d < 9; ++d) {
-        const int sy = py + d / 3 - 1, sx = px + d % 3 - 1;
-        if (sy < 0 || sy >= h || sx < 0 || sx >= w) continue;    // convB tap on zero padding
-        const float* pp = pairp + ((size_t)(e * 9 + d) * COND_C) * HID_C + co;
+  for (int e = 0; e < 9; ++e) {
+    const int py = y + e / 3 - 1, px = x + e % 3 - 1;
+    if (py >= 0 && py < h && px >= 0 && px < w) continue;      // pred.0 tap inside the image: nothing to take out
+    if (sideways_only && (py < 0 || py >= h)) continue;
+    for (int d = 0; d < 9; ++d) {
+      const int sy = py + d / 3 - 1, sx = px + d % 3 - 1;
+      if (sy < 0 || sy >= h || sx < 0 || sx >= w) continue;    // convB tap on zero padding
+      const float* pp = pairp + ((size_t)(e * 9 + d) * COND_C) * HID_C + co;
 #pragma unroll
-        for (int k = 0; k < COND_C / ACT_CB / 4; ++k) {
-          const int cb = part * (COND_C / ACT_CB / 4) + k;
-          const size_t off = act_offset(COND_C, h, w, b, cb * ACT_CB, sy, sx);
-          float v[ACT_CB], wv[ACT_CB];
-          if constexpr (EK == EK_F32) {
+      for (int k = 0; k < COND_C / ACT_CB / 4; ++k) {
+        const int cb = part * (COND_C / ACT_CB / 4) + k;
+        const size_t off = act_offset(COND_C, h, w, b, cb * ACT_CB, sy, sx);
+        float v[ACT_CB], wv[ACT_CB];
+        if constexpr (EK == EK_F32) {
 #pragma unroll
-            for (int q = 0; q < ACT_CB / 4; ++q) {
-              const float4 t = reinterpret_cast<const float4*>(static_cast<const float*>(sa) + off)[q];
-              v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-            }
-          } else {
+          for (int q = 0; q < ACT_CB / 4; ++q) {
+            const float4 t = reinterpret_cast<const float4*>(static_cast<const float*>(sa) + off)[q];
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+          }
+        } else {
 #pragma unroll
-            for (int q = 0; q < ACT_CB / 8; ++q) {
-              const uint4 t = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(sa) + off)[q];
-              const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+          for (int q = 0; q < ACT_CB / 8; ++q) {
+            const uint4 t = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(sa) + off)[q];
+            const uint32_t u[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[8 * q + 2 * i] = EK == EK_BF16 ? bf16_to_f32(u[i] & 0xFFFFu) : f16_to_f32(u[i] & 0xFFFFu);
-                v[8 * q + 2 * i + 1] = EK == EK_BF16 ? bf16_to_f32(u[i] >> 16) : f16_to_f32(u[i] >> 16);
-              }
+            for (int i = 0; i < 4; ++i) {
+              v[8 * q + 2 * i] = EK == EK_BF16 ? bf16_to_f32(u[i] & 0xFFFFu) : f16_to_f32(u[i] & 0xFFFFu);
+              v[8 * q + 2 * i + 1] = EK == EK_BF16 ? bf16_to_f32(u[i] >> 16) : f16_to_f32(u[i] >> 16);
             }
           }
-#pragma unroll
-          for (int c = 0; c < ACT_CB; ++c) wv[c] = pp[(size_t)(cb * ACT_CB + c) * HID_C];
-#pragma unroll
-          for (int c = 0; c < ACT_CB; ++c) acc[c & 3] = fmaf(wv[c], v[c], acc[c & 3]);
         }
+#pragma unroll
+        for (int c = 0; c < ACT_CB; ++c) wv[c] = pp[(size_t)(cb * ACT_CB + c) * HID_C];
+#pragma unroll
+        for (int c = 0; c < ACT_CB; ++c) acc[c & 3] = fmaf(wv[c], v[c], acc[c & 3]);
       }
     }
   }
   red[part][co] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   __syncthreads();
-  if (part == 0) {
-    float* dst = bcorr + ((size_t)b * swin_ring_size(h, w) + r) * HID_C + co;
-    const float v = (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
-    *dst = corners ? *dst + v : v;
-  }
+  return (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
+}
+// every border pixel by pair sums: one block per ring index and image (the fp32 kind, and images with an axis shorter than three pixels)
+template <int EK>
+__global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict__ sa, const float* __restrict__ pairp, float* __restrict__ bcorr, int h, int w) {
+  __shared__ float red[4][HID_C];
+  const int r = blockIdx.x, b = blockIdx.y;
+  int y, x;      // inverse of swin_ring_index
+  if (r < w) { y = 0; x = r; }
+  else if (r < 2 * w) { y = h - 1; x = r - w; }
+  else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
+  else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
+  const bool used = y < h && x < w && swin_ring_index(y, x, h, w) == r;      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
+  const float v = swin_bcorr_pixel<EK>(sa, pairp, b, used ? y : 0, used ? x : 0, h, w, false, red);
+  if (threadIdx.x < HID_C) bcorr[((size_t)b * swin_ring_stride(h, w) + r) * HID_C + threadIdx.x] = used ? v : 0.f;
 }
 
 // The same correction for the 2-byte kinds as four LINE convolutions on the matrix cores.  At a pixel of the top row every pred.0 tap of kernel row
@@ -607,12 +611,23 @@ __global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict_
 // K_top[u] = sum over ex + dx = u of P[(-1, ex)][(+1, dx)] (zero padding at the row's ends = convB's own padding); bottom row, left and right
 // column (rows 1 .. h-2) likewise.  kside: the four 5-tap kernels in MFMA fragment order [side][u][k-step][cout half][lane] x 8 elements
 // (lane (i, g): cout 32 nt + i, channels 16 kk + 8 g ..+7), built by swin_kside_kernel per parameter generation.
-// One wave = 32 consecutive pixels of one side x 64 couts: 5 x 16 steps of (1 activation fragment from HBM/L2, 2 weight fragments, 2 MFMAs).
+// One block = 32 consecutive pixels of one side x 64 couts; its four waves take four k-steps (64 input channels) each -- per tap 4 activation and
+// 8 weight fragments in flight, 8 MFMAs -- and wave 0 sums the four partial tiles through LDS.  The last four blocks of the grid are the image's
+// corners: the taps that leave sideways (swin_bcorr_pixel), into the four entries behind the ring.
 template <int EK>
-__global__ void __launch_bounds__(64) swin_bcorr_line_kernel(const uint16_t* __restrict__ sa, const uint4* __restrict__ kside, float* __restrict__ bcorr, int h, int w) {
-  const int b = blockIdx.y, lane = threadIdx.x, li = lane & 31, g = lane >> 5;
+__global__ void __launch_bounds__(256) swin_bcorr_line_kernel(const uint16_t* __restrict__ sa, const uint4* __restrict__ kside, const float* __restrict__ pairp,
+                                                              float* __restrict__ bcorr, int h, int w) {
+  __shared__ float red[4][HID_C];
+  __shared__ float part_acc[3][64][33];
+  const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, g = lane >> 5;
   const int nrow = (w + 31) / 32, ncol = (h - 2 + 31) / 32;
   int side, seg = blockIdx.x;
+  if (seg >= 2 * nrow + 2 * ncol) {
+    const int cid = seg - (2 * nrow + 2 * ncol);
+    const float v = swin_bcorr_pixel<EK>(sa, pairp, b, (cid >> 1) ? h - 1 : 0, (cid & 1) ? w - 1 : 0, h, w, true, red);
+    if (threadIdx.x < HID_C) bcorr[((size_t)b * swin_ring_stride(h, w) + swin_ring_size(h, w) + cid) * HID_C + threadIdx.x] = v;
+    return;
+  }
   if (seg < nrow) side = 0;
   else if (seg < 2 * nrow) { side = 1; seg -= nrow; }
   else if (seg < 2 * nrow + ncol) { side = 2; seg -= 2 * nrow; }
@@ -632,17 +647,30 @@ __global__ void __launch_bounds__(64) swin_bcorr_line_kernel(const uint16_t* __r
     const int tc = valid ? tp : 0;
     const int sy = side == 0 ? 0 : side == 1 ? h - 1 : tc, sx = side == 2 ? 0 : side == 3 ? w - 1 : tc;
 #pragma unroll
-    for (int kk = 0; kk < COND_C / 16; ++kk) {
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int kk = wave * 4 + k4;
       uint4 pf = *reinterpret_cast<const uint4*>(sa + act_offset(COND_C, h, w, b, kk * 16 + g * 8, sy, sx));
       if (!valid) pf = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
       for (int n = 0; n < 2; ++n) mma_step<EK>(acc[n], ks[((size_t)(u * 16 + kk) * 2 + n) * 64], pf);
     }
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) part_acc[wave - 1][lane][n * 16 + i] = acc[n][i];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] += (part_acc[0][lane][n * 16 + i] + part_acc[1][lane][n * 16 + i]) + part_acc[2][lane][n * 16 + i];
   const bool store = side < 2 ? t < w : t <= h - 2;
   if (store) {
     const int ridx = side == 0 ? t : side == 1 ? w + t : side == 2 ? 2 * w + (t - 1) : 2 * w + (h - 2) + (t - 1);
-    float* dst = bcorr + ((size_t)b * swin_ring_size(h, w) + ridx) * HID_C;
+    float* dst = bcorr + ((size_t)b * swin_ring_stride(h, w) + ridx) * HID_C;
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -679,22 +707,18 @@ hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float
 }
 hipError_t launch_swin_bcorr(const void* sa, int ek, const float* pairp, const void* kside, float* bcorr, int B, int h, int w, hipStream_t s) {
   if ((ek == EK_BF16 || ek == EK_F16) && h >= 3 && w >= 3) {
-    // matrix-core line convolutions, then the corners' sideways taps
-    const dim3 grid((unsigned)(2 * ((w + 31) / 32) + 2 * ((h - 2 + 31) / 32)), (unsigned)B);
+    // matrix-core line convolutions + the corners' sideways taps, one launch
+    const dim3 grid((unsigned)(2 * ((w + 31) / 32) + 2 * ((h - 2 + 31) / 32) + 4), (unsigned)B);
     const uint4* ks = static_cast<const uint4*>(kside) + (ek == EK_F16 ? SWIN_KSIDE_BYTES / 32 : 0);
-    if (ek == EK_BF16) {
-      hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_BF16>, grid, dim3(64), 0, s, static_cast<const uint16_t*>(sa), ks, bcorr, h, w);
-      hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, dim3(4, (unsigned)B), dim3(256), 0, s, sa, pairp, bcorr, h, w, 1);
-    } else {
-      hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_F16>, grid, dim3(64), 0, s, static_cast<const uint16_t*>(sa), ks, bcorr, h, w);
-      hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, dim3(4, (unsigned)B), dim3(256), 0, s, sa, pairp, bcorr, h, w, 1);
-    }
+    if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_BF16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(sa), ks, pairp, bcorr, h, w);
+    else hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_F16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(sa), ks, pairp, bcorr, h, w);
     return hipGetLastError();
   }
+  // (the four entries behind the ring stay zero: cleared when the plan allocated the buffer)
   const dim3 grid((unsigned)swin_ring_size(h, w), (unsigned)B);
-  if (ek == EK_F32) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F32>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w, 0);
-  else if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w, 0);
-  else if (ek == EK_F16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w, 0);
+  if (ek == EK_F32) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F32>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
+  else if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
+  else if (ek == EK_F16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
