@@ -697,8 +697,10 @@ def main():
             "value": round(maps / elapsed, 3), "unit": "maps/s", "n_gpus": n_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
-            "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, cond 256x{h}x{w}, Res head denoiser "
-                                   f"(mmbev_res50 config), T={T}, encoder+loop+decoder, inputs resident in HBM",
+            "config": {"workload": f"{args.size} {H}x{W} image -> latent 16x{h}x{w}, " +
+                                   (f"cond 256x{h}x{w}, Res head denoiser (mmbev_res50 config)" if args.variant == "res" else
+                                    f"cond 256x{(H + 3) // 4}x{(W + 3) // 4} (stride 4) upsampled in the library, Swin / MPViT head denoiser (UpSample_add fuse)") +
+                                   f", T={T}, encoder+loop+decoder, inputs resident in HBM",
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "ranks_seen": ranks_seen, "streams": args.streams, "options": args.set,
                        "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant},

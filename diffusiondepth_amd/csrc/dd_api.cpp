@@ -731,6 +731,25 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
 
 int ensure_bytes(dd_handle_t h, DevBuf& dst, size_t bytes);
 
+// Swin variant, hoisted 5x5 form: pred.0 o convB of the current parameter generation -- fp32 composition, tap-pair products and line kernels of the
+// border correction, packed images of the one-plane kinds -- on stream s.  Handle-wide data: dd_denoise calls this on the caller's stream BEFORE it
+// forks its lanes (a lane that found it stale would rebuild it on its own stream under the other lanes' feet).
+int ensure_swin_w5(dd_handle_t h, hipStream_t s) {
+  if (h->w5_weights == h->weights_serial) return DD_OK;
+  if (!h->LB.w_oihw.p || !h->L[2].w_oihw.p) return h->fail(DD_ERR_STATE, "hoisted Swin form: the fp32 weights of convB / pred.0 are not on the device");
+  if (!h->w5_oihw.p) {
+    DD_HIP(h->w5_oihw.alloc((size_t)HID_C * COND_C * 25 * 4)); DD_HIP(h->pairp.alloc((size_t)81 * COND_C * HID_C * 4)); DD_HIP(h->kside.alloc(SWIN_KSIDE_BYTES));
+  }
+  DD_HIP(launch_swin_compose(h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->w5_oihw.as<float>(), h->pairp.as<float>(), h->kside.p, s));
+  for (int ekk = 0; ekk < NUM_EK; ++ekk) {
+    const PackGeom g5 = conv_pack_geom2(SWIN_PRED5_H, ekk);
+    int rc = ensure_bytes(h, h->w5pack[ekk], pack_weights_bytes(g5, ekk)); if (rc) return rc;
+    DD_HIP(launch_pack_weights(h->w5_oihw.as<float>(), h->w5pack[ekk].p, g5, ekk, true, false, s));
+  }
+  h->w5_weights = h->weights_serial;
+  return DD_OK;
+}
+
 // Swin variant, hoisted form: the per-image term pred.0(convB(convA(up(feat)) + a) + b) without pred.0's bias, left in the accumulator-fragment
 // order of pred.0's tiles (layer 8), and -- once per plan and parameter generation -- the E[t] tables of the loop's steps.  The upsampled
 // condition map is in the plan's buffer; Plan::sa / sf are free until the loop starts.
@@ -742,19 +761,7 @@ int enqueue_swin_hoist(dd_handle_t h, Plan* pl, hipStream_t s) {
                             pl->tsteps.as<long long>(), k.T, k.h, k.w, pl->tt_scratch.as<float>(), pl->ttab.as<float>(), s));
     pl->ttab_weights = h->weights_serial;
   }
-  if (pl->bcorr.p && h->w5_weights != h->weights_serial) {
-    // pred.0 o convB of this parameter generation: fp32 composition, then the packed images of the one-plane kinds
-    if (!h->w5_oihw.p) {
-      DD_HIP(h->w5_oihw.alloc((size_t)HID_C * COND_C * 25 * 4)); DD_HIP(h->pairp.alloc((size_t)81 * COND_C * HID_C * 4)); DD_HIP(h->kside.alloc(SWIN_KSIDE_BYTES));
-    }
-    DD_HIP(launch_swin_compose(h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->w5_oihw.as<float>(), h->pairp.as<float>(), h->kside.p, s));
-    for (int ekk = 0; ekk < NUM_EK; ++ekk) {
-      const PackGeom g5 = conv_pack_geom2(SWIN_PRED5_H, ekk);
-      int rc = ensure_bytes(h, h->w5pack[ekk], pack_weights_bytes(g5, ekk)); if (rc) return rc;
-      DD_HIP(launch_pack_weights(h->w5_oihw.as<float>(), h->w5pack[ekk].p, g5, ekk, true, false, s));
-    }
-    h->w5_weights = h->weights_serial;
-  }
+  if (pl->bcorr.p) { int rc = ensure_swin_w5(h, s); if (rc) return rc; }
   const int tk = thin_kind(pl->ek);           // once per image: f16 kernels in the bf16 mode, as the Res variant's conv3(cond)
   ConvParams p{};
   p.B = k.B; p.h = k.h; p.w = k.w;
@@ -1698,6 +1705,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   // ("keep_trajectory") keeps every lane's states and activations in that lane's plan under ONE ticket; dd_denoise_backward splits alike.
   const int S = lane_count(h, B, precision);
   const int64_t ticket = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? ++h->traj_serial : 0;
+  if (h->variant == DD_VARIANT_SWIN && h->swin_w5 && want_hoist(h, precision, T, h->keep_traj ? 1 : 0)) { rc = ensure_swin_w5(h, s); if (rc) return rc; }
   if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket);
   for (int l = 1; l < S; ++l) {
     if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));

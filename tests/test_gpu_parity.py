@@ -416,6 +416,27 @@ def test_swin_with_and_without_hoisting_the_step_invariant_terms(U, golden, case
         be.set_option("swin_w5", 1)
 
 
+def test_swin_hoisted_tables_follow_a_parameter_update(U):
+    """The hoisted Swin form carries per-parameter-generation data outside the packed weight images: the 5x5 composition pred.0 o convB, the
+    tap-pair products / line kernels of its border correction (handle-wide, rebuilt on the caller's stream before the lanes fork) and the E[t]
+    border-class tables (per plan).  Load a second set of weights into the SAME handle: the next call must follow it (two lanes: B = 2)."""
+    import diffusiondepth_amd as dda
+    from oracle import ddim_oracle as O
+    be = dda.HipDenoiser(variant="swin")
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    B, h, w, ch, cw, T = 2, 9, 40, 5, 20, 2
+    inp = synth.make_inputs(470, B, h, w, (ch, cw))
+    for wseed in (7245, 7399, 7245):
+        sd = synth.make_state_dict(wseed, "swin")
+        be.load_state_dict(sd)
+        ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], T, "swin")
+        for prec in ("f16", "bf16"):
+            x0 = be.denoise(U.cu(inp["x_T"]), U.cu(inp["cond"]), T, prec).cpu().numpy()
+            e = U.maxabs(x0, ref) / float(np.abs(ref).max())
+            U.record("swin_hoist_reload", wseed=wseed, prec=prec, latent_rel=e)
+            assert e < LATENT_TOL[prec], (wseed, prec, e)
+
+
 def test_conv3_without_hoisting_the_condition_term(U, golden, cases):
     """A/B switch of conv3: hoist_cond (conv3(cond) + conv3(E[t]) taken out of the loop by linearity).  Both forms must match the reference."""
     from oracle import ddim_oracle as O
