@@ -89,9 +89,9 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
                                          loss_cfgs=[], precision=prec).eval(), sd)
             errs[prec] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
         U.record(case + "_16bit", depth_rmse_bf16=errs["bf16"], depth_rmse_f16=errs["f16"], pred_max=float(g["pred"].max()))
-        # bounds = 2x the measured values (2.7e-3 / 4.0e-4): f16 is inside the 1e-3 RMSE tolerance, bf16 -- this denoiser's TRAINING precision --
+        # bounds = 2x the measured values (1.4e-3 / 3.5e-4 with the step-invariant terms hoisted; 2.7e-3 / 4.0e-4 before): f16 is inside the 1e-3 RMSE tolerance, bf16 -- this denoiser's TRAINING precision --
         # is not and is held here only against drift
-        assert errs["bf16"] < 6e-3 and errs["f16"] < 1e-3
+        assert errs["bf16"] < 3e-3 and errs["f16"] < 1e-3
         # the abs-clean inference mode of the same head (split f16: neck / FPN on the fp32 kernels, loop on f16 pairs): 1e-3 abs on every pixel
         hs = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
                                      loss_cfgs=[], precision="f16x3").eval(), sd)
@@ -122,9 +122,9 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
                                          loss_cfgs=[], precision=prec).eval(), sd)
             errs[prec] = U.rms(_run(hb, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
         U.record(case + "_16bit", depth_rmse_bf16=errs["bf16"], depth_rmse_f16=errs["f16"], pred_max=float(g["pred"].max()))
-        # bounds = 2x the measured values (2.7e-3 / 4.0e-4): f16 is inside the 1e-3 RMSE tolerance, bf16 -- this denoiser's TRAINING precision --
+        # bounds = 2x the measured values (1.4e-3 / 3.5e-4 with the step-invariant terms hoisted; 2.7e-3 / 4.0e-4 before): f16 is inside the 1e-3 RMSE tolerance, bf16 -- this denoiser's TRAINING precision --
         # is not and is held here only against drift
-        assert errs["bf16"] < 6e-3 and errs["f16"] < 1e-3
+        assert errs["bf16"] < 3e-3 and errs["f16"] < 1e-3
         # the abs-clean inference mode of the same head (split f16: neck / FPN on the fp32 kernels, loop on f16 pairs): 1e-3 abs on every pixel
         hs = _load(getattr(dda, cls)(in_channels=list(chans), inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16,
                                      loss_cfgs=[], precision="f16x3").eval(), sd)
