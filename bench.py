@@ -563,7 +563,9 @@ def main():
                 "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch", "traffic_note": traffic_note,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PIXEL.get(dom, 0) * STORE_BYTES[args.precision] * nb * h * w,
+                # (Swin forward-only plans in their hoisted form: convA reads y2 and writes its result, 1024 B/pixel -- the condition map is not read in
+                # the loop; the 5x5 launch reads that result 512 + the hoisted term 128 and writes y3 128)
+                "algorithmic_bytes_per_launch": ({5: 1024, 7: 768}.get(dom, 0) if 6 in merged else ALGO_BYTES_PER_PIXEL.get(dom, 0)) * STORE_BYTES[args.precision] * nb * h * w,
                 "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops, "batch": nb, "streams_in_this_pass": 1,
                 "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
                 "per_layer_frac_of_peak": {str(l): round(lflops[l] / (per_layer[l][0] / max(per_layer[l][1], 1) * 1e-3) / 1e12 / peak, 4) for l in per_layer},
