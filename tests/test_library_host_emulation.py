@@ -245,7 +245,7 @@ def test_swin_loop_vs_oracle(lib, late, prec):
     assert maxabs(x0, ref) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("h,w,T", [(5, 17, 2)] + ([(8, 9, 1), (3, 4, 1)] if FULL else []))
+@pytest.mark.parametrize("h,w,T", [(5, 17, 2)] + ([(8, 9, 1), (3, 4, 1), (2, 5, 1), (4, 1, 1)] if FULL else []))
 def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
     """Forward-only Swin plans (kernel ids SWIN_CONVA_H / SWIN_PRED_H, dd_kernels.h): pred.0(convB(convA(.))) is linear in its input, so the
     condition map's part runs once per image and the time embedding's part is a table with one row per border class (three pixels deep: every
