@@ -198,7 +198,7 @@ struct dd_handle_s {
   DevBuf etab;               // [EMB_ROWS][10][64] per-tap W3 . E[t] (hoisted time-embedding term of conv3)
   // Swin variant, hoisted 5x5 form (SWIN_PRED5_H, dd_kernels.h): pred.0 o convB as one kernel (fp32 OIHW and the packed images of the one-plane
   // kinds), the tap-pair products of the border correction; built by the first hoisted plan that runs after a parameter update
-  DevBuf w5_oihw, w5pack[NUM_EK], pairp, kside;
+  DevBuf w5_oihw, w5pack[NUM_WIMG], pairp, kside;
   int64_t w5_weights = -1;
   int swin_w5 = 1;           // option "swin_w5": 1 = the 5x5 form, 0 = convB and pred.0 as two kernels (SWIN_PRED_H)
   DevBuf zero_bias;          // 256 zeros
@@ -447,12 +447,12 @@ int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::share
 // Swin variant (SWIN_CONVA_H / SWIN_PRED_H, dd_kernels.h): the whole step-invariant part of pred.0(convB(convA(.))) -- condition map and
 // time embedding through three convolutions -- in the plans of the loop that keep nothing for a backward (T > 0, keep == 0): the weight
 // gradients of convB / pred.0 need the un-split activations, so training plans and the single-call plans (per-sample timesteps) run the
-// reference's order.  -1 = in the 2-byte modes; 1 also in the fp32 mode; never in the split-f16 mode (no such kernels).
+// reference's order.  -1 = in the 2-byte modes and the split-f16 mode; 1 also in the fp32 mode.
 int want_hoist(dd_handle_t h, int precision, int T = 1, int keep = 0) {
   if (precision == DD_PREC_NAIVE_FP32) return 0;
   const int ek = ek_of_precision(precision, h->bf16_pure);
   if (h->variant == DD_VARIANT_SWIN) {
-    if (T <= 0 || keep != 0 || ek == EK_F16S || h->hoist_cond == 0) return 0;
+    if (T <= 0 || keep != 0 || h->hoist_cond == 0 || (ek == EK_F16S && !h->swin_w5)) return 0;      // (split f16: the 5x5 form only)
     return (h->hoist_cond == 1 || ek != EK_F32) ? 1 : 0;
   }
   if (h->variant != DD_VARIANT_RES) return 0;
@@ -647,8 +647,8 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     p.cadd = pl->ccond.as<float>(); p.ttab = pl->ttab.as<float>() + (size_t)step * SWIN_TT_ROWS * HID_C;
     if (pl->bcorr.p) {
       // pred.0 o convB as one 5x5 convolution on convA's result; the border ring's correction first
-      DD_HIP(launch_swin_bcorr(sa_, opnd_kind(ek), h->pairp.as<float>(), h->kside.p, pl->bcorr.as<float>(), k.B, k.h, k.w, s));
-      p.in = sa_; p.wpack = h->w5pack[opnd_kind(ek)].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
+      DD_HIP(launch_swin_bcorr(sa_, ek == EK_F16S ? (int)EK_F32 : opnd_kind(ek), h->pairp.as<float>(), h->kside.p, pl->bcorr.as<float>(), k.B, k.h, k.w, s));     // (kind convA' stored its result in)
+      p.in = sa_; p.wpack = h->w5pack[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
       p.stats_out = pl->stat_ptr(step, 2); p.bcorr = pl->bcorr.as<float>();
       DD_HIP(timed_launch(7, p, SWIN_PRED5_H));
     } else {
@@ -741,10 +741,11 @@ int ensure_swin_w5(dd_handle_t h, hipStream_t s) {
     DD_HIP(h->w5_oihw.alloc((size_t)HID_C * COND_C * 25 * 4)); DD_HIP(h->pairp.alloc((size_t)81 * COND_C * HID_C * 4)); DD_HIP(h->kside.alloc(SWIN_KSIDE_BYTES));
   }
   DD_HIP(launch_swin_compose(h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->w5_oihw.as<float>(), h->pairp.as<float>(), h->kside.p, s));
-  for (int ekk = 0; ekk < NUM_EK; ++ekk) {
+  for (int wi = 0; wi < NUM_WIMG; ++wi) {
+    const int ekk = wimg_kind(wi);
     const PackGeom g5 = conv_pack_geom2(SWIN_PRED5_H, ekk);
-    int rc = ensure_bytes(h, h->w5pack[ekk], pack_weights_bytes(g5, ekk)); if (rc) return rc;
-    DD_HIP(launch_pack_weights(h->w5_oihw.as<float>(), h->w5pack[ekk].p, g5, ekk, true, false, s));
+    int rc = ensure_bytes(h, h->w5pack[wi], pack_weights_bytes(g5, ekk)); if (rc) return rc;
+    DD_HIP(launch_pack_weights(h->w5_oihw.as<float>(), h->w5pack[wi].p, g5, ekk, true, false, s));
   }
   h->w5_weights = h->weights_serial;
   return DD_OK;

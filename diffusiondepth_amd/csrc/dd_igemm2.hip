@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             cv = reinterpret_cast<const float4*>(p.cadd)[fi];
           }
         }
-        if constexpr (C::SPLIT && C::ADD_C) { constexpr float IS = 1.f / split_oscale(C::PRO); cv.x *= IS; cv.y *= IS; cv.z *= IS; cv.w *= IS; }   // accumulators run at the operands' scale
+        if constexpr (C::SPLIT && C::ADD_ACC) { constexpr float IS = 1.f / split_oscale(C::PRO); cv.x *= IS; cv.y *= IS; cv.z *= IS; cv.w *= IS; }   // accumulators run at the operands' scale
         acc[n][m][q * 4 + 0] = cv.x; acc[n][m][q * 4 + 1] = cv.y; acc[n][m][q * 4 + 2] = cv.z; acc[n][m][q * 4 + 3] = cv.w;
       }
   }
@@ -900,6 +900,8 @@ static hipError_t launch_layer2_split(int layer, const ConvParams& p, hipStream_
     case 7: return launch_one2<EK_F16S, 7>(p, s);
     case 8: return launch_one2<EK_F16S, 8>(p, s);
     case 9: return launch_one2<EK_F16S, 9>(p, s);
+    case SWIN_CONVA_H: return launch_one2<EK_F16S, SWIN_CONVA_H>(p, s);
+    case SWIN_PRED5_H: return launch_one2<EK_F16S, SWIN_PRED5_H>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -986,6 +988,8 @@ static PackGeom geom2_layer_split(int layer) {
     case 6: return geom2_of<EK_F16S, 6>();
     case 7: return geom2_of<EK_F16S, 7>();
     case 8: return geom2_of<EK_F16S, 8>();
+    case SWIN_CONVA_H: return geom2_of<EK_F16S, 5>();
+    case SWIN_PRED5_H: return geom2_of<EK_F16S, SWIN_PRED5_H>();
     default: return geom2_of<EK_F16S, 9>();
   }
 }

@@ -98,7 +98,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int OUT_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
   static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
   static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 9), "EK_F16S is instantiated for the denoiser's layers only");
-  static_assert(!SPLIT || !(HOIST_A || ADD_T), "the hoisted Swin forms exist in the one-plane kinds only");
+  static_assert(!SPLIT || LAYER_ID_ != SWIN_PRED_H, "split f16: the hoisted Swin plans always run the 5x5 form");
   static constexpr int ESZ = ElemSize<EK>::V;
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
   //   5 = upsample_fuse.convA 256->256 (prologue relu(gn2(y2)) + up(cond) + E[t]), 6 = upsample_fuse.convB 256->256

@@ -178,8 +178,8 @@ hipError_t launch_etab(const float* w3_oihw, const float* emb, float* etab, hipS
 hipError_t launch_swin_ttab(const float* wa_oihw, const float* wb_oihw, const float* w3_oihw, const float* emb, const long long* ts, int T,
                             int h, int w, float* scratch, float* ttab, hipStream_t s);
 // Swin hoist, 5x5 form: w5 (64,256,5,5) OIHW fp32 and the tap-pair products pairp[e][d][ci][co] = sum_cm W3[co][cm][e] * WB[cm][ci][d] (81 x 256 x 64)
-// ... and kside: the four 5-tap line kernels of the border correction in MFMA fragment order, bf16 then f16 (SWIN_KSIDE_BYTES; swin_bcorr_line_kernel)
-constexpr size_t SWIN_KSIDE_BYTES = (size_t)2 * 4 * 5 * 16 * 2 * 64 * 8 * 2;
+// ... and kside: the four 5-tap line kernels of the border correction in MFMA fragment order, bf16, f16, then fp32 (SWIN_KSIDE_BYTES; swin_bcorr_line_kernel)
+constexpr size_t SWIN_KSIDE_BYTES = (size_t)4 * 5 * COND_C * HID_C * (2 + 2 + 4);
 hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float* w5_oihw, float* pairp, void* kside, hipStream_t s);
 // bcorr[b][ring(q)][co] = sum over taps e with q + e outside the image, taps d with q + e + d inside, ci: pairp[e][d][ci][co] * sa[b][q + e + d][ci]
 // (sa: convA's result in the activation layout, element kind ek)

@@ -591,19 +591,90 @@ __device__ __forceinline__ float swin_bcorr_pixel(const void* __restrict__ sa, c
   __syncthreads();
   return (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
 }
-// every border pixel by pair sums: one block per ring index and image (the fp32 kind, and images with an axis shorter than three pixels)
+// every border pixel by pair sums (the fp32 kind -- fp32 and split-f16 modes -- and images with an axis shorter than three pixels): one block per
+// SWIN_BCORR_NPX consecutive ring indices and image, so that a tap pair's 64-KB weight matrix is read once for all of them (one block per pixel
+// re-read nine of them per pixel: 3.7 GB of L2 traffic per KITTI step, 190 us); thread = (cout, quarter of the input channels)
+constexpr int SWIN_BCORR_NPX = 8;
 template <int EK>
 __global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict__ sa, const float* __restrict__ pairp, float* __restrict__ bcorr, int h, int w) {
-  __shared__ float red[4][HID_C];
-  const int r = blockIdx.x, b = blockIdx.y;
-  int y, x;      // inverse of swin_ring_index
-  if (r < w) { y = 0; x = r; }
-  else if (r < 2 * w) { y = h - 1; x = r - w; }
-  else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
-  else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
-  const bool used = y < h && x < w && swin_ring_index(y, x, h, w) == r;      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
-  const float v = swin_bcorr_pixel<EK>(sa, pairp, b, used ? y : 0, used ? x : 0, h, w, false, red);
-  if (threadIdx.x < HID_C) bcorr[((size_t)b * swin_ring_stride(h, w) + r) * HID_C + threadIdx.x] = used ? v : 0.f;
+  constexpr int NPX = SWIN_BCORR_NPX;
+  __shared__ float red[NPX][4][HID_C];
+  const int r0 = blockIdx.x * NPX, b = blockIdx.y, co = threadIdx.x & (HID_C - 1), part = threadIdx.x >> 6;
+  int ys[NPX], xs[NPX];
+  unsigned used = 0;
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) {
+    const int r = r0 + i;
+    int y, x;      // inverse of swin_ring_index
+    if (r < w) { y = 0; x = r; }
+    else if (r < 2 * w) { y = h - 1; x = r - w; }
+    else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
+    else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
+    const bool u = r < swin_ring_size(h, w) && y < h && x < w && swin_ring_index(y, x, h, w) == r;      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
+    ys[i] = u ? y : 0; xs[i] = u ? x : 0;
+    if (u) used |= 1u << i;
+  }
+  float acc[NPX];
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) acc[i] = 0.f;
+  for (int e = 0; e < 9; ++e) {
+    for (int d = 0; d < 9; ++d) {
+      // the pixels of this block that take tap pair (e, d): pred.0 tap e leaves the image, convB tap d comes back into it
+      unsigned m = 0;
+#pragma unroll
+      for (int i = 0; i < NPX; ++i) {
+        const int py = ys[i] + e / 3 - 1, px = xs[i] + e % 3 - 1;
+        const int sy = py + d / 3 - 1, sx = px + d % 3 - 1;
+        if (((used >> i) & 1u) && !(py >= 0 && py < h && px >= 0 && px < w) && sy >= 0 && sy < h && sx >= 0 && sx < w) m |= 1u << i;
+      }
+      if (!m) continue;
+      const float* pp = pairp + ((size_t)(e * 9 + d) * COND_C) * HID_C + co;
+#pragma unroll
+      for (int k = 0; k < COND_C / ACT_CB / 4; ++k) {
+        const int cb = part * (COND_C / ACT_CB / 4) + k;
+        float wv[ACT_CB];
+#pragma unroll
+        for (int c = 0; c < ACT_CB; ++c) wv[c] = pp[(size_t)(cb * ACT_CB + c) * HID_C];
+#pragma unroll
+        for (int i = 0; i < NPX; ++i) {
+          if (!((m >> i) & 1u)) continue;
+          const size_t off = act_offset(COND_C, h, w, b, cb * ACT_CB, ys[i] + e / 3 + d / 3 - 2, xs[i] + e % 3 + d % 3 - 2);
+          float v[ACT_CB];
+          if constexpr (EK == EK_F32) {
+#pragma unroll
+            for (int q = 0; q < ACT_CB / 4; ++q) {
+              const float4 t = reinterpret_cast<const float4*>(static_cast<const float*>(sa) + off)[q];
+              v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < ACT_CB / 8; ++q) {
+              const uint4 t = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(sa) + off)[q];
+              const uint32_t u[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                v[8 * q + 2 * j] = EK == EK_BF16 ? bf16_to_f32(u[j] & 0xFFFFu) : f16_to_f32(u[j] & 0xFFFFu);
+                v[8 * q + 2 * j + 1] = EK == EK_BF16 ? bf16_to_f32(u[j] >> 16) : f16_to_f32(u[j] >> 16);
+              }
+            }
+          }
+          float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < ACT_CB; ++c) a4[c & 3] = fmaf(wv[c], v[c], a4[c & 3]);
+          acc[i] += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NPX; ++i) red[i][part][co] = acc[i];
+  __syncthreads();
+  if (part == 0) {
+#pragma unroll
+    for (int i = 0; i < NPX; ++i)
+      if (r0 + i < swin_ring_size(h, w))
+        bcorr[((size_t)b * swin_ring_stride(h, w) + r0 + i) * HID_C + co] = ((used >> i) & 1u) ? (red[i][0][co] + red[i][1][co]) + (red[i][2][co] + red[i][3][co]) : 0.f;
+  }
 }
 
 // The same correction for the 2-byte kinds as four LINE convolutions on the matrix cores.  At a pixel of the top row every pred.0 tap of kernel row
@@ -615,8 +686,10 @@ __global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict_
 // 8 weight fragments in flight, 8 MFMAs -- and wave 0 sums the four partial tiles through LDS.  The last four blocks of the grid are the image's
 // corners: the taps that leave sideways (swin_bcorr_pixel), into the four entries behind the ring.
 template <int EK>
-__global__ void __launch_bounds__(256) swin_bcorr_line_kernel(const uint16_t* __restrict__ sa, const uint4* __restrict__ kside, const float* __restrict__ pairp,
+__global__ void __launch_bounds__(256) swin_bcorr_line_kernel(const void* __restrict__ sa, const uint4* __restrict__ kside, const float* __restrict__ pairp,
                                                               float* __restrict__ bcorr, int h, int w) {
+  // channels per MFMA step: 16 in the 2-byte kinds (lane (i, g): 8 g ..+7), 8 in fp32 (mma_step<EK_F32> = four 32x32x2 MFMAs; lane (i, g): 4 g ..+3)
+  constexpr int CPS = EK == EK_F32 ? 8 : 16, NSTEP = COND_C / CPS, ESZ = EK == EK_F32 ? 4 : 2;
   __shared__ float red[4][HID_C];
   __shared__ float part_acc[3][64][33];
   const int b = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, g = lane >> 5;
@@ -639,7 +712,7 @@ __global__ void __launch_bounds__(256) swin_bcorr_line_kernel(const uint16_t* __
   for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
-  const uint4* ks = kside + (size_t)side * 5 * 16 * 2 * 64 + lane;
+  const uint4* ks = kside + (size_t)side * 5 * NSTEP * 2 * 64 + lane;
 #pragma unroll 1
   for (int u = 0; u < 5; ++u) {
     const int tp = t + u - 2;
@@ -647,12 +720,12 @@ __global__ void __launch_bounds__(256) swin_bcorr_line_kernel(const uint16_t* __
     const int tc = valid ? tp : 0;
     const int sy = side == 0 ? 0 : side == 1 ? h - 1 : tc, sx = side == 2 ? 0 : side == 3 ? w - 1 : tc;
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      const int kk = wave * 4 + k4;
-      uint4 pf = *reinterpret_cast<const uint4*>(sa + act_offset(COND_C, h, w, b, kk * 16 + g * 8, sy, sx));
+    for (int k4 = 0; k4 < NSTEP / 4; ++k4) {
+      const int kk = wave * (NSTEP / 4) + k4;
+      uint4 pf = *reinterpret_cast<const uint4*>(static_cast<const char*>(sa) + act_offset(COND_C, h, w, b, kk * CPS + g * (CPS / 2), sy, sx) * ESZ);
       if (!valid) pf = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-      for (int n = 0; n < 2; ++n) mma_step<EK>(acc[n], ks[((size_t)(u * 16 + kk) * 2 + n) * 64], pf);
+      for (int n = 0; n < 2; ++n) mma_step<EK>(acc[n], ks[((size_t)(u * NSTEP + kk) * 2 + n) * 64], pf);
     }
   }
   if (wave > 0) {
@@ -679,13 +752,22 @@ __global__ void __launch_bounds__(256) swin_bcorr_line_kernel(const uint16_t* __
   }
 }
 // kside[kind][side][u][kk][nt][lane][j] (16-bit elements; kind 0 = bf16, 1 = f16) from the tap-pair products: one thread per element
+// ... then the fp32 section [side][u][k-step of 8 channels][nt][lane] x 4 floats (lane (i, g): cout 32 nt + i, channels 8 kk + 4 g ..+3)
 __global__ void __launch_bounds__(256) swin_kside_kernel(const float* __restrict__ pairp, uint16_t* __restrict__ kside) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  constexpr int PER_KIND = 4 * 5 * 16 * 2 * 64 * 8;
-  if (i >= 2 * PER_KIND) return;
-  const int j = i & 7, lane = (i >> 3) & 63, nt = (i >> 9) & 1, kk = (i >> 10) & 15, us = (i >> 14) % 20, kind = i / PER_KIND;
-  const int u = us % 5, side = us / 5;
-  const int co = nt * 32 + (lane & 31), ci = kk * 16 + (lane >> 5) * 8 + j;
+  constexpr int PER_KIND = 4 * 5 * 16 * 2 * 64 * 8;      // elements of a 16-bit section = 4 sides x 5 taps x 256 channels x 64 couts
+  if (i >= 3 * PER_KIND) return;
+  int kind, side, u, co, ci;
+  if (i < 2 * PER_KIND) {
+    const int j = i & 7, lane = (i >> 3) & 63, nt = (i >> 9) & 1, kk = (i >> 10) & 15, us = (i >> 14) % 20;
+    kind = i / PER_KIND; u = us % 5; side = us / 5;
+    co = nt * 32 + (lane & 31); ci = kk * 16 + (lane >> 5) * 8 + j;
+  } else {
+    const int f = i - 2 * PER_KIND;
+    const int j = f & 3, lane = (f >> 2) & 63, nt = (f >> 8) & 1, kk = (f >> 9) & 31, us = f >> 14;
+    kind = 2; u = us % 5; side = us / 5;
+    co = nt * 32 + (lane & 31); ci = kk * 8 + (lane >> 5) * 4 + j;
+  }
   float v = 0.f;
   for (int a = -1; a <= 1; ++a) {        // a: the pred.0 tap's free coordinate, c = (u - 2) - a: convB's
     const int c = (u - 2) - a;
@@ -697,25 +779,27 @@ __global__ void __launch_bounds__(256) swin_kside_kernel(const float* __restrict
     else { e = (a + 1) * 3 + 2; d = (c + 1) * 3 + 0; }                      // e = (a, +1), d = (c, -1)
     v += pairp[((size_t)(e * 9 + d) * COND_C + ci) * HID_C + co];
   }
-  kside[i] = (uint16_t)(kind == 0 ? f32_to_bf16(v) : f32_to_f16(v));
+  if (kind == 2) reinterpret_cast<float*>(kside + 2 * PER_KIND)[i - 2 * PER_KIND] = v;
+  else kside[i] = (uint16_t)(kind == 0 ? f32_to_bf16(v) : f32_to_f16(v));
 }
 hipError_t launch_swin_compose(const float* wb_oihw, const float* w3_oihw, float* w5_oihw, float* pairp, void* kside, hipStream_t s) {
   hipLaunchKernelGGL(swin_w5_kernel, dim3((HID_C * COND_C * 25 + 255) / 256), dim3(256), 0, s, wb_oihw, w3_oihw, w5_oihw);
   hipLaunchKernelGGL(swin_pair_kernel, dim3(81 * COND_C), dim3(HID_C), 0, s, wb_oihw, w3_oihw, pairp);
-  hipLaunchKernelGGL(swin_kside_kernel, dim3((unsigned)(SWIN_KSIDE_BYTES / 2 + 255) / 256), dim3(256), 0, s, (const float*)pairp, static_cast<uint16_t*>(kside));
+  hipLaunchKernelGGL(swin_kside_kernel, dim3((unsigned)(3 * (SWIN_KSIDE_BYTES / 8) + 255) / 256), dim3(256), 0, s, (const float*)pairp, static_cast<uint16_t*>(kside));
   return hipGetLastError();
 }
 hipError_t launch_swin_bcorr(const void* sa, int ek, const float* pairp, const void* kside, float* bcorr, int B, int h, int w, hipStream_t s) {
-  if ((ek == EK_BF16 || ek == EK_F16) && h >= 3 && w >= 3) {
-    // matrix-core line convolutions + the corners' sideways taps, one launch
+  if ((ek == EK_BF16 || ek == EK_F16 || ek == EK_F32) && h >= 3 && w >= 3) {
+    // matrix-core line convolutions + the corners' sideways taps, one launch; kside sections: bf16, f16 (a quarter of the bytes each), fp32 (half)
     const dim3 grid((unsigned)(2 * ((w + 31) / 32) + 2 * ((h - 2 + 31) / 32) + 4), (unsigned)B);
-    const uint4* ks = static_cast<const uint4*>(kside) + (ek == EK_F16 ? SWIN_KSIDE_BYTES / 32 : 0);
-    if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_BF16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(sa), ks, pairp, bcorr, h, w);
-    else hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_F16>, grid, dim3(256), 0, s, static_cast<const uint16_t*>(sa), ks, pairp, bcorr, h, w);
+    const uint4* ks = static_cast<const uint4*>(kside) + (ek == EK_BF16 ? 0 : ek == EK_F16 ? SWIN_KSIDE_BYTES / 64 : SWIN_KSIDE_BYTES / 32);
+    if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_BF16>, grid, dim3(256), 0, s, sa, ks, pairp, bcorr, h, w);
+    else if (ek == EK_F16) hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_F16>, grid, dim3(256), 0, s, sa, ks, pairp, bcorr, h, w);
+    else hipLaunchKernelGGL(swin_bcorr_line_kernel<EK_F32>, grid, dim3(256), 0, s, sa, ks, pairp, bcorr, h, w);
     return hipGetLastError();
   }
   // (the four entries behind the ring stay zero: cleared when the plan allocated the buffer)
-  const dim3 grid((unsigned)swin_ring_size(h, w), (unsigned)B);
+  const dim3 grid((unsigned)((swin_ring_size(h, w) + SWIN_BCORR_NPX - 1) / SWIN_BCORR_NPX), (unsigned)B);
   if (ek == EK_F32) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F32>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
   else if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
   else if (ek == EK_F16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);

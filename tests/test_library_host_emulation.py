@@ -275,6 +275,11 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
         x16_chain = be.denoise(inp["x_T"], inp["cond"], T, "f16")
         be.set_option("swin_w5", 1)
         assert maxabs(x16_chain, ref) < LATENT_TOL["f16"] * scale and maxabs(x16, x16_chain) < LATENT_TOL["f16"] * scale
+    if FULL or (h, w) == (5, 17):
+        # split f16 (the abs-clean mode): hoisted by default as well, always in the 5x5 form (two-plane packed image of the composed kernel,
+        # fp32 tensors, per-pixel border correction); fp32-class agreement with the oracle
+        xs = be.denoise(inp["x_T"], inp["cond"], T, "f16x3")
+        assert np.isfinite(xs).all() and maxabs(xs, ref) < LATENT_TOL["f16x3"] * scale
 
 
 @full_only
