@@ -215,8 +215,8 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * condition map is re-added in conv3's prologue every step; -1 [default] = hoisted in the bf16 and f16 modes of the Res variant.  Swin variant,
  * plans of the loop that keep nothing for a backward: the step-invariant part of pred.0(convB(convA(.))) -- the upsampled condition map through
  * all three convolutions once per image, the time embedding as a per-step table of border classes -- is taken out of the loop: -1 = in the 2-byte
- * modes, 1 = also in the fp32 mode, 0 = never; training plans always run the reference's order), "swin_w5" (1 [default] = those plans run
- * pred.0 o convB as ONE 5x5 convolution with a per-step border-ring correction, 0 = as two kernels: A/B switch), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
+ * modes and DD_PREC_F16X3, 1 = also in the fp32 mode, 0 = never; training plans always run the reference's order), "swin_w5" (1 [default] = those plans run
+ * pred.0 o convB as ONE 5x5 convolution with a per-step border-ring correction, 0 = as two kernels (DD_PREC_F16X3: the reference's order): A/B switch), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
