@@ -6,7 +6,7 @@ kernel entry / GroupNorm table done / first patch + weights in LDS / main loop d
 the eager loop and summarises: phase durations, workgroup lifetime, concurrency per CU, launch span.
 
     python tools/phase_prof.py build                      (here: hipcc cross-compiles)
-    python tools/phase_prof.py run [layers] [B] [prec]    (on the GPU box; layers e.g. 2,9,1,4)
+    python tools/phase_prof.py run [layers] [B] [prec] [res|swin]    (on the GPU box; layers e.g. 2,9,1,4)
 """
 import os, subprocess, sys
 os.environ.setdefault("DDEPTH_STREAMS", "1")      # kernel-level measurements: one stream (the binding defaults to two concurrent lanes)
@@ -31,15 +31,15 @@ def build():
     print(VARIANT)
 
 
-def run(layers, B, prec):
+def run(layers, B, prec, variant="res"):
     os.environ["DDEPTH_LIBRARY"] = VARIANT
     import numpy as np, torch
     import diffusiondepth_amd as dda
     from diffusiondepth_amd import synth
     h, w, T = 176, 608, 3
-    be = dda.HipDenoiser(); be.load_state_dict(synth.make_state_dict(7240)); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    be = dda.HipDenoiser(variant=variant); be.load_state_dict(synth.make_state_dict(7240 if variant == "res" else 7245, variant)); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
     be.set_option("graph", 0)
-    inp = synth.make_inputs(7240, B, h, w)
+    inp = synth.make_inputs(7240, B, h, w, None if variant == "res" else ((352 + 3) // 4, (1216 + 3) // 4))      # Swin: the stride-4 condition map
     x, cond = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
     buf = torch.zeros(8 * 16384 + 4 * 8 * 16384, dtype=torch.int64, device="cuda")
     for _ in range(2):
@@ -94,4 +94,4 @@ if __name__ == "__main__":
     else:
         layers = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2,9,1,4").split(",")]
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        run(layers, int(sys.argv[3]) if len(sys.argv) > 3 else 4, sys.argv[4] if len(sys.argv) > 4 else "bf16")
+        run(layers, int(sys.argv[3]) if len(sys.argv) > 3 else 4, sys.argv[4] if len(sys.argv) > 4 else "bf16", sys.argv[5] if len(sys.argv) > 5 else "res")
