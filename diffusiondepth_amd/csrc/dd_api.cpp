@@ -491,7 +491,8 @@ bool keep2_fits(dd_handle_t h, size_t need) {
 // fit the chip's resident workgroup slots at once; a function of the plan key only, so that the once-per-image kernel, the loop kernel, the
 // buffer of the hoisted term and every backward recompute agree.  Option "big_tiles": -1 = this rule, 0 / 1 = forced (A/B, tests).
 bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
-  if (!key.hoist || key.prec == DD_PREC_NAIVE_FP32 || h->variant != DD_VARIANT_RES) return false;
+  if (!key.hoist || key.prec == DD_PREC_NAIVE_FP32) return false;
+  if (h->variant != DD_VARIANT_RES && !(h->variant == DD_VARIANT_SWIN && h->swin_w5)) return false;      // Swin: the 5x5 form and its once-per-image layer 8
   const int ek = ek_of_precision(key.prec, h->bf16_pure);
   if (ek == EK_F32 || ek == EK_F16S) return false;
   if (h->big_tiles >= 0) return h->big_tiles != 0;
@@ -650,7 +651,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       DD_HIP(launch_swin_bcorr(sa_, ek == EK_F16S ? (int)EK_F32 : opnd_kind(ek), h->pairp.as<float>(), h->kside.p, pl->bcorr.as<float>(), k.B, k.h, k.w, s));     // (kind convA' stored its result in)
       p.in = sa_; p.wpack = h->w5pack[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
       p.stats_out = pl->stat_ptr(step, 2); p.bcorr = pl->bcorr.as<float>();
-      DD_HIP(timed_launch(7, p, SWIN_PRED5_H));
+      DD_HIP(timed_launch(7, p, plan_big_tiles(h, k) ? (int)SWIN_PRED5B_H : (int)SWIN_PRED5_H));
     } else {
       p.in = sa_; p.wpack = h->LB.wpack2[wk].p; p.out = sf_;
       DD_HIP(timed_launch(6, p));
@@ -772,9 +773,10 @@ int enqueue_swin_hoist(dd_handle_t h, Plan* pl, hipStream_t s) {
   DD_HIP(launch_conv_igemm2(6, tk, p, s));
   p.in = pl->sa.p; p.wpack = h->LB.wpack2[wimg_slot(tk)].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
   DD_HIP(launch_conv_igemm2(6, tk, p, s));
-  p.tiles_y = (k.h + conv_pack_geom2(8, pl->ek).th - 1) / conv_pack_geom2(8, pl->ek).th;
+  const int kid8 = conv3c_kid(h, k);          // (16x32 tiles when the loop's pred.0 kernel runs on them: the two agree on the fragment order)
+  p.tiles_y = (k.h + conv_pack_geom2(kid8, pl->ek).th - 1) / conv_pack_geom2(kid8, pl->ek).th;
   p.in = pl->sf.p; p.wpack = h->L[2].wpack2[wimg_slot(tk)].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
-  DD_HIP(launch_conv_igemm2(8, pl->ek, p, s));
+  DD_HIP(launch_conv_igemm2(kid8, pl->ek, p, s));
   return DD_OK;
 }
 

@@ -852,6 +852,7 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case SWIN_CONVA_H: return launch_one2<EK, SWIN_CONVA_H>(p, s);
     case SWIN_PRED_H: return launch_one2<EK, SWIN_PRED_H>(p, s);
     case SWIN_PRED5_H: return launch_one2<EK, SWIN_PRED5_H>(p, s);
+    case SWIN_PRED5B_H: if constexpr (EK != EK_F32) return launch_one2<EK, SWIN_PRED5B_H>(p, s); else return hipErrorInvalidValue;
     case 54: return launch_one2<EK, 54>(p, s);
     case 55: return launch_one2<EK, 55>(p, s);
     case 56: return launch_one2<EK, 56>(p, s);
@@ -882,6 +883,7 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     case SWIN_CONVA_H: return launch_one2<EK_BF16M, SWIN_CONVA_H>(p, s);
     case SWIN_PRED_H: return launch_one2<EK_BF16M, SWIN_PRED_H>(p, s);
     case SWIN_PRED5_H: return launch_one2<EK_BF16M, SWIN_PRED5_H>(p, s);
+    case SWIN_PRED5B_H: return launch_one2<EK_BF16M, SWIN_PRED5B_H>(p, s);
     case 10: return launch_one2<EK_BF16M, 10>(p, s);
     case 15: return launch_one2<EK_BF16M, 15>(p, s);
     case 24: return launch_one2<EK_BF16M, 24>(p, s);
@@ -963,6 +965,7 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case SWIN_CONVA_H: return geom2_of<EK, 5>();          // same packed images as layers 5 / 7
     case SWIN_PRED_H: return geom2_of<EK, 7>();
     case SWIN_PRED5_H: return geom2_of<EK, SWIN_PRED5_H>();
+    case SWIN_PRED5B_H: if constexpr (EK != EK_F32) return geom2_of<EK, SWIN_PRED5B_H>(); else return geom2_of<EK, SWIN_PRED5_H>();      // same packed image, th = 16
     case 54: return geom2_of<EK, 54>();
     case 55: return geom2_of<EK, 55>();
     case 56: return geom2_of<EK, 56>();

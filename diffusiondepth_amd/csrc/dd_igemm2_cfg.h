@@ -76,10 +76,10 @@ namespace dd {
 
 template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // kernel ids BIG_CONV3C / BIG_CONV3H (dd_kernels.h) = layers 8 / 9 on 16x32-pixel tiles
-  static constexpr bool BIG = LAYER_ID_ == BIG_CONV3C || LAYER_ID_ == BIG_CONV3H;
+  static constexpr bool BIG = LAYER_ID_ == BIG_CONV3C || LAYER_ID_ == BIG_CONV3H || LAYER_ID_ == SWIN_PRED5B_H;
   // kernel ids SWIN_CONVA_H / SWIN_PRED_H (dd_kernels.h) = layers 5 / 7 of the Swin denoiser with the step-invariant terms hoisted
   // SWIN_PRED5_H = pred.0 o convB as one 5x5 convolution (layer 7's tiling with five taps per stage)
-  static constexpr bool PRED5 = LAYER_ID_ == SWIN_PRED5_H;
+  static constexpr bool PRED5 = LAYER_ID_ == SWIN_PRED5_H || LAYER_ID_ == SWIN_PRED5B_H;
   static constexpr bool HOIST_A = LAYER_ID_ == SWIN_CONVA_H, ADD_T = LAYER_ID_ == SWIN_PRED_H || PRED5;
   static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : LAYER_ID_ == BIG_CONV3H ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
   // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands

@@ -123,6 +123,9 @@ constexpr int SWIN_CONVA_H = 50, SWIN_PRED_H = 52;
 //   reference's pred.0 zero-pads away; they are computed per step from the border rows / columns of convA's result (swin_bcorr: ring
 //   buffer ConvParams::bcorr) and subtracted in the epilogue.  Accumulator start values and E[t] rows as SWIN_PRED_H.
 constexpr int SWIN_PRED5_H = 53;
+// the same on 16x32-pixel tiles (the tiling of BIG_CONV3C / BIG_CONV3H: half the weight stream per pixel, 40 MFMAs per stage, 0.75 LDS reads per
+// MFMA), picked with the same rule (plan_big_tiles, dd_api.cpp); its accumulator start values come from BIG_CONV3C
+constexpr int SWIN_PRED5B_H = 51;
 // ring buffer of the border pixels of an h x w image: top row, bottom row, left column, right column (without the corners)
 __host__ __device__ inline int swin_ring_size(int h, int w) { return 2 * w + 2 * (h > 2 ? h - 2 : 0); }
 __host__ __device__ inline int swin_ring_stride(int h, int w) { return swin_ring_size(h, w) + 4; }      // + one entry per corner: its sideways taps (swin_bcorr_line_kernel)

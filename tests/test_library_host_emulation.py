@@ -276,6 +276,12 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
         be.set_option("swin_w5", 1)
         assert maxabs(x16_chain, ref) < LATENT_TOL["f16"] * scale and maxabs(x16, x16_chain) < LATENT_TOL["f16"] * scale
     if FULL or (h, w) == (5, 17):
+        # the 5x5 kernel on 16x32-pixel tiles (kernel id SWIN_PRED5B_H; the library picks it when the 8x32 tiles exceed the resident slots) with the
+        # once-per-image term from BIG_CONV3C: same result class as the 8x32 form
+        be.set_option("big_tiles", 1)
+        xb = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+        be.set_option("big_tiles", -1)
+        assert maxabs(xb, ref) < LATENT_TOL["f16"] * scale and maxabs(xb, x16) < LATENT_TOL["f16"] * scale
         # split f16 (the abs-clean mode): hoisted by default as well, always in the 5x5 form (two-plane packed image of the composed kernel,
         # fp32 tensors, per-pixel border correction); fp32-class agreement with the oracle
         xs = be.denoise(inp["x_T"], inp["cond"], T, "f16x3")
