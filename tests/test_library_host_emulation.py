@@ -275,6 +275,16 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
         x16_chain = be.denoise(inp["x_T"], inp["cond"], T, "f16")
         be.set_option("swin_w5", 1)
         assert maxabs(x16_chain, ref) < LATENT_TOL["f16"] * scale and maxabs(x16, x16_chain) < LATENT_TOL["f16"] * scale
+    if (h, w) == (5, 17):
+        # a forward that keeps its trajectory for a backward never runs the hoisted form (the weight gradients of convB / pred.0 need the
+        # un-split activations): bit-identical to the reference's order
+        be.set_option("hoist_cond", 0)
+        plain16 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+        be.set_option("hoist_cond", -1)
+        be.set_option("keep_trajectory", 1)
+        kept16 = be.denoise(inp["x_T"], inp["cond"], T, "f16")
+        be.set_option("keep_trajectory", 0)
+        assert np.array_equal(kept16, plain16) and not np.array_equal(x16, plain16)
     if FULL or (h, w) == (5, 17):
         # the 5x5 kernel on 16x32-pixel tiles (kernel id SWIN_PRED5B_H; the library picks it when the 8x32 tiles exceed the resident slots) with the
         # once-per-image term from BIG_CONV3C: same result class as the 8x32 form
