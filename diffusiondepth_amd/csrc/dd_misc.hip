@@ -591,93 +591,23 @@ __device__ __forceinline__ float swin_bcorr_pixel(const void* __restrict__ sa, c
   __syncthreads();
   return (red[0][co] + red[1][co]) + (red[2][co] + red[3][co]);
 }
-// every border pixel by pair sums (the fp32 kind -- fp32 and split-f16 modes -- and images with an axis shorter than three pixels): one block per
-// SWIN_BCORR_NPX consecutive ring indices and image, so that a tap pair's 64-KB weight matrix is read once for all of them (one block per pixel
-// re-read nine of them per pixel: 3.7 GB of L2 traffic per KITTI step, 190 us); thread = (cout, quarter of the input channels)
-constexpr int SWIN_BCORR_NPX = 8;
+// every border pixel by pair sums, one block per ring index and image: images with an axis shorter than three pixels only (the line kernel below
+// needs three), so the nine 64-KB tap-pair matrices a pixel reads do not matter
 template <int EK>
 __global__ void __launch_bounds__(256) swin_bcorr_kernel(const void* __restrict__ sa, const float* __restrict__ pairp, float* __restrict__ bcorr, int h, int w) {
-  constexpr int NPX = SWIN_BCORR_NPX;
-  __shared__ float red[NPX][4][HID_C];
-  const int r0 = blockIdx.x * NPX, b = blockIdx.y, co = threadIdx.x & (HID_C - 1), part = threadIdx.x >> 6;
-  int ys[NPX], xs[NPX];
-  unsigned used = 0;
-#pragma unroll
-  for (int i = 0; i < NPX; ++i) {
-    const int r = r0 + i;
-    int y, x;      // inverse of swin_ring_index
-    if (r < w) { y = 0; x = r; }
-    else if (r < 2 * w) { y = h - 1; x = r - w; }
-    else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
-    else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
-    const bool u = r < swin_ring_size(h, w) && y < h && x < w && swin_ring_index(y, x, h, w) == r;      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
-    ys[i] = u ? y : 0; xs[i] = u ? x : 0;
-    if (u) used |= 1u << i;
-  }
-  float acc[NPX];
-#pragma unroll
-  for (int i = 0; i < NPX; ++i) acc[i] = 0.f;
-  for (int e = 0; e < 9; ++e) {
-    for (int d = 0; d < 9; ++d) {
-      // the pixels of this block that take tap pair (e, d): pred.0 tap e leaves the image, convB tap d comes back into it
-      unsigned m = 0;
-#pragma unroll
-      for (int i = 0; i < NPX; ++i) {
-        const int py = ys[i] + e / 3 - 1, px = xs[i] + e % 3 - 1;
-        const int sy = py + d / 3 - 1, sx = px + d % 3 - 1;
-        if (((used >> i) & 1u) && !(py >= 0 && py < h && px >= 0 && px < w) && sy >= 0 && sy < h && sx >= 0 && sx < w) m |= 1u << i;
-      }
-      if (!m) continue;
-      const float* pp = pairp + ((size_t)(e * 9 + d) * COND_C) * HID_C + co;
-#pragma unroll
-      for (int k = 0; k < COND_C / ACT_CB / 4; ++k) {
-        const int cb = part * (COND_C / ACT_CB / 4) + k;
-        float wv[ACT_CB];
-#pragma unroll
-        for (int c = 0; c < ACT_CB; ++c) wv[c] = pp[(size_t)(cb * ACT_CB + c) * HID_C];
-#pragma unroll
-        for (int i = 0; i < NPX; ++i) {
-          if (!((m >> i) & 1u)) continue;
-          const size_t off = act_offset(COND_C, h, w, b, cb * ACT_CB, ys[i] + e / 3 + d / 3 - 2, xs[i] + e % 3 + d % 3 - 2);
-          float v[ACT_CB];
-          if constexpr (EK == EK_F32) {
-#pragma unroll
-            for (int q = 0; q < ACT_CB / 4; ++q) {
-              const float4 t = reinterpret_cast<const float4*>(static_cast<const float*>(sa) + off)[q];
-              v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < ACT_CB / 8; ++q) {
-              const uint4 t = reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(sa) + off)[q];
-              const uint32_t u[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                v[8 * q + 2 * j] = EK == EK_BF16 ? bf16_to_f32(u[j] & 0xFFFFu) : f16_to_f32(u[j] & 0xFFFFu);
-                v[8 * q + 2 * j + 1] = EK == EK_BF16 ? bf16_to_f32(u[j] >> 16) : f16_to_f32(u[j] >> 16);
-              }
-            }
-          }
-          float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < ACT_CB; ++c) a4[c & 3] = fmaf(wv[c], v[c], a4[c & 3]);
-          acc[i] += (a4[0] + a4[1]) + (a4[2] + a4[3]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NPX; ++i) red[i][part][co] = acc[i];
-  __syncthreads();
-  if (part == 0) {
-#pragma unroll
-    for (int i = 0; i < NPX; ++i)
-      if (r0 + i < swin_ring_size(h, w))
-        bcorr[((size_t)b * swin_ring_stride(h, w) + r0 + i) * HID_C + co] = ((used >> i) & 1u) ? (red[i][0][co] + red[i][1][co]) + (red[i][2][co] + red[i][3][co]) : 0.f;
-  }
+  __shared__ float red[4][HID_C];
+  const int r = blockIdx.x, b = blockIdx.y;
+  int y, x;      // inverse of swin_ring_index
+  if (r < w) { y = 0; x = r; }
+  else if (r < 2 * w) { y = h - 1; x = r - w; }
+  else if (r < 2 * w + (h - 2)) { y = r - 2 * w + 1; x = 0; }
+  else { y = r - 2 * w - (h - 2) + 1; x = w - 1; }
+  const bool used = y < h && x < w && swin_ring_index(y, x, h, w) == r;      // (an index the image's ring does not use -- h == 1, w == 1 -- stays zero)
+  const float v = swin_bcorr_pixel<EK>(sa, pairp, b, used ? y : 0, used ? x : 0, h, w, false, red);
+  if (threadIdx.x < HID_C) bcorr[((size_t)b * swin_ring_stride(h, w) + r) * HID_C + threadIdx.x] = used ? v : 0.f;
 }
 
-// The same correction for the 2-byte kinds as four LINE convolutions on the matrix cores.  At a pixel of the top row every pred.0 tap of kernel row
+// The same correction as four LINE convolutions on the matrix cores (2-byte kinds: 32x32x16 MFMA; fp32 kind: 32x32x2).  At a pixel of the top row every pred.0 tap of kernel row
 // -1 leaves the image, whatever its column, and convB reaches back into row 0 only: the correction is a 1x5 convolution along row 0 with
 // K_top[u] = sum over ex + dx = u of P[(-1, ex)][(+1, dx)] (zero padding at the row's ends = convB's own padding); bottom row, left and right
 // column (rows 1 .. h-2) likewise.  kside: the four 5-tap kernels in MFMA fragment order [side][u][k-step][cout half][lane] x 8 elements
@@ -799,7 +729,7 @@ hipError_t launch_swin_bcorr(const void* sa, int ek, const float* pairp, const v
     return hipGetLastError();
   }
   // (the four entries behind the ring stay zero: cleared when the plan allocated the buffer)
-  const dim3 grid((unsigned)((swin_ring_size(h, w) + SWIN_BCORR_NPX - 1) / SWIN_BCORR_NPX), (unsigned)B);
+  const dim3 grid((unsigned)swin_ring_size(h, w), (unsigned)B);
   if (ek == EK_F32) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F32>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
   else if (ek == EK_BF16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_BF16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
   else if (ek == EK_F16) hipLaunchKernelGGL(swin_bcorr_kernel<EK_F16>, grid, dim3(256), 0, s, sa, pairp, bcorr, h, w);
