@@ -49,9 +49,16 @@ LAYERS = {"res": (1, 2, 9, 4), "res_nohoist": (1, 2, 3, 4), "swin": (1, 2, 5, 6,
 ALGO_BYTES_PER_PIXEL = {1: 320, 2: 640, 3: 1152, 4: 192, 5: 1536, 6: 1024, 7: 640, 9: 768}     # 9: y2 512 + conv3(cond) f16 128 + y3 128 (the split / fp32 modes keep the term in fp32)
 # MI355X_MICROARCH.md dense MFMA peaks.  f16x3 (split f16, DD_PREC_F16X3): every algorithmic multiply-add costs three f16 MFMA
 # multiply-adds (Whi.Phi + Whi.Plo + Wlo.Phi), so its ceiling in ALGORITHMIC FLOP/s is a third of the f16 peak
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16x3": 2500.0 / 3, "fp32": 157.3, "naive_fp32": 157.3}
-DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "f16x3": "f16x3 (f16 hi+lo operand pairs, fp32 tensors)", "fp32": "f32", "naive_fp32": "f32"}
-STORE_BYTES = {"bf16": 1, "f16": 1, "f16x3": 2, "fp32": 2, "naive_fp32": 2}      # multiples of the 2-byte activation terms of ALGO_BYTES_PER_PIXEL
+# f16r (refined f16, DD_PREC_F16R; dd_kernels.h): the two large convolutions -- 94 % of the flops -- run ONE f16 MFMA per product, so the f16 peak is
+# its ceiling (the split operands of conv1 and the second MFMA of "f16r_p4" touch 3 % of the flops each)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16r": 2500.0, "f16x3": 2500.0 / 3, "fp32": 157.3, "naive_fp32": 157.3}
+DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "f16r": "f16 (f16 MFMA operands, fp32 accumulation; refined mode: split-f16 thin layers, fp32 hand-over of y3 and conv3(cond))",
+              "f16x3": "f16x3 (f16 hi+lo operand pairs, fp32 tensors)", "fp32": "f32", "naive_fp32": "f32"}
+STORE_BYTES = {"bf16": 1, "f16": 1, "f16r": 1, "f16x3": 2, "fp32": 2, "naive_fp32": 2}      # multiples of the 2-byte activation terms of ALGO_BYTES_PER_PIXEL
+ALGO_BYTES_F16R_WIDE = {9: 512 + 256 + 256, 4: 256 + 64}      # f16r with "f16r_wide": conv3 reads y2 f16 + the hoisted term fp32 and writes y3 fp32; conv4 reads y3 fp32
+# what the line's value must hold: the north star's depth RMSE <= 1e-3 vs the reference's CPU path -- on this workload AND with the same latents decoded
+# at KITTI's depth range (FAR_LOG_SCALE below) -- with a margin (>= 1.5x)
+DEPTH_RMSE_TOL, DEPTH_RMSE_MARGIN = 1e-3, 1.5
 FAR_LOG_SCALE = 1.8      # decoder shifted to KITTI's depth range: every depth times e^1.8 (~0.5 .. 80 m); synth.make_state_dict(decoder_log_scale=)
 
 
@@ -324,7 +331,12 @@ def train_dp(args, dev, dist, world, rank):
             # activations the backward needs -- nothing is recomputed); the whole step's time is in the denominator
             "loop_fwd_bwd_tflops": round(3.0 * B * T * h * w * FPS / (elapsed / args.steps) / 1e12, 1),
             "backward_reads_kept_states": head._bound.backend.counter("trajectory_reuses") > 0,
-            "roofline": None, "cpu_baseline": None}
+            # the whole step against the MFMA peak: algorithmic flops of the loop's forward + data gradients + weight gradients (3 x B x T x P x F) over the
+            # step's wall time, everything included (FPN / codec in PyTorch, loss, optimizer, parameter refresh); per-kernel figures: profiles/
+            "roofline": {"bound": "mfma", "kernel": "whole training step (loop forward + dgrad + wgrad convolutions; no single dominant launch)",
+                         "achieved": round(3.0 * B * T * h * w * FPS / (elapsed / args.steps) / 1e12, 1), "peak": PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                         "frac": round(3.0 * B * T * h * w * FPS / (elapsed / args.steps) / 1e12 / PEAK_TFLOPS[args.precision], 4), "traffic": None},
+            "cpu_baseline": None}
 
 
 def main():
@@ -333,8 +345,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--precision", default=None, choices=sorted(PEAK_TFLOPS),
-                    help="default: bf16; f16 for the inference line of --variant swin (BASELINE config 5 names fp16, and the Swin denoiser's "
-                         "bf16 mode is OUT of the depth tolerance: RMSE 3.4e-3 at KITTI size against 4.3e-4 in f16 -- it is the training mode)")
+                    help="default: f16r (refined f16) -- the fastest mode whose depth RMSE vs the reference stays under 1e-3 with margin at KITTI's "
+                         "depth range (the bf16 / f16 modes do not: 2.9e-3 / 9e-4 there; they are timed beside it, `named_dtype_mode`); "
+                         "train-dp: bf16; f16 for the inference line of --variant swin (BASELINE config 5 names fp16)")
     ap.add_argument("--batch", type=int, default=4,
                     help="depth maps per GPU per step (throughput setting; 4 = the per-GPU batch of BASELINE config 4). "
                          "The B=1 latency of the reference's test() setting is reported alongside as `latency_b1`.")
@@ -366,7 +379,7 @@ def main():
     if args.streams is None:
         args.streams = 2
     if args.precision is None:
-        args.precision = "f16" if (args.variant == "swin" and args.mode != "train-dp") else "bf16"
+        args.precision = "bf16" if args.mode == "train-dp" else ("f16" if args.variant == "swin" else "f16r")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # invoked plainly: this process becomes the launcher of N ranks (each re-enters main() with WORLD_SIZE set)
@@ -423,7 +436,8 @@ def main():
     for kv in args.set:
         k_, v_ = kv.split("=", 1)
         be.set_option(k_, int(v_))
-    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision in ("f16", "f16x3"))))
+    f16r_wide = not any(kv.replace(" ", "") == "f16r_wide=0" for kv in args.set)
+    hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision in ("f16", "f16x3"))) or args.precision == "f16r")
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
     x_T = torch.from_numpy(inp["x_T"]).to(dev)
@@ -552,7 +566,7 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json is stale: taken on library sources {pt.get('lib_source_sha')}, these are {lib_source_sha()}"
             else:
                 # kernel names carry the element kind / mode: 0 fp32, 1 bf16, 2 f16, 3 = the default bf16 mode, 4 = split f16 (dd_kernels.h)
-                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,), "f16x3": (4,)}[args.precision]:
+                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,), "f16x3": (4,), "f16r": (5, 2)}[args.precision]:
                     if f"layer{dom}_ek{ekid}" in pt["kernels"]:
                         traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
                         traffic_note = f"rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/pmc_traffic.json, sources {pt.get('lib_source_sha')}, {pt.get('taken', '')})"
@@ -565,7 +579,9 @@ def main():
                 "traffic_unit": "HBM bytes per launch", "traffic_note": traffic_note,
                 # (Swin forward-only plans in their hoisted form: convA reads y2 and writes its result, 1024 B/pixel -- the condition map is not read in
                 # the loop; the 5x5 launch reads that result 512 + the hoisted term 128 and writes y3 128)
-                "algorithmic_bytes_per_launch": ({5: 1024, 7: 768}.get(dom, 0) if 6 in merged else ALGO_BYTES_PER_PIXEL.get(dom, 0)) * STORE_BYTES[args.precision] * nb * h * w,
+                "algorithmic_bytes_per_launch": ({5: 1024, 7: 768}.get(dom, 0) if 6 in merged else
+                                                 (ALGO_BYTES_F16R_WIDE.get(dom) if (args.precision == "f16r" and f16r_wide and dom in ALGO_BYTES_F16R_WIDE) else ALGO_BYTES_PER_PIXEL.get(dom, 0)))
+                                                * STORE_BYTES[args.precision] * nb * h * w,
                 "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": flops, "batch": nb, "streams_in_this_pass": 1,
                 "per_layer_avg_us": {str(l): round(per_layer[l][0] / max(per_layer[l][1], 1) * 1e3, 2) for l in per_layer},
                 "per_layer_frac_of_peak": {str(l): round(lflops[l] / (per_layer[l][0] / max(per_layer[l][1], 1) * 1e-3) / 1e12 / peak, 4) for l in per_layer},
@@ -593,18 +609,28 @@ def main():
     # ---- CPU baseline: torch-CPU port of the reference path, ONE map, this host's cores -----------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import reference_path as RP
         from oracle import torch_cpu_port as P
         sdt = P.to_torch_sd(sd)
         xc, cc = torch.from_numpy(inp["x_T"][:1]), torch.from_numpy(inp["cond"][:1])
+        use_ref = RP.available()          # the reference's own classes: /root/reference, or the bytecode staged from it (oracle/ref_py/build_ref.py -> oracle/_ref/py)
         with torch.no_grad():
             P.denoiser(sdt, xc, 950, cc, args.variant)        # warm-up (thread pool, oneDNN primitives)
-            c0 = time.perf_counter()
-            lat_cpu = P.ddim_loop(sdt, xc, cc, T, variant=args.variant)
-            d_cpu = P.decode(sdt, lat_cpu)
-            cpu_s = time.perf_counter() - c0
-        cpu = {"value": round(1.0 / cpu_s, 5), "unit": "maps/s", "cores": int(torch.get_num_threads()), "kind": "port",
-               "sample": f"1 map: {T}-step DDIM loop + decoder at latent 16x{h}x{w}, fp32 torch-CPU port of the reference ops "
-                         f"({cpu_s:.2f} s)",
+            if use_ref:
+                pipe_ref, codec_ref = RP.build(sd, args.variant)
+                c0 = time.perf_counter()
+                lat_cpu, d_cpu = RP.ddim_loop_and_decode(pipe_ref, codec_ref, xc, cc, T)      # CNNDDIMPipiline.__call__ + depth_transform.inv_t, as the head calls them
+                cpu_s = time.perf_counter() - c0
+            else:
+                c0 = time.perf_counter()
+                lat_cpu = P.ddim_loop(sdt, xc, cc, T, variant=args.variant)
+                d_cpu = P.decode(sdt, lat_cpu)
+                cpu_s = time.perf_counter() - c0
+        cpu = {"value": round(1.0 / cpu_s, 5), "unit": "maps/s", "cores": int(torch.get_num_threads()), "kind": "reference" if use_ref else "port",
+               "sample": f"1 map: {T}-step DDIM loop + decoder at latent 16x{h}x{w}, fp32, " +
+                         (f"the reference's own CNNDDIMPipiline / ScheduledCNNRefine / DDIMScheduler / DeepDepthTransformWithUpsampling classes ({RP.kind()})"
+                          if use_ref else "torch-CPU port of the reference ops (oracle/torch_cpu_port.py: no reference tree and no staged bytecode on this host)") +
+                         f" ({cpu_s:.2f} s)",
                "gflops": round(T * h * w * FPS / cpu_s / 1e9, 1)}
         # parity spot check of the timed GPU configuration against the same CPU result
         dg = depth[:1].cpu() if rank == 0 else None
@@ -616,9 +642,10 @@ def main():
         # the decoder ends in exp(-z): a 16-bit mode's depth error is RELATIVE, so its absolute RMSE grows with the depths decoded.  With
         # these untrained weights (the loop amplifies the latent to |x_0| ~ 5e2) the 1e-3 absolute RMSE of the north star holds up to:
         cpu["abs_rmse_1e3_holds_to_rms_depth_m"] = round(1e-3 / max(rel, 1e-12), 2)
-        if not args.no_abs_extra and args.variant == "res":
-            # the SAME latents decoded at KITTI's depth range (decoder bias shifted: every depth x e^1.8), and the abs-clean mode beside
-            # the timed one: split f16 (f16x3) -- throughput of the same step and its max-abs error, near and far range
+        if args.variant == "res":
+            # the SAME latents decoded at KITTI's depth range (decoder bias shifted: every depth x e^1.8) -- part of the parity gate below -- and,
+            # unless --no-abs-extra, two modes beside the timed one: the abs-clean split f16 (f16x3) and BASELINE.json's named dtype (bf16 operands):
+            # throughput of the same step and depth error, near and far range
             sd_far = synth.make_state_dict(7240, args.variant, decoder_log_scale=FAR_LOG_SCALE)
             bf = dda.HipDenoiser(dev, args.variant)
             bf.load_state_dict({k: v for k, v in sd_far.items() if k.startswith("depth_transform.")})
@@ -630,7 +657,36 @@ def main():
                                 "gpu_vs_cpu_depth_rmse": float(torch.sqrt(torch.mean((dg_far - d_cpu_far) ** 2))),
                                 "gpu_vs_cpu_depth_maxabs": float((dg_far - d_cpu_far).abs().max()),
                                 "gpu_vs_cpu_depth_rel_rmse": float(torch.sqrt(torch.mean(((dg_far - d_cpu_far) / d_cpu_far.clamp_min(1e-6)) ** 2)))}
-            if args.precision != "f16x3":
+            fr = cpu["far_range"]
+            cpu["rmse_gate"] = {"tolerance": DEPTH_RMSE_TOL, "required_margin": DEPTH_RMSE_MARGIN,
+                                "margin_near": round(DEPTH_RMSE_TOL / max(cpu["gpu_vs_cpu_depth_rmse"], 1e-12), 2),
+                                "margin_kitti_range": round(DEPTH_RMSE_TOL / max(fr["gpu_vs_cpu_depth_rmse"], 1e-12), 2)}
+            cpu["rmse_gate"]["holds_with_margin"] = bool(min(cpu["rmse_gate"]["margin_near"], cpu["rmse_gate"]["margin_kitti_range"]) >= DEPTH_RMSE_MARGIN)
+
+            def side_mode(prec):
+                """the same step in another precision: throughput + depth error near / far (same inputs, same CPU result)"""
+                xs_ = torch.empty_like(x_T)
+                for _ in range(2):
+                    be.encode(gt); be.denoise(x_T, cond, T, prec, out=xs_); ds_ = be.decode(xs_)
+                torch.cuda.synchronize(dev)
+                ns_ = max(3, args.steps // 4)
+                t3_ = time.perf_counter()
+                for _ in range(ns_):
+                    be.encode(gt); be.denoise(x_T, cond, T, prec, out=xs_); ds_ = be.decode(xs_)
+                torch.cuda.synchronize(dev)
+                el_ = time.perf_counter() - t3_
+                d1_, dfar_ = ds_[:1].cpu(), bf.decode(xs_[:1]).cpu()
+                return {"maps_per_s": round(B * ns_ / el_, 2), "ms_per_step": round(el_ / ns_ * 1e3, 3),
+                        "step_frac_of_peak": round(B * T * h * w * FPS * ns_ / el_ / 1e12 / PEAK_TFLOPS[prec], 4),
+                        "gpu_vs_cpu_depth_rmse": float(torch.sqrt(torch.mean((d1_ - d_cpu) ** 2))), "gpu_vs_cpu_depth_maxabs": float((d1_ - d_cpu).abs().max()),
+                        "far_range_depth_rmse": float(torch.sqrt(torch.mean((dfar_ - d_cpu_far) ** 2))), "far_range_depth_maxabs": float((dfar_ - d_cpu_far).abs().max())}
+            if not args.no_abs_extra and args.precision not in ("bf16", "fp32", "naive_fp32"):
+                nm = side_mode("bf16")
+                nm["what"] = ("the same step in BASELINE.json's named dtype: bf16 MFMA operands on the two large convolutions (precision bf16).  Its depth RMSE at "
+                              "KITTI's range is OUTSIDE the 1e-3 tolerance -- which is why it is not the line's value")
+                nm["inside_tolerance_at_kitti_range"] = bool(nm["far_range_depth_rmse"] <= DEPTH_RMSE_TOL)
+                cpu["named_dtype_mode"] = nm
+            if not args.no_abs_extra and args.precision != "f16x3":
                 xs = torch.empty_like(x_T)
                 for _ in range(2):
                     be.encode(gt); be.denoise(x_T, cond, T, "f16x3", out=xs); ds = be.decode(xs)
@@ -654,14 +710,15 @@ def main():
 
     # ---- training extra: one T-step loop forward + backward (dd_denoise + dd_denoise_backward) ----
     train = None
-    if (rank == 0 and world == 1 and args.precision in ("bf16", "f16") and args.variant == "res" and not args.no_train_extra):
+    tprec = "f16" if args.precision == "f16r" else args.precision      # (f16r is forward-only: its training sibling is the f16 mode)
+    if (rank == 0 and world == 1 and tprec in ("bf16", "f16") and args.variant == "res" and not args.no_train_extra):
         g0 = torch.randn_like(x_T[:1])
         xb, cb = x_T[:1].contiguous(), cond[:1].contiguous()
 
         def train_step():          # as modules._DenoiseLoopFn runs it: the forward keeps what the backward reads
             be.zero_grad()
-            be.denoise(xb, cb, T, args.precision, keep_trajectory=True)
-            be.denoise_backward(xb, cb, g0, T, args.precision, trajectory_ticket=be.last_trajectory_ticket)
+            be.denoise(xb, cb, T, tprec, keep_trajectory=True)
+            be.denoise_backward(xb, cb, g0, T, tprec, trajectory_ticket=be.last_trajectory_ticket)
         train_step()
         tt_ = []
         for _ in range(5):            # median of individually timed steps (the host-launch-bound B = 1 backward feels every host pause)
@@ -671,7 +728,7 @@ def main():
             torch.cuda.synchronize(dev)
             tt_.append((time.perf_counter() - t2) * 1e3)
         tms = sorted(tt_)[2]
-        train = {"what": f"{T}-step loop forward (states + activations kept) + backward (nothing recomputed), batch 1, {args.precision}", "ms": round(tms, 3),
+        train = {"what": f"{T}-step loop forward (states + activations kept) + backward (nothing recomputed), batch 1, {tprec}", "ms": round(tms, 3),
                  "tflops_fwd_dgrad_wgrad": round(3.0 * T * h * w * FPS / tms / 1e9, 1)}
 
     # ---- NLSPN refinement extra (BASELINE config 5 "+ NLSPN refine"): the 18-iteration spatial propagation at
@@ -695,7 +752,9 @@ def main():
         maps = maps_done                       # summed over the ranks by the census all-reduce
         n_world = dist.get_world_size() if dist is not None else 1
         out = {
-            "metric": f"depth-maps/sec ({T}-step DDIM, {args.size.upper()} {H}x{W} {args.precision}, B={B} maps per GPU per step)",
+            "metric": f"depth-maps/sec ({T}-step DDIM, {args.size.upper()} {H}x{W} {args.precision}, B={B} maps per GPU per step" +
+                      ("; depth RMSE vs the reference's CPU path <= 1e-3 on this workload AND at KITTI's depth range 0-80 m: see cpu_baseline.rmse_gate)"
+                       if (cpu is not None and cpu.get("rmse_gate", {}).get("holds_with_margin")) else ")"),
             "value": round(maps / elapsed, 3), "unit": "maps/s", "n_gpus": n_world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
@@ -713,11 +772,14 @@ def main():
         # is not a result.  fp32 additionally holds the 1e-3 abs reading.
         if cpu is not None and not args.no_parity_gate:
             rmse, mx = cpu["gpu_vs_cpu_depth_rmse"], cpu["gpu_vs_cpu_depth_maxabs"]
-            if args.precision in ("fp32", "naive_fp32", "f16x3") and "far_range" in cpu:
-                mx = max(mx, cpu["far_range"]["gpu_vs_cpu_depth_maxabs"])        # the abs-clean modes hold 1e-3 abs at KITTI's depth range too
-            if rmse > 1e-3 or (args.precision in ("fp32", "naive_fp32", "f16x3") and mx > 1e-3):
-                print(f"[bench] PARITY GATE FAILED: {args.precision} depth RMSE {rmse:.3e} (max abs {mx:.3e}) vs the CPU reference path exceeds 1e-3",
-                      file=sys.stderr, flush=True)
+            if "far_range" in cpu:
+                # the TIMED precision is held to the tolerance where KITTI lives too: RMSE for every mode, max-abs for the abs-clean ones
+                rmse = max(rmse, cpu["far_range"]["gpu_vs_cpu_depth_rmse"])
+                if args.precision in ("fp32", "naive_fp32", "f16x3"):
+                    mx = max(mx, cpu["far_range"]["gpu_vs_cpu_depth_maxabs"])
+            if rmse > DEPTH_RMSE_TOL or (args.precision in ("fp32", "naive_fp32", "f16x3") and mx > 1e-3):
+                print(f"[bench] PARITY GATE FAILED: {args.precision} depth RMSE {rmse:.3e} (worst of this workload and KITTI's depth range; max abs {mx:.3e}) "
+                      f"vs the CPU reference path exceeds {DEPTH_RMSE_TOL:g}", file=sys.stderr, flush=True)
                 if dist is not None:
                     dist.destroy_process_group()
                 raise SystemExit(3)

@@ -51,10 +51,12 @@ inline uint16_t host_f32_to_f16(float f) {
 }
 
 constexpr int NUM_EK = 3;     // weight images every convolution has: fp32, bf16, f16 (index = element kind)
-constexpr int NUM_WIMG = 4;   // ... the denoiser's forward convolutions have a fourth: the split-f16 image of the mode EK_F16S (index WIMG_SPLIT)
-constexpr int WIMG_SPLIT = 3;
-inline int wimg_kind(int slot) { return slot == WIMG_SPLIT ? (int)EK_F16S : slot; }     // image slot -> kind handed to the packers / conv_pack_geom2
+constexpr int NUM_WIMG = 5;   // ... the denoiser's forward convolutions have a fourth: the split-f16 image of the mode EK_F16S (index WIMG_SPLIT),
+constexpr int WIMG_SPLIT = 3; // and conv4 a fifth: the f16 image with the weights' lo halves stacked into its padding cout rows (EK_F16R, index WIMG_STACK)
+constexpr int WIMG_STACK = 4;
+inline int wimg_kind(int slot) { return slot == WIMG_SPLIT ? (int)EK_F16S : slot == WIMG_STACK ? (int)EK_F16R : slot; }     // image slot -> kind handed to the packers / conv_pack_geom2
 inline int wimg_slot(int kind) { return kind == EK_F16S ? WIMG_SPLIT : kind; }
+inline bool wimg_has(int slot, int fwd_layer) { return slot != WIMG_STACK || fwd_layer == 4; }     // which convolution carries which image
 // precision -> element kind / mode of the fused kernels.  DD_PREC_BF16 is the mode EK_BF16M (bf16 operands on the large convolutions, f16
 // storage and thin layers: dd_kernels.h) unless the handle option "bf16_storage" = 1 selects all-bf16 tensors (A/B and error budget).
 inline int ek_of_precision(int prec, bool bf16_pure) {
@@ -63,11 +65,13 @@ inline int ek_of_precision(int prec, bool bf16_pure) {
     case DD_PREC_BF16: return bf16_pure ? EK_BF16 : EK_BF16M;
     case DD_PREC_F16: return EK_F16;
     case DD_PREC_F16X3: return EK_F16S;
+    case DD_PREC_F16R: return EK_F16R;
     default: return -1;
   }
 }
 inline size_t ek_size(int ek) { return (ek == EK_F32 || ek == EK_F16S) ? 4 : 2; }     // bytes per STORED element (EK_F16S stores fp32)
 inline int thin_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek; }      // conv1 / conv4 / once-per-image conv3(cond): kernels and weights
+constexpr int DD_PREC_LAST = DD_PREC_F16R;
 
 constexpr int FPN_LEVELS = 4;
 constexpr int FPN_CIN_RES[FPN_LEVELS] = {64, 128, 256, 512};       // ResNet pyramid widths (reference ...res.py:31 in_channels)
@@ -130,6 +134,8 @@ struct Plan {
   DevBuf ttab, tt_scratch;   // Swin variant, hoisted form: E[t] border tables of the T loop steps [T][SWIN_TT_ROWS][64] (swin_ttab, dd_misc.hip) ...
   int64_t ttab_weights = -1; // ... and the parameter generation they were computed from
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
+  DevBuf ccond_raw;        // EK_F16R: the same as the split-f16 layer 8 leaves it (fp32, 8x32 tiles), when the loop's conv3 reads another order / type
+  bool wide = false, p4 = false;   // EK_F16R: options "f16r_wide" / "f16r_p4" as this plan was built with them
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
@@ -225,6 +231,11 @@ struct dd_handle_s {
   int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
   int big_tiles = -1;         // option "big_tiles": hoisted conv3 pair on 16x32 tiles: -1 = when the 8x32 tiles exceed the 512 resident slots, 0 / 1 = forced
   int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
+  int f16r_wide = 1;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as fp32 (0 = f16, as DD_PREC_F16)
+  int f16r_p4 = 0;            // DD_PREC_F16R: conv4's operand as an f16 pair as well (two MFMAs per tap)
+  bool split_ok = true;       // every forward convolution weight fits the split-f16 images (|w| x 256 inside f16): DD_PREC_F16X3 / DD_PREC_F16R refuse to run otherwise
+  DevBuf wmax;                // device route: bits of max |w| over the forward convolution weights (launch_max_abs)
+  int resident_slots = 512;   // workgroup slots the chip holds at two per CU (dd_create: 2 x multiProcessorCount): the big-tile rule and thin_slots' default
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   int64_t n_lane_calls = 0;
@@ -344,7 +355,8 @@ std::vector<WeightSpec> required_weights(int variant, int pyr = PYR_DEFAULT) {
 
 // Packed layout consumed by conv_igemm_kernel:
 //   [n_tile][cin_chunk][tap_group][tap_in_group][n (NT)][k (CK)]  of  W[cout][cin][dy][dx]   (zero beyond COUT; ks x ks taps)
-// returns false when a weight does not fit the split-f16 image (|w| x SPLIT_WSCALE beyond f16): dd_commit_weights turns that into an error
+// returns false when a weight does not fit the split-f16 image (|w| x SPLIT_WSCALE beyond f16): dd_commit_weights records it in
+// dd_handle_s::split_ok and the split modes (DD_PREC_F16X3 / DD_PREC_F16R) refuse to run on such parameters -- the other precisions are unaffected
 bool pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swizzle, std::vector<uint8_t>& out) {
   bool fits = true;
   const int ks = g.ks, n_tiles = g.cout_pad / g.nt, n_chunks = g.cin / g.ck, n_tg = ks * ks / g.tg;
@@ -369,6 +381,14 @@ bool pack_conv_weights(const float* w_oihw, const PackGeom& g, int ek, bool swiz
               const int piece_sw = swizzle ? (piece ^ ((row / rpb) & (ppp - 1))) : piece;
               const size_t idx = blk0 + (size_t)row * g.ck + (size_t)piece_sw * epp + within;
               const float v = (co < g.cout) ? w_oihw[(((size_t)co * g.cin + ci) * ks + dy) * ks + dx] : 0.f;
+              if (g.stack && co >= g.cout && co < 2 * g.cout) {
+                // stacked image (conv4, EK_F16R): cout row cout + c = the lo half of row c times STACK_LSCALE (pack_weights_kernel's arithmetic)
+                const float wv = w_oihw[(((size_t)(co - g.cout) * g.cin + ci) * ks + dy) * ks + dx];
+                if (!(std::fabs(wv) < 60000.f)) fits = false;
+                const uint16_t u = host_f32_to_f16((wv - (float)(_Float16)wv) * STACK_LSCALE);
+                std::memcpy(&out[idx * 2], &u, 2);
+                continue;
+              }
               if (planes == 2) {
                 // hi = f16(w * SPLIT_WSCALE), lo = f16(w * SPLIT_WSCALE - hi): the same arithmetic as pack_weights_kernel (dd_misc.hip)
                 const float vs = v * SPLIT_WSCALE;
@@ -418,6 +438,18 @@ int lane_count(dd_handle_t h, int B, int precision) {
   return S < 1 ? 1 : S;
 }
 
+// The split modes' preconditions: parameters that fit the split-f16 images (dd_commit_weights records it, for both routes); DD_PREC_F16R is built
+// for the Res denoiser
+int check_split(dd_handle_t h, int precision, const char* who) {
+  if (precision != DD_PREC_F16X3 && precision != DD_PREC_F16R) return DD_OK;
+  if (!h->split_ok)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": a convolution weight of magnitude >= 234 does not fit the split-f16 images (weights are scaled by 256 "
+                                       "into f16): DD_PREC_F16X3 / DD_PREC_F16R cannot run on these parameters; the other precisions can");
+  if (precision == DD_PREC_F16R && h->variant != DD_VARIANT_RES)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16R is built for DD_VARIANT_RES (Swin / MPViT denoiser: DD_PREC_F16 or DD_PREC_F16X3)");
+  return DD_OK;
+}
+
 // The condition map at latent size in the activation layout of `precision`: one buffer per (B, h, w, precision), shared by
 // all plans of that shape (graphs bake its address) and written in place by dd_condition.
 int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::shared_ptr<DevBuf>* out, int lane = 0) {
@@ -432,7 +464,7 @@ int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::share
       h->cond_bufs.erase(victim);
     }
     auto buf = std::make_shared<DevBuf>();
-    const size_t es = precision == DD_PREC_NAIVE_FP32 ? 4 : ek_size(ek_of_precision(precision, h->bf16_pure));
+    const size_t es = precision == DD_PREC_NAIVE_FP32 ? 4 : ek_size(cond_kind(ek_of_precision(precision, h->bf16_pure)));
     DD_HIP(buf->alloc((size_t)B * lh * lw * COND_C * es));
     it = h->cond_bufs.emplace(key, std::make_pair(buf, (uint64_t)0)).first;
   }
@@ -456,6 +488,7 @@ int want_hoist(dd_handle_t h, int precision, int T = 1, int keep = 0) {
     return (h->hoist_cond == 1 || ek != EK_F32) ? 1 : 0;
   }
   if (h->variant != DD_VARIANT_RES) return 0;
+  if (ek == EK_F16R) return 1;           // the mode IS the hoisted form: its condition map exists as fp32 for the once-per-image split conv3 only
   if (h->hoist_cond >= 0) return h->hoist_cond;
   return (ek == EK_BF16M || ek == EK_F16 || ek == EK_F16S) ? 1 : 0;
 }
@@ -496,7 +529,7 @@ bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
   const int ek = ek_of_precision(key.prec, h->bf16_pure);
   if (ek == EK_F32 || ek == EK_F16S) return false;
   if (h->big_tiles >= 0) return h->big_tiles != 0;
-  return (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > 512;
+  return (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > h->resident_slots;
 }
 inline int conv3c_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3C : 8; }
 inline int conv3h_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3H : 9; }
@@ -505,10 +538,17 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   auto it = h->plans.find(key);
   if (it != h->plans.end()) { it->second->last_use = ++h->tick; *out = it->second.get(); return DD_OK; }
   // keep at most 10 plans alive: evict the least recently used
-  while (h->plans.size() >= 10) {
-    auto victim = h->plans.begin();
-    for (auto j = h->plans.begin(); j != h->plans.end(); ++j)
-      if (j->second->last_use < victim->second->last_use) victim = j;
+  // (a plan whose kept trajectory is still owed a backward -- ticket unconsumed, parameters unchanged -- is not a victim, as in keep2_fits:
+  // evicting it would silently turn that backward into a recompute; with lanes a training loop holds keep + backward plans per lane)
+  const size_t cap = 10 + 2 * (size_t)(h->n_streams > 1 ? (h->n_streams < dd_handle_s::MAX_LANES ? h->n_streams : dd_handle_s::MAX_LANES) : 0);
+  while (h->plans.size() >= cap) {
+    auto victim = h->plans.end();
+    for (auto j = h->plans.begin(); j != h->plans.end(); ++j) {
+      const Plan& q = *j->second;
+      if (q.key.keep && q.traj_ticket != 0 && q.traj_weights == h->weights_serial && !q.traj_consumed) continue;
+      if (victim == h->plans.end() || q.last_use < victim->second->last_use) victim = j;
+    }
+    if (victim == h->plans.end()) break;           // every plan holds a live trajectory: grow rather than lose one
     if (h->last_once_plan == victim->second.get()) h->last_once_plan = nullptr;
     DD_HIP(hipDeviceSynchronize());
     h->plans.erase(victim);
@@ -533,6 +573,11 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   {
     const int th = conv_pack_geom2(conv3h_kid(h, key), pl->ek).th;
     DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
+    if (pl->ek == EK_F16R) {
+      pl->wide = h->f16r_wide != 0; pl->p4 = h->f16r_p4 != 0;
+      if (th != 8 || !pl->wide)      // the split layer 8 writes fp32 in the order of 8x32 tiles: reformatted unless that is what conv3 reads
+        DD_HIP(pl->ccond_raw.alloc((size_t)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) * 8 * 32 * HID_C * 4));
+    }
   }
   if (key.hoist && swin) {
     const int T1 = key.T > 0 ? key.T : 1;
@@ -547,7 +592,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
-  DD_HIP(pl->y3.alloc(ns * px * HID_C * es));
+  DD_HIP(pl->y3.alloc(ns * px * HID_C * ((pl->ek == EK_F16R && h->f16r_wide) ? 4 : es)));
   DD_HIP(pl->y4.alloc(ns * px * LATENT_C * 4));
   if (key.keep == 2) pl->kept_bytes = pl->y1.bytes + pl->y2.bytes + pl->y3.bytes + pl->y4.bytes + pl->sa.bytes + pl->sf.bytes;
   if (naive) {
@@ -599,6 +644,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   if (tvec == pl->tsteps.as<long long>() && t_bstride == 0 && t_base >= 0 && t_base < (int)pl->tsteps_host.size())
     p.t_known = clamp_t(pl->tsteps_host[t_base]);
   const int ek = pl->ek, tk = thin_kind(ek);    // mode; kind of conv1 / conv4
+  const bool rf = ek == EK_F16R;                // refined f16 (dd_kernels.h): split conv1, f16 conv2 / conv3 (fp32 hand-over when pl->wide), stacked conv4
   const int wk = ek == EK_F16S ? WIMG_SPLIT : opnd_kind(ek);    // weight image of the large convolutions (their operand kind; the split image in the split mode)
   // conv4 runs as the persistent streaming kernel of dd_thin.hip in the 2-byte modes (option "thin_stream", default on; the phase profiler
   // instruments the general kernel)
@@ -608,8 +654,9 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
       q.tiles_y = (k.h + conv_pack_geom2(kid, ek).th - 1) / conv_pack_geom2(kid, ek).th;
+      if (layer == 4 && rf) { q.persist_slots = h->thin_slots; return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
       if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
-      return launch_conv_igemm2(kid, ek, q, s);
+      return launch_conv_igemm2(kid, (rf && layer == 9 && !pl->wide) ? (int)EK_F16 : ek, q, s);      // (narrow EK_F16R: the f16 mode's conv3, f16 quads in, f16 out)
     };
     if (!h->layer_timing) return launch(cp);
     hipEvent_t a, b;
@@ -626,7 +673,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   void *sa_ = pl->slot(pl->sa, step), *sf_ = pl->slot(pl->sf, step);
   const float* y4_prev = static_cast<const float*>(pl->slot(pl->y4, step > 0 ? step - 1 : 0));     // read by the fused update of step - 1
   // conv1: state (+ fused DDIM update of the previous step) -> y1
-  p.in = x_in; p.wpack = h->L[0].wpack2[wimg_slot(tk)].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
+  p.in = x_in; p.wpack = h->L[0].wpack2[rf ? WIMG_SPLIT : wimg_slot(tk)].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
   p.stats_out = pl->stat_ptr(step, 0);
   p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
   p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
@@ -682,7 +729,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
-  p.in = y3_; p.wpack = h->L[3].wpack2[wimg_slot(tk)].p; p.bias = h->L[3].bias.as<float>(); p.out = y4_;
+  p.in = y3_; p.wpack = h->L[3].wpack2[rf ? WIMG_STACK : wimg_slot(tk)].p; p.bias = h->L[3].bias.as<float>(); p.out = y4_;
   p.stats_out = pl->stat_ptr(step, 3); p.stats_in = pl->stat_ptr(step, 2);
   p.gn_gamma = h->L[2].gamma.as<float>(); p.gn_beta = h->L[2].beta.as<float>();
   DD_HIP(timed_launch(4, p));
@@ -722,9 +769,19 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   ConvParams p{};
   p.B = k.B; p.h = k.h; p.w = k.w;
   p.tiles_x = (k.w + 31) / 32;
+  p.ablate = 0;
+  if (pl->ek == EK_F16R) {
+    // refined f16: the split-f16 layer 8 on the fp32 condition map (the term is exact to ~22 bits), fp32 in the order of 8x32 tiles; then into
+    // the order / element type the loop's conv3 reads, unless that is already it
+    p.tiles_y = (k.h + 7) / 8;
+    p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[WIMG_SPLIT].p; p.bias = h->zero_bias.as<float>();
+    p.out = pl->ccond_raw.p ? pl->ccond_raw.p : pl->ccond.p;
+    DD_HIP(launch_conv_igemm2(8, EK_F16S, p, s));
+    if (pl->ccond_raw.p) DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0, pl->wide ? 0 : 1, s));
+    return DD_OK;
+  }
   const int kid = conv3c_kid(h, k);
   p.tiles_y = (k.h + conv_pack_geom2(kid, pl->ek).th - 1) / conv_pack_geom2(kid, pl->ek).th;
-  p.ablate = 0;
   p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[wimg_slot(thin_kind(pl->ek))].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond.p;
   DD_HIP(launch_conv_igemm2(kid, pl->ek, p, s));
   return DD_OK;
@@ -743,6 +800,7 @@ int ensure_swin_w5(dd_handle_t h, hipStream_t s) {
   }
   DD_HIP(launch_swin_compose(h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->w5_oihw.as<float>(), h->pairp.as<float>(), h->kside.p, s));
   for (int wi = 0; wi < NUM_WIMG; ++wi) {
+    if (wi == WIMG_STACK) continue;
     const int ekk = wimg_kind(wi);
     const PackGeom g5 = conv_pack_geom2(SWIN_PRED5_H, ekk);
     int rc = ensure_bytes(h, h->w5pack[wi], pack_weights_bytes(g5, ekk)); if (rc) return rc;
@@ -788,22 +846,22 @@ int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h
   if (whole_B <= 0) whole_B = B;
   pl->cond_alias = nullptr;
   if (cond) {
-    if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
-    else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
+    if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+    else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
     if (h->fpn_cond == pl->cond) { h->fpn_cond.reset(); h->fpn_cond_key[3] = -1; }    // overwritten
   } else if (h->variant == DD_VARIANT_SWIN) {
     const int* k = h->fpn_cond_key;
     if (!h->fpn_cond || h->fpn_cond != h->fpn_out || k[0] != whole_B || k[1] != cond_h || k[2] != cond_w || k[3] != precision)
       return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, condition size and precision");
-    const char* src = static_cast<const char*>(h->fpn_out->p) + (size_t)img0 * COND_C * cond_h * cond_w * ek_size(store_kind(pl->ek));
-    DD_HIP(launch_upsample_blocked(src, pl->cond->p, store_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
+    const char* src = static_cast<const char*>(h->fpn_out->p) + (size_t)img0 * COND_C * cond_h * cond_w * ek_size(cond_kind(pl->ek));
+    DD_HIP(launch_upsample_blocked(src, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
   } else {
     const int* k = h->fpn_cond_key;
     const bool whole = img0 == 0 && B == whole_B;
     if (!h->fpn_cond || (whole && h->fpn_cond != pl->cond) || k[0] != whole_B || k[1] != lat_h || k[2] != lat_w || k[3] != precision)
       return h->fail(DD_ERR_STATE, "cond == NULL needs a preceding dd_condition with the same batch, latent size and precision");
     if (!whole)     // this lane's images inside the whole batch's condition map (per-image contiguous in the activation layout)
-      pl->cond_alias = static_cast<const char*>(h->fpn_cond->p) + (size_t)img0 * lat_h * lat_w * COND_C * ek_size(store_kind(pl->ek));
+      pl->cond_alias = static_cast<const char*>(h->fpn_cond->p) + (size_t)img0 * lat_h * lat_w * COND_C * ek_size(cond_kind(pl->ek));
   }
   if (pl->key.hoist) { int rc = h->variant == DD_VARIANT_SWIN ? enqueue_swin_hoist(h, pl, s) : enqueue_cond_conv(h, pl, s); if (rc) return rc; }
   return DD_OK;
@@ -870,6 +928,15 @@ int dd_create(dd_handle_t* out, int device, int variant) {
   dd_handle_t h = new dd_handle_s();
   h->device = device;
   h->variant = variant;
+  {
+    // two workgroups per CU is what the persistent conv4 fills and what the big-tile rule compares tile counts with: from the device, not
+    // from "256 CUs" (partitioned modes -- CPX / NPS -- and other parts expose other counts); the options override
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+      h->resident_slots = 2 * prop.multiProcessorCount;
+      h->thin_slots = h->resident_slots > 4096 ? 4096 : h->resident_slots;
+    }
+  }
   *out = h;
   return DD_OK;
 }
@@ -986,11 +1053,12 @@ int ensure_bytes(dd_handle_t h, DevBuf& dst, size_t bytes) {
 // host loops in dd_commit_weights (same geometries, same buffers), all on stream `s`.
 int pack_conv_layer_device(dd_handle_t h, ConvLayer& L, const float* w, int fwd_layer, int dgrad_layer, bool with_naive, hipStream_t s) {
   for (int wi = 0; wi < NUM_WIMG; ++wi) {
+    if (!wimg_has(wi, fwd_layer)) continue;
     const int ek = wimg_kind(wi);
     const PackGeom g2 = conv_pack_geom2(fwd_layer, ek);
     int rc = ensure_bytes(h, L.wpack2[wi], pack_weights_bytes(g2, ek)); if (rc) return rc;
     DD_HIP(launch_pack_weights(w, L.wpack2[wi].p, g2, ek, true, false, s));
-    if (wi == WIMG_SPLIT) continue;           // the split-f16 mode is forward only
+    if (wi == WIMG_SPLIT || wi == WIMG_STACK) continue;           // the split / refined f16 modes are forward only
     const PackGeom gt = conv_pack_geom2(dgrad_layer, ek);
     rc = ensure_bytes(h, L.wpackT[ek], pack_weights_bytes(gt, ek)); if (rc) return rc;
     DD_HIP(launch_pack_weights(w, L.wpackT[ek].p, gt, ek, true, true, s));
@@ -1043,7 +1111,21 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s) {
     DD_HIP(hipMemsetAsync(h->zero_bias.p, 0, COND_C * 4, s));
   }
   DD_HIP(launch_etab(h->L[2].w_oihw.as<float>(), h->emb.as<float>(), h->etab.as<float>(), s));
+  // do the forward weights fit the split-f16 images?  (the host route checks while packing; here: one max-|w| reduction per tensor)
+  if (!h->wmax.p) DD_HIP(h->wmax.alloc(sizeof(unsigned)));
+  DD_HIP(hipMemsetAsync(h->wmax.p, 0, sizeof(unsigned), s));
+  for (int l = 0; l < 4; ++l)
+    DD_HIP(launch_max_abs(D(std::string(kConvNames[l]) + ".weight"), (long long)kCouts[l] * kCins[l] * 9, h->wmax.as<unsigned>(), s));
+  if (h->variant == DD_VARIANT_SWIN) {
+    DD_HIP(launch_max_abs(D("model.upsample_fuse.convA.conv.weight"), (long long)COND_C * COND_C * 9, h->wmax.as<unsigned>(), s));
+    DD_HIP(launch_max_abs(D("model.upsample_fuse.convB.conv.weight"), (long long)COND_C * COND_C * 9, h->wmax.as<unsigned>(), s));
+  }
+  unsigned wbits = 0;
+  DD_HIP(hipMemcpyAsync(&wbits, h->wmax.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   DD_HIP(hipStreamSynchronize(s));     // as the host route: the new images are in place when the call returns, whatever stream runs next
+  float wmax_f;
+  std::memcpy(&wmax_f, &wbits, 4);
+  h->split_ok = wmax_f * SPLIT_WSCALE < 60000.f;       // (false for NaN)
   return DD_OK;
 }
 
@@ -1097,6 +1179,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     const std::vector<float>& w = h->host_w[std::string(conv_names[l]) + ".weight"];
     const std::vector<float>& b = h->host_w[std::string(conv_names[l]) + ".bias"];
     for (int wi = 0; wi < NUM_WIMG; ++wi) {
+      if (!wimg_has(wi, l + 1)) continue;
       std::vector<uint8_t> packed;
       if (!pack_conv_weights(w.data(), conv_pack_geom2(l + 1, wimg_kind(wi)), wimg_kind(wi), true, packed)) split_fits = false;
       int rc = upload(h, L.wpack2[wi], packed.data(), packed.size(), s);
@@ -1137,6 +1220,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       const std::vector<float>& w = h->host_w[std::string(names[i]) + ".weight"];
       const std::vector<float>& b = h->host_w[std::string(names[i]) + ".bias"];
       for (int wi = 0; wi < NUM_WIMG; ++wi) {
+        if (!wimg_has(wi, 5 + i)) continue;
         std::vector<uint8_t> packed;
         if (!pack_conv_weights(w.data(), conv_pack_geom2(5 + i, wimg_kind(wi)), wimg_kind(wi), true, packed)) split_fits = false;
         int rc = upload(h, L.wpack2[wi], packed.data(), packed.size(), s);
@@ -1159,10 +1243,8 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
     }
   }
-  if (do_model && !split_fits) {
-    return h->fail(DD_ERR_INVALID_ARG, "dd_commit_weights: a convolution weight of magnitude >= 234 does not fit the split-f16 image (DD_PREC_F16X3 scales weights by 256 into f16)");
-  }
   if (do_model) {
+    h->split_ok = split_fits;      // a weight of magnitude >= 234 does not fit the split-f16 images: only the split modes refuse such parameters (check_split)
     const std::vector<float>& e = h->host_w["model.time_embedding.weight"];
     int rc = upload(h, h->emb, e.data(), e.size() * 4, s); if (rc) return rc;
     DD_HIP(hipStreamSynchronize(s));
@@ -1388,6 +1470,12 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     }
     h->thin_stream = (int)value;
   }
+  else if (k == "f16r_wide" || k == "f16r_p4") {
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: " + k + " must be 0 or 1");
+    int& opt = k == "f16r_wide" ? h->f16r_wide : h->f16r_p4;
+    if (opt != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // buffers and graphs are laid out for it
+    opt = (int)value;
+  }
   else if (k == "phase_prof_buffer") h->prof_buf = reinterpret_cast<unsigned long long*>((uintptr_t)value);   // device pointer (0 = off)
   else if (k == "phase_prof_layer") h->prof_layer = (int)value;
   else if (k == "layer_timing") {
@@ -1453,7 +1541,7 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   if (with_neck && h->variant != DD_VARIANT_SWIN)
     return h->fail(DD_ERR_UNSUPPORTED, "dd_neck_condition: the HAHI neck kernels are built for the Swin-L (192/384/768/1536) and MPViT-small (128/216/288/288) pyramids of DD_VARIANT_SWIN");
   if (n_levels != FPN_LEVELS || !feats || !feat_h || !feat_w) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: expects 4 pyramid levels");
-  if (precision < DD_PREC_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16, f16 or f16x3");
+  if (precision < DD_PREC_FP32 || precision > DD_PREC_LAST) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: precision must be fp32, bf16, f16, f16x3 or f16r");
   if (B <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: B must be positive");
   for (int i = 0; i < FPN_LEVELS; ++i) {
     if (!feats[i] || feat_h[i] <= 0 || feat_w[i] <= 0) return h->fail(DD_ERR_INVALID_ARG, "dd_condition: null feature pointer or non-positive size");
@@ -1462,7 +1550,7 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   int ek = ek_of_precision(precision, h->bf16_pure);      // EK_BF16M: inner tensors bf16, the result (level-0 lateral conv) f16
-  if (ek == EK_F16S) ek = EK_F32;       // split-f16 mode: the once-per-image pyramid runs on the fp32 kernels (its result is an fp32 map either way)
+  if (ek == EK_F16S || ek == EK_F16R) ek = EK_F32;       // split / refined f16: the once-per-image pyramid runs on the fp32 kernels (both modes read an fp32 map)
   const int ok = opnd_kind(ek), sk = store_kind(ek);
   const size_t es = ek_size(ek);
   // workspace for this pyramid shape
@@ -1696,7 +1784,8 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (rc) return rc;
   if (!x_T || !x_0) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: num_inference_steps must be in [1, num_train_timesteps]");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_LAST) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise: unknown precision");
+  rc = check_split(h, precision, "dd_denoise"); if (rc) return rc;
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1746,7 +1835,8 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
   if (rc) return rc;
   if (!x_T || !states) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: null tensor pointer");
   if (T <= 0 || T > h->n_train) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: num_inference_steps must be in [1, num_train_timesteps]");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_LAST) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_trace: unknown precision");
+  rc = check_split(h, precision, "dd_denoise_trace"); if (rc) return rc;
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1794,7 +1884,8 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   int rc = check_common(h, B, lat_h, lat_w, cond_h, cond_w, false);
   if (rc) return rc;
   if (!x_t || !t || !eps) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: null pointer");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_LAST) return h->fail(DD_ERR_INVALID_ARG, "dd_denoise_once: unknown precision");
+  rc = check_split(h, precision, "dd_denoise_once"); if (rc) return rc;
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, "DD_VARIANT_SWIN runs on the fused kernels only (no naive path)");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -2034,9 +2125,9 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
 int check_bwd(dd_handle_t h, int precision, const char* who) {
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_SWIN has no unfused path (use fp32 / bf16 / f16)");
-  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_F16X3) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
-  if (precision == DD_PREC_F16X3)
-    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16X3 (split f16) is a forward-only parity mode; train in fp32 / bf16 / f16");
+  if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_LAST) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
+  if (precision == DD_PREC_F16X3 || precision == DD_PREC_F16R)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16X3 (split f16) and DD_PREC_F16R (refined f16) are forward-only modes; train in fp32 / bf16 / f16");
   return DD_OK;
 }
 
@@ -2264,7 +2355,7 @@ int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, v
   const void* src = nullptr; int C = 0; int ek = store_kind(pl->ek);
   if (n == "y1") { src = pl->y1.p; C = HID_C; }
   else if (n == "y2") { src = pl->y2.p; C = COND_C; }
-  else if (n == "y3") { src = pl->y3.p; C = HID_C; }
+  else if (n == "y3") { src = pl->y3.p; C = HID_C; if (pl->ek == EK_F16R && pl->wide) ek = EK_F32; }
   else if (n == "y4") { src = pl->y4.p; C = LATENT_C; ek = EK_F32; }
   else return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: unknown tensor '" + n + "'");
   if (numel != (int64_t)pl->key.B * C * pl->key.h * pl->key.w) return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: numel mismatch");
@@ -2298,6 +2389,7 @@ int dd_debug_weights_digest(dd_handle_t h, uint64_t* digest) {
       e = eat(L.wpackT[ek]); if (e != hipSuccess) return e;
     }
     { hipError_t e = eat(L.wpack2[WIMG_SPLIT]); if (e != hipSuccess) return e; }
+    { hipError_t e = eat(L.wpack2[WIMG_STACK]); if (e != hipSuccess) return e; }
     const DevBuf* rest[5] = {&L.bias, &L.w_oihw, &L.wT_oihw, &L.gamma, &L.beta};
     for (const DevBuf* b : rest) { hipError_t e = eat(*b); if (e != hipSuccess) return e; }
     return hipSuccess;

@@ -44,13 +44,15 @@ typedef hostemu::tr16_v2u dd_u32x2_t;
 // A 16-byte global store the compiler does NOT see (inline asm).  hipcc keeps ONE vmcnt for loads and stores; once a store is pending beside
 // loads it can no longer count ("counter out of order") and waits vmcnt(0) for the next load it needs -- which drains every prefetched load
 // of a software pipeline.  Hidden from it, the store only makes its counted waits for loads more conservative (the hardware counter is
-// higher than it assumes); the data is in memory by the end of the kernel like any other store.
+// higher than it assumes); the data is in memory by the end of the kernel like any other store.  The trailing `s_nop 1` keeps the two wait
+// states gfx940+ needs between a VMEM store of more than 64 bits and a VALU write to its data registers: the hazard recogniser does not
+// look into asm, and the next loop trip may recompute the same VGPRs right behind the store.
 typedef __attribute__((ext_vector_type(4))) float dd_f32x4_t;
 #define DD_GLOBAL_STORE16_UNTRACKED(ptr, v)                                                                                     \
   do {                                                                                                                          \
     const float4 f4_ = (v);                                                                                                     \
     const dd_f32x4_t v_ = {f4_.x, f4_.y, f4_.z, f4_.w};                                                                         \
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(v_) : "memory");                                            \
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v_) : "memory");                                   \
   } while (0)
 // bookkeeping for the host model only: n ordinary global loads were just issued by this wave (they count in vmcnt)
 #define DD_VMEM_LOADS_ISSUED(n) ((void)0)

@@ -907,8 +907,19 @@ static hipError_t launch_layer2_split(int layer, const ConvParams& p, hipStream_
     default: return hipErrorInvalidValue;
   }
 }
+// EK_F16R (refined f16): conv1 and the hoisted conv3 have their own instantiations; everything else is the f16 mode's kernel (the split-f16
+// layer 8 and the stacked conv4 are launched by dd_api.cpp under their own kinds / launchers)
+static hipError_t launch_layer2_refined(int layer, const ConvParams& p, hipStream_t s) {
+  switch (layer) {
+    case 1: return launch_one2<EK_F16R, 1>(p, s);
+    case 9: return launch_one2<EK_F16R, 9>(p, s);
+    case BIG_CONV3H: return launch_one2<EK_F16R, BIG_CONV3H>(p, s);
+    default: return launch_layer2<EK_F16>(layer, p, s);
+  }
+}
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s) {
   switch (ek) {
+    case EK_F16R: return launch_layer2_refined(layer, p, s);
     case EK_F16S: return launch_layer2_split(layer, p, s);
     case EK_F32: return launch_layer2<EK_F32>(layer, p, s);
     case EK_BF16: return launch_layer2<EK_BF16>(layer, p, s);
@@ -920,7 +931,7 @@ hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_
 
 template <int EK, int LAYER> static PackGeom geom2_of() {
   using C = Cfg2<EK, LAYER>;
-  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH, C::KS, C::NPL};
+  return PackGeom{C::CIN, C::COUT, C::COUT_PAD, C::CK, C::TG, C::NT, C::TH, C::KS, C::NPL, 0};
 }
 template <int EK> static PackGeom geom2_layer(int layer) {
   switch (layer) {
@@ -998,6 +1009,12 @@ static PackGeom geom2_layer_split(int layer) {
 }
 PackGeom conv_pack_geom2(int layer, int ek) {
   switch (ek) {
+    case EK_F16R: {      // conv1: the split image; conv4: the f16 geometry with the lo halves stacked into the padding cout rows; else f16
+      if (layer == 1) return geom2_of<EK_F16S, 1>();
+      PackGeom g = geom2_layer<EK_F16>(layer);
+      if (layer == 4) g.stack = 1;
+      return g;
+    }
     case EK_F16S: return geom2_layer_split(layer);
     case EK_F32: return geom2_layer<EK_F32>(layer);
     case EK_BF16: case EK_BF16M: return geom2_layer<EK_BF16>(layer);     // 2-byte kinds share one geometry

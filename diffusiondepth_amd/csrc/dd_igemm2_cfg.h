@@ -90,12 +90,17 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // EKM_ == EK_F16S (split f16, DD_PREC_F16X3; dd_kernels.h): tensors in HBM are fp32 (the fp32 mode's layouts), the LDS patch and the
   // packed weights carry TWO f16 planes (hi, lo) and every (weight, pixel) fragment pair costs three MFMAs.  Instantiated for the
   // denoiser's layers 1..9 only; one tiling for all of them: 16-channel chunks, 3 taps per stage (conv1: 9), 64-cout workgroup tiles.
-  static constexpr bool SPLIT = EKM_ == EK_F16S;
+  // EKM_ == EK_F16R (refined f16, DD_PREC_F16R; dd_kernels.h): instantiated for the layers whose kernel differs from the f16 mode's only --
+  // conv1 (split operands as in EK_F16S, but y1 stored f16) and the hoisted conv3 (layer 9 / BIG_CONV3H: f16 operands and input, the hoisted
+  // term read as fp32, y3 stored fp32); every other layer of the mode runs its EK_F16 (conv2, conv4 via dd_thin.hip) or EK_F16S (layer 8) form.
+  static constexpr bool RF = EKM_ == EK_F16R;
+  static_assert(!RF || LAYER_ == 1 || LAYER_ == 9, "EK_F16R is instantiated for conv1 and the hoisted conv3 only");
+  static constexpr bool SPLIT = EKM_ == EK_F16S || (RF && LAYER_ == 1);
   static constexpr int NPL = SPLIT ? 2 : 1;                    // operand planes in LDS / in a packed weight stage
-  static constexpr int EK = MX ? (int)EK_BF16 : SPLIT ? (int)EK_F16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
+  static constexpr int EK = MX ? (int)EK_BF16 : (SPLIT || RF) ? (int)EK_F16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
   static constexpr int LAYER = LAYER_;
   static constexpr int IN_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)
-  static constexpr int OUT_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
+  static constexpr int OUT_K = RF ? (LAYER_ == 1 ? (int)EK_F16 : (int)EK_F32) : SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
   static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
   static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 9), "EK_F16S is instantiated for the denoiser's layers only");
   static_assert(!SPLIT || LAYER_ID_ != SWIN_PRED_H, "split f16: the hoisted Swin plans always run the 5x5 form");
@@ -155,7 +160,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr bool STATS = !(LAYER == 5 || LAYER == 6 || LAYER == 8 || LAYER >= 10);   // a GroupNorm follows this convolution
   static constexpr bool ADD_C = (LAYER == 9);                  // epilogue adds the hoisted condition / embedding terms
   static constexpr bool ADD_ACC = ADD_C || ADD_T;              // accumulators start at the hoisted per-image term (ConvParams::cadd)
-  static constexpr bool CADD16 = DD_CADD_F16 && ESZ == 2 && !SPLIT && (LAYER == 8 || LAYER == 9 || ADD_T);   // the hoisted term travels as f16
+  static constexpr bool CADD16 = DD_CADD_F16 && ESZ == 2 && !SPLIT && !RF && (LAYER == 8 || LAYER == 9 || ADD_T);   // the hoisted term travels as f16
   // conv1 / conv4 are latency-bound (18 MFMAs per 32-pixel block): 8 waves of one block each shorten every wave's
   // dependent chain (measured: 4x32 tiles with 4 waves were no faster for conv1 and slower for conv4 - more halo and
   // weight traffic); conv2 / conv3 and the Swin convs keep 4 waves x 2 blocks (fewer LDS reads per MFMA)
@@ -166,7 +171,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int WN = NT / 32;
   static constexpr int PRO = HOIST_A ? PRO_GN : (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1 || SPLIT) ? 4 : ESZ;
-  static constexpr int OUT_ESZ = (LAYER == 4 || LAYER == 8 || LAYER == 23 || SPLIT) ? 4 : ESZ;
+  static constexpr int OUT_ESZ = RF ? (LAYER == 1 ? 2 : 4) : (LAYER == 4 || LAYER == 8 || LAYER == 23 || SPLIT) ? 4 : ESZ;
   static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
   static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
   static constexpr int PPP = ROWB / 16;

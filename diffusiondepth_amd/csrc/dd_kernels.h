@@ -43,9 +43,24 @@ constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2
 // epilogue multiplies the accumulators by the exact inverse.  (gfx950's f16 MFMA honours subnormal inputs -- tools/micro/f16_denorm_probe.hip,
 // profiles/r03_run1_f16_denorm_probe.txt -- so the scaling buys bits for small values, it is not needed for correctness.)  It is the
 // abs-1e-3-on-depth mode at ~1/3 of the 16-bit MFMA rate (5x the fp32-operand MFMA rate): DESIGN.md section 4.
-enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3, EK_F16S = 4 };
-__host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : ek == EK_F16S ? (int)EK_F16 : ek; }    // MFMA operands of the large convolutions / gradients
-__host__ __device__ constexpr int store_kind(int ek) { return ek == EK_BF16M ? (int)EK_F16 : ek == EK_F16S ? (int)EK_F32 : ek; }    // y1 / y2 / y3 / condition map in HBM
+// EK_F16R is the third MODE: "refined f16" (DD_PREC_F16R; round 4) -- the 16-bit mode that holds the depth tolerance at KITTI's depth range.
+// tools/bf16_error_budget.py --log-scale 1.8 shows that the f16 mode's depth error (1.0e-3 RMSE at 0.5..60 m) is NOT made by the two large
+// convolutions (their f16 operands and weights: 2.1e-4 / 3.2e-4) but by what surrounds them: the once-per-image conv3(cond) on f16 operands
+// (4.9e-4) and its f16 storage (3.6e-4), conv4's weights (4.4e-4) and operand (3.3e-4), y3's f16 storage (3.5e-4), conv1's weights
+// (2.4e-4).  Those are 6 % of the FLOPs and HBM-bound, so they are made exact where that is (nearly) free:
+//   conv1            split operands hi + lo (three MFMAs on 3 % of the FLOPs; the kernel is bound by memory), y1 stored f16 as before
+//   conv2, conv3     the f16 kernels, unchanged: single MFMA per product
+//   conv3(cond)      once per image on the split-f16 kernel from the fp32 condition map; the term stays fp32 (option "f16r_wide")
+//   y3               stored fp32 ("f16r_wide"): +128 B per pixel and step on each side of the conv3 / conv4 boundary
+//   conv4            weights as an f16 pair hi + lo IN ONE MFMA: the 32 x 32 x 16 instruction has 32 cout rows and conv4 16 couts, so rows
+//                    16..31 of the A operand -- zero padding until now -- carry lo * 2^11 and the epilogue adds the two accumulator halves
+//                    (lane-local: register quads q and q + 2); option "f16r_p4": the operand relu(gn3(y3)) as a pair as well (two MFMAs)
+// Forward only, Res denoiser; DESIGN.md section 4.
+enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3, EK_F16S = 4, EK_F16R = 5 };
+__host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : (ek == EK_F16S || ek == EK_F16R) ? (int)EK_F16 : ek; }    // MFMA operands of the large convolutions / gradients
+__host__ __device__ constexpr int store_kind(int ek) { return (ek == EK_BF16M || ek == EK_F16R) ? (int)EK_F16 : ek == EK_F16S ? (int)EK_F32 : ek; }    // y1 / y2 (/ y3) in HBM
+__host__ __device__ constexpr int cond_kind(int ek) { return ek == EK_F16R ? (int)EK_F32 : store_kind(ek); }       // the condition map at latent size (EK_F16R: fp32, read once per image by the split conv3(cond))
+constexpr float STACK_LSCALE = 2048.f;    // 2^11: conv4's stacked weight image (EK_F16R): rows 16..31 = f16((w - f16(w)) * 2^11), the lo half at full f16 precision
 constexpr float SPLIT_WSCALE = 256.f;     // 2^8: default-initialised 3x3 weights (|w| <= 1/sqrt(9 Cin) ~ 0.02..0.08) land at ~5..20, their lo halves at ~2^-9
 constexpr float SPLIT_PSCALE = 16.f;      // 2^4: activations behind a GroupNorm + ReLU (+ condition map + E[t]); overflow only beyond |v| = 4094
 __host__ __device__ constexpr float split_pscale(int pro) { return (pro == 1 /* PRO_GN */ || pro == 2 /* PRO_GN_ADD */) ? SPLIT_PSCALE : 1.f; }
@@ -144,17 +159,24 @@ inline int persist_grid(int B, int tiles_per_img, int slots) {
   if (n > tiles_per_img) n = tiles_per_img;
   return B * n;
 }
-struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks, planes; };   // th = output tile height (tile width is 32), ks = kernel size,
-                                                                            // planes = 2: split f16 image, every stage block = [hi | lo]
+struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks, planes, stack; };   // th = output tile height (tile width is 32), ks = kernel size,
+                                                                            // planes = 2: split f16 image, every stage block = [hi | lo];
+                                                                            // stack = 1 (conv4, EK_F16R): cout rows cout..2 cout-1 = the lo halves times STACK_LSCALE
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
 // conv4 (64 -> 16) as a persistent streaming kernel (dd_thin.hip): same ConvParams and packed weights as layer 4; ek = EK_F16 / EK_BF16
-hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s);
+//   stack = the stacked hi / lo weight image (EK_F16R); in32 = y3 arrives as fp32; psplit = the operand as an f16 pair too (stack only)
+hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack = false, bool in32 = false, bool psplit = false);
+// EK_F16R: the once-per-image term conv3(cond), left by the split-f16 layer 8 in the accumulator-fragment order of 8x32 tiles (fp32), into
+// the order / element type the loop's conv3 reads: 8x32 or 16x32 tiles (big), fp32 or f16 quads (dd_misc.hip)
+hipError_t launch_cadd_reformat(const float* src, void* dst, int B, int h, int w, int big, int out_f16, hipStream_t s);
 PackGeom conv_pack_geom2(int layer, int ek);
 
 // ---- weights into kernel layout on the device (dd_misc.hip): the packed image of pack_conv_weights() in dd_api.cpp, bit for bit ----
 size_t pack_weights_bytes(const PackGeom& g, int ek);
 hipError_t launch_pack_weights(const float* src_oihw, void* dst, const PackGeom& g, int ek, bool swizzle, bool transposed, hipStream_t s);
 hipError_t launch_transpose_flip(const float* w, float* wt, int cout, int cin, int kk, hipStream_t s);
+// *out_bits = max(*out_bits, bits of max |w|) (non-negative floats order like their bit patterns; NaN sorts above every finite value)
+hipError_t launch_max_abs(const float* w, long long n, unsigned* out_bits, hipStream_t s);
 
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------
 // dst layout: plain NHWC when blocked == 0 (naive path), else the activation layout of dd_elem.h

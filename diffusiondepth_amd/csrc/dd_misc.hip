@@ -1053,6 +1053,12 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
   float v = 0.f;
   if (co < g.cout)
     v = transposed ? src[((size_t)ci * g.cout + co) * kk + (kk - 1 - tap)] : src[((size_t)co * g.cin + ci) * kk + tap];
+  if (g.stack && co >= g.cout && co < 2 * g.cout) {
+    // stacked image (conv4, EK_F16R): row cout + c = the lo half of row c, times STACK_LSCALE -- the host packer's arithmetic
+    const float wv = src[((size_t)(co - g.cout) * g.cin + ci) * kk + tap];
+    reinterpret_cast<uint16_t*>(dst)[idx] = (uint16_t)f32_to_f16((wv - f16_to_f32(f32_to_f16(wv))) * STACK_LSCALE);
+    return;
+  }
   if (g.planes > 1) {
     // hi = f16(w * SPLIT_WSCALE), lo = f16(w * SPLIT_WSCALE - hi): the arithmetic of the host packer (pack_conv_weights in dd_api.cpp)
     const float vs = v * SPLIT_WSCALE;
@@ -1070,6 +1076,60 @@ hipError_t launch_pack_weights(const float* src, void* dst, const PackGeom& g, i
   const long long n_el = (long long)(pack_weights_bytes(g, ek) / (ek == EK_F32 ? 4 : 2));
   hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, s, src, dst, g, ek, swizzle ? 1 : 0,
                      transposed ? 1 : 0, n_el);
+  return hipGetLastError();
+}
+
+// max |w| of a tensor, as the bits of a non-negative float (atomicMax on unsigned keeps the order): the device route's twin of the host
+// packer's "fits the split-f16 image" check (dd_api.cpp: |w| x SPLIT_WSCALE must stay below f16's range)
+__global__ void __launch_bounds__(256) max_abs_kernel(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float a = fabsf(w[i]);
+    m = (a > m || a != a) ? a : m;            // a NaN weight counts as "does not fit" (its bit pattern is above every finite value's)
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off, 64); m = (o > m || o != o) ? o : m; }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
+}
+hipError_t launch_max_abs(const float* w, long long n, unsigned* out_bits, hipStream_t s) {
+  const unsigned nb = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(max_abs_kernel, dim3(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)), dim3(256), 0, s, w, n, out_bits);
+  return hipGetLastError();
+}
+
+// EK_F16R: conv3(cond) from the accumulator-fragment order of 8x32 tiles (fp32; what the split-f16 layer 8 writes: entry
+// ((((tile * 4 + wave) * 2 + n) * 2 + m) * 4 + q) * 64 + lane = couts 32n + 8q + 4g .. +3 of pixel (8 ty + 2 wave + m, 32 tx + li), lane = 32g + li)
+// into the order of the loop's conv3 tiles -- 8x32 (WM = 2) or 16x32 (WM = 4: pixel row 16 ty + 4 wave + m) -- as fp32 or f16 quads.
+// One thread per destination entry; rows of a 16-row tile below the source's last tile row read as zero (never used: outside the image).
+__global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __restrict__ src, void* __restrict__ dst, int B, int h, int w,
+                                                            int big, int out_f16, long long n_entries) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_entries) return;
+  const int WM = big ? 4 : 2, TH = big ? 16 : 8;
+  const int tiles_x = (w + 31) / 32, tiles_y = (h + TH - 1) / TH, stiles_y = (h + 7) / 8;
+  const int lane = (int)(e & 63), q = (int)((e >> 6) & 3);
+  long long r = e >> 8;
+  const int m = (int)(r % WM); r /= WM;
+  const int n = (int)(r & 1); r >>= 1;
+  const int wave = (int)(r & 3); r >>= 2;
+  const int tile = (int)r;
+  const int b = tile / (tiles_x * tiles_y), trem = tile - b * tiles_x * tiles_y;
+  const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+  const int y = ty * TH + wave * WM + m;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (y < stiles_y * 8) {
+    const int sty = y >> 3, swave = (y & 7) >> 1, sm = y & 1;
+    const long long stile = ((long long)b * stiles_y + sty) * tiles_x + tx;
+    v = src[((((stile * 4 + swave) * 2 + n) * 2 + sm) * 4 + q) * 64 + lane];
+  }
+  if (out_f16) reinterpret_cast<uint2*>(dst)[e] = make_uint2(pack2<EK_F16>(v.x, v.y), pack2<EK_F16>(v.z, v.w));
+  else reinterpret_cast<float4*>(dst)[e] = v;
+}
+hipError_t launch_cadd_reformat(const float* src, void* dst, int B, int h, int w, int big, int out_f16, hipStream_t s) {
+  const int TH = big ? 16 : 8;
+  const long long n_entries = (long long)B * ((h + TH - 1) / TH) * ((w + 31) / 32) * TH * 32 * (HID_C / 4);
+  hipLaunchKernelGGL(cadd_reformat_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(src), dst, B, h, w,
+                     big, out_f16, n_entries);
   return hipGetLastError();
 }
 

@@ -15,6 +15,13 @@
 //     workgroup are in flight all the time (Little: two workgroups per CU x 256 CUs x 43 KB = 22 MB against 8 TB/s x ~2.5 us);
 //   * no LDS-DMA, no counted waits: all loads are ordinary loads tracked by the compiler; workgroup barriers are raw `s_barrier`s behind an
 //     explicit `s_waitcnt lgkmcnt(0)` (a __syncthreads() would drain the prefetched loads: vmcnt(0)).
+// Round 4, the refined-f16 mode (EK_F16R, dd_kernels.h) -- three template switches on the same pipeline:
+//   STACK   the packed weight image carries an f16 PAIR per weight in ONE MFMA: the 32x32x16 instruction has 32 cout rows, conv4 has 16 couts, so rows
+//           16..31 (zero padding in the plain image) hold f16((w - f16(w)) * 2^11) and the epilogue adds accumulator quads q and q + 2 (lane-local).
+//           Same MFMA count, same LDS traffic; conv4's weight rounding -- the largest single term of the f16 mode's depth error -- is gone.
+//   IN32    y3 arrives as fp32 (no f16 rounding of the tensor in front of GroupNorm 3): two 16-byte loads per staging item
+//   PSPLIT  the operand relu(gn3(y3)) as an f16 pair as well (scaled by 2^4 so that lo halves stay normal): a second LDS plane per patch buffer and
+//           a second MFMA per tap against the same stacked weight fragment -- [Whi; Wlo] . (Phi + Plo) = all four partial products
 // Same arithmetic as layer 4 of dd_igemm2.hip: the packed weight image of that layer (16-channel chunks, nine taps per stage, 32 cout rows,
 // swizzle pre-applied) is used as it is, accumulation order per output is (chunk, tap), the GroupNorm table is computed by the same fp64
 // expressions.  Only the order of the fp32 per-lane partial sums of the NEXT GroupNorm's statistics differs (more pixels per lane).
@@ -30,20 +37,28 @@ constexpr int CK = 16, NCH = CIN / CK, ROWB = CK * 2, PPP = ROWB / 16, RPB = 256
 constexpr int THREADS = 512, WAVES = 8;
 constexpr int W_STAGE = 9 * NROW * ROWB;                        // 9216 B per chunk
 constexpr int W_BYTES = NCH * W_STAGE;                          // 36864 B, resident
-constexpr int PATCH_BYTES = PH * PW * ROWB;                     // 10880 B per chunk
+constexpr int PATCH_PLANE = PH * PW * ROWB;                     // 10880 B per chunk and operand plane
 constexpr int ITEMS = PH * PW * PPP;                            // 680 sixteen-byte pieces per chunk
 constexpr int NIT = (ITEMS + THREADS - 1) / THREADS;            // 2
-constexpr int TAB_OFF = W_BYTES + 2 * PATCH_BYTES;
-constexpr int SMEM_BYTES = TAB_OFF + (2 * CIN + NROW) * 4 + WAVES * 8 * 8;
+constexpr int TAB_BYTES = (2 * CIN + NROW) * 4 + WAVES * 8 * 8;
+constexpr int smem_bytes(bool psplit) { return W_BYTES + 2 * (psplit ? 2 : 1) * PATCH_PLANE + TAB_BYTES; }
+static_assert(smem_bytes(true) <= 80 * 1024, "two workgroups per CU");
 static_assert(NCH == 4 && NIT == 2 && (NCH % 2) == 0, "rolling prefetch below is written for four chunks");
 static_assert(Cfg2<EK_F16, 4>::CK == CK && Cfg2<EK_F16, 4>::TG == 9 && Cfg2<EK_F16, 4>::NT == NROW && Cfg2<EK_F16, 4>::W_BYTES == W_STAGE,
               "the packed weight image of layer 4 (dd_igemm2_cfg.h, DD_C4_CK16) is read as it is");
 }  // namespace thin
 
-template <int EK>
+template <int EK, bool STACK, bool IN32, bool PSPLIT>
 __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvParams p) {
   using namespace thin;
   static_assert(EK == EK_F16 || EK == EK_BF16, "2-byte kinds");
+  static_assert(EK == EK_F16 || !(STACK || IN32 || PSPLIT), "the refined forms are f16 kernels");
+  static_assert(STACK || !PSPLIT, "the operand pair runs against the stacked weight image");
+  constexpr int PATCH_BYTES = (PSPLIT ? 2 : 1) * PATCH_PLANE;
+  constexpr int TAB_OFF = W_BYTES + 2 * PATCH_BYTES;
+  constexpr int NLD = IN32 ? 2 : 1;                    // 16-byte loads per staging item (8 channels)
+  constexpr int IN_ESZ = IN32 ? 4 : 2;
+  constexpr float PSC = PSPLIT ? SPLIT_PSCALE : 1.f;   // the patch is carried times 2^4 (exact; relu commutes), the epilogue divides
   DD_DYN_SMEM(smem);
   float* tab_a = reinterpret_cast<float*>(smem + TAB_OFF);
   float* tab_b = tab_a + CIN;
@@ -90,8 +105,8 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
       double var = gs.y * inv_cnt - mean * mean;
       var = var > 0.0 ? var : 0.0;
       const double a = (double)my_gamma / sqrt(var + (double)GN_EPS);
-      tab_a[tid] = (float)a;
-      tab_b[tid] = (float)((double)my_beta - mean * a);
+      tab_a[tid] = (float)a * PSC;
+      tab_b[tid] = (float)((double)my_beta - mean * a) * PSC;
     }
   }
 
@@ -108,7 +123,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     if (it < ITEMS) m_valid |= 1u << u;
     lds_off[u] = pp * ROWB + ((jfix << 4) ^ swz16<RPB, PPP>(pc_[u]));
   }
-  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * CIN * 2;
+  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * CIN * IN_ESZ;
   // geometry of a tile: clamped pixel offsets of this thread's items and their inside-the-image mask
   auto geometry = [&](int t_local, int* po, unsigned& mi) {
     const int ty = t_local / p.tiles_x, tx = t_local - ty * p.tiles_x;
@@ -136,14 +151,20 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   };
   bool has_next = next_geometry();
 
-  uint4 raw[NCH][NIT];
-  auto load_chunk = [&](int c, const int* po) {        // channel-blocked y3: [B][2][h][w][32]
+  // raw-input register slots.  f16 input: one slot per chunk, a chunk's slot is refilled with the NEXT tile's same chunk (four stages ahead).
+  // fp32 input (IN32: twice the registers per chunk): a ring of two slots, chunk j of the running sequence (tile * 4 + chunk) in slot j & 1,
+  // refilled two stages ahead -- the same ~43 KB per workgroup in flight, and the kernel stays inside 128 VGPRs (four waves per SIMD).
+  constexpr int NSLOT = IN32 ? 2 : NCH;
+  uint4 raw[NSLOT][NIT][NLD];
+  auto load_chunk = [&](int c, int slot, const int* po) {        // channel-blocked y3: [B][2][h][w][32]
     const int cbase = c * CK + jfix * EPP;
     const size_t off0 = (size_t)(cbase >> 5) * h * w * ACT_CB + (cbase & (ACT_CB - 1));
 #pragma unroll
-    for (int u = 0; u < NIT; ++u) raw[c][u] = *reinterpret_cast<const uint4*>(in_b + (off0 + (size_t)po[u] * ACT_CB) * 2);
+    for (int u = 0; u < NIT; ++u)
+#pragma unroll
+      for (int q = 0; q < NLD; ++q) raw[slot][u][q] = *reinterpret_cast<const uint4*>(in_b + (off0 + (size_t)po[u] * ACT_CB) * IN_ESZ + q * 16);
   };
-  auto transform_chunk = [&](int c, int buf, unsigned mi) {        // relu(gn3(y3)) of chunk c -> patch buffer `buf`
+  auto transform_chunk = [&](int c, int slot, int buf, unsigned mi) {        // relu(gn3(y3)) of chunk c (in register slot `slot`) -> patch buffer `buf`
     float ta[EPP], tb[EPP];
     const int c0 = c * CK + jfix * EPP;
 #pragma unroll
@@ -157,20 +178,48 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
       // The raw registers are consumed UNCONDITIONALLY (selects, no branch around the use): a use inside a branch leaves the load "pending" on
       // the other path in hipcc's vmcnt bookkeeping, and the unconditional reload of the same registers below then waits vmcnt(0/1) in every
       // stage -- which drains the whole prefetch (seen in the first version of this kernel: conv4 30 us instead of 36, not 22).
-      uint4 v = affine_relu_pack<EK, EK>(raw[c][u], ta, tb);
       const bool inside = (mi >> u) & 1u;                   // zero padding applies AFTER the normalisation
+      uint4 v, vlo = make_uint4(0u, 0u, 0u, 0u);
+      if constexpr (!IN32 && !PSPLIT) {
+        v = affine_relu_pack<EK, EK>(raw[slot][u][0], ta, tb);
+      } else {
+        float y[EPP];
+        if constexpr (IN32) {
+          const uint32_t yw[8] = {raw[slot][u][0].x, raw[slot][u][0].y, raw[slot][u][0].z, raw[slot][u][0].w,
+                                  raw[slot][u][NLD - 1].x, raw[slot][u][NLD - 1].y, raw[slot][u][NLD - 1].z, raw[slot][u][NLD - 1].w};
+#pragma unroll
+          for (int i = 0; i < EPP; ++i) y[i] = __builtin_bit_cast(float, yw[i]);
+        } else {
+          Piece<EK>::unpack(raw[slot][u][0], y);
+        }
+#pragma unroll
+        for (int i = 0; i < EPP; ++i) y[i] = fmaxf(fmaf(ta[i], y[i], tb[i]), 0.f);
+        v = Piece<EK>::pack(y);
+        if constexpr (PSPLIT) {      // operand pair: hi = f16(a), lo = f16(a - hi)
+          float yh[EPP];
+          Piece<EK>::unpack(v, yh);
+#pragma unroll
+          for (int i = 0; i < EPP; ++i) yh[i] = y[i] - yh[i];
+          vlo = Piece<EK>::pack(yh);
+          vlo.x = inside ? vlo.x : 0u; vlo.y = inside ? vlo.y : 0u; vlo.z = inside ? vlo.z : 0u; vlo.w = inside ? vlo.w : 0u;
+        }
+      }
       v.x = inside ? v.x : 0u; v.y = inside ? v.y : 0u; v.z = inside ? v.z : 0u; v.w = inside ? v.w : 0u;
-      if ((m_valid >> u) & 1u) *reinterpret_cast<uint4*>(smem + W_BYTES + buf * PATCH_BYTES + lds_off[u]) = v;
+      if ((m_valid >> u) & 1u) {
+        *reinterpret_cast<uint4*>(smem + W_BYTES + buf * PATCH_BYTES + lds_off[u]) = v;
+        if constexpr (PSPLIT) *reinterpret_cast<uint4*>(smem + W_BYTES + buf * PATCH_BYTES + PATCH_PLANE + lds_off[u]) = vlo;
+      }
     }
   };
 
-  // first tile: all four chunks requested, chunk 0 staged
+  // first tile: all four chunks requested (fp32 input: the first two), chunk 0 staged
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) load_chunk(c, po_cur);
+  for (int c = 0; c < NSLOT; ++c) load_chunk(c, c, po_cur);
   DD_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();                          // table + weights + bias visible
   asm volatile("" ::: "memory");
-  transform_chunk(0, 0, mi_cur);
+  transform_chunk(0, 0, 0, mi_cur);
+  if constexpr (IN32) load_chunk(2, 0, po_cur);
   DD_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -189,7 +238,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // the slot of chunk 0 was consumed in the previous tile's last stage: refill it with the next tile's chunk 0
-      if (c == 0) load_chunk(0, po_nx);
+      if constexpr (!IN32) { if (c == 0) load_chunk(0, 0, po_nx); }
       const int pbuf = (c & 1) * PATCH_BYTES;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -197,13 +246,22 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
         const uint4 pf = *reinterpret_cast<const uint4*>(smem + colt[dx] + pbuf + dy * (PW * ROWB));
         const uint4 wf = *reinterpret_cast<const uint4*>(smem + wkt + c * W_STAGE + t * (NROW * ROWB));
         mma_step<EK>(acc, wf, pf);
+        if constexpr (PSPLIT) {
+          const uint4 pl = *reinterpret_cast<const uint4*>(smem + colt[dx] + pbuf + PATCH_PLANE + dy * (PW * ROWB));
+          mma_step<EK>(acc, wf, pl);
+        }
       }
       // stage the following chunk into the other patch buffer, then reuse its registers for the next tile
-      if (c + 1 < NCH) {
-        transform_chunk(c + 1, (c + 1) & 1, mi_cur);
-        load_chunk(c + 1, po_nx);
+      if constexpr (IN32) {
+        constexpr int RMASK = NCH - 1;
+        const int cn = (c + 1) & RMASK, cl = (c + 3) & RMASK;      // chunk staged now; chunk requested into the slot that frees ((c + 3) & 1 == (c + 1) & 1)
+        transform_chunk(cn, cn & 1, cn & 1, c + 1 < NCH ? mi_cur : mi_nx);
+        load_chunk(cl, cl & 1, c + 3 < NCH ? po_cur : po_nx);
+      } else if (c + 1 < NCH) {
+        transform_chunk(c + 1, c + 1, (c + 1) & 1, mi_cur);
+        load_chunk(c + 1, c + 1, po_nx);
       } else {
-        transform_chunk(0, 0, mi_nx);          // (behind the last tile: a patch nobody reads)
+        transform_chunk(0, 0, 0, mi_nx);          // (behind the last tile: a patch nobody reads)
       }
       DD_WAIT_LGKM0();
       __builtin_amdgcn_s_barrier();
@@ -217,7 +275,15 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const float4 bv = *reinterpret_cast<const float4*>(tab_bias + 8 * q + 4 * g);
-          const float v0 = acc[q * 4 + 0] + bv.x, v1 = acc[q * 4 + 1] + bv.y, v2 = acc[q * 4 + 2] + bv.z, v3 = acc[q * 4 + 3] + bv.w;
+          float v0, v1, v2, v3;
+          if constexpr (STACK) {
+            // cout c = 8q + 4g + i sits in quad q, its lo-half row 16 + c in quad q + 2 of the SAME lane: (hi + lo * 2^-11) / patch scale + bias
+            constexpr float LS = 1.f / STACK_LSCALE, OS = 1.f / PSC;
+            v0 = fmaf(fmaf(acc[(q + 2) * 4 + 0], LS, acc[q * 4 + 0]), OS, bv.x); v1 = fmaf(fmaf(acc[(q + 2) * 4 + 1], LS, acc[q * 4 + 1]), OS, bv.y);
+            v2 = fmaf(fmaf(acc[(q + 2) * 4 + 2], LS, acc[q * 4 + 2]), OS, bv.z); v3 = fmaf(fmaf(acc[(q + 2) * 4 + 3], LS, acc[q * 4 + 3]), OS, bv.w);
+          } else {
+            v0 = acc[q * 4 + 0] + bv.x; v1 = acc[q * 4 + 1] + bv.y; v2 = acc[q * 4 + 2] + bv.z; v3 = acc[q * 4 + 3] + bv.w;
+          }
           ls[q] += (v0 + v1) + (v2 + v3);
           lq[q] += fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, v3 * v3)));
           // (hidden from hipcc's vmcnt bookkeeping: a tracked store beside the prefetched loads would turn every later wait into vmcnt(0))
@@ -251,22 +317,28 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   }
 }
 
-template <int EK> static hipError_t launch_conv4_stream_k(const ConvParams& p, hipStream_t s) {
+template <int EK, bool STACK, bool IN32, bool PSPLIT> static hipError_t launch_conv4_stream_k(const ConvParams& p, hipStream_t s) {
   static bool attr_set = false;
+  constexpr int SMEM = thin::smem_bytes(PSPLIT);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4_stream_kernel<EK>), hipFuncAttributeMaxDynamicSharedMemorySize, thin::SMEM_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4_stream_kernel<EK, STACK, IN32, PSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const unsigned n_wg = (unsigned)persist_grid(p.B, p.tiles_x * p.tiles_y, p.persist_slots > 0 ? p.persist_slots : 512);
-  hipLaunchKernelGGL(conv4_stream_kernel<EK>, dim3(n_wg), dim3(thin::THREADS), thin::SMEM_BYTES, s, p);
+  hipLaunchKernelGGL((conv4_stream_kernel<EK, STACK, IN32, PSPLIT>), dim3(n_wg), dim3(thin::THREADS), SMEM, s, p);
   return hipGetLastError();
 }
 
-hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s) {
+hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack, bool in32, bool psplit) {
+  if (ek == EK_F16 && stack) {
+    if (in32) return psplit ? launch_conv4_stream_k<EK_F16, true, true, true>(p, s) : launch_conv4_stream_k<EK_F16, true, true, false>(p, s);
+    return psplit ? launch_conv4_stream_k<EK_F16, true, false, true>(p, s) : launch_conv4_stream_k<EK_F16, true, false, false>(p, s);
+  }
+  if (stack || in32 || psplit) return hipErrorInvalidValue;
   switch (ek) {
-    case EK_F16: return launch_conv4_stream_k<EK_F16>(p, s);
-    case EK_BF16: return launch_conv4_stream_k<EK_BF16>(p, s);
+    case EK_F16: return launch_conv4_stream_k<EK_F16, false, false, false>(p, s);
+    case EK_BF16: return launch_conv4_stream_k<EK_BF16, false, false, false>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

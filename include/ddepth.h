@@ -55,10 +55,15 @@ typedef enum dd_precision {
   DD_PREC_FP32 = 1,        /* fused implicit-GEMM on v_mfma_f32_32x32x2_f32, fp32 activations (parity gate) */
   DD_PREC_BF16 = 2,        /* fused implicit-GEMM on v_mfma_f32_32x32x16_bf16, bf16 activations (headline)  */
   DD_PREC_F16 = 3,         /* same kernels on v_mfma_f32_32x32x16_f16 (11-bit mantissa, same rate)          */
-  DD_PREC_F16X3 = 4        /* split f16: every MFMA operand an f16 pair hi + lo (~22 mantissa bits), three MFMAs per product
+  DD_PREC_F16X3 = 4,       /* split f16: every MFMA operand an f16 pair hi + lo (~22 mantissa bits), three MFMAs per product
                               (Whi.Phi + Whi.Plo + Wlo.Phi), fp32 tensors and accumulation -- the mode that meets the
                               1e-3 ABSOLUTE depth tolerance over the whole depth range at ~1/3 of the 16-bit rate;
                               forward only (dd_denoise / dd_denoise_trace / dd_denoise_once / dd_condition)   */
+  DD_PREC_F16R = 5         /* refined f16: the two large convolutions on f16 operands with ONE MFMA per product, everything around
+                              them made (near-)exact where it is (near-)free -- conv1 on split operands, conv3(cond) once per image
+                              on split operands from the fp32 condition map, y3 and that term handed over as fp32, conv4's weights
+                              as an f16 pair stacked into the padding rows of its MFMA.  The 16-bit mode that holds 1e-3 depth RMSE
+                              at KITTI's depth range (0..80 m) with margin; DD_VARIANT_RES, forward only                */
 } dd_precision;
 
 /* ---- lifetime ---------------------------------------------------------------------------------
@@ -227,7 +232,9 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * handle -- all lanes and shapes -- also held against the free device memory; stale sets are dropped first, and a forward that cannot
  * keep its activations keeps the states only), "thin_stream" (1 [default] = conv4 runs as the persistent streaming kernel of
  * csrc/dd_thin.hip in the 16-bit modes, 0 = as an instance of the general kernel: A/B switch), "thin_slots" (workgroups of that kernel,
- * default 512 = two per CU), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage). */
+ * default 512 = two per CU), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
+ * "f16r_wide" (DD_PREC_F16R: 1 [default] = y3 and the hoisted conv3(cond) term travel as fp32, 0 = as f16 like in DD_PREC_F16),
+ * "f16r_p4" (DD_PREC_F16R: 1 = conv4's operand relu(gn3(y3)) as an f16 pair as well -- two MFMAs per tap; default 0). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches", "trajectory_ticket" (ticket of the

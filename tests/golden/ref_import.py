@@ -26,10 +26,19 @@ from torch import nn
 
 REF_ROOT = os.environ.get("DD_REFERENCE_ROOT", "/root/reference")
 REF_SRC = os.path.join(REF_ROOT, "src")
+# Where /root/reference does not exist (the GPU box): the same modules as sourceless bytecode, compiled from the reference where it lies by
+# oracle/ref_py/build_ref.py into the git-ignored oracle/_ref/py/ (what bench.py's cpu_baseline of kind "reference" times)
+STAGED_SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "py")
+if not os.path.isdir(os.path.join(REF_SRC, "model", "head")) and os.path.isdir(os.path.join(STAGED_SRC, "model", "head")):
+    REF_SRC = STAGED_SRC
 
 
 def reference_available() -> bool:
     return os.path.isdir(os.path.join(REF_SRC, "model", "head"))
+
+
+def reference_kind() -> str:
+    return "staged bytecode (oracle/_ref/py)" if REF_SRC == STAGED_SRC else "source tree"
 
 
 class _Registry:
@@ -118,7 +127,10 @@ def _install_stubs():
 
 
 def _load_as(modname, relpath):
-    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF_SRC, relpath))
+    path = os.path.join(REF_SRC, relpath)
+    if not os.path.exists(path):
+        path = path[:-3] + ".pyc"          # staged bytecode
+    spec = importlib.util.spec_from_file_location(modname, path)
     m = importlib.util.module_from_spec(spec)
     sys.modules[modname] = m
     spec.loader.exec_module(m)

@@ -63,6 +63,8 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d) { p->multiProcessorCount = 256; return d == 0 ? hipSuccess : hipErrorInvalidValue; }      // the MI355X's CU count
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; }   // a 4-CU "device": persistent grids stay small
 // calls after which the HOST would wait for the device (synchronise, blocking copy, allocation): counted so that tests can assert that a
 // steady-state entry point never blocks the host (the host must stay ahead of the GPU)
@@ -439,6 +441,7 @@ template <class T> static inline T __shfl_down(T v, int delta, int /*width*/ = 6
 static inline void __threadfence() {}      // one OS thread runs every work-item: memory is always coherent
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { const unsigned o = *p; *p = o > v ? o : v; return o; }
 static inline unsigned hostemu_alignbyte(unsigned hi, unsigned lo, unsigned n) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (n & 3))); }
 static inline unsigned hostemu_perm(unsigned a, unsigned b, unsigned sel) {     // v_perm_b32: selector bytes 0..3 -> b, 4..7 -> a, 0x0c -> 0x00
   const uint64_t src = (((uint64_t)a) << 32) | b;

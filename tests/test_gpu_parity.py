@@ -17,6 +17,10 @@ Tolerances (stated per north-star: <= 1e-3 abs on predicted depth; depth RMSE wi
   over which (a) holds is recorded (`abs_rmse_1e3_holds_to_rms_depth_m`) and printed by bench.py.  "bf16" is the library's default bf16
   mode (bf16 MFMA operands on the large convolutions, f16 storage / thin layers); the all-bf16 variant (option
   bf16_storage=1) is measured beside it and only recorded -- it sits at ~1.2e-3, which is why it is not the default.
+  f16r (refined f16, DD_PREC_F16R; round 4): the 16-bit mode that is held to the RMSE reading WHERE KITTI LIVES -- depth RMSE <= 1e-3 / 1.5
+  (the margin VERDICT r3 asks of a headline mode) at the full NYU and KITTI sizes with the decoder at near range AND shifted to 0..80 m.  f16
+  operands with one MFMA per product on the two large convolutions; conv1 / conv3(cond) on split operands, conv4's weights as a stacked f16
+  pair, y3 and the hoisted term handed over as fp32 (tools/bf16_error_budget.py: those, not the large convolutions, made the f16 mode's error).
 """
 import numpy as np
 import pytest
@@ -26,13 +30,14 @@ from diffusiondepth_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16x3": 2e-5, "f16": 1.5e-3, "bf16": 1e-2}   # x max|x_0|  (measured: 1e-6, 1e-6, 1e-6, 5e-4, 4e-3)
-EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16x3": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}      # abs on eps (values O(1..4); measured 1e-5, 1e-5, 1e-5, 5e-3, 4e-2)
-ALL_PREC = ["naive_fp32", "fp32", "f16x3", "bf16", "f16"]
+LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16x3": 2e-5, "f16": 1.5e-3, "bf16": 1e-2, "f16r": 8e-4}   # x max|x_0|  (measured: 1e-6, 1e-6, 1e-6, 5e-4, 4e-3; f16r 1.9e-4 emulated)
+EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16x3": 5e-5, "f16": 1.5e-2, "bf16": 1e-1, "f16r": 1e-2}      # abs on eps (values O(1..4); measured 1e-5, 1e-5, 1e-5, 5e-3, 4e-2)
+ALL_PREC = ["naive_fp32", "fp32", "f16x3", "bf16", "f16", "f16r"]
 ABS_PREC = ("naive_fp32", "fp32", "f16x3")                                      # the modes held to 1e-3 ABS on every pixel of the depth map
 DEPTH_RMSE_TOL = 1e-3                                                           # north star, asserted for every precision at full size
-DEPTH_MAXABS_TOL = {"fp32": 1e-3, "f16x3": 1e-3, "bf16": 2e-2, "f16": 5e-3}     # fp32 / f16x3: the north star's abs reading; 16-bit: regression bounds
-DEPTH_REL_RMSE_TOL = {"bf16": 1.2e-3, "f16": 4e-4}                              # rms of (d - d_ref) / d_ref, every case incl. far range: 2x the worst measured (5.8e-4 / 1.9e-4 on loop_res_far)
+DEPTH_MAXABS_TOL = {"fp32": 1e-3, "f16x3": 1e-3, "bf16": 2e-2, "f16": 5e-3, "f16r": 4e-3}     # fp32 / f16x3: the north star's abs reading; 16-bit: regression bounds
+DEPTH_REL_RMSE_TOL = {"bf16": 1.2e-3, "f16": 4e-4, "f16r": 2e-4}                # rms of (d - d_ref) / d_ref, every case incl. far range: 2x the worst measured (5.8e-4 / 1.9e-4 / 9.9e-5 on loop_res_far)
+HEADLINE_MARGIN = 1.5                                                           # f16r: depth RMSE <= 1e-3 / 1.5 near AND at KITTI's depth range
 
 
 def rel_rmse(d, dref):
@@ -142,7 +147,7 @@ def test_ddim_loop_vs_reference_golden(U, golden, cases, name, prec):
             assert rr < DEPTH_REL_RMSE_TOL[prec], (name, prec, rr)      # 16-bit modes: the error is relative; absolute 1e-3 only at short range
 
 
-@pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16", "f16r"])
 def test_ragged_sizes_and_batch_vs_oracle(U, prec):
     """Tile edges: sizes that are not multiples of the 8x32 tile, 1-pixel-wide, taller than wide, B=3."""
     from oracle import ddim_oracle as O
@@ -260,7 +265,7 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
     cfar = {"wseed": 7240, "decoder_log_scale": FAR_LOG_SCALE}
     be_far, sd_far = U.backend_for(cfar), U.sd_for(cfar)
     dref_far = P.decode(P.to_torch_sd(sd_far), torch.from_numpy(ref)).numpy()
-    for prec in ("fp32", "f16x3", "bf16", "f16"):
+    for prec in ("fp32", "f16x3", "bf16", "f16", "f16r"):
         x0 = be.denoise(x, cond, 20, prec)
         d = be.decode(x0).cpu().numpy()
         d_far = be_far.decode(x0).cpu().numpy()
@@ -280,6 +285,11 @@ def test_full_size_loop_vs_torch_cpu_port(U, size):
             assert dref_far.max() > 40.0 and U.maxabs(d_far, dref_far) <= 1e-3, (size, prec, U.maxabs(d_far, dref_far))   # NYU 52 m, KITTI 69 m
         else:
             assert rel_rmse(d_far, dref_far) < DEPTH_REL_RMSE_TOL[prec], (size, prec, rel_rmse(d_far, dref_far))
+        if prec == "f16r":
+            # the headline mode: the north star's RMSE reading with margin, on this workload and with the same latents decoded at 0..80 m
+            assert dref_far.max() > 40.0
+            assert U.rms(d, dref) <= DEPTH_RMSE_TOL / HEADLINE_MARGIN, (size, prec, U.rms(d, dref))
+            assert U.rms(d_far, dref_far) <= DEPTH_RMSE_TOL / HEADLINE_MARGIN, (size, prec, U.rms(d_far, dref_far))
     # the all-bf16 variant beside the default bf16 mode: recorded, not gated (it is the reason the default stores f16)
     import diffusiondepth_amd as dda
     pure = dda.HipDenoiser()
@@ -303,14 +313,14 @@ def test_big_tile_and_lane_paths_agree_with_the_single_image_path_at_kitti_size(
     h, w, T = 176, 608, 4
     inp = synth.make_inputs(91, 3, h, w)
     x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
-    for prec in ("bf16", "fp32"):
+    for prec in ("bf16", "fp32", "f16r"):      # f16r: the reformatted hoisted term (fp32, 16x32-tile order) and the two-slot fp32 ring of the stacked conv4
         batch = be.denoise(x, cond, T, prec).cpu().numpy()
         scale = float(np.abs(batch).max())
         for i in range(3):
             solo = be.denoise(x[i:i + 1].contiguous(), cond[i:i + 1].contiguous(), T, prec).cpu().numpy()
             e = U.maxabs(batch[i:i + 1], solo)
             U.record("batch_vs_solo_kitti", prec=prec, image=i, maxabs=e, scale=scale)
-            assert e < (LATENT_TOL[prec] if prec == "bf16" else 2e-6) * scale, (prec, i, e, scale)
+            assert e < (2e-6 if prec == "fp32" else LATENT_TOL[prec]) * scale, (prec, i, e, scale)
     try:
         be.set_option("big_tiles", 0)
         small = be.denoise(x, cond, T, "bf16").cpu().numpy()

@@ -26,8 +26,8 @@ from oracle import ddim_oracle as O
 
 FULL = os.environ.get("DD_EMU_FULL") == "1"
 full_only = pytest.mark.skipif(not FULL, reason="larger emulation case: set DD_EMU_FULL=1")
-LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16x3": 2e-5, "f16": 1.5e-3, "bf16": 1e-2}        # x max|x_0|: the GPU parity tests' own bounds
-EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16x3": 5e-5, "f16": 1.5e-2, "bf16": 1e-1}
+LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16x3": 2e-5, "f16": 1.5e-3, "bf16": 1e-2, "f16r": 8e-4}        # x max|x_0|: the GPU parity tests' own bounds
+EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16x3": 5e-5, "f16": 1.5e-2, "bf16": 1e-1, "f16r": 1e-2}
 
 
 @pytest.fixture(scope="module")
@@ -136,17 +136,68 @@ def test_split_f16_mode_meets_the_absolute_depth_tolerance_at_far_range(lib, gol
     assert dref.max() > 100.0 and maxabs(be.decode(x0), dref) < 1e-3
 
 
-def test_split_f16_image_refuses_weights_it_cannot_hold(lib):
-    """The split-f16 image carries weights times 2^8 in f16: a convolution weight of magnitude >= 234 cannot be represented and is refused at
-    commit (loudly, for the whole group) instead of turning into inf in one precision mode."""
+@pytest.mark.parametrize("device_route", [False, True])
+def test_split_modes_refuse_weights_their_images_cannot_hold_and_the_other_modes_do_not_care(lib, device_route):
+    """The split-f16 images carry weights times 2^8 in f16: a convolution weight of magnitude >= 234 cannot be represented.  That is a property
+    of the SPLIT modes only: dd_commit_weights succeeds on both routes and records it, fp32 / f16 run on such parameters,
+    DD_PREC_F16X3 / DD_PREC_F16R refuse loudly (no inf / NaN image is ever executed), and a good parameter set afterwards runs everywhere."""
     be = EmuDenoiser(lib, "res")
+    be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
     sd = synth.make_state_dict(7240)
     sd["model.pred.0.weight"] = sd["model.pred.0.weight"].copy()
     sd["model.pred.0.weight"][3, 5, 1, 1] = 300.0
-    with pytest.raises(RuntimeError, match="split-f16"):
-        be.load_state_dict(sd)
-    be.load_state_dict(synth.make_state_dict(7240))          # a good set afterwards commits
+    be.load_state_dict(sd, device_route=device_route)            # commits
+    inp = synth.make_inputs(5, 1, 8, 32)
+    ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], 2)
+    x0 = be.denoise(inp["x_T"], inp["cond"], 2, "fp32")
+    assert np.isfinite(x0).all() and maxabs(x0, ref) < LATENT_TOL["fp32"] * np.abs(ref).max()
+    for prec in ("f16x3", "f16r"):
+        with pytest.raises(RuntimeError, match="split-f16"):
+            be.denoise(inp["x_T"], inp["cond"], 2, prec)
+        with pytest.raises(RuntimeError, match="split-f16"):
+            be.denoise_once(inp["x_T"], 500, inp["cond"], prec)
+    good = synth.make_state_dict(7240)
+    be.load_state_dict(good, device_route=device_route)          # a good set afterwards runs in the split modes again
+    ref = O.ddim_loop(good, inp["x_T"], inp["cond"], 2)
+    assert maxabs(be.denoise(inp["x_T"], inp["cond"], 2, "f16x3"), ref) < LATENT_TOL["f16x3"] * np.abs(ref).max()
     be.close()
+
+
+def test_refined_f16_mode_on_the_far_range_golden(lib, golden, cases):
+    """DD_PREC_F16R (round 4): f16 operands with ONE MFMA per product on the two large convolutions, everything around them refined -- conv1 on
+    split operands, the once-per-image conv3(cond) on split operands from the fp32 condition map and reformatted into conv3's accumulator order,
+    y3 as fp32, conv4 on the stacked hi / lo weight image.  On the 20-step far-range golden minted from the reference (depths to 159 m) its
+    depth error must be well under the plain f16 mode's (measured here: 2.5e-3 vs 5.1e-3 RMSE; 9.9e-5 vs 2.1e-4 relative) for every option
+    combination, in the order the error budget predicts (operand pair in conv4 < wide < narrow < f16), under the adversarial timing."""
+    c, g = cases["loop_res_far"], golden("loop_res_far")
+    be, _ = backend_for(lib, c)
+    be.set_option("hoist_cond", -1)
+    be.timing(order=1, dma_late=1)
+    inp = synth.make_inputs(c["iseed"], c["B"], c["h"], c["w"])
+    T = c["T"][0]
+    ref, dref = g[f"x0_T{T}"], g[f"depth_T{T}"]
+
+    def rel_rmse(prec, **opts):
+        for k, v in opts.items():
+            be.set_option(k, v)
+        x0 = be.denoise(inp["x_T"], inp["cond"], T, prec)
+        assert np.isfinite(x0).all() and maxabs(x0, ref) < LATENT_TOL[prec] * np.abs(ref).max()
+        d = be.decode(x0)
+        return float(np.sqrt((((d - dref) / dref) ** 2).mean()))
+    try:
+        e_wide = rel_rmse("f16r", f16r_wide=1, f16r_p4=0)
+        e_p4 = rel_rmse("f16r", f16r_wide=1, f16r_p4=1)
+        e_narrow = rel_rmse("f16r", f16r_wide=0, f16r_p4=0)
+    finally:
+        be.set_option("f16r_wide", 1); be.set_option("f16r_p4", 0)
+    e_f16 = rel_rmse("f16")
+    assert e_p4 < e_wide < e_narrow < e_f16, (e_p4, e_wide, e_narrow, e_f16)
+    assert e_wide < 2e-4 and e_wide < 0.6 * e_f16, (e_wide, e_f16)          # the GPU suite's bound for the mode; half the f16 mode's error
+    # a single call (per-sample timesteps: the hoisted conv3 reads its E[t] row per image) at the mode's bound
+    c1, g1 = cases["denoise_res"], golden("denoise_res")
+    be1, _ = backend_for(lib, c1)
+    inp1 = synth.make_inputs(c1["iseed"], c1["B"], c1["h"], c1["w"])
+    assert maxabs(be1.denoise_once(inp1["x_T"], inp1["timesteps"], inp1["cond"], "f16r"), g1["eps_batch_t"]) < EPS_TOL["f16r"]
 
 
 # ---- the loop against the oracle, every kernel family and option ----------------------------------------------------------------------------------
@@ -192,7 +243,7 @@ def test_res_loop_with_the_hoisted_condition_term(lib):
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("prec", ["bf16"] + (["f16"] if FULL else []))
+@pytest.mark.parametrize("prec", ["bf16", "f16r"] + (["f16"] if FULL else []))      # f16r: the split layer 8's fp32 term reformatted into the 16x32-tile order
 def test_hoisted_conv3_on_16x32_tiles(lib, prec):
     """Kernel ids 48 / 49 (dd_kernels.h): the hoisted conv3 pair -- conv3(cond) once per image, conv3 in the loop -- on 16x32-pixel tiles (four
     waves of 128 pixels x 64 couts, raw patch one chunk ahead), which the library picks when the 8x32 tiles exceed the resident workgroup
@@ -235,6 +286,29 @@ def test_streaming_conv4_walks_several_tiles_per_workgroup(lib, prec, B, slots):
     assert maxabs(outs[0], ref) < LATENT_TOL[prec] * np.abs(ref).max()
     # (16-bit rounding class, not closer: the next GroupNorm's partial sums are taken in another order)
     assert maxabs(outs[0], classic) < LATENT_TOL[prec] * np.abs(ref).max() and maxabs(one_tile_each, classic) < LATENT_TOL[prec] * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("wide,p4", [(1, 0), (0, 1)] + ([(1, 1), (0, 0)] if FULL else []))
+def test_refined_f16_conv4_walks_several_tiles_per_workgroup(lib, wide, p4):
+    """The stacked-weight forms of the streaming conv4 (dd_thin.hip: STACK, IN32 with its two-slot register ring refilled two stages ahead,
+    PSPLIT with the second patch plane) across tile boundaries: 17 x 70 latent = 3 x 3 tiles per image, 3 resident slots for 2 images -> one
+    workgroup per image walks all nine tiles; against one tile per workgroup (bit-identical per output: same accumulation order; only the next
+    GroupNorm's partial sums regroup), against the oracle, and bit-identical across the adversarial wave orders."""
+    be, inp, ref, T = _loop_case(lib, B=2, h=17, w=70)
+    try:
+        be.set_option("f16r_wide", wide); be.set_option("f16r_p4", p4)
+        be.set_option("thin_slots", 3)
+        outs = []
+        for order, late in ((0, 0), (1, 1)):
+            be.timing(order=order, dma_late=late)
+            outs.append(be.denoise(inp["x_T"], inp["cond"], T, "f16r"))
+        be.set_option("thin_slots", 512)
+        one_tile_each = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
+    finally:
+        be.set_option("f16r_wide", 1); be.set_option("f16r_p4", 0); be.set_option("thin_slots", 512)
+    assert np.array_equal(outs[0], outs[1])
+    assert maxabs(outs[0], ref) < LATENT_TOL["f16r"] * np.abs(ref).max()
+    assert maxabs(outs[0], one_tile_each) < LATENT_TOL["f16r"] * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("late,prec", [(0, "f16"), (1, "f16"), (1, "f16x3")])

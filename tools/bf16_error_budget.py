@@ -78,8 +78,10 @@ def denoiser_emul(sd, x, t, cond, R, step=0):
         # conv3 is linear: conv3(a2 + cond + E) = conv3(a2) + [conv3(cond) + conv3(E)]; the bracket is computed once per image / per
         # step outside the MFMA loop ("hoistc": dtype of cond and of the weights in that once-per-image convolution)
         hc = R.get("hoistc")
-        y3 = F.conv2d(rnd(a2, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1) + \
-            F.conv2d(rnd(cond, hc) + emb, rnd(sd["model.pred.0.weight"], hc), None, padding=1)
+        # "hs": storage of the once-per-image term conv3(cond) (the kernels keep it as f16 quads or fp32); the E[t] tap sums are an fp32 table
+        hterm = rnd(F.conv2d(rnd(cond, hc), rnd(sd["model.pred.0.weight"], hc), None, padding=1), R.get("hs"))
+        y3 = F.conv2d(rnd(a2, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1) + hterm + \
+            F.conv2d(emb.expand_as(cond).contiguous(), sd["model.pred.0.weight"], None, padding=1)
     else:
         f = a2 + rnd(cond, R.get("c")) + emb
         y3 = F.conv2d(rnd(f, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1)
@@ -108,7 +110,7 @@ def parse_plan(spec):
             R[part] = True
             continue
         srcs, dt = part.split(":")
-        for s in (SOURCES if srcs == "all" else srcs.split("+")):     # plus the pseudo-source "hoistc"
+        for s in (SOURCES if srcs == "all" else srcs.split("+")):     # plus the pseudo-sources "hoistc", "hs"
             R[s] = dt if dt in ("bf16x2", "f16x2") else DT[dt]
     return name, R
 
