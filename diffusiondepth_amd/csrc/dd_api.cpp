@@ -135,7 +135,10 @@ struct Plan {
   int64_t ttab_weights = -1; // ... and the parameter generation they were computed from
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
   DevBuf ccond_raw;        // EK_F16R: the same as the split-f16 layer 8 leaves it (fp32, 8x32 tiles), when the loop's conv3 reads another order / type
-  bool wide = false, p4 = false;   // EK_F16R: options "f16r_wide" / "f16r_p4" as this plan was built with them
+  DevBuf ccond_scale;      // EK_F16R, hand-over 2: one fp32 scale per accumulator block of the int16 hoisted term (dd_kernels.h, EK_F16Q)
+  DevBuf y3_scale;         // ... and one per pixel of y3 (per-step slots like y3)
+  int wide = 0, c1 = 0;    // EK_F16R: options "f16r_wide" (hand-over of y3 / the hoisted term: 0 f16, 1 fp32, 2 scaled int16) and "f16r_c1" (conv1:
+  bool p4 = false;         // 0 plain f16, 1 weights as an f16 pair, 2 weights and state as pairs), "f16r_p4", as this plan was built with them
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
@@ -231,7 +234,8 @@ struct dd_handle_s {
   int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
   int big_tiles = -1;         // option "big_tiles": hoisted conv3 pair on 16x32 tiles: -1 = when the 8x32 tiles exceed the 512 resident slots, 0 / 1 = forced
   int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
-  int f16r_wide = 1;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as fp32 (0 = f16, as DD_PREC_F16)
+  int f16r_wide = 2;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as 0 = f16 (as DD_PREC_F16), 1 = fp32, 2 = block-scaled int16
+  int f16r_c1 = 1;            // DD_PREC_F16R: conv1 as 0 = the f16 kernel, 1 = weights as an f16 pair (two MFMAs), 2 = weights and state as pairs (three)
   int f16r_p4 = 0;            // DD_PREC_F16R: conv4's operand as an f16 pair as well (two MFMAs per tap)
   bool split_ok = true;       // every forward convolution weight fits the split-f16 images (|w| x 256 inside f16): DD_PREC_F16X3 / DD_PREC_F16R refuse to run otherwise
   DevBuf wmax;                // device route: bits of max |w| over the forward convolution weights (launch_max_abs)
@@ -574,9 +578,10 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
     const int th = conv_pack_geom2(conv3h_kid(h, key), pl->ek).th;
     DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
     if (pl->ek == EK_F16R) {
-      pl->wide = h->f16r_wide != 0; pl->p4 = h->f16r_p4 != 0;
-      if (th != 8 || !pl->wide)      // the split layer 8 writes fp32 in the order of 8x32 tiles: reformatted unless that is what conv3 reads
+      pl->wide = h->f16r_wide; pl->c1 = h->f16r_c1; pl->p4 = h->f16r_p4 != 0;
+      if (th != 8 || pl->wide != 1)      // the split layer 8 writes fp32 in the order of 8x32 tiles: reformatted unless that is what conv3 reads
         DD_HIP(pl->ccond_raw.alloc((size_t)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) * 8 * 32 * HID_C * 4));
+      if (pl->wide == 2) DD_HIP(pl->ccond_scale.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * 4 * 2 * (th / 4) * 4));
     }
   }
   if (key.hoist && swin) {
@@ -592,7 +597,8 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
-  DD_HIP(pl->y3.alloc(ns * px * HID_C * ((pl->ek == EK_F16R && h->f16r_wide) ? 4 : es)));
+  DD_HIP(pl->y3.alloc(ns * px * HID_C * ((pl->ek == EK_F16R && h->f16r_wide == 1) ? 4 : es)));
+  if (pl->ek == EK_F16R && h->f16r_wide == 2) DD_HIP(pl->y3_scale.alloc(ns * px * 4));
   DD_HIP(pl->y4.alloc(ns * px * LATENT_C * 4));
   if (key.keep == 2) pl->kept_bytes = pl->y1.bytes + pl->y2.bytes + pl->y3.bytes + pl->y4.bytes + pl->sa.bytes + pl->sf.bytes;
   if (naive) {
@@ -654,9 +660,12 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
       q.tiles_y = (k.h + conv_pack_geom2(kid, ek).th - 1) / conv_pack_geom2(kid, ek).th;
-      if (layer == 4 && rf) { q.persist_slots = h->thin_slots; return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
+      if (layer == 4 && rf) { q.persist_slots = h->thin_slots; q.cadd_scale = static_cast<const float*>(pl->slot(pl->y3_scale, step)); return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
       if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
-      return launch_conv_igemm2(kid, (rf && layer == 9 && !pl->wide) ? (int)EK_F16 : ek, q, s);      // (narrow EK_F16R: the f16 mode's conv3, f16 quads in, f16 out)
+      int lek = ek;
+      if (rf && layer == 9) lek = pl->wide == 0 ? (int)EK_F16 : pl->wide == 2 ? (int)EK_F16Q : (int)EK_F16R;      // hand-over of y3 / the hoisted term: f16 (the f16 mode's conv3), scaled int16, fp32
+      if (rf && layer == 1) lek = pl->c1 == 0 ? (int)EK_F16 : pl->c1 == 1 ? (int)EK_F16Q : (int)EK_F16R;          // conv1: plain f16, weights as a pair, weights and state as pairs
+      return launch_conv_igemm2(kid, lek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
     hipEvent_t a, b;
@@ -673,7 +682,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   void *sa_ = pl->slot(pl->sa, step), *sf_ = pl->slot(pl->sf, step);
   const float* y4_prev = static_cast<const float*>(pl->slot(pl->y4, step > 0 ? step - 1 : 0));     // read by the fused update of step - 1
   // conv1: state (+ fused DDIM update of the previous step) -> y1
-  p.in = x_in; p.wpack = h->L[0].wpack2[rf ? WIMG_SPLIT : wimg_slot(tk)].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
+  p.in = x_in; p.wpack = h->L[0].wpack2[rf ? (pl->c1 ? WIMG_SPLIT : (int)EK_F16) : wimg_slot(tk)].p; p.bias = h->L[0].bias.as<float>(); p.out = y1_;
   p.stats_out = pl->stat_ptr(step, 0);
   p.stats_in = apply_update ? pl->stat_ptr(step - 1, 3) : nullptr;
   p.gn_gamma = h->L[3].gamma.as<float>(); p.gn_beta = h->L[3].beta.as<float>();
@@ -726,7 +735,9 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond_ptr(); p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
   p.cadd = pl->ccond.as<float>(); p.etab = h->etab.as<float>();
+  p.cadd_scale = pl->ccond_scale.as<float>(); p.out_scale = static_cast<float*>(pl->slot(pl->y3_scale, step));      // (EK_F16Q forms only)
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
+  p.cadd_scale = nullptr; p.out_scale = nullptr;
   }
   // conv4: relu(gn3(y3)) -> y4 (fp32)
   p.in = y3_; p.wpack = h->L[3].wpack2[rf ? WIMG_STACK : wimg_slot(tk)].p; p.bias = h->L[3].bias.as<float>(); p.out = y4_;
@@ -777,7 +788,8 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
     p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[WIMG_SPLIT].p; p.bias = h->zero_bias.as<float>();
     p.out = pl->ccond_raw.p ? pl->ccond_raw.p : pl->ccond.p;
     DD_HIP(launch_conv_igemm2(8, EK_F16S, p, s));
-    if (pl->ccond_raw.p) DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0, pl->wide ? 0 : 1, s));
+    if (pl->ccond_raw.p) DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, pl->ccond_scale.as<float>(), k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0,
+                                                     pl->wide == 0 ? 1 : pl->wide == 2 ? 2 : 0, s));
     return DD_OK;
   }
   const int kid = conv3c_kid(h, k);
@@ -1470,9 +1482,9 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     }
     h->thin_stream = (int)value;
   }
-  else if (k == "f16r_wide" || k == "f16r_p4") {
-    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: " + k + " must be 0 or 1");
-    int& opt = k == "f16r_wide" ? h->f16r_wide : h->f16r_p4;
+  else if (k == "f16r_wide" || k == "f16r_p4" || k == "f16r_c1") {
+    if (value < 0 || value > (k == "f16r_p4" ? 1 : 2)) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: " + k + " out of range");
+    int& opt = k == "f16r_wide" ? h->f16r_wide : k == "f16r_c1" ? h->f16r_c1 : h->f16r_p4;
     if (opt != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // buffers and graphs are laid out for it
     opt = (int)value;
   }
@@ -2355,7 +2367,11 @@ int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, v
   const void* src = nullptr; int C = 0; int ek = store_kind(pl->ek);
   if (n == "y1") { src = pl->y1.p; C = HID_C; }
   else if (n == "y2") { src = pl->y2.p; C = COND_C; }
-  else if (n == "y3") { src = pl->y3.p; C = HID_C; if (pl->ek == EK_F16R && pl->wide) ek = EK_F32; }
+  else if (n == "y3") {
+    src = pl->y3.p; C = HID_C;
+    if (pl->ek == EK_F16R && pl->wide == 1) ek = EK_F32;
+    if (pl->ek == EK_F16R && pl->wide == 2) return h->fail(DD_ERR_UNSUPPORTED, "dd_debug_fetch: y3 travels as scaled int16 in this plan (option f16r_wide = 2)");
+  }
   else if (n == "y4") { src = pl->y4.p; C = LATENT_C; ek = EK_F32; }
   else return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: unknown tensor '" + n + "'");
   if (numel != (int64_t)pl->key.B * C * pl->key.h * pl->key.w) return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: numel mismatch");

@@ -18,6 +18,7 @@
 #define DD_VMEM_LOADS_ISSUED(n) hostemu::vmem_loads_issued(n)
 #define DD_GLOBAL_STORE16_UNTRACKED(ptr, v) (*reinterpret_cast<float4*>(ptr) = (v))
 typedef hostemu::tr16_v2u dd_u32x2_t;
+#define DD_CVT_PKNORM_I16(a, b) hostemu::cvt_pknorm_i16((a), (b))
 #define DD_LDS_READ_TR16(smem, byte_off) hostemu::lds_read_tr16((smem) + (byte_off))
 
 #else
@@ -54,6 +55,8 @@ typedef __attribute__((ext_vector_type(4))) float dd_f32x4_t;
     const dd_f32x4_t v_ = {f4_.x, f4_.y, f4_.z, f4_.w};                                                                         \
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(v_) : "memory");                                   \
   } while (0)
+// v_cvt_pknorm_i16_f32: two floats in [-1, 1] -> two signed normalised 16-bit integers round(x * 32767), packed (lo = a)
+#define DD_CVT_PKNORM_I16(a, b) __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pknorm_i16((a), (b)))
 // bookkeeping for the host model only: n ordinary global loads were just issued by this wave (they count in vmcnt)
 #define DD_VMEM_LOADS_ISSUED(n) ((void)0)
 // ds_read_b64_tr_b16: the lane's 8-byte-aligned LDS address -> 4 x 16 bit, transposed inside each group of 16 lanes (see dd_wgrad2.hip)

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #pragma unroll
       for (int i = 0; i < EPP; ++i) v[i] = 0.f;       // zero padding applies AFTER the normalisation
     }
-    if constexpr (C::SPLIT) {
+    if constexpr (C::NPLP == 2) {
       // operand pair: hi = f16(v), lo = f16(v - hi); the two planes of the patch buffer
       const uint4 hi = Piece<EK_F16>::pack(v);
       float vh[EPP];
@@ -381,7 +381,12 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           // layer 8 stored conv3(cond) in accumulator-fragment order: every load is one contiguous KiB (f16: half a KiB) per wave
           (void)pv;
           const size_t fi = ((((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m) * 256 + q * 64 + lane;
-          if constexpr (C::CADD16) {
+          if constexpr (C::Q15) {
+            // int16 quads, one fp32 scale per (tile, wave, n, m) block of 32 pixels x 32 couts: a wave-uniform scalar
+            const uint2 h2 = reinterpret_cast<const uint2*>(p.cadd)[fi];
+            const float sc = p.cadd_scale[(((size_t)tile * C::WAVES + wave) * C::WN + n) * C::WM + m];
+            cv = make_float4((float)(short)(h2.x & 0xFFFFu) * sc, (float)((int)h2.x >> 16) * sc, (float)(short)(h2.y & 0xFFFFu) * sc, (float)((int)h2.y >> 16) * sc);
+          } else if constexpr (C::CADD16) {
             const uint2 h2 = reinterpret_cast<const uint2*>(p.cadd)[fi];
             cv = make_float4(f16_to_f32(h2.x & 0xFFFFu), f16_to_f32(h2.x >> 16), f16_to_f32(h2.y & 0xFFFFu), f16_to_f32(h2.y >> 16));
           } else {
@@ -460,8 +465,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       // are issued between the MFMAs of group g, into the other half of a two-deep register buffer, so a wave's MFMA
       // stream does not wait for LDS latency inside a stage (only the first group of a stage is exposed).
       constexpr int NG = C::TG * NKQ;          // fragment groups per stage
-      constexpr int NF = C::NPL * (C::WM + C::WN);        // fragments (ds_read_b128) per group; split f16: [pixel hi | pixel lo | weight hi | weight lo]
-      constexpr int NM = C::WM * C::WN * ((EK == EK_F32) ? 4 : C::SPLIT ? 3 : 1);   // MFMA instructions per group
+      constexpr int NF = C::NPLP * C::WM + C::NPL * C::WN;        // fragments (ds_read_b128) per group; split f16: [pixel hi | pixel lo | weight hi | weight lo]
+      constexpr int NM = C::WM * C::WN * ((EK == EK_F32) ? 4 : C::SPLIT ? (C::WONLY ? 2 : 3) : 1);   // MFMA instructions per group
       constexpr int FD = C::FRAG_DEPTH;        // register buffers: FD-1 groups of ds_reads are in flight ahead of the MFMAs
       uint4 fr[FD][NF];
       auto load_group = [&](int gi, uint4 (&f)[NF]) {
@@ -471,15 +476,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         const int pa = colt[dx][kq] + poff + dy * (PW * ROWB);
 #pragma unroll
         for (int m = 0; m < C::WM; ++m) f[m] = *reinterpret_cast<const uint4*>(smem + pa + m * (PW * ROWB));
-        if constexpr (C::SPLIT) {
+        if constexpr (C::NPLP == 2) {
 #pragma unroll
           for (int m = 0; m < C::WM; ++m) f[C::WM + m] = *reinterpret_cast<const uint4*>(smem + pa + C::PATCH_PLANE + m * (PW * ROWB));
         }
 #pragma unroll
-        for (int n = 0; n < C::WN; ++n) f[C::NPL * C::WM + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + (t * C::NT + n * 32) * ROWB);
+        for (int n = 0; n < C::WN; ++n) f[C::NPLP * C::WM + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + (t * C::NT + n * 32) * ROWB);
         if constexpr (C::SPLIT) {
 #pragma unroll
-          for (int n = 0; n < C::WN; ++n) f[2 * C::WM + C::WN + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + C::W_PLANE + (t * C::NT + n * 32) * ROWB);
+          for (int n = 0; n < C::WN; ++n) f[C::NPLP * C::WM + C::WN + n] = *reinterpret_cast<const uint4*>(smem + wa[kq] + C::W_PLANE + (t * C::NT + n * 32) * ROWB);
         }
       };
       if constexpr (FD > 1) {
@@ -497,15 +502,17 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
         if constexpr (C::SPLIT) {
           // W.P = Whi.Phi + Whi.Plo + Wlo.Phi (the product kind outermost: consecutive MFMAs hit different accumulators)
-          constexpr int PH_ = 0, PL_ = C::WM, WH_ = 2 * C::WM, WL_ = 2 * C::WM + C::WN;
+          constexpr int PH_ = 0, PL_ = C::WM, WH_ = C::NPLP * C::WM, WL_ = C::NPLP * C::WM + C::WN;
 #pragma unroll
           for (int n = 0; n < C::WN; ++n)
 #pragma unroll
             for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][WH_ + n], fr[gi % FD][PH_ + m]);
+          if constexpr (!C::WONLY) {      // (weights-only pair: the patch has one plane)
 #pragma unroll
           for (int n = 0; n < C::WN; ++n)
 #pragma unroll
             for (int m = 0; m < C::WM; ++m) mma_step<EK>(acc[n][m], fr[gi % FD][WH_ + n], fr[gi % FD][PL_ + m]);
+          }
 #pragma unroll
           for (int n = 0; n < C::WN; ++n)
 #pragma unroll
@@ -631,13 +638,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
       const unsigned rx = (gx >= 1 ? 1u : 0u) | 2u | (gx + 1 < w ? 4u : 0u);
       tapmask = ((ry & 1u) ? rx : 0u) | ((ry & 2u) ? (rx << 3) : 0u) | ((ry & 4u) ? (rx << 6) : 0u);
     }
-#pragma unroll
-    for (int n = 0; n < C::WN; ++n) {
-      uint2 pk[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (C::COUT < 32 && q >= 2) continue;            // conv4: couts 16..31 are zero padding
-        const int co = n0 + n * 32 + 8 * q + 4 * g;
+    // value (n, q) of this pixel row: accumulator quad + bias (+ the hoisted terms' border corrections, ReLU / FPN addend of the once-per-image layers)
+    auto value_of = [&](int n, int q, float (&v)[4]) {
+      const int co = n0 + n * 32 + 8 * q + 4 * g;
+      (void)co;
         float4 bv = *reinterpret_cast<const float4*>(tab_bias + sp * C::NT + n * 32 + 8 * q + 4 * g);
         if constexpr (C::ADD_C) {
           // tab_bias already holds bias + the full 9-tap E[t] sum; pixels on the image border take the missing taps out
@@ -670,7 +674,6 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             }
           }
         }
-        float v[4];
         if constexpr (C::SPLIT) {      // accumulators carry the operands' scales: one exact power-of-two multiply, fused with the bias add
           constexpr float OS = split_oscale(C::PRO);
           v[0] = fmaf(acc[n][m][q * 4 + 0], OS, bv.x); v[1] = fmaf(acc[n][m][q * 4 + 1], OS, bv.y);
@@ -703,6 +706,57 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
             }
           }
         }
+    };
+    if constexpr (C::Q15) {
+      // y3 as int16 with one fp32 scale per pixel (dd_kernels.h, EK_F16Q): pass 1 finishes the values in place (statistics from the fp32 values),
+      // and finds the pixel's max |.| -- its 64 couts sit in this lane and in lane ^ 32; pass 2 normalises, packs (v_cvt_pknorm_i16_f32) and stores
+      float pmax = 0.f;
+#pragma unroll
+      for (int n = 0; n < C::WN; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+          value_of(n, q, v);
+          if (pvalid) {
+            const float s = (v[0] + v[1]) + (v[2] + v[3]);
+            const float sq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+            const int lg = 2 * n + (q >> 1);
+            ls[lg] += s; lq[lg] += sq;
+          }
+          pmax = fmaxf(pmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[n][m][q * 4 + i] = v[i];
+        }
+      pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+      const float inv = pmax > 0.f ? 1.f / pmax : 0.f;
+      if (pvalid && g == 0) p.out_scale[(size_t)e_b * h * w + (size_t)gy * w + gx] = pmax * (1.f / Q15_ONE);
+#pragma unroll
+      for (int n = 0; n < C::WN; ++n) {
+        uint2 pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          pk[q].x = DD_CVT_PKNORM_I16(acc[n][m][q * 4 + 0] * inv, acc[n][m][q * 4 + 1] * inv);
+          pk[q].y = DD_CVT_PKNORM_I16(acc[n][m][q * 4 + 2] * inv, acc[n][m][q * 4 + 3] * inv);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto rx = __builtin_amdgcn_permlane32_swap(pk[2 * k].x, pk[2 * k + 1].x, false, false);
+          const auto ry = __builtin_amdgcn_permlane32_swap(pk[2 * k].y, pk[2 * k + 1].y, false, false);
+          const int co = n0 + n * 32 + 16 * k + 8 * g;
+          if (pvalid) *reinterpret_cast<uint4*>(out_b + act_offset(C::COUT, h, w, 0, co, gy, gx) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int n = 0; n < C::WN; ++n) {
+      uint2 pk[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (C::COUT < 32 && q >= 2) continue;            // conv4: couts 16..31 are zero padding
+        const int co = n0 + n * 32 + 8 * q + 4 * g;
+        float v[4];
+        value_of(n, q, v);
         if (C::STATS && pvalid) {
           const float s = (v[0] + v[1]) + (v[2] + v[3]);
           const float sq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
@@ -917,8 +971,18 @@ static hipError_t launch_layer2_refined(int layer, const ConvParams& p, hipStrea
     default: return launch_layer2<EK_F16>(layer, p, s);
   }
 }
+// EK_F16Q: the refined forms with block-scaled int16 hand-overs (conv3) and the weights-only pair (conv1)
+static hipError_t launch_layer2_refined_q(int layer, const ConvParams& p, hipStream_t s) {
+  switch (layer) {
+    case 1: return launch_one2<EK_F16Q, 1>(p, s);
+    case 9: return launch_one2<EK_F16Q, 9>(p, s);
+    case BIG_CONV3H: return launch_one2<EK_F16Q, BIG_CONV3H>(p, s);
+    default: return launch_layer2<EK_F16>(layer, p, s);
+  }
+}
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s) {
   switch (ek) {
+    case EK_F16Q: return launch_layer2_refined_q(layer, p, s);
     case EK_F16R: return launch_layer2_refined(layer, p, s);
     case EK_F16S: return launch_layer2_split(layer, p, s);
     case EK_F32: return launch_layer2<EK_F32>(layer, p, s);
@@ -1009,6 +1073,7 @@ static PackGeom geom2_layer_split(int layer) {
 }
 PackGeom conv_pack_geom2(int layer, int ek) {
   switch (ek) {
+    case EK_F16Q:
     case EK_F16R: {      // conv1: the split image; conv4: the f16 geometry with the lo halves stacked into the padding cout rows; else f16
       if (layer == 1) return geom2_of<EK_F16S, 1>();
       PackGeom g = geom2_layer<EK_F16>(layer);

@@ -4,6 +4,7 @@
 // per DDIM step; they are written for coalescing (consecutive lanes <-> consecutive addresses on the
 // wide side of every transfer), not for the matrix cores.
 #include "dd_elem.h"
+#include "dd_gcn.h"
 
 namespace dd {
 
@@ -1097,18 +1098,20 @@ hipError_t launch_max_abs(const float* w, long long n, unsigned* out_bits, hipSt
   return hipGetLastError();
 }
 
-// EK_F16R: conv3(cond) from the accumulator-fragment order of 8x32 tiles (fp32; what the split-f16 layer 8 writes: entry
+// EK_F16R / EK_F16Q: conv3(cond) from the accumulator-fragment order of 8x32 tiles (fp32; what the split-f16 layer 8 writes: entry
 // ((((tile * 4 + wave) * 2 + n) * 2 + m) * 4 + q) * 64 + lane = couts 32n + 8q + 4g .. +3 of pixel (8 ty + 2 wave + m, 32 tx + li), lane = 32g + li)
-// into the order of the loop's conv3 tiles -- 8x32 (WM = 2) or 16x32 (WM = 4: pixel row 16 ty + 4 wave + m) -- as fp32 or f16 quads.
-// One thread per destination entry; rows of a 16-row tile below the source's last tile row read as zero (never used: outside the image).
-__global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __restrict__ src, void* __restrict__ dst, int B, int h, int w,
-                                                            int big, int out_f16, long long n_entries) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n_entries) return;
+// into the order of the loop's conv3 tiles -- 8x32 (WM = 2) or 16x32 (WM = 4: pixel row 16 ty + 4 wave + m) -- as fp32, f16 quads, or int16 quads
+// with one fp32 scale per (tile, wave, n, m) block of 32 pixels x 32 couts (out_kind 2: max |.| of the block / 32767).  One workgroup of 256 threads
+// per destination block (thread = (q, lane)); rows of a 16-row tile below the source's last tile row read as zero (never used: outside the image).
+__global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __restrict__ src, void* __restrict__ dst, float* __restrict__ scales, int B, int h, int w,
+                                                            int big, int out_kind) {
+  __shared__ float s_max[4];
   const int WM = big ? 4 : 2, TH = big ? 16 : 8;
   const int tiles_x = (w + 31) / 32, tiles_y = (h + TH - 1) / TH, stiles_y = (h + 7) / 8;
-  const int lane = (int)(e & 63), q = (int)((e >> 6) & 3);
-  long long r = e >> 8;
+  const long long blk = blockIdx.x;                   // ((tile * 4 + wave) * 2 + n) * WM + m
+  const long long e = blk * 256 + threadIdx.x;        // destination entry
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  long long r = blk;
   const int m = (int)(r % WM); r /= WM;
   const int n = (int)(r & 1); r >>= 1;
   const int wave = (int)(r & 3); r >>= 2;
@@ -1116,20 +1119,30 @@ __global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __rest
   const int b = tile / (tiles_x * tiles_y), trem = tile - b * tiles_x * tiles_y;
   const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
   const int y = ty * TH + wave * WM + m;
+  (void)B;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (y < stiles_y * 8) {
     const int sty = y >> 3, swave = (y & 7) >> 1, sm = y & 1;
     const long long stile = ((long long)b * stiles_y + sty) * tiles_x + tx;
     v = src[((((stile * 4 + swave) * 2 + n) * 2 + sm) * 4 + q) * 64 + lane];
   }
-  if (out_f16) reinterpret_cast<uint2*>(dst)[e] = make_uint2(pack2<EK_F16>(v.x, v.y), pack2<EK_F16>(v.z, v.w));
+  if (out_kind == 2) {
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_max[q] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const float inv = mx > 0.f ? 1.f / mx : 0.f;
+    if (threadIdx.x == 0) scales[blk] = mx * (1.f / Q15_ONE);
+    reinterpret_cast<uint2*>(dst)[e] = make_uint2(DD_CVT_PKNORM_I16(v.x * inv, v.y * inv), DD_CVT_PKNORM_I16(v.z * inv, v.w * inv));
+  } else if (out_kind == 1) reinterpret_cast<uint2*>(dst)[e] = make_uint2(pack2<EK_F16>(v.x, v.y), pack2<EK_F16>(v.z, v.w));
   else reinterpret_cast<float4*>(dst)[e] = v;
 }
-hipError_t launch_cadd_reformat(const float* src, void* dst, int B, int h, int w, int big, int out_f16, hipStream_t s) {
-  const int TH = big ? 16 : 8;
-  const long long n_entries = (long long)B * ((h + TH - 1) / TH) * ((w + 31) / 32) * TH * 32 * (HID_C / 4);
-  hipLaunchKernelGGL(cadd_reformat_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4*>(src), dst, B, h, w,
-                     big, out_f16, n_entries);
+hipError_t launch_cadd_reformat(const float* src, void* dst, float* scales, int B, int h, int w, int big, int out_kind, hipStream_t s) {
+  const int TH = big ? 16 : 8, WM = big ? 4 : 2;
+  const long long n_blocks = (long long)B * ((h + TH - 1) / TH) * ((w + 31) / 32) * 4 * 2 * WM;
+  hipLaunchKernelGGL(cadd_reformat_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(src), dst, scales, B, h, w, big, out_kind);
   return hipGetLastError();
 }
 

@@ -19,7 +19,9 @@
 //   STACK   the packed weight image carries an f16 PAIR per weight in ONE MFMA: the 32x32x16 instruction has 32 cout rows, conv4 has 16 couts, so rows
 //           16..31 (zero padding in the plain image) hold f16((w - f16(w)) * 2^11) and the epilogue adds accumulator quads q and q + 2 (lane-local).
 //           Same MFMA count, same LDS traffic; conv4's weight rounding -- the largest single term of the f16 mode's depth error -- is gone.
-//   IN32    y3 arrives as fp32 (no f16 rounding of the tensor in front of GroupNorm 3): two 16-byte loads per staging item
+//   INK     how y3 arrives: 0 = the 2-byte kind; 1 = fp32 (no f16 rounding of the tensor in front of GroupNorm 3): two 16-byte loads per staging item;
+//           2 = int16 with one fp32 scale per pixel (EK_F16Q, dd_kernels.h: f16's bytes, ~15 bits relative to the pixel's largest channel):
+//           one more 4-byte load per staging item, the scale folded into the GroupNorm table's slope
 //   PSPLIT  the operand relu(gn3(y3)) as an f16 pair as well (scaled by 2^4 so that lo halves stay normal): a second LDS plane per patch buffer and
 //           a second MFMA per tap against the same stacked weight fragment -- [Whi; Wlo] . (Phi + Plo) = all four partial products
 // Same arithmetic as layer 4 of dd_igemm2.hip: the packed weight image of that layer (16-channel chunks, nine taps per stage, 32 cout rows,
@@ -48,11 +50,12 @@ static_assert(Cfg2<EK_F16, 4>::CK == CK && Cfg2<EK_F16, 4>::TG == 9 && Cfg2<EK_F
               "the packed weight image of layer 4 (dd_igemm2_cfg.h, DD_C4_CK16) is read as it is");
 }  // namespace thin
 
-template <int EK, bool STACK, bool IN32, bool PSPLIT>
+template <int EK, bool STACK, int INK, bool PSPLIT>
 __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvParams p) {
   using namespace thin;
+  constexpr bool IN32 = INK == 1, INQ = INK == 2;
   static_assert(EK == EK_F16 || EK == EK_BF16, "2-byte kinds");
-  static_assert(EK == EK_F16 || !(STACK || IN32 || PSPLIT), "the refined forms are f16 kernels");
+  static_assert(EK == EK_F16 || !(STACK || INK != 0 || PSPLIT), "the refined forms are f16 kernels");
   static_assert(STACK || !PSPLIT, "the operand pair runs against the stacked weight image");
   constexpr int PATCH_BYTES = (PSPLIT ? 2 : 1) * PATCH_PLANE;
   constexpr int TAB_OFF = W_BYTES + 2 * PATCH_BYTES;
@@ -156,13 +159,17 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   // refilled two stages ahead -- the same ~43 KB per workgroup in flight, and the kernel stays inside 128 VGPRs (four waves per SIMD).
   constexpr int NSLOT = IN32 ? 2 : NCH;
   uint4 raw[NSLOT][NIT][NLD];
+  float rsc[INQ ? NSLOT : 1][NIT];                               // INQ: the pixel's scale (travels with the item)
+  const float* sc_b = INQ ? p.cadd_scale + (size_t)b * h * w : nullptr;
   auto load_chunk = [&](int c, int slot, const int* po) {        // channel-blocked y3: [B][2][h][w][32]
     const int cbase = c * CK + jfix * EPP;
     const size_t off0 = (size_t)(cbase >> 5) * h * w * ACT_CB + (cbase & (ACT_CB - 1));
 #pragma unroll
-    for (int u = 0; u < NIT; ++u)
+    for (int u = 0; u < NIT; ++u) {
 #pragma unroll
       for (int q = 0; q < NLD; ++q) raw[slot][u][q] = *reinterpret_cast<const uint4*>(in_b + (off0 + (size_t)po[u] * ACT_CB) * IN_ESZ + q * 16);
+      if constexpr (INQ) rsc[slot][u] = sc_b[po[u]];
+    }
   };
   auto transform_chunk = [&](int c, int slot, int buf, unsigned mi) {        // relu(gn3(y3)) of chunk c (in register slot `slot`) -> patch buffer `buf`
     float ta[EPP], tb[EPP];
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
       // stage -- which drains the whole prefetch (seen in the first version of this kernel: conv4 30 us instead of 36, not 22).
       const bool inside = (mi >> u) & 1u;                   // zero padding applies AFTER the normalisation
       uint4 v, vlo = make_uint4(0u, 0u, 0u, 0u);
-      if constexpr (!IN32 && !PSPLIT) {
+      if constexpr (INK == 0 && !PSPLIT) {
         v = affine_relu_pack<EK, EK>(raw[slot][u][0], ta, tb);
       } else {
         float y[EPP];
@@ -189,6 +196,11 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
                                   raw[slot][u][NLD - 1].x, raw[slot][u][NLD - 1].y, raw[slot][u][NLD - 1].z, raw[slot][u][NLD - 1].w};
 #pragma unroll
           for (int i = 0; i < EPP; ++i) y[i] = __builtin_bit_cast(float, yw[i]);
+        } else if constexpr (INQ) {
+          const uint32_t qw[4] = {raw[slot][u][0].x, raw[slot][u][0].y, raw[slot][u][0].z, raw[slot][u][0].w};
+          const float sc = rsc[slot][u];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { y[2 * i] = (float)(short)(qw[i] & 0xFFFFu) * sc; y[2 * i + 1] = (float)((int)qw[i] >> 16) * sc; }
         } else {
           Piece<EK>::unpack(raw[slot][u][0], y);
         }
@@ -317,7 +329,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   }
 }
 
-template <int EK, bool STACK, bool IN32, bool PSPLIT> static hipError_t launch_conv4_stream_k(const ConvParams& p, hipStream_t s) {
+template <int EK, bool STACK, int IN32, bool PSPLIT> static hipError_t launch_conv4_stream_k(const ConvParams& p, hipStream_t s) {
   static bool attr_set = false;
   constexpr int SMEM = thin::smem_bytes(PSPLIT);
   if (!attr_set) {
@@ -330,15 +342,16 @@ template <int EK, bool STACK, bool IN32, bool PSPLIT> static hipError_t launch_c
   return hipGetLastError();
 }
 
-hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack, bool in32, bool psplit) {
+hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack, int in_kind, bool psplit) {
   if (ek == EK_F16 && stack) {
-    if (in32) return psplit ? launch_conv4_stream_k<EK_F16, true, true, true>(p, s) : launch_conv4_stream_k<EK_F16, true, true, false>(p, s);
-    return psplit ? launch_conv4_stream_k<EK_F16, true, false, true>(p, s) : launch_conv4_stream_k<EK_F16, true, false, false>(p, s);
+    if (in_kind == 2) return psplit ? launch_conv4_stream_k<EK_F16, true, 2, true>(p, s) : launch_conv4_stream_k<EK_F16, true, 2, false>(p, s);
+    if (in_kind == 1) return psplit ? launch_conv4_stream_k<EK_F16, true, 1, true>(p, s) : launch_conv4_stream_k<EK_F16, true, 1, false>(p, s);
+    return psplit ? launch_conv4_stream_k<EK_F16, true, 0, true>(p, s) : launch_conv4_stream_k<EK_F16, true, 0, false>(p, s);
   }
-  if (stack || in32 || psplit) return hipErrorInvalidValue;
+  if (stack || in_kind != 0 || psplit) return hipErrorInvalidValue;
   switch (ek) {
-    case EK_F16: return launch_conv4_stream_k<EK_F16, false, false, false>(p, s);
-    case EK_BF16: return launch_conv4_stream_k<EK_BF16, false, false, false>(p, s);
+    case EK_F16: return launch_conv4_stream_k<EK_F16, false, 0, false>(p, s);
+    case EK_BF16: return launch_conv4_stream_k<EK_BF16, false, 0, false>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -42,7 +42,7 @@ class DDIMDepthEstimate_Res(nn.Module):
 
     def __init__(self, in_channels=(64, 128, 256, 512), up_scale_factor=1, inference_steps=20, num_train_timesteps=1000,
                  return_indices=None, depth_transform_cfg=None, depth_feature_dim=16, detach_fp=False, loss_cfgs=(),
-                 init_cfg=None, precision=None, condition_backend="hip", eval_ddim_loss=True, loss_noise_device="cpu", **kwargs):
+                 init_cfg=None, precision=None, condition_backend="hip", eval_ddim_loss=True, loss_noise_device="auto", **kwargs):
         """Beyond the reference's keywords (src/model/diffusion_dcbase_model.py:77-91):
         precision          operand mode of the HIP kernels ("fp32" parity / "bf16" / "f16"; None = the library default)
         condition_backend  "hip" (dd_condition) or "torch" for the FPN
@@ -51,10 +51,12 @@ class DDIMDepthEstimate_Res(nn.Module):
                            outside .train() and returns a zero scalar under 'ddim_loss' (inference-only deployments).
         loss_noise_device  "cpu" = draw the loss noise on the host and copy it over, as the reference does (…res.py:203, quirk q3: same
                            RNG stream as the reference); "device" = draw it on the GPU (same distribution, different stream; saves the
-                           6.8 MB-per-KITTI-map host RNG + H2D copy per forward)."""
+                           6.8 MB-per-KITTI-map host RNG + H2D copy per forward: 15.6 -> 8.0 ms per KITTI eval forward, BENCH_r03
+                           `head_forward`); "auto" [default] = "cpu" in .train() -- the reference's training RNG stream -- and "device" in
+                           eval, where the loss value is an output nobody trains on and `pred` does not depend on it."""
         super().__init__()
-        if loss_noise_device not in ("cpu", "device"):
-            raise ValueError("loss_noise_device must be 'cpu' or 'device'")
+        if loss_noise_device not in ("cpu", "device", "auto"):
+            raise ValueError("loss_noise_device must be 'cpu', 'device' or 'auto'")
         # HAHI heads only: True runs the PyTorch neck under autocast in the kernels' 16-bit type.  Default False = the reference's fp32
         # arithmetic (the reference never autocasts the neck; VERDICT r1 weak #10)
         self.neck_autocast = bool(kwargs.pop("neck_autocast", False))
@@ -179,10 +181,11 @@ class DDIMDepthEstimate_Res(nn.Module):
 
     def ddim_loss(self, gt_depth, refine_module_inputs, blur_depth_t, weight, **kwargs):
         """…res.py:201-217: same RNG draw order (CPU randn for the noise, device randint for t)."""
-        if self.loss_noise_device == "cpu":
+        on_host = self.loss_noise_device == "cpu" or (self.loss_noise_device == "auto" and self.training)
+        if on_host:
             noise = torch.randn(blur_depth_t.shape).to(blur_depth_t.device)
         else:
-            noise = torch.randn(blur_depth_t.shape, device=blur_depth_t.device)
+            noise = torch.randn(blur_depth_t.shape, device=blur_depth_t.device).to(blur_depth_t.device)     # (.to: a no-op unless a test injects its own draw)
         bs = blur_depth_t.shape[0]
         timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bs,), device=gt_depth.device).long()
         # the loop output is not detached in the reference: when it carries gradient, q_sample stays a torch op so that

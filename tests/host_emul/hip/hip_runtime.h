@@ -348,6 +348,15 @@ inline v2u permlane32_swap(unsigned vdst, unsigned src0) {
 // ds_read_b64_tr_b16 (gfx950): every lane supplies the LDS address of 4 contiguous 16-bit elements; inside each group of 16 lanes the
 // 16 x 4 matrix M[lane r][element c] comes back transposed in 4-row blocks: lane l = 4 r0 + i receives (M[r0][i], M[r0+4][i], M[r0+8][i],
 // M[r0+12][i]) -- measured on an MI355X with tools/micro/tr16_probe.hip (the ISA manual is not in this image).
+// v_cvt_pknorm_i16_f32: clamp to [-1, 1], times 32767, round to nearest even; lo half = a
+inline unsigned cvt_pknorm_i16(float a, float b) {
+  auto one = [](float x) -> unsigned {
+    if (!(x == x)) return 0u;
+    x = x < -1.f ? -1.f : (x > 1.f ? 1.f : x);
+    return (unsigned)(unsigned short)(short)__builtin_nearbyintf(x * 32767.f);
+  };
+  return one(a) | (one(b) << 16);
+}
 typedef __attribute__((ext_vector_type(2))) unsigned tr16_v2u;
 inline tr16_v2u lds_read_tr16(const char* addr) {
   State& s = st();

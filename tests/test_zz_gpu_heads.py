@@ -174,7 +174,7 @@ def test_head_inference_switches(U, cases):
     h, w = synth.latent_hw(H, W)
     inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
     outs = {}
-    for name, kw in (("ref", {}), ("inf", dict(eval_ddim_loss=False)), ("dev", dict(loss_noise_device="device"))):
+    for name, kw in (("ref", dict(loss_noise_device="cpu")), ("inf", dict(eval_ddim_loss=False)), ("dev", {})):      # (the default draws on the device in eval)
         head = _load(dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=5, num_train_timesteps=1000,
                                                depth_feature_dim=16, loss_cfgs=[], precision="fp32", **kw).eval(), sd)
         x_T = U.cu(inp["x_T"])

@@ -41,6 +41,16 @@ def rnd(x, dt):
         return x
     if dt == "bf16x2":
         return split2(x)
+    if dt == "q15p":           # int16 with one fp32 scale per PIXEL (max |.| over its channels): what y3 travels as in the refined f16 mode
+        sc = x.abs().amax(dim=1, keepdim=True).clamp_min(1e-30) / 32767.0
+        return torch.round(x / sc) * sc
+    if dt == "q15b":           # int16 with one scale per 32-pixel x 32-channel block (a wave's accumulator block): the hoisted conv3(cond) term
+        B, C, h, w = x.shape
+        wp = (w + 31) // 32 * 32
+        xp = F.pad(x, (0, wp - w))
+        blk = xp.view(B, C // 32, 32, h, wp // 32, 32)
+        sc = blk.abs().amax(dim=(2, 5), keepdim=True).clamp_min(1e-30) / 32767.0
+        return (torch.round(blk / sc) * sc).view(B, C, h, wp)[..., :w]
     if dt == "f16x2":          # hi + lo f16 pair (the split-f16 mode's operands: ~22 mantissa bits)
         hi = x.to(torch.float16).float()
         return hi + (x - hi).to(torch.float16).float()
@@ -111,7 +121,7 @@ def parse_plan(spec):
             continue
         srcs, dt = part.split(":")
         for s in (SOURCES if srcs == "all" else srcs.split("+")):     # plus the pseudo-sources "hoistc", "hs"
-            R[s] = dt if dt in ("bf16x2", "f16x2") else DT[dt]
+            R[s] = dt if dt in ("bf16x2", "f16x2", "q15p", "q15b") else DT[dt]
     return name, R
 
 

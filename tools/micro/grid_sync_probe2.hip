@@ -11,11 +11,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-constexpr unsigned SPIN_MAX = 1u << 21;
+constexpr unsigned SPIN_MAX = 1u << 17;      // ~20 ms: a barrier that does not work ends the kernel quickly
 
-template <int SCOPE> __device__ __forceinline__ bool spin_until(const unsigned* ctr, unsigned target) {
+// Agent scope: an sc1 load (misses the CU's vector L1, coherent across XCDs).  "Workgroup" scope is used here for the counters that live in ONE
+// XCD's L2: a workgroup-scope LOAD may hit the CU's own L1 (the scope only promises coherence inside a workgroup), so the poll is an atomic
+// read-modify-write of zero -- atomics always execute at the L2, which is shared by the XCD's CUs (first version of this probe polled with
+// sc0 loads and timed out: profiles/r04_call2_grid_sync_probe2.txt).
+template <int SCOPE> __device__ __forceinline__ bool spin_until(unsigned* ctr, unsigned target) {
   for (unsigned s = 0; s < SPIN_MAX; ++s) {
-    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, SCOPE) >= target) return true;
+    const unsigned v = SCOPE == __HIP_MEMORY_SCOPE_WORKGROUP ? __hip_atomic_fetch_add(ctr, 0u, __ATOMIC_RELAXED, SCOPE) : __hip_atomic_load(ctr, __ATOMIC_RELAXED, SCOPE);
+    if (v >= target) return true;
     __builtin_amdgcn_s_sleep(1);
   }
   return false;
@@ -65,7 +70,7 @@ __global__ void __launch_bounds__(256) barrier_kernel(Ctl* c, unsigned* slots, i
           unsigned nx = 0;
           for (int x = 0; x < 8; ++x) nx += __hip_atomic_load(&c->reg[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
           if (!spin_until<__HIP_MEMORY_SCOPE_AGENT>(&c->top[which], round * nx)) *err = 1;
-          __hip_atomic_store(&c->flag[xcc][which], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_exchange(&c->flag[xcc][which], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (an atomic: executed at the L2)
         } else {
           if (!spin_until<__HIP_MEMORY_SCOPE_WORKGROUP>(&c->flag[xcc][which], round)) *err = 1;
         }
@@ -74,6 +79,7 @@ __global__ void __launch_bounds__(256) barrier_kernel(Ctl* c, unsigned* slots, i
     __syncthreads();
   };
   for (int it = 0; it < n; ++it) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // somebody timed out: everybody leaves
     const unsigned tok = (unsigned)(it * 131 + b);
     if (threadIdx.x == 0) {
       if (MODE == 2) slots[b * 64] = tok;
@@ -89,25 +95,6 @@ __global__ void __launch_bounds__(256) barrier_kernel(Ctl* c, unsigned* slots, i
       barrier((unsigned)it + 1, 1);        // nobody overwrites a slot before its reader has looked
     }
   }
-}
-
-// 64 KB per workgroup through the same data path: what a layer hand-over would move (per-workgroup throughput of sc1 stores + sc1 loads vs plain)
-typedef __attribute__((ext_vector_type(4))) float f4_t;
-template <int SC1>
-__global__ void __launch_bounds__(256) stream_kernel(f4_t* buf, int reps) {
-  f4_t* p = buf + (size_t)blockIdx.x * 4096 + threadIdx.x;
-  f4_t acc = {0.f, 0.f, 0.f, 0.f};
-  for (int r = 0; r < reps; ++r) {
-    for (int i = 0; i < 16; ++i) {
-      const f4_t v = {(float)r, (float)i, 1.f, 2.f};
-      if (SC1) __builtin_nontemporal_store(v, p + i * 256); else p[i * 256] = v;
-    }
-    for (int i = 0; i < 16; ++i) {
-      const f4_t v = SC1 ? __builtin_nontemporal_load(p + i * 256) : p[i * 256];
-      acc.x += v.x; acc.y += v.y;
-    }
-  }
-  if (acc.x == -1.f) buf[0] = acc;
 }
 
 template <int MODE> float run(int nb, int n, int check, int* herr) {
@@ -131,7 +118,7 @@ int main() {
   const char* names[3] = {"(d) flat agent-scope counter, data by sc1 store / sc1 load, no fences", "(d)+(e) two-level barrier (per-XCD L2 counter + 8 leaders), data by sc1",
                           "(e) two-level barrier, PLAIN data stores / loads (control: stale expected)"};
   for (int nb : {256, 418, 512}) {
-    printf("== %d workgroups of 256 threads\n", nb);
+    printf("== %d workgroups of 256 threads\n", nb); fflush(stdout);
     for (int mode = 0; mode < 3; ++mode) {
       int herr[2] = {0, 0};
       float msc = mode == 0 ? run<0>(nb, 50, 1, herr) : mode == 1 ? run<1>(nb, 50, 1, herr) : run<2>(nb, 50, 1, herr);
@@ -141,21 +128,7 @@ int main() {
       float t1 = mode == 0 ? run<0>(nb, n, 0, herr) : mode == 1 ? run<1>(nb, n, 0, herr) : run<2>(nb, n, 0, herr);
       printf("  %-78s %7.2f us per barrier   (spin timeouts %d, stale tokens in 50 checked rounds %d; checked pass %.2f ms)\n", names[mode], (t1 - t0) * 1e3f / n,
              e0 | herr[0], stale, msc);
-    }
-  }
-  {
-    // the price of the sc1 data path itself: 512 workgroups x 64 KB written and read back, 50 times
-    f4_t* buf; hipMalloc(&buf, (size_t)512 * 4096 * 16);
-    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int sc1 = 0; sc1 < 2; ++sc1) {
-      for (int w = 0; w < 2; ++w) {
-        hipEventRecord(a, 0);
-        if (sc1) hipLaunchKernelGGL(stream_kernel<1>, dim3(512), dim3(256), 0, 0, buf, 50); else hipLaunchKernelGGL(stream_kernel<0>, dim3(512), dim3(256), 0, 0, buf, 50);
-        hipEventRecord(b, 0); hipDeviceSynchronize();
-      }
-      float ms = 0; hipEventElapsedTime(&ms, a, b);
-      printf("== 512 workgroups x 64 KB written + read back x 50, %s: %.3f ms = %.2f TB/s\n", sc1 ? "nontemporal (nt) stores / loads" : "plain stores / loads", ms,
-             2.0 * 512 * 65536 * 50 / (ms * 1e-3) / 1e12);
+      fflush(stdout);
     }
   }
   return 0;
