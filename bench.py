@@ -645,7 +645,7 @@ def main():
         # the decoder ends in exp(-z): a 16-bit mode's depth error is RELATIVE, so its absolute RMSE grows with the depths decoded.  With
         # these untrained weights (the loop amplifies the latent to |x_0| ~ 5e2) the 1e-3 absolute RMSE of the north star holds up to:
         cpu["abs_rmse_1e3_holds_to_rms_depth_m"] = round(1e-3 / max(rel, 1e-12), 2)
-        if args.variant == "res":
+        if True:
             # the SAME latents decoded at KITTI's depth range (decoder bias shifted: every depth x e^1.8) -- part of the parity gate below -- and,
             # unless --no-abs-extra, two modes beside the timed one: the abs-clean split f16 (f16x3) and BASELINE.json's named dtype (bf16 operands):
             # throughput of the same step and depth error, near and far range

@@ -106,8 +106,9 @@ struct PlanKey {
   int keep = 0;        // option "keep_trajectory" (what dd_denoise_backward needs): 1 = the loop leaves every state x_k in Plan::xstash;
                        // 2 = ... and every step's raw conv outputs y1..y4 (Swin: + convA / convB results) in per-step slots
   int lane = 0;        // dd_denoise with option "streams" > 1 runs a batch as concurrent sub-batches: one plan (buffers, graph) per lane
+  int lanes = 1;       // ... and how many lanes the call runs as: the tile shape of the hoisted conv3 pair depends on it (plan_big_tiles)
   bool operator<(const PlanKey& o) const {
-    return std::tie(B, h, w, ch, cw, T, prec, hoist, keep, lane) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist, o.keep, o.lane);
+    return std::tie(B, h, w, ch, cw, T, prec, hoist, keep, lane, lanes) < std::tie(o.B, o.h, o.w, o.ch, o.cw, o.T, o.prec, o.hoist, o.keep, o.lane, o.lanes);
   }
 };
 
@@ -233,6 +234,7 @@ struct dd_handle_s {
   int n_streams = 1;          // option "streams": concurrent sub-batches of dd_denoise (1 = off)
   int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
   int big_tiles = -1;         // option "big_tiles": hoisted conv3 pair on 16x32 tiles: -1 = when the 8x32 tiles exceed the 512 resident slots, 0 / 1 = forced
+  int one_buffer = 1;         // option "one_buffer": the hoisted conv3 on 8x32 tiles in its one-patch-buffer form when the tiles exceed the resident slots (A/B switch)
   int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
   int f16r_wide = 2;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as 0 = f16 (as DD_PREC_F16), 1 = fp32, 2 = block-scaled int16
   int f16r_c1 = 1;            // DD_PREC_F16R: conv1 as 0 = the f16 kernel, 1 = weights as an f16 pair (two MFMAs), 2 = weights and state as pairs (three)
@@ -533,10 +535,20 @@ bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
   const int ek = ek_of_precision(key.prec, h->bf16_pure);
   if (ek == EK_F32 || ek == EK_F16S) return false;
   if (h->big_tiles >= 0) return h->big_tiles != 0;
-  return (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > h->resident_slots;
+  // more 8x32 tiles than resident slots: 16x32 tiles under concurrent lanes (half the weight stream and 0.75 LDS reads per MFMA: what counts when
+  // the other lane keeps the chip full anyway); a call that runs as ONE lane keeps the 8x32 tiles in their one-patch-buffer form (three workgroups
+  // per CU: conv3 140 -> 132 us at KITTI B=4, profiles/r04_call3_*) -- the Res denoiser's conv3; the Swin 5x5 form has no such kernel
+  const bool many = (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > h->resident_slots;
+  return many && (key.lanes > 1 || h->variant == DD_VARIANT_SWIN);
 }
 inline int conv3c_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3C : 8; }
-inline int conv3h_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3H : 9; }
+// the loop's hoisted conv3: 16x32 tiles, or 8x32 tiles -- with ONE patch buffer (kernel id ONE_CONV3H: same tiles, same fragment order, 52 KB
+// of LDS = three workgroups per CU) when there are more tiles than the chip holds at two per CU
+inline int conv3h_kid(dd_handle_t h, const PlanKey& key) {
+  if (plan_big_tiles(h, key)) return (int)BIG_CONV3H;
+  const bool many = (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > h->resident_slots;
+  return (h->one_buffer == 2 || (many && h->one_buffer)) ? (int)ONE_CONV3H : 9;      // (2 = always: tests)
+}
 
 int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   auto it = h->plans.find(key);
@@ -1474,6 +1486,11 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     if (h->thin_slots != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }
     h->thin_slots = (int)value;
   }
+  else if (k == "one_buffer") {
+    if (value < 0 || value > 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: one_buffer must be 0, 1 or 2");
+    if (h->one_buffer != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // the kernel choice is baked into captured graphs
+    h->one_buffer = (int)value;
+  }
   else if (k == "thin_stream") {
     if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_stream must be 0 or 1");
     if (h->thin_stream != (int)value) {          // the kernel choice is baked into captured graphs
@@ -1679,7 +1696,7 @@ namespace {
 // The loop on B images (a whole call, or one lane of it: images img0 .. img0 + B - 1 of a batch of whole_B whose tensors start at the
 // pointers given -- already offset to the lane's first image) on stream s.
 int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
-                 int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0, int whole_B, int64_t ticket) {
+                 int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0, int whole_B, int64_t ticket, int S) {
   int rc = DD_OK;
   const bool timed = h->timing && lane == 0 && B == whole_B;      // lanes: the caller brackets fork .. join
   Plan* pl = nullptr;
@@ -1691,15 +1708,15 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
     const size_t per_step = (size_t)B * lat_h * lat_w * ((2 * HID_C + COND_C + (h->variant == DD_VARIANT_SWIN ? 2 * COND_C : 0)) * es + LATENT_C * 4);
     const size_t need = per_step * (size_t)T;
     if (need <= ((size_t)h->keep_act_mb << 20) &&
-        (h->plans.count(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 2), 2, lane}) || keep2_fits(h, need))) keep = 2;
+        (h->plans.count(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 2), 2, lane, S}) || keep2_fits(h, need))) keep = 2;
   }
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, keep), keep, lane}, &pl);
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, keep), keep, lane, S}, &pl);
   if (rc && keep == 2) {
     // the per-step slots did not fit after all (fragmentation, another process): states only -- the backward then recomputes the activations
     (void)hipGetLastError();
-    h->plans.erase(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 2), 2, lane});
+    h->plans.erase(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 2), 2, lane, S});
     keep = 1;
-    rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, keep), keep, lane}, &pl);
+    rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, keep), keep, lane, S}, &pl);
   }
   if (rc) return rc;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;
@@ -1810,7 +1827,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   const int S = lane_count(h, B, precision);
   const int64_t ticket = (h->keep_traj && precision != DD_PREC_NAIVE_FP32) ? ++h->traj_serial : 0;
   if (h->variant == DD_VARIANT_SWIN && h->swin_w5 && want_hoist(h, precision, T, h->keep_traj ? 1 : 0)) { rc = ensure_swin_w5(h, s); if (rc) return rc; }
-  if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket);
+  if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, 1);
   for (int l = 1; l < S; ++l) {
     if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
     if (!h->lane_done[l]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
@@ -1828,7 +1845,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
     hipStream_t ls = l == 0 ? s : h->lane_stream[l];
     if (l > 0) DD_HIP(hipStreamWaitEvent(ls, h->lane_fork, 0));
     rc = denoise_lane(h, x_T + img0 * n_x, cond ? cond + img0 * n_c : nullptr, x_0 + img0 * n_x, n, lat_h, lat_w, cond_h, cond_w, T, precision,
-                      ls, l, img0, B, ticket);
+                      ls, l, img0, B, ticket, S);
     if (l > 0) {                                           // join even after an error: the caller's stream must not run ahead of a lane
       (void)hipEventRecord(h->lane_done[l], ls);
       (void)hipStreamWaitEvent(s, h->lane_done[l], 0);
@@ -2188,10 +2205,10 @@ namespace {
 // The loop backward on B images (a whole call or one lane of it, see denoise_lane); parameter gradients go to gradient set `lane`.
 int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, const float* grad_x0, float* grad_xT, float* grad_cond,
                           int B, int lat_h, int lat_w, int cond_h, int cond_w, int T, int precision, hipStream_t s, int lane, int img0,
-                          int whole_B, int64_t ticket, bool* reused) {
+                          int whole_B, int64_t ticket, bool* reused, int S) {
   int rc = DD_OK;
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 1), 0, lane}, &pl);      // recompute = the kernels of the forward that kept the trajectory
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 1), 0, lane, S}, &pl);      // recompute = the kernels of the forward that kept the trajectory
   if (rc) return rc;
   rc = ensure_bwd_buffers(h, pl);
   if (rc) return rc;
@@ -2201,7 +2218,7 @@ int denoise_backward_lane(dd_handle_t h, const float* x_T, const float* cond, co
   // shape, same parameters, nothing run on that plan since), else regenerated here by running the forward loop again.
   const Plan* kept = nullptr;
   for (int lvl = 2; lvl >= 1 && !kept && ticket != 0 && !naive; --lvl) {
-    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, lvl), lvl, lane});
+    auto it = h->plans.find(PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, lvl), lvl, lane, S});
     if (it != h->plans.end() && it->second->traj_ticket == ticket && it->second->traj_weights == h->weights_serial) kept = it->second.get();
   }
   const Plan* kept_act = (kept && kept->key.keep == 2 && kept->ek == pl->ek) ? kept : nullptr;      // activations too: no recompute
@@ -2269,7 +2286,7 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   const int S = lane_count(h, B, precision);
   bool reused = false;
   if (S <= 1) {
-    rc = denoise_backward_lane(h, x_T, cond, grad_x0, grad_xT, grad_cond, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, &reused);
+    rc = denoise_backward_lane(h, x_T, cond, grad_x0, grad_xT, grad_cond, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, &reused, 1);
     if (rc == DD_OK && reused) h->n_traj_reuse++;
     return rc;
   }
@@ -2288,7 +2305,7 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
     hipStream_t ls = l == 0 ? s : h->lane_stream[l];
     if (l > 0) DD_HIP(hipStreamWaitEvent(ls, h->lane_fork, 0));
     rc = denoise_backward_lane(h, x_T + img0 * n_x, cond ? cond + img0 * n_c : nullptr, grad_x0 + img0 * n_x, grad_xT ? grad_xT + img0 * n_x : nullptr,
-                               grad_cond ? grad_cond + img0 * n_c : nullptr, n, lat_h, lat_w, cond_h, cond_w, T, precision, ls, l, img0, B, ticket, &reused);
+                               grad_cond ? grad_cond + img0 * n_c : nullptr, n, lat_h, lat_w, cond_h, cond_w, T, precision, ls, l, img0, B, ticket, &reused, S);
     all_reused = all_reused && reused;
     if (l > 0) {
       (void)hipEventRecord(h->lane_done[l], ls);

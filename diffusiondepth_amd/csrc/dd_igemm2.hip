@@ -559,8 +559,15 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     DD_PROF_LOOP_ADD(3);
     if (!(abl & 8)) mfma_block(chunk, tg);
     DD_PROF_LOOP_ADD(0);
-    if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1))
+    if (C::NCHUNK > 1 && tg == C::NTG - 1 && chunk + 1 < C::NCHUNK && !(abl & 1)) {
+      if constexpr (C::ONEBUF) {
+        // one patch buffer: every wave has taken its last fragment of this chunk out of it before anybody overwrites it
+        DD_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
       transform_write(chunk + 1, ((chunk + 1) & (C::NPB - 1)) * C::PATCH_BYTES, (par + 1) % RD);
+    }
     DD_PROF_LOOP_ADD(1);
     // The next stage's weights (this wave's DMA pieces) must have landed before the barrier.  VMEM ops retire in
     // issue order and the DMA was issued BEFORE this stage's raw patch loads, so when those loads were issued in
@@ -903,6 +910,7 @@ static hipError_t launch_layer2(int layer, const ConvParams& p, hipStream_t s) {
     case 41: return launch_one2<EK, 41>(p, s);
     case BIG_CONV3C: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3C>(p, s); else return hipErrorInvalidValue;
     case BIG_CONV3H: if constexpr (EK != EK_F32) return launch_one2<EK, BIG_CONV3H>(p, s); else return hipErrorInvalidValue;
+    case ONE_CONV3H: if constexpr (EK == EK_F16) return launch_one2<EK, ONE_CONV3H>(p, s); else return launch_one2<EK, 9>(p, s);      // (instantiated for the kinds the denoiser's modes run)
     case SWIN_CONVA_H: return launch_one2<EK, SWIN_CONVA_H>(p, s);
     case SWIN_PRED_H: return launch_one2<EK, SWIN_PRED_H>(p, s);
     case SWIN_PRED5_H: return launch_one2<EK, SWIN_PRED5_H>(p, s);
@@ -934,6 +942,7 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     case 9: return launch_one2<EK_BF16M, 9>(p, s);
     case BIG_CONV3C: return launch_one2<EK_F16, BIG_CONV3C>(p, s);          // (the once-per-image conv3(cond) is an f16 kernel in this mode)
     case BIG_CONV3H: return launch_one2<EK_BF16M, BIG_CONV3H>(p, s);
+    case ONE_CONV3H: return launch_one2<EK_BF16M, ONE_CONV3H>(p, s);
     case SWIN_CONVA_H: return launch_one2<EK_BF16M, SWIN_CONVA_H>(p, s);
     case SWIN_PRED_H: return launch_one2<EK_BF16M, SWIN_PRED_H>(p, s);
     case SWIN_PRED5_H: return launch_one2<EK_BF16M, SWIN_PRED5_H>(p, s);
@@ -955,7 +964,7 @@ static hipError_t launch_layer2_split(int layer, const ConvParams& p, hipStream_
     case 6: return launch_one2<EK_F16S, 6>(p, s);
     case 7: return launch_one2<EK_F16S, 7>(p, s);
     case 8: return launch_one2<EK_F16S, 8>(p, s);
-    case 9: return launch_one2<EK_F16S, 9>(p, s);
+    case 9: case ONE_CONV3H: return launch_one2<EK_F16S, 9>(p, s);
     case SWIN_CONVA_H: return launch_one2<EK_F16S, SWIN_CONVA_H>(p, s);
     case SWIN_PRED5_H: return launch_one2<EK_F16S, SWIN_PRED5_H>(p, s);
     default: return hipErrorInvalidValue;
@@ -968,6 +977,7 @@ static hipError_t launch_layer2_refined(int layer, const ConvParams& p, hipStrea
     case 1: return launch_one2<EK_F16R, 1>(p, s);
     case 9: return launch_one2<EK_F16R, 9>(p, s);
     case BIG_CONV3H: return launch_one2<EK_F16R, BIG_CONV3H>(p, s);
+    case ONE_CONV3H: return launch_one2<EK_F16R, 9>(p, s);      // (the fp32 hand-over is an A/B form: two buffers)
     default: return launch_layer2<EK_F16>(layer, p, s);
   }
 }
@@ -977,6 +987,7 @@ static hipError_t launch_layer2_refined_q(int layer, const ConvParams& p, hipStr
     case 1: return launch_one2<EK_F16Q, 1>(p, s);
     case 9: return launch_one2<EK_F16Q, 9>(p, s);
     case BIG_CONV3H: return launch_one2<EK_F16Q, BIG_CONV3H>(p, s);
+    case ONE_CONV3H: return launch_one2<EK_F16Q, ONE_CONV3H>(p, s);
     default: return launch_layer2<EK_F16>(layer, p, s);
   }
 }
@@ -1037,6 +1048,7 @@ template <int EK> static PackGeom geom2_layer(int layer) {
     case 41: return geom2_of<EK, 41>();
     case BIG_CONV3C: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3C>(); else return geom2_of<EK, 8>();      // same packed image as layers 8 / 9, th = 16
     case BIG_CONV3H: if constexpr (EK != EK_F32) return geom2_of<EK, BIG_CONV3H>(); else return geom2_of<EK, 9>();
+    case ONE_CONV3H: return geom2_of<EK, 9>();
     case SWIN_CONVA_H: return geom2_of<EK, 5>();          // same packed images as layers 5 / 7
     case SWIN_PRED_H: return geom2_of<EK, 7>();
     case SWIN_PRED5_H: return geom2_of<EK, SWIN_PRED5_H>();

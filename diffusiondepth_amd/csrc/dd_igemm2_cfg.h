@@ -81,7 +81,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // SWIN_PRED5_H = pred.0 o convB as one 5x5 convolution (layer 7's tiling with five taps per stage)
   static constexpr bool PRED5 = LAYER_ID_ == SWIN_PRED5_H || LAYER_ID_ == SWIN_PRED5B_H;
   static constexpr bool HOIST_A = LAYER_ID_ == SWIN_CONVA_H, ADD_T = LAYER_ID_ == SWIN_PRED_H || PRED5;
-  static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : LAYER_ID_ == BIG_CONV3H ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
+  static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : (LAYER_ID_ == BIG_CONV3H || LAYER_ID_ == ONE_CONV3H) ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
   // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands
   // are instantiated here -- conv2 / conv3 / hoisted conv3 / Swin convA (f16 in, bf16 operands), the producers of f16 tensors in front
   // of them (conv2, conv3, Swin pred.0, the level-0 lateral conv of the condition FPN); the launcher sends every other layer to its
@@ -187,7 +187,14 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int NCHUNK = CIN / CK;
   static constexpr int NTG = NTAPS / TG;
   static constexpr int NSTAGE = NCHUNK * NTG;
-  static constexpr int NPB = (NCHUNK > 1) ? 2 : 1;       // patch buffers
+  // kernel id ONE_CONV3H: the hoisted conv3 on 8x32 tiles with ONE patch buffer -- the next chunk's patch is written into the buffer the MFMAs just
+  // read, behind a second workgroup barrier per stage, instead of into a twin buffer under the running stage.  63 -> 52 KB of LDS = THREE
+  // workgroups per CU (12 waves, three per SIMD; the kernel needs 160 VGPRs) where the two-buffer form has two: a wave spends ~20 % of a stage in
+  // its MFMA block and the rest waiting for memory, the weight DMA or a barrier -- it lacks co-resident waves, not issue slots.  Measured
+  // (round 4, profiles/r04_call3_*): conv3 at KITTI B=4 on one stream 140 -> 132 us (bf16), 147 -> 137 (f16r); neutral under two lanes and at B=1
+  static constexpr bool ONEBUF = LAYER_ID_ == ONE_CONV3H;
+  static_assert(!ONEBUF || (C3 == 1 && NCHUNK > 1), "one-buffer form: the 8x32 tiling of the 2-byte kinds");
+  static constexpr int NPB = (NCHUNK > 1 && !ONEBUF) ? 2 : 1;       // patch buffers
   static constexpr int PATCH_PLANE = PH * PW * ROWB;      // one operand plane of a patch buffer (split f16: hi plane, then lo plane)
   static constexpr int PATCH_BYTES = NPLP * PATCH_PLANE;
   static constexpr int W_PLANE = TG * NT * ROWB;          // one operand plane of a weight stage
@@ -211,7 +218,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int FRAG_DEPTH = (LAYER == 5 && !SPLIT && !(SWIN3 && DD_SWIN_FD2)) ? 1 : DD_FRAG_DEPTH;
   // registers: two workgroups per CU for conv2 / conv3 (8 waves = 2 per SIMD, <= 256 VGPR+AGPR);
   // conv1 / conv4 want >= 2 eight-wave workgroups per CU (<= 128 registers)
-  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS
+  static constexpr int MIN_WAVES_PER_SIMD = (WAVES == 8) ? ((SMEM_BYTES <= 80 * 1024) ? 4 : 2) : (ONEBUF && SMEM_BYTES <= 160 * 1024 / 3) ? 3 : ((SMEM_BYTES <= 80 * 1024) ? 2 : 1);   // 80 KiB = half the CU's LDS
   static_assert(CIN % CK == 0 && NTAPS % TG == 0 && COUT_PAD % NT == 0, "tiling");
   static_assert(PATCH_BYTES % 16 == 0 && W_BYTES % 1024 == 0, "LDS carve / DMA granularity");
   static_assert(WAVES <= 8 && (COUT_PAD / NT) % SPW == 0 && (SPW == 1 || NCHUNK == 1), "scratch size; splits per workgroup");

@@ -132,6 +132,9 @@ struct ConvParams {
 // weight stream per pixel -- chosen per launch when there are more 8x32 tiles than resident workgroup slots (the two must agree: layer 8
 // leaves its result in the accumulator-fragment order of layer 9's tiles).  Same packed weights as layers 8 / 9.
 constexpr int BIG_CONV3C = 48, BIG_CONV3H = 49;
+// layer 9 on its 8x32 tiles with ONE patch buffer (dd_igemm2_cfg.h, ONEBUF): the next chunk's patch goes into the buffer the MFMAs just read, behind a
+// second workgroup barrier per stage; 52 KB of LDS = three workgroups per CU.  Same tiles, packed weights and accumulator-fragment order as layer 9.
+constexpr int ONE_CONV3H = 46;
 // Swin / MPViT denoiser, forward-only plans: upsample_fuse (convA, convB: no norm, no activation) and pred.0 are ONE linear map of
 // s = up(feat) + E[t] + NE(x_t) (reference ...swin_addHAHI.py:321-333,378-380), so
 //   pred.0(convB(convA(s))) = W3*WB*WA*NE(x_t)  +  [W3*(WB*(WA*up(feat) + a) + b)]  +  W3*WB*WA*(E[t] on every pixel)  + b3

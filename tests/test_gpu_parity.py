@@ -336,7 +336,7 @@ def test_big_tile_and_lane_paths_agree_with_the_single_image_path_at_kitti_size(
     if lanes == 2:
         assert np.array_equal(auto[:2], big[:2]) and np.array_equal(auto[2:], small[2:])
     elif lanes == 1:
-        assert np.array_equal(auto, big)
+        assert np.array_equal(auto, small)          # a call that runs as one lane keeps the 8x32 tiles (their one-patch-buffer form: three workgroups per CU)
 
 
 # ---- Swin / MPViT variant of the denoiser: UpSample_add fuse, stride-4 condition map ----

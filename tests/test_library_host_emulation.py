@@ -247,6 +247,28 @@ def test_res_loop_with_the_hoisted_condition_term(lib):
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16r"] + (["f16"] if FULL else []))
+def test_hoisted_conv3_with_one_patch_buffer(lib, prec):
+    """Kernel id ONE_CONV3H (dd_kernels.h): the loop's hoisted conv3 on its 8x32 tiles with ONE patch buffer -- the next chunk's patch is written into the
+    buffer the MFMAs just read, behind a second workgroup barrier per stage (52 KB of LDS: three workgroups per CU on the GPU).  Same tiles, same
+    accumulation order as the two-buffer kernel: the results must be BIT-IDENTICAL to it, under every adversarial timing (the hazard is a wave
+    overwriting a patch row another wave has not read yet: the wave-run-ahead orders are what would show it)."""
+    be, inp, ref, T = _loop_case(lib, B=2, h=25, w=40)
+    be.set_option("hoist_cond", 1)
+    be.set_option("big_tiles", 0)
+    be.set_option("one_buffer", 0)
+    two = be.denoise(inp["x_T"], inp["cond"], T, prec)
+    be.set_option("one_buffer", 2)
+    outs = []
+    for order, late in (((0, 0), (1, 0), (0, 1), (1, 1)) if FULL else ((0, 0), (1, 1))):
+        be.timing(order=order, dma_late=late)
+        outs.append(be.denoise(inp["x_T"], inp["cond"], T, prec))
+    be.set_option("one_buffer", 1); be.set_option("big_tiles", -1)
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    assert np.array_equal(outs[0], two)
+    assert maxabs(outs[0], ref) < LATENT_TOL[prec] * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("prec", ["bf16", "f16r"] + (["f16"] if FULL else []))      # f16r: the split layer 8's fp32 term reformatted into the 16x32-tile order
 def test_hoisted_conv3_on_16x32_tiles(lib, prec):
     """Kernel ids 48 / 49 (dd_kernels.h): the hoisted conv3 pair -- conv3(cond) once per image, conv3 in the loop -- on 16x32-pixel tiles (four
