@@ -293,6 +293,16 @@ class HipDenoiser:
         self._cond_token = None           # an explicit map overwrites the handle's copy
         return cond.data_ptr()
 
+    def suggested_batch(self, lat_h: int, lat_w: int) -> int:
+        """Images per dd_denoise call that keep the chip full for a latent of lat_h x lat_w (throughput serving; the reference's own
+        test() feeds one image at a time): a launch of the two large convolutions has ceil(h / 8) * ceil(w / 32) workgroups per image
+        and the chip holds `resident_slots` of them (two per CU), so a lane needs about two rounds of them for the tail of one
+        round to disappear under the next -- lanes x ceil(2 * slots / tiles per image).  KITTI 176x608: 6; NYU 114x152: 28
+        (measured: KITTI B=4 -> 16 +5 %; NYU B=4 -> 16 +48 %, profiles/r03_*, r04_*)."""
+        tiles = ((int(lat_h) + 7) // 8) * ((int(lat_w) + 31) // 32)
+        slots = self.counter("resident_slots")
+        return self.n_streams * max(1, -(-2 * slots // tiles))
+
     # -- hot path -----------------------------------------------------------------------------
     def denoise(self, x_T, cond, num_inference_steps: int, precision="fp32", out=None, keep_trajectory=False):
         """The T-step loop (one hipGraph).  ``keep_trajectory=True`` (training forward): the library keeps the state entering every step

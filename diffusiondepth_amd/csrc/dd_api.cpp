@@ -1525,6 +1525,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   else if (k == "neck_launches") *value = h->n_neck_launches;
   else if (k == "trajectory_ticket") *value = h->traj_serial;
   else if (k == "lane_calls") *value = h->n_lane_calls;
+  else if (k == "resident_slots") *value = h->resident_slots;      // workgroup slots at two per CU (2 x multiProcessorCount): what the tile rules compare tile counts with
   else if (k == "trajectory_reuses") *value = h->n_traj_reuse;
   else return h->fail(DD_ERR_INVALID_ARG, "dd_get_counter: unknown key '" + k + "'");
   return DD_OK;

@@ -73,6 +73,9 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   const int li = lane & 31, g = lane >> 5;
   const int h = p.h, w = p.w;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
+  // timing experiments (-DDD_ABLATE=1 builds only; results are wrong): bit0 no patch transform / LDS writes, bit1 no prefetch loads, bit3 no fragment
+  // reads / MFMAs, bit4 no output stores, bit5 no statistics atomics, bit6 no per-stage barrier, bit7 no weight copy
+  const int abl = DD_ABLATE ? p.ablate : 0;
   // workgroup -> (image, first tile, stride): persist_grid() launches B * n workgroups
   const int wg = blockIdx.x, n_per_img = (int)gridDim.x / p.B;
   const int b = wg % p.B;
@@ -82,7 +85,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   {
     const uint4* src = reinterpret_cast<const uint4*>(p.wpack);
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = tid; i < W_BYTES / 16; i += THREADS) dst[i] = src[i];
+    if (!(abl & 128)) for (int i = tid; i < W_BYTES / 16; i += THREADS) dst[i] = src[i];
     if (tid < NROW) tab_bias[tid] = p.bias[tid];
   }
   {
@@ -164,6 +167,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   auto load_chunk = [&](int c, int slot, const int* po) {        // channel-blocked y3: [B][2][h][w][32]
     const int cbase = c * CK + jfix * EPP;
     const size_t off0 = (size_t)(cbase >> 5) * h * w * ACT_CB + (cbase & (ACT_CB - 1));
+    if (abl & 2) return;
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
 #pragma unroll
@@ -172,6 +176,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     }
   };
   auto transform_chunk = [&](int c, int slot, int buf, unsigned mi) {        // relu(gn3(y3)) of chunk c (in register slot `slot`) -> patch buffer `buf`
+    if (abl & 1) return;
     float ta[EPP], tb[EPP];
     const int c0 = c * CK + jfix * EPP;
 #pragma unroll
@@ -254,6 +259,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
       const int pbuf = (c & 1) * PATCH_BYTES;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
+        if (abl & 8) break;
         const int dy = t / 3, dx = t % 3;
         const uint4 pf = *reinterpret_cast<const uint4*>(smem + colt[dx] + pbuf + dy * (PW * ROWB));
         const uint4 wf = *reinterpret_cast<const uint4*>(smem + wkt + c * W_STAGE + t * (NROW * ROWB));
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
         transform_chunk(0, 0, 0, mi_nx);          // (behind the last tile: a patch nobody reads)
       }
       DD_WAIT_LGKM0();
-      __builtin_amdgcn_s_barrier();
+      if (!(abl & 64)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
     // ---- epilogue of this tile: bias, statistics, fp32 NHWC store (lane: pixel (wave, li), couts 4g..4g+3 and 8+4g..8+4g+3) ----
@@ -299,7 +305,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
           ls[q] += (v0 + v1) + (v2 + v3);
           lq[q] += fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, v3 * v3)));
           // (hidden from hipcc's vmcnt bookkeeping: a tracked store beside the prefetched loads would turn every later wait into vmcnt(0))
-          DD_GLOBAL_STORE16_UNTRACKED(out_b + (((size_t)gy * w + gx) * COUT + 8 * q + 4 * g) * 4, make_float4(v0, v1, v2, v3));
+          if (!(abl & 16)) DD_GLOBAL_STORE16_UNTRACKED(out_b + (((size_t)gy * w + gx) * COUT + 8 * q + 4 * g) * 4, make_float4(v0, v1, v2, v3));
         }
       }
     }
@@ -321,7 +327,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     s_red[wave * 8 + (2 + g) * 2 + 0] = (double)ls[1]; s_red[wave * 8 + (2 + g) * 2 + 1] = (double)lq[1];
   }
   __syncthreads();
-  if (tid < 8) {
+  if (tid < 8 && !(abl & 32)) {
     double tot = 0.0;
 #pragma unroll
     for (int wv = 0; wv < WAVES; ++wv) tot += s_red[wv * 8 + tid];

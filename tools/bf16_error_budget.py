@@ -89,7 +89,8 @@ def denoiser_emul(sd, x, t, cond, R, step=0):
         # step outside the MFMA loop ("hoistc": dtype of cond and of the weights in that once-per-image convolution)
         hc = R.get("hoistc")
         # "hs": storage of the once-per-image term conv3(cond) (the kernels keep it as f16 quads or fp32); the E[t] tap sums are an fp32 table
-        hterm = rnd(F.conv2d(rnd(cond, hc), rnd(sd["model.pred.0.weight"], hc), None, padding=1), R.get("hs"))
+        # ("hcc" / "hcw": the condition map / the weights of that once-per-image convolution separately; default = "hoistc" for both)
+        hterm = rnd(F.conv2d(rnd(cond, R.get("hcc", hc)), rnd(sd["model.pred.0.weight"], R.get("hcw", hc)), None, padding=1), R.get("hs"))
         y3 = F.conv2d(rnd(a2, R.get("f")), W("model.pred.0", "w3", 3), sd["model.pred.0.bias"], padding=1) + hterm + \
             F.conv2d(emb.expand_as(cond).contiguous(), sd["model.pred.0.weight"], None, padding=1)
     else:

@@ -14,7 +14,7 @@ def main():
     b.build()                                             # default objects up to date
     outdir = os.path.join(ROOT, "build_variants"); os.makedirs(outdir, exist_ok=True)
     hipcc = b.find_hipcc()
-    redo = ["dd_igemm2.hip"] + (["dd_api.cpp"] if "--api" in sys.argv else [])
+    redo = ["dd_igemm2.hip", "dd_thin.hip"] + (["dd_api.cpp"] if "--api" in sys.argv else [])
     objs = []
     for src in b.SOURCES:
         base = os.path.splitext(src)[0]

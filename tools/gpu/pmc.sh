@@ -4,7 +4,7 @@ cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R="$PWD"
-CFG="${BENCH_CFG:---precision bf16 --batch 4 --size kitti --variant res}"
+CFG="${BENCH_CFG:---precision f16r --batch 4 --size kitti --variant res}"
 ARGS="--steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-train-extra --no-latency-b1 --no-streams-extra --no-head-extra --no-nlspn-extra --no-graph $CFG"
 (cd /tmp && rocprofv3 -L > "$R/gpurun_out/counters_list.txt" 2>&1)
 grep -c . gpurun_out/counters_list.txt

@@ -109,6 +109,14 @@ template <int MODE> float run(int nb, int n, int check, int* herr) {
   hipDeviceSynchronize();
   float ms = 0; hipEventElapsedTime(&ms, a, b);
   hipMemcpy(herr, err, 8, hipMemcpyDeviceToHost);
+  if (MODE == 1 && check) {                    // how the workgroups registered: workgroups per XCC_ID, local / top / flag counters of the last round
+    Ctl hc; hipMemcpy(&hc, c, sizeof(Ctl), hipMemcpyDeviceToHost);
+    printf("    registered per XCC_ID:");
+    for (int x = 0; x < 8; ++x) printf(" %u", hc.reg[x][0]);
+    printf("   loc:"); for (int x = 0; x < 8; ++x) printf(" %u", hc.loc[x][0]);
+    printf("   top %u   flag:", hc.top[0]); for (int x = 0; x < 8; ++x) printf(" %u", hc.flag[x][0]);
+    printf("\n"); fflush(stdout);
+  }
   if (e != hipSuccess) { herr[0] = -1; printf("  launch error: %s\n", hipGetErrorString(e)); }
   hipFree(c); hipFree(slots); hipFree(err);
   return ms;

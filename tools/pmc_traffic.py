@@ -18,10 +18,11 @@ def per_kernel(d, counter):
             m = re.search(r"conv_igemm2?_kernel<dd::Cfg2?<(\d+), (\d+)>", name)
             if m:
                 # kernel ids 48 / 49 are layers 8 / 9 on 16x32 tiles, 50 / 52 / 53 the hoisted forms of the Swin layers 5 / 7 / 7 (53: pred.0 o convB as one 5x5 kernel) (dd_kernels.h): booked under the layer they implement
-                layer = {48: 8, 49: 9, 50: 5, 52: 7, 53: 7}.get(int(m.group(2)), int(m.group(2)))
+                # 46 = layer 9 on 8x32 tiles with one patch buffer; 51 = the 5x5 form on 16x32 tiles
+                layer = {46: 9, 48: 8, 49: 9, 50: 5, 51: 7, 52: 7, 53: 7}.get(int(m.group(2)), int(m.group(2)))
                 key = f"layer{layer}_ek{m.group(1)}"
             else:
-                m = re.search(r"conv4_stream_kernel<(\d+)>", name)      # dd_thin.hip: conv4 as the persistent streaming kernel
+                m = re.search(r"conv4_stream_kernel<(\d+)[,>]", name)      # dd_thin.hip: conv4 as the persistent streaming kernel (<kind, stacked, input kind, operand pair>)
                 if not m:
                     continue
                 key = f"layer4_ek{m.group(1)}"
