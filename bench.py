@@ -55,9 +55,9 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f16r": 2500.0, "f16x3": 2500.0 / 
 DTYPE_NAME = {"bf16": "bf16", "f16": "f16", "f16r": "f16 (f16 MFMA operands, fp32 accumulation; refined mode: f16-pair weights in conv1 / conv4 / conv3(cond), block-scaled int16 hand-over of y3 and conv3(cond))",
               "f16x3": "f16x3 (f16 hi+lo operand pairs, fp32 tensors)", "fp32": "f32", "naive_fp32": "f32"}
 STORE_BYTES = {"bf16": 1, "f16": 1, "f16r": 1, "f16x3": 2, "fp32": 2, "naive_fp32": 2}      # multiples of the 2-byte activation terms of ALGO_BYTES_PER_PIXEL
-# f16r hand-overs (option "f16r_wide"): 2 [default] = block-scaled int16: conv3 reads y2 f16 512 + the hoisted term 128 (+ a scale per 1024 values) and writes
-# y3 128 + a scale per pixel 4; conv4 reads y3 128 + 4, writes y4 64.  1 = fp32: conv3 512 + 256 + 256, conv4 256 + 64
-ALGO_BYTES_F16R = {2: {9: 512 + 128 + 132, 4: 132 + 64}, 1: {9: 512 + 256 + 256, 4: 256 + 64}}
+# f16r hand-overs (option "f16r_wide" = 1, the default): block-scaled int16: conv3 reads y2 f16 512 + the hoisted term 128 (+ a scale per 1024 values) and
+# writes y3 128 + a scale per pixel 4; conv4 reads y3 128 + 4, writes y4 64
+ALGO_BYTES_F16R = {1: {9: 512 + 128 + 132, 4: 132 + 64}}
 # what the line's value must hold: the north star's depth RMSE <= 1e-3 vs the reference's CPU path -- on this workload AND with the same latents decoded
 # at KITTI's depth range (FAR_LOG_SCALE below) -- with a margin (>= 1.5x)
 DEPTH_RMSE_TOL, DEPTH_RMSE_MARGIN = 1e-3, 1.5
@@ -439,7 +439,7 @@ def main():
     for kv in args.set:
         k_, v_ = kv.split("=", 1)
         be.set_option(k_, int(v_))
-    f16r_wide = ([int(kv.split("=")[1]) for kv in args.set if kv.replace(" ", "").startswith("f16r_wide=")] or [2])[-1]
+    f16r_wide = ([int(kv.split("=")[1]) for kv in args.set if kv.replace(" ", "").startswith("f16r_wide=")] or [1])[-1]
     hoisted = args.variant == "res" and args.precision != "naive_fp32" and (args.hoist == 1 or (args.hoist == -1 and ((args.precision == "bf16" and not args.bf16_storage) or args.precision in ("f16", "f16x3"))) or args.precision == "f16r")
     layer_set = LAYERS["swin" if args.variant == "swin" else ("res" if hoisted else "res_nohoist")]
     inp = synth.make_inputs(7240 + rank, B, h, w, cond_hw)
@@ -569,7 +569,7 @@ def main():
                 traffic_note = f"profiles/pmc_traffic.json is stale: taken on library sources {pt.get('lib_source_sha')}, these are {lib_source_sha()}"
             else:
                 # kernel names carry the element kind / mode: 0 fp32, 1 bf16, 2 f16, 3 = the default bf16 mode, 4 = split f16 (dd_kernels.h)
-                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,), "f16x3": (4,), "f16r": (6, 5, 2)}[args.precision]:
+                for ekid in {"fp32": (0,), "bf16": (3, 1), "f16": (2,), "f16x3": (4,), "f16r": (5, 2)}[args.precision]:
                     if f"layer{dom}_ek{ekid}" in pt["kernels"]:
                         traffic = pt["kernels"][f"layer{dom}_ek{ekid}"]["hbm_bytes"]
                         traffic_note = f"rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/pmc_traffic.json, sources {pt.get('lib_source_sha')}, {pt.get('taken', '')})"

@@ -135,11 +135,11 @@ struct Plan {
   DevBuf ttab, tt_scratch;   // Swin variant, hoisted form: E[t] border tables of the T loop steps [T][SWIN_TT_ROWS][64] (swin_ttab, dd_misc.hip) ...
   int64_t ttab_weights = -1; // ... and the parameter generation they were computed from
   DevBuf ccond;            // Res variant, hoisted condition term: conv3(cond), fp32 in accumulator-fragment order of 8x32 tiles
-  DevBuf ccond_raw;        // EK_F16R: the same as the split-f16 layer 8 leaves it (fp32, 8x32 tiles), when the loop's conv3 reads another order / type
-  DevBuf ccond_scale;      // EK_F16R, hand-over 2: one fp32 scale per accumulator block of the int16 hoisted term (dd_kernels.h, EK_F16Q)
+  DevBuf ccond_raw;        // EK_F16R: the same as the split-f16 layer 8 leaves it (fp32, 8x32 tiles); reformatted into `ccond` (launch_cadd_reformat)
+  DevBuf ccond_scale;      // EK_F16R, "f16r_wide": one fp32 scale per accumulator block of the int16 hoisted term (dd_kernels.h)
   DevBuf y3_scale;         // ... and one per pixel of y3 (per-step slots like y3)
-  int wide = 0, c1 = 0;    // EK_F16R: options "f16r_wide" (hand-over of y3 / the hoisted term: 0 f16, 1 fp32, 2 scaled int16) and "f16r_c1" (conv1:
-  bool p4 = false;         // 0 plain f16, 1 weights as an f16 pair, 2 weights and state as pairs), "f16r_p4", as this plan was built with them
+  bool wide = false, c1 = false, p4 = false;      // EK_F16R: options "f16r_wide" (y3 / the hoisted term as block-scaled int16, else f16), "f16r_c1" (conv1's
+                                                  // weights as an f16 pair, else the plain f16 kernel), "f16r_p4", as this plan was built with them
   DevBuf stats;       // [(T+1)*4][B][STAT_SLOTS][STAT_STRIDE] doubles
   DevBuf c1c2;        // [T][2] fp32
   DevBuf tsteps;      // [T] int64
@@ -236,8 +236,8 @@ struct dd_handle_s {
   int big_tiles = -1;         // option "big_tiles": hoisted conv3 pair on 16x32 tiles: -1 = when the 8x32 tiles exceed the 512 resident slots, 0 / 1 = forced
   int one_buffer = 1;         // option "one_buffer": the hoisted conv3 on 8x32 tiles in its one-patch-buffer form when the tiles exceed the resident slots (A/B switch)
   int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
-  int f16r_wide = 2;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as 0 = f16 (as DD_PREC_F16), 1 = fp32, 2 = block-scaled int16
-  int f16r_c1 = 1;            // DD_PREC_F16R: conv1 as 0 = the f16 kernel, 1 = weights as an f16 pair (two MFMAs), 2 = weights and state as pairs (three)
+  int f16r_wide = 1;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as block-scaled int16 (0 = as f16, like DD_PREC_F16)
+  int f16r_c1 = 1;            // DD_PREC_F16R: conv1's weights as an f16 pair (two MFMAs; 0 = the plain f16 kernel)
   int f16r_p4 = 0;            // DD_PREC_F16R: conv4's operand as an f16 pair as well (two MFMAs per tap)
   bool split_ok = true;       // every forward convolution weight fits the split-f16 images (|w| x 256 inside f16): DD_PREC_F16X3 / DD_PREC_F16R refuse to run otherwise
   DevBuf wmax;                // device route: bits of max |w| over the forward convolution weights (launch_max_abs)
@@ -590,10 +590,9 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
     const int th = conv_pack_geom2(conv3h_kid(h, key), pl->ek).th;
     DD_HIP(pl->ccond.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * th * 32 * HID_C * 4));
     if (pl->ek == EK_F16R) {
-      pl->wide = h->f16r_wide; pl->c1 = h->f16r_c1; pl->p4 = h->f16r_p4 != 0;
-      if (th != 8 || pl->wide != 1)      // the split layer 8 writes fp32 in the order of 8x32 tiles: reformatted unless that is what conv3 reads
-        DD_HIP(pl->ccond_raw.alloc((size_t)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) * 8 * 32 * HID_C * 4));
-      if (pl->wide == 2) DD_HIP(pl->ccond_scale.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * 4 * 2 * (th / 4) * 4));
+      pl->wide = h->f16r_wide != 0; pl->c1 = h->f16r_c1 != 0; pl->p4 = h->f16r_p4 != 0;
+      DD_HIP(pl->ccond_raw.alloc((size_t)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) * 8 * 32 * HID_C * 4));      // what the split layer 8 writes
+      if (pl->wide) DD_HIP(pl->ccond_scale.alloc((size_t)key.B * ((key.h + th - 1) / th) * ((key.w + 31) / 32) * 4 * 2 * (th / 4) * 4));
     }
   }
   if (key.hoist && swin) {
@@ -609,8 +608,8 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   }
   DD_HIP(pl->y1.alloc(ns * px * HID_C * es));
   DD_HIP(pl->y2.alloc(ns * px * COND_C * es));
-  DD_HIP(pl->y3.alloc(ns * px * HID_C * ((pl->ek == EK_F16R && h->f16r_wide == 1) ? 4 : es)));
-  if (pl->ek == EK_F16R && h->f16r_wide == 2) DD_HIP(pl->y3_scale.alloc(ns * px * 4));
+  DD_HIP(pl->y3.alloc(ns * px * HID_C * es));
+  if (pl->ek == EK_F16R && h->f16r_wide) DD_HIP(pl->y3_scale.alloc(ns * px * 4));
   DD_HIP(pl->y4.alloc(ns * px * LATENT_C * 4));
   if (key.keep == 2) pl->kept_bytes = pl->y1.bytes + pl->y2.bytes + pl->y3.bytes + pl->y4.bytes + pl->sa.bytes + pl->sf.bytes;
   if (naive) {
@@ -675,8 +674,8 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       if (layer == 4 && rf) { q.persist_slots = h->thin_slots; q.cadd_scale = static_cast<const float*>(pl->slot(pl->y3_scale, step)); return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
       if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
       int lek = ek;
-      if (rf && layer == 9) lek = pl->wide == 0 ? (int)EK_F16 : pl->wide == 2 ? (int)EK_F16Q : (int)EK_F16R;      // hand-over of y3 / the hoisted term: f16 (the f16 mode's conv3), scaled int16, fp32
-      if (rf && layer == 1) lek = pl->c1 == 0 ? (int)EK_F16 : pl->c1 == 1 ? (int)EK_F16Q : (int)EK_F16R;          // conv1: plain f16, weights as a pair, weights and state as pairs
+      if (rf && layer == 9 && !pl->wide) lek = EK_F16;      // hand-over of y3 / the hoisted term as f16: the f16 mode's conv3
+      if (rf && layer == 1 && !pl->c1) lek = EK_F16;        // conv1 without the weight pair: the f16 mode's conv1
       return launch_conv_igemm2(kid, lek, q, s);
     };
     if (!h->layer_timing) return launch(cp);
@@ -747,7 +746,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
   p.gn_gamma = h->L[1].gamma.as<float>(); p.gn_beta = h->L[1].beta.as<float>();
   p.cond = pl->cond_ptr(); p.emb = h->emb.as<float>(); p.tvec = tvec; p.t_base = t_base; p.t_bstride = t_bstride;
   p.cadd = pl->ccond.as<float>(); p.etab = h->etab.as<float>();
-  p.cadd_scale = pl->ccond_scale.as<float>(); p.out_scale = static_cast<float*>(pl->slot(pl->y3_scale, step));      // (EK_F16Q forms only)
+  p.cadd_scale = pl->ccond_scale.as<float>(); p.out_scale = static_cast<float*>(pl->slot(pl->y3_scale, step));      // (EK_F16R forms only)
   DD_HIP(timed_launch(k.hoist ? 9 : 3, p));
   p.cadd_scale = nullptr; p.out_scale = nullptr;
   }
@@ -795,13 +794,12 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
   p.ablate = 0;
   if (pl->ek == EK_F16R) {
     // refined f16: the split-f16 layer 8 on the fp32 condition map (the term is exact to ~22 bits), fp32 in the order of 8x32 tiles; then into
-    // the order / element type the loop's conv3 reads, unless that is already it
+    // the order / element type the loop's conv3 reads (block-scaled int16 or f16 quads, 8x32 or 16x32 tiles)
     p.tiles_y = (k.h + 7) / 8;
     p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[WIMG_SPLIT].p; p.bias = h->zero_bias.as<float>();
-    p.out = pl->ccond_raw.p ? pl->ccond_raw.p : pl->ccond.p;
+    p.out = pl->ccond_raw.p;
     DD_HIP(launch_conv_igemm2(8, EK_F16S, p, s));
-    if (pl->ccond_raw.p) DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, pl->ccond_scale.as<float>(), k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0,
-                                                     pl->wide == 0 ? 1 : pl->wide == 2 ? 2 : 0, s));
+    DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, pl->ccond_scale.as<float>(), k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0, pl->wide ? 2 : 1, s));
     return DD_OK;
   }
   const int kid = conv3c_kid(h, k);
@@ -1500,7 +1498,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->thin_stream = (int)value;
   }
   else if (k == "f16r_wide" || k == "f16r_p4" || k == "f16r_c1") {
-    if (value < 0 || value > (k == "f16r_p4" ? 1 : 2)) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: " + k + " out of range");
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: " + k + " must be 0 or 1");
     int& opt = k == "f16r_wide" ? h->f16r_wide : k == "f16r_c1" ? h->f16r_c1 : h->f16r_p4;
     if (opt != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // buffers and graphs are laid out for it
     opt = (int)value;
@@ -2387,8 +2385,7 @@ int dd_debug_fetch(dd_handle_t h, const char* name, float* out, int64_t numel, v
   else if (n == "y2") { src = pl->y2.p; C = COND_C; }
   else if (n == "y3") {
     src = pl->y3.p; C = HID_C;
-    if (pl->ek == EK_F16R && pl->wide == 1) ek = EK_F32;
-    if (pl->ek == EK_F16R && pl->wide == 2) return h->fail(DD_ERR_UNSUPPORTED, "dd_debug_fetch: y3 travels as scaled int16 in this plan (option f16r_wide = 2)");
+    if (pl->ek == EK_F16R && pl->wide) return h->fail(DD_ERR_UNSUPPORTED, "dd_debug_fetch: y3 travels as scaled int16 in this plan (option f16r_wide = 1)");
   }
   else if (n == "y4") { src = pl->y4.p; C = LATENT_C; ek = EK_F32; }
   else return h->fail(DD_ERR_INVALID_ARG, "dd_debug_fetch: unknown tensor '" + n + "'");

@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
     };
     if constexpr (C::Q15) {
-      // y3 as int16 with one fp32 scale per pixel (dd_kernels.h, EK_F16Q): pass 1 finishes the values in place (statistics from the fp32 values),
+      // y3 as int16 with one fp32 scale per pixel (dd_kernels.h, EK_F16R): pass 1 finishes the values in place (statistics from the fp32 values),
       // and finds the pixel's max |.| -- its 64 couts sit in this lane and in lane ^ 32; pass 2 normalises, packs (v_cvt_pknorm_i16_f32) and stores
       float pmax = 0.f;
 #pragma unroll
@@ -977,23 +977,12 @@ static hipError_t launch_layer2_refined(int layer, const ConvParams& p, hipStrea
     case 1: return launch_one2<EK_F16R, 1>(p, s);
     case 9: return launch_one2<EK_F16R, 9>(p, s);
     case BIG_CONV3H: return launch_one2<EK_F16R, BIG_CONV3H>(p, s);
-    case ONE_CONV3H: return launch_one2<EK_F16R, 9>(p, s);      // (the fp32 hand-over is an A/B form: two buffers)
-    default: return launch_layer2<EK_F16>(layer, p, s);
-  }
-}
-// EK_F16Q: the refined forms with block-scaled int16 hand-overs (conv3) and the weights-only pair (conv1)
-static hipError_t launch_layer2_refined_q(int layer, const ConvParams& p, hipStream_t s) {
-  switch (layer) {
-    case 1: return launch_one2<EK_F16Q, 1>(p, s);
-    case 9: return launch_one2<EK_F16Q, 9>(p, s);
-    case BIG_CONV3H: return launch_one2<EK_F16Q, BIG_CONV3H>(p, s);
-    case ONE_CONV3H: return launch_one2<EK_F16Q, ONE_CONV3H>(p, s);
+    case ONE_CONV3H: return launch_one2<EK_F16R, ONE_CONV3H>(p, s);
     default: return launch_layer2<EK_F16>(layer, p, s);
   }
 }
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s) {
   switch (ek) {
-    case EK_F16Q: return launch_layer2_refined_q(layer, p, s);
     case EK_F16R: return launch_layer2_refined(layer, p, s);
     case EK_F16S: return launch_layer2_split(layer, p, s);
     case EK_F32: return launch_layer2<EK_F32>(layer, p, s);
@@ -1085,7 +1074,6 @@ static PackGeom geom2_layer_split(int layer) {
 }
 PackGeom conv_pack_geom2(int layer, int ek) {
   switch (ek) {
-    case EK_F16Q:
     case EK_F16R: {      // conv1: the split image; conv4: the f16 geometry with the lo halves stacked into the padding cout rows; else f16
       if (layer == 1) return geom2_of<EK_F16S, 1>();
       PackGeom g = geom2_layer<EK_F16>(layer);

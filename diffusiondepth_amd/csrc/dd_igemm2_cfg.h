@@ -91,21 +91,20 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // packed weights carry TWO f16 planes (hi, lo) and every (weight, pixel) fragment pair costs three MFMAs.  Instantiated for the
   // denoiser's layers 1..9 only; one tiling for all of them: 16-channel chunks, 3 taps per stage (conv1: 9), 64-cout workgroup tiles.
   // EKM_ == EK_F16R (refined f16, DD_PREC_F16R; dd_kernels.h): instantiated for the layers whose kernel differs from the f16 mode's only --
-  // conv1 (split operands as in EK_F16S, but y1 stored f16) and the hoisted conv3 (layer 9 / BIG_CONV3H: f16 operands and input, the hoisted
-  // term read as fp32, y3 stored fp32); every other layer of the mode runs its EK_F16 (conv2, conv4 via dd_thin.hip) or EK_F16S (layer 8) form.
-  // EKM_ == EK_F16Q: the same two layers with the hand-overs as block-scaled int16 (dd_kernels.h) and conv1's WEIGHTS only as a pair
-  static constexpr bool RQ = EKM_ == EK_F16Q;
-  static constexpr bool RF = EKM_ == EK_F16R || RQ;
-  static_assert(!RF || LAYER_ == 1 || LAYER_ == 9, "EK_F16R / EK_F16Q are instantiated for conv1 and the hoisted conv3 only");
+  // conv1 (its weights as an f16 pair against a single-plane patch, y1 stored f16) and the hoisted conv3 (layer 9 and its tile forms: f16 operands
+  // and input, the hoisted term read as block-scaled int16, y3 written as int16 with a per-pixel scale); every other layer of the mode runs its
+  // EK_F16 (conv2, conv4 via dd_thin.hip) or EK_F16S (layer 8) form.
+  static constexpr bool RF = EKM_ == EK_F16R;
+  static_assert(!RF || LAYER_ == 1 || LAYER_ == 9, "EK_F16R is instantiated for conv1 and the hoisted conv3 only");
   static constexpr bool SPLIT = EKM_ == EK_F16S || (RF && LAYER_ == 1);
-  static constexpr bool WONLY = RQ && LAYER_ == 1;             // split weights against a single-plane patch: W.P = Whi.P + Wlo.P
+  static constexpr bool WONLY = RF && LAYER_ == 1;             // split weights against a single-plane patch: W.P = Whi.P + Wlo.P
   static constexpr int NPL = SPLIT ? 2 : 1;                    // operand planes of a packed weight stage
   static constexpr int NPLP = (SPLIT && !WONLY) ? 2 : 1;       // operand planes of the LDS patch
-  static constexpr bool Q15 = RQ && LAYER_ == 9;               // hoisted term read as scaled int16 quads, y3 written as int16 with a per-pixel scale
+  static constexpr bool Q15 = RF && LAYER_ == 9;               // hoisted term read as scaled int16 quads, y3 written as int16 with a per-pixel scale
   static constexpr int EK = MX ? (int)EK_BF16 : (SPLIT || RF) ? (int)EK_F16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
   static constexpr int LAYER = LAYER_;
   static constexpr int IN_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)
-  static constexpr int OUT_K = RF ? ((LAYER_ == 1 || RQ) ? (int)EK_F16 : (int)EK_F32) : SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
+  static constexpr int OUT_K = RF ? (int)EK_F16 : SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
   static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
   static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 9), "EK_F16S is instantiated for the denoiser's layers only");
   static_assert(!SPLIT || LAYER_ID_ != SWIN_PRED_H, "split f16: the hoisted Swin plans always run the 5x5 form");
@@ -176,7 +175,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int WN = NT / 32;
   static constexpr int PRO = HOIST_A ? PRO_GN : (LAYER == 1) ? PRO_X : (LAYER == 3 || LAYER == 5) ? PRO_GN_ADD : (LAYER == 9) ? PRO_GN : (LAYER >= 6) ? PRO_RAW : PRO_GN;
   static constexpr int IN_ESZ = (LAYER == 1 || SPLIT) ? 4 : ESZ;
-  static constexpr int OUT_ESZ = RF ? ((LAYER == 1 || RQ) ? 2 : 4) : (LAYER == 4 || LAYER == 8 || LAYER == 23 || SPLIT) ? 4 : ESZ;
+  static constexpr int OUT_ESZ = RF ? 2 : (LAYER == 4 || LAYER == 8 || LAYER == 23 || SPLIT) ? 4 : ESZ;
   static constexpr int PH = TH + 2 * HALO, PW = TW + 2 * HALO;
   static constexpr int ROWB = CK * ESZ;                  // 32 / 64 / 128 bytes
   static constexpr int PPP = ROWB / 16;

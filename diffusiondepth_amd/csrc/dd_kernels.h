@@ -47,22 +47,22 @@ constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2
 // tools/bf16_error_budget.py --log-scale 1.8 shows that the f16 mode's depth error (1.0e-3 RMSE at 0.5..60 m) is NOT made by the two large
 // convolutions (their f16 operands and weights: 2.1e-4 / 3.2e-4) but by what surrounds them: the once-per-image conv3(cond) on f16 operands
 // (4.9e-4) and its f16 storage (3.6e-4), conv4's weights (4.4e-4) and operand (3.3e-4), y3's f16 storage (3.5e-4), conv1's weights
-// (2.4e-4).  Those are 6 % of the FLOPs and HBM-bound, so they are made exact where that is (nearly) free:
-//   conv1            split operands hi + lo (three MFMAs on 3 % of the FLOPs; the kernel is bound by memory), y1 stored f16 as before
-//   conv2, conv3     the f16 kernels, unchanged: single MFMA per product
-//   conv3(cond)      once per image on the split-f16 kernel from the fp32 condition map; the term stays fp32 (option "f16r_wide")
-//   y3               stored fp32 ("f16r_wide"): +128 B per pixel and step on each side of the conv3 / conv4 boundary
+// (2.4e-4).  Those are 6 % of the FLOPs and HBM-bound, so they are made (near-)exact where that is (nearly) free:
+//   conv1            its WEIGHTS as an f16 pair hi + lo (two MFMAs on 3 % of the FLOPs; the state x stays a single f16 operand: 1.5e-4)
+//   conv2, conv3     the f16 kernels' arithmetic, unchanged: single MFMA per product
+//   conv3(cond)      once per image on the split-f16 kernel (EK_F16S) from the fp32 condition map, then reformatted (launch_cadd_reformat)
+//   hand-overs       y3 and that hoisted term travel as BLOCK-SCALED INT16 (option "f16r_wide" = 1): y3 as int16 with one fp32 scale per PIXEL
+//                    (the maximum |.| over its 64 channels: conv3's epilogue has a pixel's channels in the two lanes li / li + 32, conv4's
+//                    staging item is 8 channels of one pixel), the hoisted term as int16 with one scale per accumulator block (32 pixels x 32
+//                    couts: a wave-uniform scalar in conv3's accumulator initialisation).  f16's bytes at ~15 bits relative to the block's largest
+//                    value: 4e-5 instead of f16's 3.5e-4 depth RMSE per tensor (the emulator; an fp32 hand-over measured the same error at
+//                    conv3 +26 us / conv4 +15 us per step and was dropped: profiles/r04_call1_*, r04_call2_*)
 //   conv4            weights as an f16 pair hi + lo IN ONE MFMA: the 32 x 32 x 16 instruction has 32 cout rows and conv4 16 couts, so rows
 //                    16..31 of the A operand -- zero padding until now -- carry lo * 2^11 and the epilogue adds the two accumulator halves
 //                    (lane-local: register quads q and q + 2); option "f16r_p4": the operand relu(gn3(y3)) as a pair as well (two MFMAs)
-// Forward only, Res denoiser; DESIGN.md section 4.
-// EK_F16Q = the same mode with the two hand-overs as BLOCK-SCALED INT16 instead of fp32 (tools/bf16_error_budget.py: 4e-5 instead of f16's
-// 3.5e-4 depth RMSE per tensor, at f16's bytes): y3 as int16 with one fp32 scale per PIXEL (the maximum |.| over its 64 channels: conv3's
-// epilogue has a pixel's channels in the two lanes li / li + 32, conv4's staging item is 8 channels of one pixel), the hoisted conv3(cond) term
-// as int16 with one scale per accumulator block (32 pixels x 32 couts: a wave-uniform scalar in conv3's accumulator initialisation); and conv1
-// with the WEIGHTS as an f16 pair only (two MFMAs; the state x stays a single f16 operand: 1.5e-4).  Kernel forms, not an API precision:
-// DD_PREC_F16R picks between them by option "f16r_wide" (2 = these, 1 = fp32 hand-over, 0 = f16 hand-over).
-enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3, EK_F16S = 4, EK_F16R = 5, EK_F16Q = 6 };
+// Instantiated (dd_igemm2_cfg.h) for the layers whose kernel differs from the f16 mode's: conv1 and the hoisted conv3.  Forward only, Res denoiser;
+// DESIGN.md section 4.
+enum ElemKind : int { EK_F32 = 0, EK_BF16 = 1, EK_F16 = 2, EK_BF16M = 3, EK_F16S = 4, EK_F16R = 5 };
 constexpr float Q15_ONE = 32767.f;
 __host__ __device__ constexpr int opnd_kind(int ek) { return ek == EK_BF16M ? (int)EK_BF16 : (ek == EK_F16S || ek == EK_F16R) ? (int)EK_F16 : ek; }    // MFMA operands of the large convolutions / gradients
 __host__ __device__ constexpr int store_kind(int ek) { return (ek == EK_BF16M || ek == EK_F16R) ? (int)EK_F16 : ek == EK_F16S ? (int)EK_F32 : ek; }    // y1 / y2 (/ y3) in HBM
@@ -105,8 +105,8 @@ struct ConvParams {
   // conv3 with the condition term hoisted out of the loop (layer 9): out += cadd[pixel][cout] + sum over the taps that
   // fall inside the image of etab[t][tap][cout]   (conv is linear: conv3(r + cond + E[t]) = conv3(r) + conv3(cond) + conv3(E[t]))
   const float* cadd;        // conv3(cond) without bias, fp32, activation layout [B][2][h][w][32]
-  const float* cadd_scale;  // EK_F16Q: cadd holds int16 quads; value = int16 * cadd_scale[block], block = ((tile * WAVES + wave) * WN + n) * WM + m
-  float* out_scale;         // EK_F16Q conv3: y3 is written as int16; out_scale[b * h * w + pixel] = that pixel's max |.| / 32767
+  const float* cadd_scale;  // EK_F16R: cadd holds int16 quads; value = int16 * cadd_scale[block], block = ((tile * WAVES + wave) * WN + n) * WM + m
+  float* out_scale;         // EK_F16R conv3: y3 is written as int16; out_scale[b * h * w + pixel] = that pixel's max |.| / 32767
   const float* etab;        // [EMB_ROWS][10][64] fp32: per-tap W3_tap . E[t] (entries 0..8) and their sum (entry 9)
   // Swin denoiser with the step-invariant part of pred.0(convB(convA(.))) hoisted (kernel id SWIN_PRED_H): this step's rows of the
   // time-embedding table [SWIN_TT_ROWS][64] fp32 -- row 0 is added to every pixel, row 1 + 7 r + c to the pixels of border class (r, c)
@@ -176,12 +176,12 @@ struct PackGeom { int cin, cout, cout_pad, ck, tg, nt, th, ks, planes, stack; };
                                                                             // stack = 1 (conv4, EK_F16R): cout rows cout..2 cout-1 = the lo halves times STACK_LSCALE
 hipError_t launch_conv_igemm2(int layer, int ek, const ConvParams& p, hipStream_t s);
 // conv4 (64 -> 16) as a persistent streaming kernel (dd_thin.hip): same ConvParams and packed weights as layer 4; ek = EK_F16 / EK_BF16
-//   stack = the stacked hi / lo weight image (EK_F16R); in_kind = how y3 arrives: 0 = the 2-byte kind, 1 = fp32, 2 = int16 with a per-pixel scale
-//   (ConvParams::cadd_scale = that scale array here); psplit = the operand as an f16 pair too (stack only)
-hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack = false, int in_kind = 0, bool psplit = false);
+//   stack = the stacked hi / lo weight image (EK_F16R); in_q15 = y3 arrives as int16 with a per-pixel scale (ConvParams::cadd_scale = that scale
+//   array here) instead of the 2-byte kind; psplit = the operand as an f16 pair too (stack only)
+hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack = false, bool in_q15 = false, bool psplit = false);
 // EK_F16R: the once-per-image term conv3(cond), left by the split-f16 layer 8 in the accumulator-fragment order of 8x32 tiles (fp32), into
-// the order / element type the loop's conv3 reads: 8x32 or 16x32 tiles (big), fp32 or f16 quads (dd_misc.hip)
-//   out_kind: 0 = fp32, 1 = f16 quads, 2 = int16 quads + one fp32 scale per (tile, wave, n, m) block of 32 pixels x 32 couts (scales)
+// the order / element type the loop's conv3 reads: 8x32 or 16x32 tiles (big); out_kind: 1 = f16 quads, 2 = int16 quads + one fp32 scale per
+// (tile, wave, n, m) block of 32 pixels x 32 couts (scales) (dd_misc.hip)
 hipError_t launch_cadd_reformat(const float* src, void* dst, float* scales, int B, int h, int w, int big, int out_kind, hipStream_t s);
 PackGeom conv_pack_geom2(int layer, int ek);
 

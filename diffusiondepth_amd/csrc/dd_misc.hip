@@ -1098,9 +1098,9 @@ hipError_t launch_max_abs(const float* w, long long n, unsigned* out_bits, hipSt
   return hipGetLastError();
 }
 
-// EK_F16R / EK_F16Q: conv3(cond) from the accumulator-fragment order of 8x32 tiles (fp32; what the split-f16 layer 8 writes: entry
+// EK_F16R: conv3(cond) from the accumulator-fragment order of 8x32 tiles (fp32; what the split-f16 layer 8 writes: entry
 // ((((tile * 4 + wave) * 2 + n) * 2 + m) * 4 + q) * 64 + lane = couts 32n + 8q + 4g .. +3 of pixel (8 ty + 2 wave + m, 32 tx + li), lane = 32g + li)
-// into the order of the loop's conv3 tiles -- 8x32 (WM = 2) or 16x32 (WM = 4: pixel row 16 ty + 4 wave + m) -- as fp32, f16 quads, or int16 quads
+// into the order of the loop's conv3 tiles -- 8x32 (WM = 2) or 16x32 (WM = 4: pixel row 16 ty + 4 wave + m) -- as f16 quads (out_kind 1) or int16 quads
 // with one fp32 scale per (tile, wave, n, m) block of 32 pixels x 32 couts (out_kind 2: max |.| of the block / 32767).  One workgroup of 256 threads
 // per destination block (thread = (q, lane)); rows of a 16-row tile below the source's last tile row read as zero (never used: outside the image).
 __global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __restrict__ src, void* __restrict__ dst, float* __restrict__ scales, int B, int h, int w,
@@ -1136,8 +1136,7 @@ __global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __rest
     const float inv = mx > 0.f ? 1.f / mx : 0.f;
     if (threadIdx.x == 0) scales[blk] = mx * (1.f / Q15_ONE);
     reinterpret_cast<uint2*>(dst)[e] = make_uint2(DD_CVT_PKNORM_I16(v.x * inv, v.y * inv), DD_CVT_PKNORM_I16(v.z * inv, v.w * inv));
-  } else if (out_kind == 1) reinterpret_cast<uint2*>(dst)[e] = make_uint2(pack2<EK_F16>(v.x, v.y), pack2<EK_F16>(v.z, v.w));
-  else reinterpret_cast<float4*>(dst)[e] = v;
+  } else reinterpret_cast<uint2*>(dst)[e] = make_uint2(pack2<EK_F16>(v.x, v.y), pack2<EK_F16>(v.z, v.w));
 }
 hipError_t launch_cadd_reformat(const float* src, void* dst, float* scales, int B, int h, int w, int big, int out_kind, hipStream_t s) {
   const int TH = big ? 16 : 8, WM = big ? 4 : 2;

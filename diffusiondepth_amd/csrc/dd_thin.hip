@@ -19,9 +19,9 @@
 //   STACK   the packed weight image carries an f16 PAIR per weight in ONE MFMA: the 32x32x16 instruction has 32 cout rows, conv4 has 16 couts, so rows
 //           16..31 (zero padding in the plain image) hold f16((w - f16(w)) * 2^11) and the epilogue adds accumulator quads q and q + 2 (lane-local).
 //           Same MFMA count, same LDS traffic; conv4's weight rounding -- the largest single term of the f16 mode's depth error -- is gone.
-//   INK     how y3 arrives: 0 = the 2-byte kind; 1 = fp32 (no f16 rounding of the tensor in front of GroupNorm 3): two 16-byte loads per staging item;
-//           2 = int16 with one fp32 scale per pixel (EK_F16Q, dd_kernels.h: f16's bytes, ~15 bits relative to the pixel's largest channel):
-//           one more 4-byte load per staging item, the scale folded into the GroupNorm table's slope
+//   INQ     y3 arrives as int16 with one fp32 scale per pixel (EK_F16R, dd_kernels.h: f16's bytes, ~15 bits relative to the pixel's largest channel)
+//           instead of the 2-byte kind: one more 4-byte load per staging item.  (An fp32 y3 -- two 16-byte loads per item, a two-slot register ring
+//           to stay inside 128 VGPRs -- was built first and measured: same depth error, conv4 30 -> 45 us; removed: profiles/r04_call1_*.)
 //   PSPLIT  the operand relu(gn3(y3)) as an f16 pair as well (scaled by 2^4 so that lo halves stay normal): a second LDS plane per patch buffer and
 //           a second MFMA per tap against the same stacked weight fragment -- [Whi; Wlo] . (Phi + Plo) = all four partial products
 // Same arithmetic as layer 4 of dd_igemm2.hip: the packed weight image of that layer (16-channel chunks, nine taps per stage, 32 cout rows,
@@ -50,17 +50,14 @@ static_assert(Cfg2<EK_F16, 4>::CK == CK && Cfg2<EK_F16, 4>::TG == 9 && Cfg2<EK_F
               "the packed weight image of layer 4 (dd_igemm2_cfg.h, DD_C4_CK16) is read as it is");
 }  // namespace thin
 
-template <int EK, bool STACK, int INK, bool PSPLIT>
+template <int EK, bool STACK, bool INQ, bool PSPLIT>
 __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvParams p) {
   using namespace thin;
-  constexpr bool IN32 = INK == 1, INQ = INK == 2;
   static_assert(EK == EK_F16 || EK == EK_BF16, "2-byte kinds");
-  static_assert(EK == EK_F16 || !(STACK || INK != 0 || PSPLIT), "the refined forms are f16 kernels");
+  static_assert(EK == EK_F16 || !(STACK || INQ || PSPLIT), "the refined forms are f16 kernels");
   static_assert(STACK || !PSPLIT, "the operand pair runs against the stacked weight image");
   constexpr int PATCH_BYTES = (PSPLIT ? 2 : 1) * PATCH_PLANE;
   constexpr int TAB_OFF = W_BYTES + 2 * PATCH_BYTES;
-  constexpr int NLD = IN32 ? 2 : 1;                    // 16-byte loads per staging item (8 channels)
-  constexpr int IN_ESZ = IN32 ? 4 : 2;
   constexpr float PSC = PSPLIT ? SPLIT_PSCALE : 1.f;   // the patch is carried times 2^4 (exact; relu commutes), the epilogue divides
   DD_DYN_SMEM(smem);
   float* tab_a = reinterpret_cast<float*>(smem + TAB_OFF);
@@ -129,7 +126,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     if (it < ITEMS) m_valid |= 1u << u;
     lds_off[u] = pp * ROWB + ((jfix << 4) ^ swz16<RPB, PPP>(pc_[u]));
   }
-  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * CIN * IN_ESZ;
+  const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * CIN * 2;
   // geometry of a tile: clamped pixel offsets of this thread's items and their inside-the-image mask
   auto geometry = [&](int t_local, int* po, unsigned& mi) {
     const int ty = t_local / p.tiles_x, tx = t_local - ty * p.tiles_x;
@@ -157,25 +154,21 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   };
   bool has_next = next_geometry();
 
-  // raw-input register slots.  f16 input: one slot per chunk, a chunk's slot is refilled with the NEXT tile's same chunk (four stages ahead).
-  // fp32 input (IN32: twice the registers per chunk): a ring of two slots, chunk j of the running sequence (tile * 4 + chunk) in slot j & 1,
-  // refilled two stages ahead -- the same ~43 KB per workgroup in flight, and the kernel stays inside 128 VGPRs (four waves per SIMD).
-  constexpr int NSLOT = IN32 ? 2 : NCH;
-  uint4 raw[NSLOT][NIT][NLD];
-  float rsc[INQ ? NSLOT : 1][NIT];                               // INQ: the pixel's scale (travels with the item)
+  // raw-input registers: one slot per chunk, a chunk's slot is refilled with the NEXT tile's same chunk (four stages ahead)
+  uint4 raw[NCH][NIT];
+  float rsc[INQ ? NCH : 1][NIT];                                 // INQ: the pixel's scale (travels with the item)
   const float* sc_b = INQ ? p.cadd_scale + (size_t)b * h * w : nullptr;
-  auto load_chunk = [&](int c, int slot, const int* po) {        // channel-blocked y3: [B][2][h][w][32]
+  auto load_chunk = [&](int c, const int* po) {        // channel-blocked y3: [B][2][h][w][32]
     const int cbase = c * CK + jfix * EPP;
     const size_t off0 = (size_t)(cbase >> 5) * h * w * ACT_CB + (cbase & (ACT_CB - 1));
     if (abl & 2) return;
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
-#pragma unroll
-      for (int q = 0; q < NLD; ++q) raw[slot][u][q] = *reinterpret_cast<const uint4*>(in_b + (off0 + (size_t)po[u] * ACT_CB) * IN_ESZ + q * 16);
-      if constexpr (INQ) rsc[slot][u] = sc_b[po[u]];
+      raw[c][u] = *reinterpret_cast<const uint4*>(in_b + (off0 + (size_t)po[u] * ACT_CB) * 2);
+      if constexpr (INQ) rsc[c][u] = sc_b[po[u]];
     }
   };
-  auto transform_chunk = [&](int c, int slot, int buf, unsigned mi) {        // relu(gn3(y3)) of chunk c (in register slot `slot`) -> patch buffer `buf`
+  auto transform_chunk = [&](int c, int buf, unsigned mi) {        // relu(gn3(y3)) of chunk c -> patch buffer `buf`
     if (abl & 1) return;
     float ta[EPP], tb[EPP];
     const int c0 = c * CK + jfix * EPP;
@@ -192,22 +185,17 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
       // stage -- which drains the whole prefetch (seen in the first version of this kernel: conv4 30 us instead of 36, not 22).
       const bool inside = (mi >> u) & 1u;                   // zero padding applies AFTER the normalisation
       uint4 v, vlo = make_uint4(0u, 0u, 0u, 0u);
-      if constexpr (INK == 0 && !PSPLIT) {
-        v = affine_relu_pack<EK, EK>(raw[slot][u][0], ta, tb);
+      if constexpr (!INQ && !PSPLIT) {
+        v = affine_relu_pack<EK, EK>(raw[c][u], ta, tb);
       } else {
         float y[EPP];
-        if constexpr (IN32) {
-          const uint32_t yw[8] = {raw[slot][u][0].x, raw[slot][u][0].y, raw[slot][u][0].z, raw[slot][u][0].w,
-                                  raw[slot][u][NLD - 1].x, raw[slot][u][NLD - 1].y, raw[slot][u][NLD - 1].z, raw[slot][u][NLD - 1].w};
-#pragma unroll
-          for (int i = 0; i < EPP; ++i) y[i] = __builtin_bit_cast(float, yw[i]);
-        } else if constexpr (INQ) {
-          const uint32_t qw[4] = {raw[slot][u][0].x, raw[slot][u][0].y, raw[slot][u][0].z, raw[slot][u][0].w};
-          const float sc = rsc[slot][u];
+        if constexpr (INQ) {
+          const uint32_t qw[4] = {raw[c][u].x, raw[c][u].y, raw[c][u].z, raw[c][u].w};
+          const float sc = rsc[c][u];
 #pragma unroll
           for (int i = 0; i < 4; ++i) { y[2 * i] = (float)(short)(qw[i] & 0xFFFFu) * sc; y[2 * i + 1] = (float)((int)qw[i] >> 16) * sc; }
         } else {
-          Piece<EK>::unpack(raw[slot][u][0], y);
+          Piece<EK>::unpack(raw[c][u], y);
         }
 #pragma unroll
         for (int i = 0; i < EPP; ++i) y[i] = fmaxf(fmaf(ta[i], y[i], tb[i]), 0.f);
@@ -229,14 +217,13 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     }
   };
 
-  // first tile: all four chunks requested (fp32 input: the first two), chunk 0 staged
+  // first tile: all four chunks requested, chunk 0 staged
 #pragma unroll
-  for (int c = 0; c < NSLOT; ++c) load_chunk(c, c, po_cur);
+  for (int c = 0; c < NCH; ++c) load_chunk(c, po_cur);
   DD_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();                          // table + weights + bias visible
   asm volatile("" ::: "memory");
-  transform_chunk(0, 0, 0, mi_cur);
-  if constexpr (IN32) load_chunk(2, 0, po_cur);
+  transform_chunk(0, 0, mi_cur);
   DD_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -255,7 +242,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // the slot of chunk 0 was consumed in the previous tile's last stage: refill it with the next tile's chunk 0
-      if constexpr (!IN32) { if (c == 0) load_chunk(0, 0, po_nx); }
+      if (c == 0) load_chunk(0, po_nx);
       const int pbuf = (c & 1) * PATCH_BYTES;
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
@@ -270,16 +257,11 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
         }
       }
       // stage the following chunk into the other patch buffer, then reuse its registers for the next tile
-      if constexpr (IN32) {
-        constexpr int RMASK = NCH - 1;
-        const int cn = (c + 1) & RMASK, cl = (c + 3) & RMASK;      // chunk staged now; chunk requested into the slot that frees ((c + 3) & 1 == (c + 1) & 1)
-        transform_chunk(cn, cn & 1, cn & 1, c + 1 < NCH ? mi_cur : mi_nx);
-        load_chunk(cl, cl & 1, c + 3 < NCH ? po_cur : po_nx);
-      } else if (c + 1 < NCH) {
-        transform_chunk(c + 1, c + 1, (c + 1) & 1, mi_cur);
-        load_chunk(c + 1, c + 1, po_nx);
+      if (c + 1 < NCH) {
+        transform_chunk(c + 1, (c + 1) & 1, mi_cur);
+        load_chunk(c + 1, po_nx);
       } else {
-        transform_chunk(0, 0, 0, mi_nx);          // (behind the last tile: a patch nobody reads)
+        transform_chunk(0, 0, mi_nx);          // (behind the last tile: a patch nobody reads)
       }
       DD_WAIT_LGKM0();
       if (!(abl & 64)) __builtin_amdgcn_s_barrier();
@@ -335,29 +317,28 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   }
 }
 
-template <int EK, bool STACK, int IN32, bool PSPLIT> static hipError_t launch_conv4_stream_k(const ConvParams& p, hipStream_t s) {
+template <int EK, bool STACK, bool INQ, bool PSPLIT> static hipError_t launch_conv4_stream_k(const ConvParams& p, hipStream_t s) {
   static bool attr_set = false;
   constexpr int SMEM = thin::smem_bytes(PSPLIT);
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4_stream_kernel<EK, STACK, IN32, PSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4_stream_kernel<EK, STACK, INQ, PSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const unsigned n_wg = (unsigned)persist_grid(p.B, p.tiles_x * p.tiles_y, p.persist_slots > 0 ? p.persist_slots : 512);
-  hipLaunchKernelGGL((conv4_stream_kernel<EK, STACK, IN32, PSPLIT>), dim3(n_wg), dim3(thin::THREADS), SMEM, s, p);
+  hipLaunchKernelGGL((conv4_stream_kernel<EK, STACK, INQ, PSPLIT>), dim3(n_wg), dim3(thin::THREADS), SMEM, s, p);
   return hipGetLastError();
 }
 
-hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack, int in_kind, bool psplit) {
+hipError_t launch_conv4_stream(int ek, const ConvParams& p, hipStream_t s, bool stack, bool in_q15, bool psplit) {
   if (ek == EK_F16 && stack) {
-    if (in_kind == 2) return psplit ? launch_conv4_stream_k<EK_F16, true, 2, true>(p, s) : launch_conv4_stream_k<EK_F16, true, 2, false>(p, s);
-    if (in_kind == 1) return psplit ? launch_conv4_stream_k<EK_F16, true, 1, true>(p, s) : launch_conv4_stream_k<EK_F16, true, 1, false>(p, s);
-    return psplit ? launch_conv4_stream_k<EK_F16, true, 0, true>(p, s) : launch_conv4_stream_k<EK_F16, true, 0, false>(p, s);
+    if (in_q15) return psplit ? launch_conv4_stream_k<EK_F16, true, true, true>(p, s) : launch_conv4_stream_k<EK_F16, true, true, false>(p, s);
+    return psplit ? launch_conv4_stream_k<EK_F16, true, false, true>(p, s) : launch_conv4_stream_k<EK_F16, true, false, false>(p, s);
   }
-  if (stack || in_kind != 0 || psplit) return hipErrorInvalidValue;
+  if (stack || in_q15 || psplit) return hipErrorInvalidValue;
   switch (ek) {
-    case EK_F16: return launch_conv4_stream_k<EK_F16, false, 0, false>(p, s);
-    case EK_BF16: return launch_conv4_stream_k<EK_BF16, false, 0, false>(p, s);
+    case EK_F16: return launch_conv4_stream_k<EK_F16, false, false, false>(p, s);
+    case EK_BF16: return launch_conv4_stream_k<EK_BF16, false, false, false>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

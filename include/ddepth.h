@@ -233,9 +233,11 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * keep its activations keeps the states only), "thin_stream" (1 [default] = conv4 runs as the persistent streaming kernel of
  * csrc/dd_thin.hip in the 16-bit modes, 0 = as an instance of the general kernel: A/B switch), "thin_slots" (workgroups of that kernel,
  * default 512 = two per CU), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
- * "f16r_wide" (DD_PREC_F16R: how y3 and the hoisted conv3(cond) term travel: 2 [default] = int16 with block scales -- one fp32 scale per pixel of y3, per
- * 32-pixel x 32-cout accumulator block of the hoisted term: f16's bytes at ~15 bits --, 1 = fp32, 0 = f16 as in DD_PREC_F16), "f16r_c1" (DD_PREC_F16R,
- * conv1: 1 [default] = its weights as an f16 pair (two MFMAs), 2 = weights and state as pairs (three), 0 = the plain f16 kernel),
+ * "f16r_wide" (DD_PREC_F16R: 1 [default] = y3 and the hoisted conv3(cond) term travel as int16 with block scales -- one fp32 scale per pixel of y3, per
+ * 32-pixel x 32-cout accumulator block of the hoisted term: f16's bytes at ~15 bits --, 0 = as f16 like in DD_PREC_F16), "f16r_c1" (DD_PREC_F16R:
+ * 1 [default] = conv1's weights as an f16 pair (two MFMAs), 0 = the plain f16 kernel), "one_buffer" (1 [default] = the loop's hoisted conv3 on
+ * 8x32 tiles runs in its one-patch-buffer form -- three workgroups per CU -- when a one-lane call has more tiles than resident slots; 0 = never,
+ * 2 = always: A/B switch and tests),
  * "f16r_p4" (DD_PREC_F16R: 1 = conv4's operand relu(gn3(y3)) as an f16 pair as well -- two MFMAs per tap; default 0). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);

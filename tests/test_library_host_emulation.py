@@ -185,18 +185,18 @@ def test_refined_f16_mode_on_the_far_range_golden(lib, golden, cases):
         d = be.decode(x0)
         return float(np.sqrt((((d - dref) / dref) ** 2).mean()))
     try:
-        e_q15 = rel_rmse("f16r", f16r_wide=2, f16r_c1=1, f16r_p4=0)          # the defaults: scaled-int16 hand-over, conv1's weights as a pair
-        e_wide = rel_rmse("f16r", f16r_wide=1, f16r_c1=2)                     # fp32 hand-over, conv1 fully split
-        e_p4 = rel_rmse("f16r", f16r_wide=1, f16r_c1=2, f16r_p4=1)
+        e_wide = rel_rmse("f16r", f16r_wide=1, f16r_c1=1, f16r_p4=0)          # the defaults: block-scaled int16 hand-over, conv1's weights as a pair
+        e_p4 = rel_rmse("f16r", f16r_wide=1, f16r_c1=1, f16r_p4=1)
         e_narrow = rel_rmse("f16r", f16r_wide=0, f16r_c1=1, f16r_p4=0)
-        e_c0 = rel_rmse("f16r", f16r_wide=2, f16r_c1=0) if FULL else None
+        e_c0 = rel_rmse("f16r", f16r_wide=1, f16r_c1=0) if FULL else None
     finally:
-        be.set_option("f16r_wide", 2); be.set_option("f16r_c1", 1); be.set_option("f16r_p4", 0)
+        be.set_option("f16r_wide", 1); be.set_option("f16r_c1", 1); be.set_option("f16r_p4", 0)
     e_f16 = rel_rmse("f16")
     assert e_p4 < e_wide < e_narrow < e_f16, (e_p4, e_wide, e_narrow, e_f16)
-    assert e_wide < 2e-4 and e_wide < 0.6 * e_f16, (e_wide, e_f16)          # the GPU suite's bound for the mode; half the f16 mode's error
-    assert e_q15 < 1.1 * e_wide, (e_q15, e_wide)                            # int16 with block scales carries what fp32 carried (measured 1.012e-4 vs 9.89e-5)
-    assert e_c0 is None or e_q15 < e_c0 < e_narrow
+    # the GPU suite's bound for the mode; half the f16 mode's error (measured 1.012e-4 vs 2.08e-4; an fp32 hand-over of y3 / the hoisted term
+    # measured 9.89e-5 before it was dropped: int16 with block scales carries what fp32 carried)
+    assert e_wide < 2e-4 and e_wide < 0.6 * e_f16, (e_wide, e_f16)
+    assert e_c0 is None or e_wide < e_c0 < e_narrow
     # a single call (per-sample timesteps: the hoisted conv3 reads its E[t] row per image) at the mode's bound
     c1, g1 = cases["denoise_res"], golden("denoise_res")
     be1, _ = backend_for(lib, c1)
@@ -314,10 +314,10 @@ def test_streaming_conv4_walks_several_tiles_per_workgroup(lib, prec, B, slots):
     assert maxabs(outs[0], classic) < LATENT_TOL[prec] * np.abs(ref).max() and maxabs(one_tile_each, classic) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("wide,p4", [(2, 0), (1, 0), (0, 1)] + ([(1, 1), (0, 0), (2, 1)] if FULL else []))
+@pytest.mark.parametrize("wide,p4", [(1, 0), (0, 1)] + ([(1, 1), (0, 0)] if FULL else []))
 def test_refined_f16_conv4_walks_several_tiles_per_workgroup(lib, wide, p4):
-    """The stacked-weight forms of the streaming conv4 (dd_thin.hip: STACK, IN32 with its two-slot register ring refilled two stages ahead,
-    PSPLIT with the second patch plane) across tile boundaries: 17 x 70 latent = 3 x 3 tiles per image, 3 resident slots for 2 images -> one
+    """The stacked-weight forms of the streaming conv4 (dd_thin.hip: STACK, INQ = y3 as int16 with a per-pixel scale, PSPLIT with the second patch
+    plane) across tile boundaries: 17 x 70 latent = 3 x 3 tiles per image, 3 resident slots for 2 images -> one
     workgroup per image walks all nine tiles; against one tile per workgroup (bit-identical per output: same accumulation order; only the next
     GroupNorm's partial sums regroup), against the oracle, and bit-identical across the adversarial wave orders."""
     be, inp, ref, T = _loop_case(lib, B=2, h=17, w=70)
@@ -331,7 +331,7 @@ def test_refined_f16_conv4_walks_several_tiles_per_workgroup(lib, wide, p4):
         be.set_option("thin_slots", 512)
         one_tile_each = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
     finally:
-        be.set_option("f16r_wide", 2); be.set_option("f16r_p4", 0); be.set_option("thin_slots", 512)
+        be.set_option("f16r_wide", 1); be.set_option("f16r_p4", 0); be.set_option("thin_slots", 512)
     assert np.array_equal(outs[0], outs[1])
     assert maxabs(outs[0], ref) < LATENT_TOL["f16r"] * np.abs(ref).max()
     assert maxabs(outs[0], one_tile_each) < LATENT_TOL["f16r"] * np.abs(ref).max()
