@@ -451,8 +451,6 @@ int check_split(dd_handle_t h, int precision, const char* who) {
   if (!h->split_ok)
     return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": a convolution weight of magnitude >= 234 does not fit the split-f16 images (weights are scaled by 256 "
                                        "into f16): DD_PREC_F16X3 / DD_PREC_F16R cannot run on these parameters; the other precisions can");
-  if (precision == DD_PREC_F16R && h->variant != DD_VARIANT_RES)
-    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16R is built for DD_VARIANT_RES (Swin / MPViT denoiser: DD_PREC_F16 or DD_PREC_F16X3)");
   return DD_OK;
 }
 
@@ -490,7 +488,7 @@ int want_hoist(dd_handle_t h, int precision, int T = 1, int keep = 0) {
   if (precision == DD_PREC_NAIVE_FP32) return 0;
   const int ek = ek_of_precision(precision, h->bf16_pure);
   if (h->variant == DD_VARIANT_SWIN) {
-    if (T <= 0 || keep != 0 || h->hoist_cond == 0 || (ek == EK_F16S && !h->swin_w5)) return 0;      // (split f16: the 5x5 form only)
+    if (T <= 0 || keep != 0 || h->hoist_cond == 0 || ((ek == EK_F16S || ek == EK_F16R) && !h->swin_w5)) return 0;      // (split / refined f16: the 5x5 form only)
     return (h->hoist_cond == 1 || ek != EK_F32) ? 1 : 0;
   }
   if (h->variant != DD_VARIANT_RES) return 0;
@@ -573,6 +571,9 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   pl->key = key;
   const bool naive = key.prec == DD_PREC_NAIVE_FP32;
   pl->ek = naive ? EK_F32 : ek_of_precision(key.prec, h->bf16_pure);
+  if (pl->ek == EK_F16R && !key.hoist)
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_PREC_F16R runs the hoisted forward-only plans: for the Swin / MPViT denoiser that is the T-step loop (dd_denoise / "
+                                       "dd_denoise_trace) with option swin_w5 = 1; single calls (dd_denoise_once) and training plans: DD_PREC_F16");
   const size_t px = (size_t)key.B * key.h * key.w;
   const size_t es = ek_size(pl->ek);
   DD_HIP(pl->x[0].alloc(px * LATENT_C * 4));
@@ -584,7 +585,10 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond, key.lane); if (rc) return rc; }
   pl->slots = (key.keep == 2 && key.T > 0) ? key.T : 1;
   const size_t ns = (size_t)pl->slots;
-  if (swin) { DD_HIP(pl->sa.alloc(ns * px * COND_C * es)); DD_HIP(pl->sf.alloc(ns * px * COND_C * es)); }
+  if (swin) {      // (refined f16: the once-per-image chain runs on split operands through fp32 tensors in these two buffers)
+    const size_t es_s = pl->ek == EK_F16R ? 4 : es;
+    DD_HIP(pl->sa.alloc(ns * px * COND_C * es_s)); DD_HIP(pl->sf.alloc(ns * px * COND_C * es_s));
+  }
   if (key.hoist)   // conv3(cond) in accumulator-fragment order: whole (th x 32)-pixel tiles
   {
     const int th = conv_pack_geom2(conv3h_kid(h, key), pl->ek).th;
@@ -674,7 +678,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       if (layer == 4 && rf) { q.persist_slots = h->thin_slots; q.cadd_scale = static_cast<const float*>(pl->slot(pl->y3_scale, step)); return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
       if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
       int lek = ek;
-      if (rf && layer == 9 && !pl->wide) lek = EK_F16;      // hand-over of y3 / the hoisted term as f16: the f16 mode's conv3
+      if (rf && (layer == 9 || layer == 7) && !pl->wide) lek = EK_F16;      // hand-over of y3 / the hoisted term as f16: the f16 mode's conv3 / 5x5 form
       if (rf && layer == 1 && !pl->c1) lek = EK_F16;        // conv1 without the weight pair: the f16 mode's conv1
       return launch_conv_igemm2(kid, lek, q, s);
     };
@@ -718,6 +722,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
       DD_HIP(launch_swin_bcorr(sa_, ek == EK_F16S ? (int)EK_F32 : opnd_kind(ek), h->pairp.as<float>(), h->kside.p, pl->bcorr.as<float>(), k.B, k.h, k.w, s));     // (kind convA' stored its result in)
       p.in = sa_; p.wpack = h->w5pack[wk].p; p.bias = h->L[2].bias.as<float>(); p.out = y3_;
       p.stats_out = pl->stat_ptr(step, 2); p.bcorr = pl->bcorr.as<float>();
+      p.cadd_scale = pl->ccond_scale.as<float>(); p.out_scale = static_cast<float*>(pl->slot(pl->y3_scale, step));      // (EK_F16R form only)
       DD_HIP(timed_launch(7, p, plan_big_tiles(h, k) ? (int)SWIN_PRED5B_H : (int)SWIN_PRED5_H));
     } else {
       p.in = sa_; p.wpack = h->LB.wpack2[wk].p; p.out = sf_;
@@ -844,10 +849,23 @@ int enqueue_swin_hoist(dd_handle_t h, Plan* pl, hipStream_t s) {
     pl->ttab_weights = h->weights_serial;
   }
   if (pl->bcorr.p) { int rc = ensure_swin_w5(h, s); if (rc) return rc; }
-  const int tk = thin_kind(pl->ek);           // once per image: f16 kernels in the bf16 mode, as the Res variant's conv3(cond)
   ConvParams p{};
   p.B = k.B; p.h = k.h; p.w = k.w;
   p.tiles_x = (k.w + 31) / 32;
+  if (pl->ek == EK_F16R) {
+    // refined f16: the whole once-per-image chain on split operands (EK_F16S kernels, fp32 tensors: the upsampled condition map is fp32 in this
+    // mode), its result in the order of 8x32 tiles, then reformatted into what the loop's 5x5 kernel reads (as the Res variant's conv3(cond))
+    p.tiles_y = (k.h + 7) / 8;
+    p.in = pl->cond_ptr(); p.wpack = h->LA.wpack2[WIMG_SPLIT].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
+    DD_HIP(launch_conv_igemm2(6, EK_F16S, p, s));
+    p.in = pl->sa.p; p.wpack = h->LB.wpack2[WIMG_SPLIT].p; p.bias = h->LB.bias.as<float>(); p.out = pl->sf.p;
+    DD_HIP(launch_conv_igemm2(6, EK_F16S, p, s));
+    p.in = pl->sf.p; p.wpack = h->L[2].wpack2[WIMG_SPLIT].p; p.bias = h->zero_bias.as<float>(); p.out = pl->ccond_raw.p;
+    DD_HIP(launch_conv_igemm2(8, EK_F16S, p, s));
+    DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, pl->ccond_scale.as<float>(), k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0, pl->wide ? 2 : 1, s));
+    return DD_OK;
+  }
+  const int tk = thin_kind(pl->ek);           // once per image: f16 kernels in the bf16 mode, as the Res variant's conv3(cond)
   p.tiles_y = (k.h + conv_pack_geom2(6, tk).th - 1) / conv_pack_geom2(6, tk).th;
   p.in = pl->cond_ptr(); p.wpack = h->LA.wpack2[wimg_slot(tk)].p; p.bias = h->LA.bias.as<float>(); p.out = pl->sa.p;
   DD_HIP(launch_conv_igemm2(6, tk, p, s));

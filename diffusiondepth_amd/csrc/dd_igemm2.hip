@@ -978,6 +978,8 @@ static hipError_t launch_layer2_refined(int layer, const ConvParams& p, hipStrea
     case 9: return launch_one2<EK_F16R, 9>(p, s);
     case BIG_CONV3H: return launch_one2<EK_F16R, BIG_CONV3H>(p, s);
     case ONE_CONV3H: return launch_one2<EK_F16R, ONE_CONV3H>(p, s);
+    case SWIN_PRED5_H: return launch_one2<EK_F16R, SWIN_PRED5_H>(p, s);
+    case SWIN_PRED5B_H: return launch_one2<EK_F16R, SWIN_PRED5B_H>(p, s);
     default: return launch_layer2<EK_F16>(layer, p, s);
   }
 }

@@ -91,16 +91,17 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // packed weights carry TWO f16 planes (hi, lo) and every (weight, pixel) fragment pair costs three MFMAs.  Instantiated for the
   // denoiser's layers 1..9 only; one tiling for all of them: 16-channel chunks, 3 taps per stage (conv1: 9), 64-cout workgroup tiles.
   // EKM_ == EK_F16R (refined f16, DD_PREC_F16R; dd_kernels.h): instantiated for the layers whose kernel differs from the f16 mode's only --
-  // conv1 (its weights as an f16 pair against a single-plane patch, y1 stored f16) and the hoisted conv3 (layer 9 and its tile forms: f16 operands
-  // and input, the hoisted term read as block-scaled int16, y3 written as int16 with a per-pixel scale); every other layer of the mode runs its
-  // EK_F16 (conv2, conv4 via dd_thin.hip) or EK_F16S (layer 8) form.
+  // conv1 (its weights as an f16 pair against a single-plane patch, y1 stored f16) and the producer of y3 -- the hoisted conv3 of the Res denoiser
+  // (layer 9 and its tile forms) / the 5x5 form pred.0 o convB of the Swin denoiser: f16 operands and input, the hoisted term read as block-scaled
+  // int16, y3 written as int16 with a per-pixel scale; every other layer of the mode runs its EK_F16 (conv2, Swin convA', conv4 via dd_thin.hip)
+  // or EK_F16S (the once-per-image chain) form.
   static constexpr bool RF = EKM_ == EK_F16R;
-  static_assert(!RF || LAYER_ == 1 || LAYER_ == 9, "EK_F16R is instantiated for conv1 and the hoisted conv3 only");
+  static_assert(!RF || LAYER_ == 1 || LAYER_ == 9 || PRED5, "EK_F16R is instantiated for conv1 and the hoisted conv3 / Swin 5x5 forms only");
   static constexpr bool SPLIT = EKM_ == EK_F16S || (RF && LAYER_ == 1);
   static constexpr bool WONLY = RF && LAYER_ == 1;             // split weights against a single-plane patch: W.P = Whi.P + Wlo.P
   static constexpr int NPL = SPLIT ? 2 : 1;                    // operand planes of a packed weight stage
   static constexpr int NPLP = (SPLIT && !WONLY) ? 2 : 1;       // operand planes of the LDS patch
-  static constexpr bool Q15 = RF && LAYER_ == 9;               // hoisted term read as scaled int16 quads, y3 written as int16 with a per-pixel scale
+  static constexpr bool Q15 = RF && (LAYER_ == 9 || PRED5);    // hoisted term read as scaled int16 quads, y3 written as int16 with a per-pixel scale
   static constexpr int EK = MX ? (int)EK_BF16 : (SPLIT || RF) ? (int)EK_F16 : EKM_;          // MFMA operand kind = kind of the LDS patch and of the packed weights
   static constexpr int LAYER = LAYER_;
   static constexpr int IN_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)

@@ -293,13 +293,16 @@ class ScheduledCNNRefine(nn.Module):
             return self._eager_forward(noisy_image, t, feat)
         be = self.bound.ensure(noisy_image.device, need=("model",))
         t = torch.as_tensor(t, device=noisy_image.device)
+        # the refined f16 mode exists as hoisted forward-only plans: for the Swin / MPViT denoiser that is the T-step loop; a single call (the
+        # ddim_loss evaluation of the heads) runs this denoiser's f16 kernels
+        prec = "f16" if (self.variant == "swin" and str(self.precision).lower() in ("f16r", "refined_f16")) else self.precision
         if _wants_grad(self, noisy_image, feat):
             tt = t.to(torch.int64).reshape(-1)
             if tt.numel() == 1 and noisy_image.shape[0] > 1:
                 tt = tt.expand(noisy_image.shape[0])
-            return _DenoiseOnceFn.apply(be, self.precision, noisy_image.float().contiguous(), tt.contiguous(), feat.float().contiguous(),
+            return _DenoiseOnceFn.apply(be, prec, noisy_image.float().contiguous(), tt.contiguous(), feat.float().contiguous(),
                                         *_ordered_params(self))
-        return be.denoise_once(noisy_image.float(), t, feat.float(), self.precision)
+        return be.denoise_once(noisy_image.float(), t, feat.float(), prec)
 
 
 def _eager_upsample_add(fuse, x, concat_with):

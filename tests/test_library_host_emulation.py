@@ -396,6 +396,17 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
         # fp32 tensors, per-pixel border correction); fp32-class agreement with the oracle
         xs = be.denoise(inp["x_T"], inp["cond"], T, "f16x3")
         assert np.isfinite(xs).all() and maxabs(xs, ref) < LATENT_TOL["f16x3"] * scale
+        # refined f16 (DD_PREC_F16R): the once-per-image chain on split operands from the fp32 upsampled condition map, reformatted into the 5x5
+        # kernel's accumulator order as block-scaled int16 (8x32 and 16x32 tiles); the 5x5 kernel writes y3 as int16 with a per-pixel scale; conv1 /
+        # conv4 in their weight-pair forms.  Closer to the oracle than the f16 mode; single calls are refused (no hoisted form)
+        xr = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
+        be.set_option("big_tiles", 1)
+        xrb = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
+        be.set_option("big_tiles", -1)
+        for got in (xr, xrb):
+            assert np.isfinite(got).all() and maxabs(got, ref) < LATENT_TOL["f16r"] * scale
+        with pytest.raises(RuntimeError, match="hoisted forward-only"):
+            be.denoise_once(inp["x_T"], 500, inp["cond"], "f16r")
 
 
 @full_only
