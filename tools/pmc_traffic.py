@@ -48,11 +48,12 @@ def lib_source_sha():
     return hsh.hexdigest()[:16]
 
 
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-import time
-out = {"bench_args": sys.argv[3] if len(sys.argv) > 3 else "", "lib_source_sha": lib_source_sha(), "taken": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
-       "note": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction), write = WRITE_SIZE KiB * 1024",
-       "kernels": {k: {"fetch_bytes": fetch[k] * 1024 * 2, "write_bytes": write.get(k, 0.0) * 1024,
-                       "hbm_bytes": fetch[k] * 1024 * 2 + write.get(k, 0.0) * 1024} for k in sorted(fetch)}}
-print(json.dumps(out, indent=1))
+if __name__ == "__main__":
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    import time
+    out = {"bench_args": sys.argv[3] if len(sys.argv) > 3 else "", "lib_source_sha": lib_source_sha(), "taken": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
+           "note": "bytes per launch; fetch = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction), write = WRITE_SIZE KiB * 1024",
+           "kernels": {k: {"fetch_bytes": fetch[k] * 1024 * 2, "write_bytes": write.get(k, 0.0) * 1024,
+                           "hbm_bytes": fetch[k] * 1024 * 2 + write.get(k, 0.0) * 1024} for k in sorted(fetch)}}
+    print(json.dumps(out, indent=1))
