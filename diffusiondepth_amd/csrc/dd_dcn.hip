@@ -868,9 +868,16 @@ int dd_nlspn_workspace_bytes(int B, int H, int W, int preserve_input, int64_t* b
   return DD_OK;
 }
 
-// The prop_time launches of one refinement on stream st (an iteration reads its whole predecessor: one launch per iteration)
-static int nlspn_enqueue(const float* feat_init, const float* offset, const float* aff, const float* feat_fix, const float* w, const float* b,
-                         float* feat_list, void* workspace, int B, int H, int W, int k_f, int prop_time, int preserve_input, hipStream_t st) {
+int dd_nlspn_propagate(const float* feat_init, const float* offset, const float* aff, const float* feat_fix, const float* w,
+                       const float* b, float* feat_list, void* workspace, int B, int H, int W, int k_f, int prop_time,
+                       int preserve_input, void* stream) {
+  if (!feat_init || !offset || !aff || !w || !b || !feat_list) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || prop_time <= 0) return dcn_fail(DD_ERR_INVALID_ARG, "B, H, W, prop_time must be positive");
+  if (preserve_input && (!feat_fix || !workspace))                          // `assert feat_init.shape == feat_fix.shape`, nlspnmodel.py:188
+    return dcn_fail(DD_ERR_INVALID_ARG, "preserve_input needs feat_fix and a workspace of dd_nlspn_workspace_bytes()");
+  if (k_f != 3 && k_f != 5 && k_f != 7)
+    return dcn_fail(DD_ERR_UNSUPPORTED, "prop_kernel %d: this build has 3, 5 and 7", k_f);
+  hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)B * H * W;
   float* ws[2] = {nullptr, nullptr};
   if (preserve_input) {
@@ -892,62 +899,6 @@ static int nlspn_enqueue(const float* feat_init, const float* offset, const floa
     if (rc) return rc;
   }
   return DD_OK;
-}
-
-// One captured hipGraph of those launches per calling thread, for the call that REPEATS: at one image a propagation iteration is an 8.5-us kernel
-// behind a ~7-us launch gap (18 launches: 0.27 ms, profiles/r03_*), which a graph replay closes.  A call is keyed by everything the launches bake in
-// (pointers, shape, options); the first call with a new key runs eagerly (it also loads the code objects: a capture must not be their first use),
-// the second captures, later ones replay.  DD_NLSPN_GRAPH=0 turns it off.
-namespace {
-struct PropKey {
-  const void *a, *b, *c, *d, *e, *f, *g, *h; int B, H, W, k, T, pres; std::string env;
-  bool operator==(const PropKey& o) const {
-    return a == o.a && b == o.b && c == o.c && d == o.d && e == o.e && f == o.f && g == o.g && h == o.h && B == o.B && H == o.H && W == o.W && k == o.k && T == o.T &&
-           pres == o.pres && env == o.env;
-  }
-};
-struct PropGraph { PropKey key{}; bool seen = false; hipGraphExec_t exec = nullptr; hipStream_t cap = nullptr; };
-thread_local PropGraph g_prop;
-}  // namespace
-
-int dd_nlspn_propagate(const float* feat_init, const float* offset, const float* aff, const float* feat_fix, const float* w,
-                       const float* b, float* feat_list, void* workspace, int B, int H, int W, int k_f, int prop_time,
-                       int preserve_input, void* stream) {
-  if (!feat_init || !offset || !aff || !w || !b || !feat_list) return dcn_fail(DD_ERR_INVALID_ARG, "null tensor pointer");
-  if (B <= 0 || H <= 0 || W <= 0 || prop_time <= 0) return dcn_fail(DD_ERR_INVALID_ARG, "B, H, W, prop_time must be positive");
-  if (preserve_input && (!feat_fix || !workspace))                          // `assert feat_init.shape == feat_fix.shape`, nlspnmodel.py:188
-    return dcn_fail(DD_ERR_INVALID_ARG, "preserve_input needs feat_fix and a workspace of dd_nlspn_workspace_bytes()");
-  if (k_f != 3 && k_f != 5 && k_f != 7)
-    return dcn_fail(DD_ERR_UNSUPPORTED, "prop_kernel %d: this build has 3, 5 and 7", k_f);
-  hipStream_t st = (hipStream_t)stream;
-  const char* genv = getenv("DD_NLSPN_GRAPH");
-  const bool want_graph = prop_time >= 4 && !(genv && genv[0] == '0');
-  if (!want_graph) return nlspn_enqueue(feat_init, offset, aff, feat_fix, w, b, feat_list, workspace, B, H, W, k_f, prop_time, preserve_input, st);
-  const char* kenv = getenv("DD_NLSPN_KERNEL");
-  const PropKey key{feat_init, offset, aff, feat_fix, w, b, feat_list, workspace, B, H, W, k_f, prop_time, preserve_input, kenv ? kenv : ""};
-  PropGraph& G = g_prop;
-  if (G.seen && G.key == key && G.exec) { DCN_HIP(hipGraphLaunch(G.exec, st)); return DD_OK; }
-  if (G.seen && G.key == key) {
-    // second call of this very refinement: capture it (on a stream of our own: the caller's may be the NULL stream, which cannot capture)
-    hipGraph_t graph = nullptr;
-    hipError_t e = hipSuccess;
-    if (!G.cap) e = hipStreamCreateWithFlags(&G.cap, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamBeginCapture(G.cap, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) {
-      const int rc = nlspn_enqueue(feat_init, offset, aff, feat_fix, w, b, feat_list, workspace, B, H, W, k_f, prop_time, preserve_input, G.cap);
-      const hipError_t e2 = hipStreamEndCapture(G.cap, &graph);
-      if (rc == DD_OK && e2 == hipSuccess && graph && hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0) != hipSuccess) G.exec = nullptr;
-      if (graph) (void)hipGraphDestroy(graph);
-    }
-    if (G.exec) { DCN_HIP(hipGraphLaunch(G.exec, st)); return DD_OK; }
-    (void)hipGetLastError();                     // capture failed: stay eager for this key
-    G.seen = false;
-  } else {
-    if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; }
-    G.key = key;
-    G.seen = true;
-  }
-  return nlspn_enqueue(feat_init, offset, aff, feat_fix, w, b, feat_list, workspace, B, H, W, k_f, prop_time, preserve_input, st);
 }
 
 }  // extern "C"

@@ -520,20 +520,10 @@ def test_nlspn_refinement_vs_reference_golden(lib, golden, name):
         assert lib.dd_nlspn_workspace_bytes(B, H, W, 1, ctypes.byref(nb)) == 0
         ws = np.zeros(nb.value // 4, np.float32)
     w1, b1 = np.ones(k_f * k_f, np.float32), np.zeros(1, np.float32)
-    f_init, f_fix = f32(g["feat_init"]).copy(), (f32(g["feat_fix"]) if pi else None)      # (a copy: the last repetition below changes it in place)
+    f_init, f_fix = f32(g["feat_init"]), (f32(g["feat_fix"]) if pi else None)
     rc = lib.dd_nlspn_propagate(_p(f_init), _p(offset), _p(aff), _p(f_fix), _p(w1), _p(b1), _p(feats), _p(ws), B, H, W, k_f, T, pi, None)
     assert rc == 0, lib.dd_dcn_last_error()
     assert maxabs(feats, g["y_inter"]) < 2e-5 * np.abs(g["y_inter"]).max()
-    # the call that repeats (same tensors, same shape) is captured into ONE hipGraph on its second occurrence and replayed from the third on
-    # (dd_dcn.hip: at one image an iteration is a launch-bound 8-us kernel): same bytes as the eager pass, and a changed input is seen
-    first = feats.copy()
-    for rep in range(3):
-        if rep == 2:
-            f_init += 0.5                      # same buffer, new content: the replayed graph reads it
-        feats[:] = np.nan
-        rc = lib.dd_nlspn_propagate(_p(f_init), _p(offset), _p(aff), _p(f_fix), _p(w1), _p(b1), _p(feats), _p(ws), B, H, W, k_f, T, pi, None)
-        assert rc == 0, lib.dd_dcn_last_error()
-        assert np.array_equal(feats, first) if rep < 2 else (np.isfinite(feats).all() and not np.array_equal(feats, first))
 
 
 def test_nlspn_guided_affinity_kernel_vs_oracle(lib):
