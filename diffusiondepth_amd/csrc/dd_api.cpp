@@ -257,14 +257,16 @@ struct dd_handle_s {
   std::map<std::tuple<int, int, int, int, int>, std::pair<std::shared_ptr<DevBuf>, uint64_t>> cond_bufs;   // (B, h, w, precision, lane) -> buffer, last use
   // condition FPN (Res variant): folded + packed weights, workspace of the last shape, and where its result lives
   bool neck_committed = false;            // hahineck.* folded + packed (DD_VARIANT_SWIN with the Swin-L pyramid only)
-  DevBuf neck_w[12][NUM_EK], neck_b[12];  // index = kernel layer - 30 (Swin-L pyramid) / - 54 (MPViT-small): 4 * kind + level
+  DevBuf neck_w[12][NUM_WIMG], neck_b[12];  // index = kernel layer - 30 (Swin-L pyramid) / - 54 (MPViT-small): 4 * kind + level
   int64_t n_neck_launches = 0;
   bool fpn_committed = false;
   int fpn_pyramid = PYR_DEFAULT;  // PYR_MPVIT once MPViT-sized lateral weights were set (DD_VARIANT_SWIN only)
-  DevBuf fpn_lat_w[FPN_LEVELS][NUM_EK], fpn_lat_b[FPN_LEVELS];
-  DevBuf fpn_up_w[FPN_LEVELS - 1][NUM_EK], fpn_up_b[FPN_LEVELS - 1];
+  DevBuf fpn_lat_w[FPN_LEVELS][NUM_WIMG], fpn_lat_b[FPN_LEVELS];        // (index = image slot: fp32, bf16, f16, WIMG_SPLIT)
+  DevBuf fpn_up_w[FPN_LEVELS - 1][NUM_WIMG], fpn_up_b[FPN_LEVELS - 1];
   std::unique_ptr<FpnWork> fpn_work;
   std::shared_ptr<DevBuf> fpn_out;       // Swin: FPN result at the pyramid's finest size (activation layout), upsampled per dd_denoise
+  bool fpn_split_ok = false, neck_split_ok = false;   // the folded FPN / neck weights fit the split-f16 images (else those modes run the pyramid on the fp32-operand kernels)
+  int cond_split = 1;                    // option "cond_split": 0 = the split / refined f16 modes run the once-per-image pyramid on the fp32-operand kernels (round 3's route)
   std::shared_ptr<DevBuf> fpn_cond;      // == the cond buffer dd_condition wrote last (valid until the next dd_condition / explicit cond of that shape)
   int fpn_cond_key[4] = {0, 0, 0, -1};   // B, h, w, precision of fpn_cond
   uint64_t tick = 0;
@@ -1309,6 +1311,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       }
     };
     std::vector<double> sc; std::vector<float> sh;
+    bool fpn_fits = true;
     for (int i = 0; i < FPN_LEVELS; ++i) {
       const std::string pre = "conv_lateral." + std::to_string(i);
       fold(pre + ".1", sc, sh);
@@ -1318,10 +1321,10 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
       std::vector<float> w((size_t)COND_C * per_pad, 0.f);
       for (int co = 0; co < COND_C; ++co)
         for (size_t k = 0; k < per; ++k) w[co * per_pad + k] = (float)((double)w0[co * per + k] * sc[co]);
-      for (int ek = 0; ek < NUM_EK; ++ek) {
+      for (int wi = 0; wi <= WIMG_SPLIT; ++wi) {        // fp32, bf16, f16 and the split-f16 image (the split / refined modes' pyramid)
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(fpn_lat_layer(h->variant, h->fpn_pyramid, i), ek), ek, true, packed);
-        int rc = upload(h, h->fpn_lat_w[i][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        if (!pack_conv_weights(w.data(), conv_pack_geom2(fpn_lat_layer(h->variant, h->fpn_pyramid, i), wimg_kind(wi)), wimg_kind(wi), true, packed)) fpn_fits = false;
+        int rc = upload(h, h->fpn_lat_w[i][wi], packed.data(), packed.size(), s); if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
       int rc = upload(h, h->fpn_lat_b[i], sh.data(), sh.size() * 4, s); if (rc) return rc;
@@ -1340,15 +1343,16 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
           for (int ci = 0; ci < COND_C; ++ci)
             w[((size_t)par * COND_C + co) * COND_C + ci] = (float)((double)wt[((size_t)ci * COND_C + co) * 4 + par] * sc[co]);
         }
-      for (int ek = 0; ek < NUM_EK; ++ek) {
+      for (int wi = 0; wi <= WIMG_SPLIT; ++wi) {
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(14, ek), ek, true, packed);
-        int rc = upload(h, h->fpn_up_w[j][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        if (!pack_conv_weights(w.data(), conv_pack_geom2(14, wimg_kind(wi)), wimg_kind(wi), true, packed)) fpn_fits = false;
+        int rc = upload(h, h->fpn_up_w[j][wi], packed.data(), packed.size(), s); if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
       int rc = upload(h, h->fpn_up_b[j], b4.data(), b4.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
     }
+    h->fpn_split_ok = fpn_fits;      // a folded weight beyond the split image's range: the split / refined modes keep the fp32-operand kernels for the pyramid
     h->fpn_committed = true;
   }
   if (do_neck) {
@@ -1356,6 +1360,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
     // The kernels' channel counts can exceed the reference's (MPViT level 1: 216 carried as 224): the folded weights are laid into
     // [cout_k][cin_k] with zeros in the padding; a fusion convolution reads the concatenation [lateral (Ck) | projection (512)] (level 0:
     // [projection | lateral]), so its reference input channel ci >= C of the lateral part's successor moves up by Ck - C.
+    bool neck_fits = true;
     for (const NeckConv& c : neck_convs(h->fpn_pyramid)) {
       const auto &g = h->host_w[c.name + ".bn.weight"], &b = h->host_w[c.name + ".bn.bias"], &m = h->host_w[c.name + ".bn.running_mean"],
                  &v = h->host_w[c.name + ".bn.running_var"];
@@ -1374,15 +1379,16 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
         }
       }
       const int slot = c.layer - neck_base(h->fpn_pyramid);
-      for (int ek = 0; ek < NUM_EK; ++ek) {
+      for (int wi = 0; wi <= WIMG_SPLIT; ++wi) {
         std::vector<uint8_t> packed;
-        pack_conv_weights(w.data(), conv_pack_geom2(c.layer, ek), ek, true, packed);
-        int rc = upload(h, h->neck_w[slot][ek], packed.data(), packed.size(), s); if (rc) return rc;
+        if (!pack_conv_weights(w.data(), conv_pack_geom2(c.layer, wimg_kind(wi)), wimg_kind(wi), true, packed)) neck_fits = false;
+        int rc = upload(h, h->neck_w[slot][wi], packed.data(), packed.size(), s); if (rc) return rc;
         DD_HIP(hipStreamSynchronize(s));
       }
       int rc = upload(h, h->neck_b[slot], sh.data(), sh.size() * 4, s); if (rc) return rc;
       DD_HIP(hipStreamSynchronize(s));
     }
+    h->neck_split_ok = neck_fits;
     h->neck_committed = true;
   }
   if (!do_codec) return DD_OK;
@@ -1507,6 +1513,10 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     if (h->one_buffer != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // the kernel choice is baked into captured graphs
     h->one_buffer = (int)value;
   }
+  else if (k == "cond_split") {      // dd_condition / dd_neck_condition are eager (no graph holds their kernels): nothing to invalidate
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: cond_split must be 0 or 1");
+    h->cond_split = (int)value;
+  }
   else if (k == "thin_stream") {
     if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_stream must be 0 or 1");
     if (h->thin_stream != (int)value) {          // the kernel choice is baked into captured graphs
@@ -1541,6 +1551,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   else if (k == "neck_launches") *value = h->n_neck_launches;
   else if (k == "trajectory_ticket") *value = h->traj_serial;
   else if (k == "lane_calls") *value = h->n_lane_calls;
+  else if (k == "cond_split_ok") *value = (h->fpn_committed && h->fpn_split_ok ? 1 : 0) | (h->neck_committed && h->neck_split_ok ? 2 : 0);   // bit 0: FPN, bit 1: neck weights fit the split-f16 images
   else if (k == "resident_slots") *value = h->resident_slots;      // workgroup slots at two per CU (2 x multiProcessorCount): what the tile rules compare tile counts with
   else if (k == "trajectory_reuses") *value = h->n_traj_reuse;
   else return h->fail(DD_ERR_INVALID_ARG, "dd_get_counter: unknown key '" + k + "'");
@@ -1596,7 +1607,16 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   int ek = ek_of_precision(precision, h->bf16_pure);      // EK_BF16M: inner tensors bf16, the result (level-0 lateral conv) f16
-  if (ek == EK_F16S || ek == EK_F16R) ek = EK_F32;       // split / refined f16: the once-per-image pyramid runs on the fp32 kernels (both modes read an fp32 map)
+  // split / refined f16: both modes read an fp32 condition map; the once-per-image pyramid runs on the split-f16 kernels (fp32 tensors, f16-pair
+  // operands, three MFMAs per product: ~22 mantissa bits at five times the fp32-operand MFMA rate) when its folded weights fit their images,
+  // else -- or with option "cond_split" = 0 -- on the fp32-operand kernels
+  bool split_pyr = false;
+  if (ek == EK_F16S || ek == EK_F16R) {
+    split_pyr = h->cond_split && h->fpn_split_ok && (!with_neck || h->neck_split_ok);
+    ek = EK_F32;                                           // tensor kind of the pyramid (layouts, conversions, workspace)
+  }
+  const int kk = split_pyr ? (int)EK_F16S : ek;            // kernel kind of its convolutions
+  const int wk = split_pyr ? WIMG_SPLIT : opnd_kind(ek);   // their weight image
   const int ok = opnd_kind(ek), sk = store_kind(ek);
   const size_t es = ek_size(ek);
   // workspace for this pyramid shape
@@ -1640,12 +1660,12 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
   }
 
   auto launch = [&](int layer, const ConvParams& q) -> hipError_t {
-    if (!h->layer_timing) return launch_conv_igemm2(layer, ek, q, s);
+    if (!h->layer_timing) return launch_conv_igemm2(layer, kk, q, s);
     hipEvent_t a, b;
     hipError_t e = hipEventCreate(&a); if (e != hipSuccess) return e;
     e = hipEventCreate(&b); if (e != hipSuccess) return e;
     (void)hipEventRecord(a, s);
-    e = launch_conv_igemm2(layer, ek, q, s);
+    e = launch_conv_igemm2(layer, kk, q, s);
     (void)hipEventRecord(b, s);
     h->pending_ev.emplace_back(layer - 1, a, b);
     return e;
@@ -1668,15 +1688,15 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
       q.tiles_y = (hh + 7) / 8;
       q.in = fw->fin[i].p; q.in_cstride = C; q.in_coff = 0;
       q.out = fw->nk_cat[i].p; q.out_cstride = CT; q.out_coff = l_off;
-      q.wpack = h->neck_w[i][ok].p; q.bias = h->neck_b[i].as<float>();
+      q.wpack = h->neck_w[i][wk].p; q.bias = h->neck_b[i].as<float>();
       DD_HIP(launch(nb + i, q));
       q.in = fw->nk_cat[i].p; q.in_cstride = CT; q.in_coff = l_off;
       q.out = fw->nk_cat[i].p; q.out_cstride = CT; q.out_coff = e_off;
-      q.wpack = h->neck_w[4 + i][ok].p; q.bias = h->neck_b[4 + i].as<float>();
+      q.wpack = h->neck_w[4 + i][wk].p; q.bias = h->neck_b[4 + i].as<float>();
       DD_HIP(launch(nb + 4 + i, q));
       q.in = fw->nk_cat[i].p; q.in_cstride = CT; q.in_coff = 0;
       q.out = fw->nk_out[i].p; q.out_cstride = C; q.out_coff = 0;
-      q.wpack = h->neck_w[8 + i][ok].p; q.bias = h->neck_b[8 + i].as<float>();
+      q.wpack = h->neck_w[8 + i][wk].p; q.bias = h->neck_b[8 + i].as<float>();
       DD_HIP(launch(nb + 8 + i, q));
       h->n_neck_launches += 3;
       lat_in = fw->nk_out[i].p;
@@ -1684,8 +1704,8 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
     ConvParams p{};
     p.B = B; p.h = hh; p.w = ww;
     p.tiles_x = (ww + 31) / 32;
-    p.tiles_y = (hh + conv_pack_geom2(lat_layer, ek).th - 1) / conv_pack_geom2(lat_layer, ek).th;
-    p.in = lat_in; p.wpack = h->fpn_lat_w[i][ok].p; p.bias = h->fpn_lat_b[i].as<float>();
+    p.tiles_y = (hh + conv_pack_geom2(lat_layer, kk).th - 1) / conv_pack_geom2(lat_layer, kk).th;
+    p.in = lat_in; p.wpack = h->fpn_lat_w[i][wk].p; p.bias = h->fpn_lat_b[i].as<float>();
     p.out = (i == 0) ? cbuf->p : fw->lat[i].p;
     p.addend = (i == FPN_LEVELS - 1) ? nullptr : (fw->pooled[i].p ? fw->pooled[i].p : fw->up[i].p);
     DD_HIP(launch(lat_layer, p));
@@ -1693,8 +1713,8 @@ static int condition_impl(dd_handle_t h, const float* const* feats, const int* f
       ConvParams u{};
       u.B = B; u.h = hh; u.w = ww;
       u.tiles_x = (ww + 31) / 32;
-      u.tiles_y = (hh + conv_pack_geom2(14, ek).th - 1) / conv_pack_geom2(14, ek).th;
-      u.in = fw->lat[i].p; u.wpack = h->fpn_up_w[i - 1][ok].p; u.bias = h->fpn_up_b[i - 1].as<float>(); u.out = fw->up[i - 1].p;
+      u.tiles_y = (hh + conv_pack_geom2(14, kk).th - 1) / conv_pack_geom2(14, kk).th;
+      u.in = fw->lat[i].p; u.wpack = h->fpn_up_w[i - 1][wk].p; u.bias = h->fpn_up_b[i - 1].as<float>(); u.out = fw->up[i - 1].p;
       DD_HIP(launch(14, u));
       if (fw->pooled[i - 1].p)
         DD_HIP(launch_adaptive_pool_blocked(fw->up[i - 1].p, fw->pooled[i - 1].p, ok, B, COND_C, 2 * hh, 2 * ww, feat_h[i - 1], feat_w[i - 1], s));

@@ -695,9 +695,10 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
           if constexpr (C::IS_LAT) {
             // FPN top-down term: x = relu(bn(conv(f))) + pooled(up(pre_x))  (reference ...res.py:113-116)
             if (p.addend != nullptr && pvalid) {
-              const char* ab = reinterpret_cast<const char*>(p.addend) + ((size_t)e_b * h * w * C::COUT + act_offset(C::COUT, h, w, 0, co, gy, gx)) * C::ESZ;
+              constexpr int AESZ = C::SPLIT ? 4 : C::ESZ;      // the addend is a tensor of this mode's inner layers: the operand kind (split f16: fp32)
+              const char* ab = reinterpret_cast<const char*>(p.addend) + ((size_t)e_b * h * w * C::COUT + act_offset(C::COUT, h, w, 0, co, gy, gx)) * AESZ;
               float a4[4];
-              if constexpr (C::ESZ == 4) {
+              if constexpr (AESZ == 4) {
                 const float4 t4 = *reinterpret_cast<const float4*>(ab);
                 a4[0] = t4.x; a4[1] = t4.y; a4[2] = t4.z; a4[3] = t4.w;
               } else {
@@ -953,9 +954,15 @@ static hipError_t launch_layer2_mixed(int layer, const ConvParams& p, hipStream_
     default: return launch_layer2<EK_BF16>(layer, p, s);
   }
 }
-// EK_F16S (split f16): the denoiser's layers only
+// EK_F16S (split f16): the denoiser's layers and the once-per-image condition layers (FPN, HAHI neck)
 static hipError_t launch_layer2_split(int layer, const ConvParams& p, hipStream_t s) {
   switch (layer) {
+#define DD_SPLIT_CASE(L) case L: return launch_one2<EK_F16S, L>(p, s);
+    DD_SPLIT_CASE(10) DD_SPLIT_CASE(11) DD_SPLIT_CASE(12) DD_SPLIT_CASE(13) DD_SPLIT_CASE(14) DD_SPLIT_CASE(15) DD_SPLIT_CASE(16) DD_SPLIT_CASE(17) DD_SPLIT_CASE(18)
+    DD_SPLIT_CASE(24) DD_SPLIT_CASE(25) DD_SPLIT_CASE(26)
+    DD_SPLIT_CASE(30) DD_SPLIT_CASE(31) DD_SPLIT_CASE(32) DD_SPLIT_CASE(33) DD_SPLIT_CASE(34) DD_SPLIT_CASE(35) DD_SPLIT_CASE(36) DD_SPLIT_CASE(37) DD_SPLIT_CASE(38) DD_SPLIT_CASE(39) DD_SPLIT_CASE(40) DD_SPLIT_CASE(41)
+    DD_SPLIT_CASE(54) DD_SPLIT_CASE(55) DD_SPLIT_CASE(56) DD_SPLIT_CASE(57) DD_SPLIT_CASE(58) DD_SPLIT_CASE(59) DD_SPLIT_CASE(60) DD_SPLIT_CASE(61) DD_SPLIT_CASE(62) DD_SPLIT_CASE(63) DD_SPLIT_CASE(64) DD_SPLIT_CASE(65)
+#undef DD_SPLIT_CASE
     case 1: return launch_one2<EK_F16S, 1>(p, s);
     case 2: return launch_one2<EK_F16S, 2>(p, s);
     case 3: return launch_one2<EK_F16S, 3>(p, s);
@@ -1061,6 +1068,12 @@ template <int EK> static PackGeom geom2_layer(int layer) {
 }
 static PackGeom geom2_layer_split(int layer) {
   switch (layer) {
+#define DD_SPLIT_CASE(L) case L: return geom2_of<EK_F16S, L>();
+    DD_SPLIT_CASE(10) DD_SPLIT_CASE(11) DD_SPLIT_CASE(12) DD_SPLIT_CASE(13) DD_SPLIT_CASE(14) DD_SPLIT_CASE(15) DD_SPLIT_CASE(16) DD_SPLIT_CASE(17) DD_SPLIT_CASE(18)
+    DD_SPLIT_CASE(24) DD_SPLIT_CASE(25) DD_SPLIT_CASE(26)
+    DD_SPLIT_CASE(30) DD_SPLIT_CASE(31) DD_SPLIT_CASE(32) DD_SPLIT_CASE(33) DD_SPLIT_CASE(34) DD_SPLIT_CASE(35) DD_SPLIT_CASE(36) DD_SPLIT_CASE(37) DD_SPLIT_CASE(38) DD_SPLIT_CASE(39) DD_SPLIT_CASE(40) DD_SPLIT_CASE(41)
+    DD_SPLIT_CASE(54) DD_SPLIT_CASE(55) DD_SPLIT_CASE(56) DD_SPLIT_CASE(57) DD_SPLIT_CASE(58) DD_SPLIT_CASE(59) DD_SPLIT_CASE(60) DD_SPLIT_CASE(61) DD_SPLIT_CASE(62) DD_SPLIT_CASE(63) DD_SPLIT_CASE(64) DD_SPLIT_CASE(65)
+#undef DD_SPLIT_CASE
     case 1: return geom2_of<EK_F16S, 1>();
     case 2: return geom2_of<EK_F16S, 2>();
     case 3: return geom2_of<EK_F16S, 3>();

@@ -89,7 +89,9 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr bool MX = EKM_ == EK_BF16M;
   // EKM_ == EK_F16S (split f16, DD_PREC_F16X3; dd_kernels.h): tensors in HBM are fp32 (the fp32 mode's layouts), the LDS patch and the
   // packed weights carry TWO f16 planes (hi, lo) and every (weight, pixel) fragment pair costs three MFMAs.  Instantiated for the
-  // denoiser's layers 1..9 only; one tiling for all of them: 16-channel chunks, 3 taps per stage (conv1: 9), 64-cout workgroup tiles.
+  // denoiser's layers 1..9 and (round 4) the once-per-image layers in front of them -- the condition FPN 10..18 / 24..26 and the HAHI neck
+  // 30..41 / 54..65, which the split / refined f16 modes used to run on the fp32-operand kernels (a fifth of this rate); one tiling for all
+  // of them: 16-channel chunks, 3 taps per stage (conv1: 9, the 1x1 layers: 1), 64-cout workgroup tiles.
   // EKM_ == EK_F16R (refined f16, DD_PREC_F16R; dd_kernels.h): instantiated for the layers whose kernel differs from the f16 mode's only --
   // conv1 (its weights as an f16 pair against a single-plane patch, y1 stored f16) and the producer of y3 -- the hoisted conv3 of the Res denoiser
   // (layer 9 and its tile forms) / the 5x5 form pred.0 o convB of the Swin denoiser: f16 operands and input, the hoisted term read as block-scaled
@@ -107,7 +109,8 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr int IN_K = SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 5 || LAYER_ == 9)) ? (int)EK_F16 : EK;      // stored input (and condition map)
   static constexpr int OUT_K = RF ? (int)EK_F16 : SPLIT ? (int)EK_F32 : (MX && (LAYER_ == 2 || LAYER_ == 3 || LAYER_ == 7 || LAYER_ == 9 || LAYER_ == 10 || LAYER_ == 15 || LAYER_ == 24)) ? (int)EK_F16 : EK;
   static_assert(!MX || IN_K != EK || OUT_K != EK, "EK_BF16M is instantiated only for the layers that change kind");
-  static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 9), "EK_F16S is instantiated for the denoiser's layers only");
+  static_assert(!SPLIT || (LAYER_ >= 1 && LAYER_ <= 18) || (LAYER_ >= 24 && LAYER_ <= 26) || (LAYER_ >= 30 && LAYER_ <= 41) || (LAYER_ >= 54 && LAYER_ <= 65),
+                "EK_F16S is instantiated for the forward layers only (denoiser, condition FPN, HAHI neck)");
   static_assert(!SPLIT || LAYER_ID_ != SWIN_PRED_H, "split f16: the hoisted Swin plans always run the 5x5 form");
   static constexpr int ESZ = ElemSize<EK>::V;
   // layers 1..4: conv1..conv4 of the Res denoiser.  Swin/MPViT variant (reference ...swin_addHAHI.py:321-382):
@@ -158,7 +161,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr bool SWIN3 = DD_SWIN_TG3 && (LAYER == 5 || LAYER == 6) && ESZ == 2 && !SPLIT;
   static constexpr bool C4K16 = DD_C4_CK16 && LAYER == 4 && ESZ == 2 && !SPLIT;
   static constexpr int CK = (SPLIT || C4K16) ? 16 : (LAYER == 1 || LAYER == 20) ? 16 : (LAYER == 2 || LAYER == 4 || LAYER == 21 || LAYER == 23) ? (128 / ESZ) : (C3 != 0 || SWIN3) ? 16 : (64 / ESZ);
-  static constexpr int TG = PRED5 ? 5 : SPLIT ? (LAYER == 1 ? 9 : 3) : (LAYER == 1 || LAYER == 20 || C3 != 0 || C4K16) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
+  static constexpr int TG = PRED5 ? 5 : SPLIT ? (LAYER == 1 ? 9 : KS == 1 ? 1 : 3) : (LAYER == 1 || LAYER == 20 || C3 != 0 || C4K16) ? 9 : (LAYER == 22 || LAYER == 23) ? 3
                           : SWIN3 ? 3 : (LAYER == 2 || LAYER == 5 || LAYER == 6 || LAYER >= 10) ? 1 : 3;
   static constexpr int NT = (IS_NECK || (SPLIT && COUT >= 64)) ? 64 : (COUT >= COND_C) ? 128 : COUT_PAD;
   static constexpr int SPW = (LAYER == 2 && ESZ == 2 && DD_CONV2_DUAL && !SPLIT) ? 2 : 1;      // cout splits one workgroup walks (over one staged patch)

@@ -119,7 +119,7 @@ int dd_set_schedule(dd_handle_t h, const float* alphas_cumprod, int num_train_ti
  * The result also stays inside the handle in the kernels' own layout: a following dd_denoise / dd_denoise_once with
  * cond == NULL, the same B and precision and cond_h == feat_h[0], cond_w == feat_w[0] (== lat_h, lat_w for
  * DD_VARIANT_RES; for DD_VARIANT_SWIN the map is upsampled to the latent size there) uses it without any conversion.
- * precision fp32 / bf16 / f16. */
+ * precision fp32 / bf16 / f16; f16x3 / f16r: an fp32 map computed on f16-pair operands (option "cond_split"). */
 int dd_condition(dd_handle_t h, const float* const* feats, const int* feat_h, const int* feat_w, int n_levels, int B,
                  float* cond_out, int precision, void* stream);
 
@@ -238,11 +238,15 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * 1 [default] = conv1's weights as an f16 pair (two MFMAs), 0 = the plain f16 kernel), "one_buffer" (1 [default] = the loop's hoisted conv3 on
  * 8x32 tiles runs in its one-patch-buffer form -- three workgroups per CU -- when a one-lane call has more tiles than resident slots; 0 = never,
  * 2 = always: A/B switch and tests),
- * "f16r_p4" (DD_PREC_F16R: 1 = conv4's operand relu(gn3(y3)) as an f16 pair as well -- two MFMAs per tap; default 0). */
+ * "f16r_p4" (DD_PREC_F16R: 1 = conv4's operand relu(gn3(y3)) as an f16 pair as well -- two MFMAs per tap; default 0),
+ * "cond_split" (DD_PREC_F16X3 / DD_PREC_F16R: 1 [default] = dd_condition / dd_neck_condition run their convolutions on the split-f16 kernels
+ * -- fp32 tensors, f16-pair operands, three MFMAs per product -- when the folded weights fit those images (counter "cond_split_ok"), 0 = on
+ * the fp32-operand kernels as before round 4: A/B switch). */
 int dd_set_option(dd_handle_t h, const char* key, int64_t value);
 int dd_last_loop_ms(dd_handle_t h, float* ms);
 /* Counters: "graph_launches", "eager_loops", "graph_capture_failures", "plans", "neck_launches", "trajectory_ticket" (ticket of the
- * last dd_denoise call that kept its states), "trajectory_reuses" (dd_denoise_backward calls that read kept states), "lane_calls" (dd_denoise calls that ran as concurrent lanes). */
+ * last dd_denoise call that kept its states), "trajectory_reuses" (dd_denoise_backward calls that read kept states), "lane_calls" (dd_denoise calls that ran as concurrent lanes),
+ * "resident_slots" (workgroup slots at two per CU), "cond_split_ok" (bit 0 / 1: the committed FPN / neck weights fit the split-f16 images). */
 int dd_get_counter(dd_handle_t h, const char* key, int64_t* value);
 /* With option "layer_timing" = 1 the loop runs eagerly with a hipEvent pair around every
  * convolution launch; this returns the accumulated milliseconds and launch count of conv `layer`

@@ -55,10 +55,11 @@ class EmuDenoiser:
 
     def load_state_dict(self, sd, device_route=False):
         """device_route: model.* through dd_set_weight_device (under emulation "device" memory is host memory)."""
-        owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.")
+        owned = ("model.", "depth_transform.", "conv_lateral.", "conv_up.", "hahineck.")
+        neck_live = ("hahineck.lateral_convs.", "hahineck.conv_proj.", "hahineck.trans_proj.", "hahineck.conv_fusion.", "hahineck.trans_fusion.")
         keep = []
         for k, v in sd.items():
-            if not k.startswith(owned) or k.endswith("num_batches_tracked"):
+            if not k.startswith(owned) or k.endswith("num_batches_tracked") or (k.startswith("hahineck.") and not k.startswith(neck_live)):
                 continue
             a = f32(v)
             if device_route and k.startswith("model."):
@@ -108,12 +109,13 @@ class EmuDenoiser:
         self.ck(self.lib.dd_decode(self.h, _p(latent), _p(out), B, h, w, None), "dd_decode")
         return out
 
-    def condition(self, fp, precision="fp32"):
+    def condition(self, fp, precision="fp32", neck=False):
         fp = [f32(f) for f in fp]
         B = fp[0].shape[0]
         ptrs = (ctypes.c_void_p * 4)(*[f.ctypes.data for f in fp])
         hs = (ctypes.c_int * 4)(*[f.shape[2] for f in fp])
         ws = (ctypes.c_int * 4)(*[f.shape[3] for f in fp])
         out = np.full((B, 256, fp[0].shape[2], fp[0].shape[3]), np.nan, np.float32)
-        self.ck(self.lib.dd_condition(self.h, ptrs, hs, ws, 4, B, _p(out), precision_id(precision), None), "dd_condition")
+        fn = self.lib.dd_neck_condition if neck else self.lib.dd_condition
+        self.ck(fn(self.h, ptrs, hs, ws, 4, B, _p(out), precision_id(precision), None), "dd_neck_condition" if neck else "dd_condition")
         return out

@@ -19,7 +19,7 @@ from diffusiondepth_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-COND_TOL = {"fp32": 2e-5, "f16": 3e-3, "bf16": 2e-2}
+COND_TOL = {"fp32": 2e-5, "f16": 3e-3, "bf16": 2e-2, "f16x3": 2e-5, "f16r": 2e-5}      # f16x3 / f16r: the pyramid on f16-PAIR operands (split-f16 kernels, fp32 tensors): the fp32 mode's bound
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +44,7 @@ def be(U, cases):
     b.close()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16", "f16x3", "f16r"])
 def test_fpn_odd_pyramid_matches_reference_golden(U, be, golden, cases, prec):
     c, g = cases["fpn_odd"], golden("fpn_odd")
     fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], c["B"], c["H"], c["W"])]
@@ -55,7 +55,13 @@ def test_fpn_odd_pyramid_matches_reference_golden(U, be, golden, cases, prec):
     esum = float(np.abs(x.astype(np.float64).sum(axis=(0, 2, 3)) - g["cond_chan_sum"]).max() / np.abs(g["cond_chan_sum"]).max())
     U.record("fpn_odd", prec=prec, maxabs=e, scale=scale, chan_sum_rel=esum)
     assert e <= COND_TOL[prec] * scale
-    assert esum <= (1e-5 if prec == "fp32" else 5e-3)
+    assert esum <= (1e-5 if prec in ("fp32", "f16x3", "f16r") else 5e-3)
+    if prec in ("f16x3", "f16r"):
+        assert be.counter("cond_split_ok") & 1                     # ... and it WAS the split-f16 kernels: the fp32-operand route gives other bits
+        be.set_option("cond_split", 0)
+        x32 = be.condition(fp, prec).cpu().numpy()
+        be.set_option("cond_split", 1)
+        assert np.array_equal(x32, be.condition(fp, "fp32").cpu().numpy()) and not np.array_equal(x32, x)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -82,6 +88,9 @@ def test_fpn_matches_oracle_ragged(U, be, cases, B, H, W):
     e = U.maxabs(x, ref)
     U.record("fpn_ragged", B=B, H=H, W=W, maxabs=e, scale=scale)
     assert e <= COND_TOL["fp32"] * scale
+    es = U.maxabs(be.condition([U.cu(f) for f in feats], "f16x3").cpu().numpy(), ref)       # the same shapes on the split-f16 kernels
+    U.record("fpn_ragged_split", B=B, H=H, W=W, maxabs=es, scale=scale)
+    assert es <= COND_TOL["f16x3"] * scale
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -165,6 +174,10 @@ def test_fpn_full_size_vs_torch_modules(U, be, cases, size):
     e = U.maxabs(x, ref)
     U.record("fpn_full", size=size, maxabs=e, scale=scale)
     assert e <= 1e-4 * scale      # two fp32 implementations with different summation orders (K up to 4608)
+    xs = be.condition(fp, "f16r").cpu().numpy()              # the headline mode's pyramid: split-f16 kernels
+    es = U.maxabs(xs, ref)
+    U.record("fpn_full_split", size=size, maxabs=es, scale=scale)
+    assert es <= 1e-4 * scale
     xb = be.condition(fp, "bf16").cpu().numpy()
     eb = U.rms(xb, ref) / float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
     U.record("fpn_full_bf16", size=size, rel_rms=eb)
@@ -184,7 +197,7 @@ def be_swin(U, cases):
     b.close()
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "f16x3"])
 def test_swin_fpn_matches_oracle(U, be_swin, cases, prec):
     """Swin-L pyramid widths (192..1536): lateral convs with 6..48 channel chunks; odd sizes -> pooling active."""
     from oracle import ddim_oracle as O

@@ -418,8 +418,10 @@ def test_swin_single_call_vs_reference_golden(lib, golden, cases):
 
 
 # ---- condition aggregation (FPN) ----------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec", ["fp32"] + (["f16"] if FULL else []))
+@pytest.mark.parametrize("prec", ["fp32", "f16x3"] + (["f16", "f16r"] if FULL else []))
 def test_fpn_condition_vs_oracle(lib, prec):
+    """f16x3 / f16r: the pyramid on the split-f16 kernels (fp32 tensors, f16-pair operands) -- held to the fp32 mode's bound; with option
+    "cond_split" = 0 the same call runs the fp32-operand kernels (round 3's route) and the two maps agree to fp32 round-off."""
     be, _ = backend_for(lib, {"wseed": 7240})
     fsd = synth.make_fpn_state_dict(7241)
     be.load_state_dict(fsd)
@@ -431,7 +433,37 @@ def test_fpn_condition_vs_oracle(lib, prec):
     ref = O.fpn_aggregate(fsd, fp)
     be.timing(order=1, dma_late=1)
     out = be.condition(fp, prec)
-    assert maxabs(out, ref) < (2e-5 if prec == "fp32" else 2e-2) * np.abs(ref).max()
+    assert maxabs(out, ref) < (2e-5 if prec in ("fp32", "f16x3", "f16r") else 2e-2) * np.abs(ref).max()
+    if prec in ("f16x3", "f16r"):
+        assert be.counter("cond_split_ok") & 1
+        be.set_option("cond_split", 0)
+        out32 = be.condition(fp, prec)
+        be.set_option("cond_split", 1)
+        assert not np.array_equal(out32, out)                     # (another kernel family ran)
+        assert maxabs(out32, out) < 2e-5 * np.abs(ref).max()
+
+
+@full_only
+def test_hahi_neck_on_the_split_f16_kernels(lib):
+    """dd_neck_condition in the split-f16 mode (the 1x1 lateral / projection and 3x3 fusion convolutions of the neck, then the FPN, all on f16-pair
+    operands) against the same call on the fp32-operand kernels: fp32 round-off apart.  MPViT-small pyramid (216 carried as 224 channels)."""
+    chans = (128, 216, 288, 288)
+    sd = synth.make_state_dict(7245, "swin")
+    fpn = synth.make_fpn_state_dict(7241, in_channels=chans)
+    nk = synth.make_hahi_state_dict(7246, chans)
+    be = EmuDenoiser(lib, "swin")
+    be.load_state_dict({**sd, **fpn, **nk}); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+    rs = np.random.RandomState(11)
+    B, h, w = 1, 9, 35
+    fp = [rs.standard_normal((B, c, max((h + (1 << i) - 1) >> i, 1), max((w + (1 << i) - 1) >> i, 1))).astype(np.float32) for i, c in enumerate(chans)]
+    a = be.condition(fp, "f16x3", neck=True)
+    assert be.counter("cond_split_ok") == 3
+    be.set_option("cond_split", 0)
+    b = be.condition(fp, "f16x3", neck=True)
+    ref32 = be.condition(fp, "fp32", neck=True)
+    assert np.array_equal(b, ref32)                                # without the switch: the fp32 mode's kernels
+    assert not np.array_equal(a, b) and maxabs(a, b) < 2e-5 * np.abs(b).max(), (maxabs(a, b), np.abs(b).max())
+    be.close()
 
 
 # ---- backward ----------------------------------------------------------------------------------------------------------------------------------------------
