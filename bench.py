@@ -21,7 +21,8 @@ Extra objects in the line (tier contract):
   roofline      dominant kernel (conv3x3 implicit GEMM) measured live with hipEvents on the launch
                 stream (library option "layer_timing"): achieved TFLOP/s = algorithmic FLOPs per launch
                 (2*9*Cin*Cout*B*h*w) / mean launch duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.
-  cpu_baseline  the torch-CPU port of the reference path (oracle/torch_cpu_port.py) timed on this
+  cpu_baseline  the reference's OWN classes (staged as bytecode under oracle/_ref/py by oracle/ref_py/build_ref.py; kind "reference") or, when
+                that staging is absent, the torch-CPU port of the reference path (oracle/torch_cpu_port.py; kind "port"), timed on this
                 host's cores for ONE map of the same workload (N = 1, rank 0 only).
 """
 from __future__ import annotations
@@ -35,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (before the HIP runtime loads): RCCL across processes needs it on this driver
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
