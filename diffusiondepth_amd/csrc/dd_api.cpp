@@ -266,6 +266,7 @@ struct dd_handle_s {
   std::unique_ptr<FpnWork> fpn_work;
   std::shared_ptr<DevBuf> fpn_out;       // Swin: FPN result at the pyramid's finest size (activation layout), upsampled per dd_denoise
   bool fpn_split_ok = false, neck_split_ok = false;   // the folded FPN / neck weights fit the split-f16 images (else those modes run the pyramid on the fp32-operand kernels)
+  int cond_direct = 1;                   // option "cond_direct": 0 = the refined f16 mode converts an explicit condition tensor into the blocked layout first (A/B switch)
   int cond_split = 1;                    // option "cond_split": 0 = the split / refined f16 modes run the once-per-image pyramid on the fp32-operand kernels (round 3's route)
   std::shared_ptr<DevBuf> fpn_cond;      // == the cond buffer dd_condition wrote last (valid until the next dd_condition / explicit cond of that shape)
   int fpn_cond_key[4] = {0, 0, 0, -1};   // B, h, w, precision of fpn_cond
@@ -793,7 +794,8 @@ int enqueue_naive_eps(dd_handle_t h, Plan* pl, int step, const float* x_in, cons
 }
 
 // conv3 applied once to the (already converted) condition map: the per-image part of the hoisted conv3 (layer 8)
-int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
+// nchw != nullptr (refined f16 only): the caller's NCHW fp32 tensor read in place by the kernel id CONV3C_NCHW -- no channel-blocked copy exists
+int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s, const float* nchw = nullptr) {
   const PlanKey& k = pl->key;
   ConvParams p{};
   p.B = k.B; p.h = k.h; p.w = k.w;
@@ -803,9 +805,9 @@ int enqueue_cond_conv(dd_handle_t h, Plan* pl, hipStream_t s) {
     // refined f16: the split-f16 layer 8 on the fp32 condition map (the term is exact to ~22 bits), fp32 in the order of 8x32 tiles; then into
     // the order / element type the loop's conv3 reads (block-scaled int16 or f16 quads, 8x32 or 16x32 tiles)
     p.tiles_y = (k.h + 7) / 8;
-    p.in = pl->cond_ptr(); p.wpack = h->L[2].wpack2[WIMG_SPLIT].p; p.bias = h->zero_bias.as<float>();
+    p.in = nchw ? static_cast<const void*>(nchw) : pl->cond_ptr(); p.wpack = h->L[2].wpack2[WIMG_SPLIT].p; p.bias = h->zero_bias.as<float>();
     p.out = pl->ccond_raw.p;
-    DD_HIP(launch_conv_igemm2(8, EK_F16S, p, s));
+    DD_HIP(launch_conv_igemm2(nchw ? CONV3C_NCHW : 8, EK_F16S, p, s));
     DD_HIP(launch_cadd_reformat(pl->ccond_raw.as<float>(), pl->ccond.p, pl->ccond_scale.as<float>(), k.B, k.h, k.w, plan_big_tiles(h, k) ? 1 : 0, pl->wide ? 2 : 1, s));
     return DD_OK;
   }
@@ -887,6 +889,10 @@ int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h
                     int precision, hipStream_t s, int img0 = 0, int whole_B = 0) {
   if (whole_B <= 0) whole_B = B;
   pl->cond_alias = nullptr;
+  // Refined f16, Res denoiser: its plans are hoisted forward-only ones -- the loop never reads the condition map, only the once-per-image
+  // conv3(cond) does, and that kernel can read the caller's NCHW tensor in place (option "cond_direct", default on): no blocked copy is made.
+  const bool direct = cond && h->cond_direct && h->variant != DD_VARIANT_SWIN && pl->ek == EK_F16R && pl->key.hoist;
+  if (direct) return enqueue_cond_conv(h, pl, s, cond);     // (the plan's blocked buffer -- possibly dd_condition's resident map -- is left alone)
   if (cond) {
     if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
     else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
@@ -1512,6 +1518,10 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     if (value < 0 || value > 2) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: one_buffer must be 0, 1 or 2");
     if (h->one_buffer != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // the kernel choice is baked into captured graphs
     h->one_buffer = (int)value;
+  }
+  else if (k == "cond_direct") {     // stage_condition runs eagerly in front of the loop's graph: nothing to invalidate
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: cond_direct must be 0 or 1");
+    h->cond_direct = (int)value;
   }
   else if (k == "cond_split") {      // dd_condition / dd_neck_condition are eager (no graph holds their kernels): nothing to invalidate
     if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: cond_split must be 0 or 1");

@@ -172,6 +172,21 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   auto load_raw = [&](int chunk, int slot) {
     const int cbase = chunk * CK + jfix * EPP;
     const size_t off0 = (C::CIN >= ACT_CB) ? ((size_t)(cbase >> 5) * h * w * ACT_CB + (cbase & (ACT_CB - 1))) : (size_t)cbase;
+    if constexpr (C::IN_NCHW) {
+      // the caller's NCHW fp32 tensor: channel c of this image is the plane at c * h * w; the piece's eight channels are eight 4-byte loads
+      // (lanes 0, 2, 4, ... = consecutive pixels of plane cbase + i, the odd lanes of plane cbase + 8 + i: two runs of 128 contiguous bytes)
+      static_assert(EPP == 8 && NLD == 2 && C::PRO == PRO_RAW, "fp32 source, eight channels per piece, no auxiliary tensor");
+      const size_t HW = (size_t)h * w;
+#pragma unroll
+      for (int u = 0; u < NIT; ++u) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(in_b) + (size_t)cbase * HW + pix_off[u];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+          raw[slot][u][q] = make_uint4(src[(4 * q + 0) * HW], src[(4 * q + 1) * HW], src[(4 * q + 2) * HW], src[(4 * q + 3) * HW]);
+      }
+      DD_VMEM_LOADS_ISSUED(NIT * NLD * 4);
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
       const size_t goff = (off0 + (size_t)pix_off[u] * C::PIXSTRIDE) * IN_ESZ;
@@ -543,7 +558,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
 #endif
   };
 
-  constexpr int NRAW = NIT * NLD * ((C::PRO == PRO_GN || C::PRO == PRO_RAW) ? 1 : 2);   // raw-patch loads per load_raw()
+  constexpr int NRAW = NIT * NLD * (C::IN_NCHW ? 4 : (C::PRO == PRO_GN || C::PRO == PRO_RAW) ? 1 : 2);   // raw-patch loads per load_raw()
   static_assert(NRAW <= 63, "vmcnt field");
 
   // par = chunk % RD as a compile-time constant at every call site (static register indexing of the raw slots)
@@ -972,6 +987,7 @@ static hipError_t launch_layer2_split(int layer, const ConvParams& p, hipStream_
     case 7: return launch_one2<EK_F16S, 7>(p, s);
     case 8: return launch_one2<EK_F16S, 8>(p, s);
     case 9: case ONE_CONV3H: return launch_one2<EK_F16S, 9>(p, s);
+    case CONV3C_NCHW: return launch_one2<EK_F16S, CONV3C_NCHW>(p, s);
     case SWIN_CONVA_H: return launch_one2<EK_F16S, SWIN_CONVA_H>(p, s);
     case SWIN_PRED5_H: return launch_one2<EK_F16S, SWIN_PRED5_H>(p, s);
     default: return hipErrorInvalidValue;
@@ -1081,7 +1097,7 @@ static PackGeom geom2_layer_split(int layer) {
     case 5: return geom2_of<EK_F16S, 5>();
     case 6: return geom2_of<EK_F16S, 6>();
     case 7: return geom2_of<EK_F16S, 7>();
-    case 8: return geom2_of<EK_F16S, 8>();
+    case 8: case CONV3C_NCHW: return geom2_of<EK_F16S, 8>();
     case SWIN_CONVA_H: return geom2_of<EK_F16S, 5>();
     case SWIN_PRED5_H: return geom2_of<EK_F16S, SWIN_PRED5_H>();
     default: return geom2_of<EK_F16S, 9>();

@@ -81,7 +81,8 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // SWIN_PRED5_H = pred.0 o convB as one 5x5 convolution (layer 7's tiling with five taps per stage)
   static constexpr bool PRED5 = LAYER_ID_ == SWIN_PRED5_H || LAYER_ID_ == SWIN_PRED5B_H;
   static constexpr bool HOIST_A = LAYER_ID_ == SWIN_CONVA_H, ADD_T = LAYER_ID_ == SWIN_PRED_H || PRED5;
-  static constexpr int LAYER_ = LAYER_ID_ == BIG_CONV3C ? 8 : (LAYER_ID_ == BIG_CONV3H || LAYER_ID_ == ONE_CONV3H) ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
+  static constexpr bool IN_NCHW = LAYER_ID_ == CONV3C_NCHW;     // layer 8 on the caller's NCHW fp32 tensor (dd_kernels.h)
+  static constexpr int LAYER_ = (LAYER_ID_ == BIG_CONV3C || IN_NCHW) ? 8 : (LAYER_ID_ == BIG_CONV3H || LAYER_ID_ == ONE_CONV3H) ? 9 : HOIST_A ? 5 : ADD_T ? 7 : LAYER_ID_;
   // EKM_ = element kind or the mode EK_BF16M (dd_kernels.h).  In that mode only the layers that CHANGE kind between storage and operands
   // are instantiated here -- conv2 / conv3 / hoisted conv3 / Swin convA (f16 in, bf16 operands), the producers of f16 tensors in front
   // of them (conv2, conv3, Swin pred.0, the level-0 lateral conv of the condition FPN); the launcher sends every other layer to its
@@ -100,6 +101,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   static constexpr bool RF = EKM_ == EK_F16R;
   static_assert(!RF || LAYER_ == 1 || LAYER_ == 9 || PRED5, "EK_F16R is instantiated for conv1 and the hoisted conv3 / Swin 5x5 forms only");
   static constexpr bool SPLIT = EKM_ == EK_F16S || (RF && LAYER_ == 1);
+  static_assert(!IN_NCHW || EKM_ == EK_F16S, "the NCHW-reading layer 8 is a split-f16 kernel");
   static constexpr bool WONLY = RF && LAYER_ == 1;             // split weights against a single-plane patch: W.P = Whi.P + Wlo.P
   static constexpr int NPL = SPLIT ? 2 : 1;                    // operand planes of a packed weight stage
   static constexpr int NPLP = (SPLIT && !WONLY) ? 2 : 1;       // operand planes of the LDS patch

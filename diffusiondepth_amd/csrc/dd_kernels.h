@@ -135,6 +135,12 @@ constexpr int BIG_CONV3C = 48, BIG_CONV3H = 49;
 // layer 9 on its 8x32 tiles with ONE patch buffer (dd_igemm2_cfg.h, ONEBUF): the next chunk's patch goes into the buffer the MFMAs just read, behind a
 // second workgroup barrier per stage; 52 KB of LDS = three workgroups per CU.  Same tiles, packed weights and accumulator-fragment order as layer 9.
 constexpr int ONE_CONV3H = 46;
+// layer 8 (the once-per-image conv3(cond)) reading the caller's NCHW fp32 condition tensor DIRECTLY: a staging item's eight channels are eight
+// 4-byte loads from eight channel planes (consecutive lanes = consecutive pixels of one plane: whole 128-byte segments) instead of two 16-byte
+// loads from the channel-blocked copy -- the copy (438 MB read + 438 MB written per four KITTI maps: 189 us of a 7.5-ms step in the refined f16
+// mode) is not made at all.  Split-f16 kernel only (the refined mode's hoisted plans with an explicit condition tensor); same tiles, packed
+// weights, arithmetic and output order as layer 8 in that kind -- bit-identical results.
+constexpr int CONV3C_NCHW = 47;
 // Swin / MPViT denoiser, forward-only plans: upsample_fuse (convA, convB: no norm, no activation) and pred.0 are ONE linear map of
 // s = up(feat) + E[t] + NE(x_t) (reference ...swin_addHAHI.py:321-333,378-380), so
 //   pred.0(convB(convA(s))) = W3*WB*WA*NE(x_t)  +  [W3*(WB*(WA*up(feat) + a) + b)]  +  W3*WB*WA*(E[t] on every pixel)  + b3

@@ -239,6 +239,9 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * 8x32 tiles runs in its one-patch-buffer form -- three workgroups per CU -- when a one-lane call has more tiles than resident slots; 0 = never,
  * 2 = always: A/B switch and tests),
  * "f16r_p4" (DD_PREC_F16R: 1 = conv4's operand relu(gn3(y3)) as an f16 pair as well -- two MFMAs per tap; default 0),
+ * "cond_direct" (DD_PREC_F16R, DD_VARIANT_RES: 1 [default] = the once-per-image conv3(cond) reads an explicit `cond` tensor of dd_denoise* in place
+ * -- NCHW fp32, eight 4-byte loads per staging item -- instead of a channel-blocked copy made first: same bits, one HBM round trip of the map less;
+ * 0 = convert first: A/B switch),
  * "cond_split" (DD_PREC_F16X3 / DD_PREC_F16R: 1 [default] = dd_condition / dd_neck_condition run their convolutions on the split-f16 kernels
  * -- fp32 tensors, f16-pair operands, three MFMAs per product -- when the folded weights fit those images (counter "cond_split_ok"), 0 = on
  * the fp32-operand kernels as before round 4: A/B switch). */

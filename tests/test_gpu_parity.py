@@ -339,6 +339,24 @@ def test_big_tile_and_lane_paths_agree_with_the_single_image_path_at_kitti_size(
         assert np.array_equal(auto, small)          # a call that runs as one lane keeps the 8x32 tiles (their one-patch-buffer form: three workgroups per CU)
 
 
+def test_refined_f16_reads_an_explicit_condition_tensor_in_place(U):
+    """Option "cond_direct" (default on): in the refined mode the once-per-image conv3(cond) reads the caller's NCHW fp32 tensor itself (kernel id
+    CONV3C_NCHW: eight 4-byte loads per staging item) instead of a channel-blocked copy made first.  Same values, same arithmetic: bit-identical
+    x_0 at KITTI size (two lanes, 16x32-tile consumers) and on a ragged size, loop and single call."""
+    be = U.backend_for({"wseed": 7240})
+    for B, h, w, T in ((3, 176, 608, 3), (2, 45, 75, 2)):
+        inp = synth.make_inputs(92, B, h, w)
+        x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+        t = torch.full((B,), 321, device="cuda", dtype=torch.long)
+        try:
+            be.set_option("cond_direct", 0)
+            a, ea = be.denoise(x, cond, T, "f16r").cpu().numpy(), be.denoise_once(x, t, cond, "f16r").cpu().numpy()
+        finally:
+            be.set_option("cond_direct", 1)
+        b, eb = be.denoise(x, cond, T, "f16r").cpu().numpy(), be.denoise_once(x, t, cond, "f16r").cpu().numpy()
+        assert np.isfinite(b).all() and np.array_equal(a, b) and np.array_equal(ea, eb), (B, h, w)
+
+
 # ---- Swin / MPViT variant of the denoiser (SURVEY.md 8a row a3): UpSample_add fuse, stride-4 condition map ----
 @pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16", "f16"])
 def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):

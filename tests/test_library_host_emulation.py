@@ -204,6 +204,33 @@ def test_refined_f16_mode_on_the_far_range_golden(lib, golden, cases):
     assert maxabs(be1.denoise_once(inp1["x_T"], inp1["timesteps"], inp1["cond"], "f16r"), g1["eps_batch_t"]) < EPS_TOL["f16r"]
 
 
+def test_refined_f16_reads_an_explicit_condition_tensor_in_place(lib):
+    """Option "cond_direct" (default on): the once-per-image conv3(cond) of the refined mode reads the caller's NCHW fp32 tensor with eight 4-byte loads
+    per staging item (kernel id CONV3C_NCHW) instead of a blocked copy made first -- the same fp32 values enter the same arithmetic: x_0 and a single
+    call's eps are bit-identical to the converting route, on ragged sizes (clamped halo addresses, several tiles, batch > 1) and under the adversarial timing."""
+    be, sd = backend_for(lib, {"wseed": 7244})
+    be.set_option("hoist_cond", -1)
+    be.timing(order=1, dma_late=1)
+    for B, h, w, T in ((2, 11, 37, 2), (1, 17, 70, 1)):
+        inp = synth.make_inputs(300 + h, B, h, w)
+        be.set_option("cond_direct", 1)
+        be.denoise(inp["x_T"], inp["cond"], T, "f16r")             # (the plan of this shape: its one-time launches)
+        l0 = lib.emu_launch_count()
+        a = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
+        l1 = lib.emu_launch_count()
+        ea = be.denoise_once(inp["x_T"], np.full((B,), 321, np.int64), inp["cond"], "f16r")
+        be.set_option("cond_direct", 0)
+        l2 = lib.emu_launch_count()
+        b = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
+        l3 = lib.emu_launch_count()
+        eb = be.denoise_once(inp["x_T"], np.full((B,), 321, np.int64), inp["cond"], "f16r")
+        be.set_option("cond_direct", 1)
+        assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(ea, eb), (B, h, w)
+        assert (l3 - l2) - (l1 - l0) == 1, (l1 - l0, l3 - l2)       # exactly the conversion kernel less
+        ref = O.ddim_loop(sd, inp["x_T"], inp["cond"], T)
+        assert maxabs(a, ref) < LATENT_TOL["f16r"] * np.abs(ref).max()
+
+
 # ---- the loop against the oracle, every kernel family and option ----------------------------------------------------------------------------------
 LOOP = dict(B=1, h=9, w=33, T=2)
 
