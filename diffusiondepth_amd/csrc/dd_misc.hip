@@ -912,12 +912,16 @@ __global__ void __launch_bounds__(256) dec1_kernel(const float* __restrict__ tmp
   depth[(size_t)b * H * W + p] = 1.f / fmaxf(sg, 1e-6f) - 1.f;
 }
 
-// Fused decoder: one workgroup produces a 16x32 tile of the depth map.  The (8+2)x(16+2) latent patch and the ReLU'd
-// transposed-convolution output of the (16+2)x(32+2) region (the 3x3 conv's halo) live in LDS, so the 16-channel full
+// Fused decoder: one workgroup produces a 14x30 tile of the depth map.  The (7+2)x(15+2) latent patch and the ReLU'd
+// transposed-convolution output of the 16x32 region (the 3x3 conv's halo) live in LDS, so the 16-channel full
 // resolution intermediate (110 MB per B=4 KITTI batch) never goes to HBM.  Wave w computes the region pixels of output
 // parity class w = ((oy+1)&1, (ox+1)&1): its 2x2 live taps of the 4x4 kernel are wave-uniform, so the weights are scalar
 // operands (tap-major copy dec_w0t).
-constexpr int DT_H = 16, DT_W = 32;                 // output tile
+// Round 4: the tile was 16x32 (region 18x34: 153 pixels per class = three passes of a 64-lane wave, the last one 39 % full) and a lane computed ONE
+// pixel per pass -- every 16 FMAs waited for a 64-byte scalar weight load (s_load results return out of order: the only wait is lgkmcnt(0), so the
+// load cannot be pipelined across iterations).  Now the region is 16x32 = 128 pixels per class = ONE pass with TWO pixels per lane: 32 FMAs per
+// weight row, a third of the loop iterations.  Same accumulation order per output: bit-identical results.
+constexpr int DT_H = 14, DT_W = 30;                 // output tile
 constexpr int DR_H = DT_H + 2, DR_W = DT_W + 2;     // region of the intermediate (halo 1)
 constexpr int DL_H = DT_H / 2 + 2, DL_W = DT_W / 2 + 2, DL_P = DL_W + 1;   // latent patch rows / cols / padded row pitch
 __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict__ latent, const float* __restrict__ w0t,
@@ -946,13 +950,14 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int pr = wave >> 1, pc = wave & 1;                      // this wave's parity class
   constexpr int NR = DR_H / 2, NC = DR_W / 2;                   // 9 x 17 pixels per class
-  for (int idx = lane; idx < NR * NC; idx += 64) {
+  static_assert((NR * NC) % 128 == 0 && 64 % NC == 0, "a pass = two pixels per lane, the second one 64 / NC class rows below the first");
+  constexpr int RSTEP = 64 / NC;                                // class rows between a lane's two pixels
+  for (int idx = lane; idx < NR * NC; idx += 128) {
     const int rr = idx / NC, cc = idx - rr * NC;
-    const int r = 2 * rr + pr, c = 2 * cc + pc;
-    const int oy = Y0 - 1 + r, ox = X0 - 1 + c;
-    float acc[LATENT_C];
+    const int r = 2 * rr + pr, c = 2 * cc + pc;                 // second pixel: (r + 2 RSTEP, c)
+    float acc[2][LATENT_C];
 #pragma unroll
-    for (int co = 0; co < LATENT_C; ++co) acc[co] = b0[co];
+    for (int co = 0; co < LATENT_C; ++co) acc[0][co] = acc[1][co] = b0[co];
     // (tap and channel loops stay rolled: each (tap, ci) row of 16 weights is one s_load_dwordx16; unrolling them made the
     //  compiler hold 256 scalar weights and spill SGPRs through v_readlane / v_writelane)
 #pragma unroll 1
@@ -964,20 +969,29 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
         const int kx = pc + 2 * d;
         const int lc = (c - kx) / 2 + 1;
         const float* wt = w0t + (size_t)(ky * 4 + kx) * LATENT_C * LATENT_C;     // wave-uniform
-#pragma unroll 2
+#pragma unroll 4
         for (int ci = 0; ci < LATENT_C; ++ci) {
-          const float v = s_lat[ci][lr][lc];
+          const float v0 = s_lat[ci][lr][lc], v1 = s_lat[ci][lr + RSTEP][lc];
 #pragma unroll
-          for (int co = 0; co < LATENT_C; ++co) acc[co] = fmaf(wt[ci * LATENT_C + co], v, acc[co]);
+          for (int co = 0; co < LATENT_C; ++co) {
+            const float wv = wt[ci * LATENT_C + co];
+            acc[0][co] = fmaf(wv, v0, acc[0][co]);
+            acc[1][co] = fmaf(wv, v1, acc[1][co]);
+          }
         }
       }
     }
-    const bool inside = oy >= 0 && oy < H && ox >= 0 && ox < W;   // the 3x3 conv zero-pads OUTSIDE the image
-    float4* dst = reinterpret_cast<float4*>(&s_mid[r][c][0]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      dst[q] = inside ? make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f))
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 2; ++k) {
+      const int rk = r + 2 * RSTEP * k;
+      const int oy = Y0 - 1 + rk, ox = X0 - 1 + c;
+      const bool inside = oy >= 0 && oy < H && ox >= 0 && ox < W;   // the 3x3 conv zero-pads OUTSIDE the image
+      float4* dst = reinterpret_cast<float4*>(&s_mid[rk][c][0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dst[q] = inside ? make_float4(fmaxf(acc[k][4 * q], 0.f), fmaxf(acc[k][4 * q + 1], 0.f), fmaxf(acc[k][4 * q + 2], 0.f), fmaxf(acc[k][4 * q + 3], 0.f))
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   __syncthreads();
   // ---- conv 16 -> 1 3x3 (+bias) -> sigmoid -> 1 / max(s, 1e-6) - 1 ----
