@@ -1422,6 +1422,9 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   std::vector<float> e1 = W("depth_transform.conv_transform.1.0.weight");
   for (int co = 0; co < 16; ++co) for (int k = 0; k < 16 * 9; ++k) e1[co * 144 + k] *= sc[co];
   const size_t o_e1 = push(e1), o_eb1 = push(sh);
+  std::vector<float> e1t(2304);          // the same weights tap-major [tap][ci][co] for enc1_kernel
+  for (int co = 0; co < 16; ++co) for (int ci = 0; ci < 16; ++ci) for (int k = 0; k < 9; ++k) e1t[(k * 16 + ci) * 16 + co] = e1[(co * 16 + ci) * 9 + k];
+  const size_t o_e1t = push(e1t);
   bn_fold("depth_transform.conv_inv_transform.1", sc, sh);
   std::vector<float> d0 = W("depth_transform.conv_inv_transform.0.weight");       // (in, out, 4, 4)
   for (int ci = 0; ci < 16; ++ci) for (int co = 0; co < 16; ++co) for (int k = 0; k < 16; ++k) d0[(ci * 16 + co) * 16 + k] *= sc[co];
@@ -1439,7 +1442,7 @@ int dd_commit_weights(dd_handle_t h, void* stream) {
   }
   const float* base = h->codec_buf.as<float>();
   h->codec.enc_w0 = base + o_e0; h->codec.enc_b0 = base + o_eb0;
-  h->codec.enc_w1 = base + o_e1; h->codec.enc_b1 = base + o_eb1;
+  h->codec.enc_w1 = base + o_e1; h->codec.enc_b1 = base + o_eb1; h->codec.enc_w1t = base + o_e1t;
   h->codec.dec_w0 = base + o_d0; h->codec.dec_b0 = base + o_db0; h->codec.dec_w0t = base + o_d0t;
   h->codec.dec_w1 = base + o_d1;
   h->codec.dec_b1 = W("depth_transform.conv_inv_transform.3.0.bias")[0];

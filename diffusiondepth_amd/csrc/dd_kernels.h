@@ -236,6 +236,7 @@ struct CodecWeights {   // device pointers, BatchNorm already folded (eval mode)
   const float* enc_b0;  // [16]
   const float* enc_w1;  // [16][16][9]  conv 16->16, scale folded (OIHW)
   const float* enc_b1;  // [16]
+  const float* enc_w1t; // [9][16 in][16 out] the same weights tap-major (enc1_kernel: a (tap, ci) row of couts is one scalar load)
   const float* dec_w0;  // [16 in][16 out][4][4] convT, scale folded over out
   const float* dec_b0;  // [16]
   const float* dec_w0t; // [4][4][16 in][16 out] the same weights tap-major (fused decoder kernel)

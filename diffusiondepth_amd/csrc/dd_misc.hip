@@ -805,34 +805,66 @@ __global__ void __launch_bounds__(256) enc0_kernel(const float* __restrict__ dep
   for (int q = 0; q < 4; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
 }
 
-__global__ void __launch_bounds__(256) enc1_kernel(const float* __restrict__ tmp, const float* __restrict__ w1,
+// Stage 1, round 4: weights TAP-MAJOR ([tap][ci][co]: CodecWeights::enc_w1t) so that a (tap, ci) row of 16 couts is ONE 64-byte scalar load (the OIHW
+// table cost one 4-byte scalar load per FMA: 257 s_load_dword per tap); cout PAIRS on v_pk_fma_f32 (two fp32 FMAs per lane and issue slot; the plain
+// v_fma_f32 runs at half the vector unit's rate); the NEXT tap's 64 input bytes are requested before the current tap's FMAs.  A tap outside the image
+// contributes exact zeros (clamped address, value selected to 0) instead of being skipped; per output the order of the accumulation is unchanged (tap,
+// then ci) and a packed FMA is two IEEE FMAs: the same bits as before.
+__global__ void __launch_bounds__(256) enc1_kernel(const float* __restrict__ tmp, const float* __restrict__ w1t,
                                                    const float* __restrict__ b1, float* __restrict__ latent, int h, int w) {
   const int b = blockIdx.y;
   const long long HW = (long long)h * w;
   const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= HW) return;
-  const int oy = (int)(p / w), ox = (int)(p - (long long)oy * w);
-  float acc[LATENT_C];
+  const bool ok = p < HW;
+  const long long pc = ok ? p : HW - 1;
+  const int oy = (int)(pc / w), ox = (int)(pc - (long long)oy * w);
+  f32x2_t acc[LATENT_C / 2];
 #pragma unroll
-  for (int c = 0; c < LATENT_C; ++c) acc[c] = b1[c];
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy - 1 + ky;
-    if (iy < 0 || iy >= h) continue;
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox - 1 + kx;
-      if (ix < 0 || ix >= w) continue;
-      const float4* src = reinterpret_cast<const float4*>(tmp + ((size_t)b * HW + (size_t)iy * w + ix) * LATENT_C);
-      float in[LATENT_C];
+  for (int c = 0; c < LATENT_C / 2; ++c) acc[c] = (f32x2_t){b1[2 * c], b1[2 * c + 1]};
+  const float* img = tmp + (size_t)b * HW * LATENT_C;
+  float4 cur[4], nx[4];
+  bool cur_in = false, nx_in = false;
+  auto fetch = [&](int tap, float4 (&dst)[4], bool& inside) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = oy - 1 + ky, ix = ox - 1 + kx;
+    inside = iy >= 0 && iy < h && ix >= 0 && ix < w;
+    const int iyc = iy < 0 ? 0 : (iy >= h ? h - 1 : iy), ixc = ix < 0 ? 0 : (ix >= w ? w - 1 : ix);
+    const float4* src = reinterpret_cast<const float4*>(img + ((size_t)iyc * w + ixc) * LATENT_C);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const float4 v = src[q]; in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w; }
+    for (int q = 0; q < 4; ++q) dst[q] = src[q];
+  };
+  fetch(0, cur, cur_in);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    fetch(tap < 8 ? tap + 1 : 8, nx, nx_in);            // (behind the last tap: tap 8 once more, discarded)
+    float in[LATENT_C];
 #pragma unroll
-      for (int co = 0; co < LATENT_C; ++co)
-#pragma unroll
-        for (int ci = 0; ci < LATENT_C; ++ci) acc[co] = fmaf(w1[(co * LATENT_C + ci) * 9 + ky * 3 + kx], in[ci], acc[co]);
+    for (int q = 0; q < 4; ++q) {
+      in[4 * q] = cur_in ? cur[q].x : 0.f; in[4 * q + 1] = cur_in ? cur[q].y : 0.f; in[4 * q + 2] = cur_in ? cur[q].z : 0.f; in[4 * q + 3] = cur_in ? cur[q].w : 0.f;
     }
-  }
+    const float* wt = w1t + (size_t)tap * LATENT_C * LATENT_C;      // wave-uniform
+    // channel groups of four, every index a compile-time constant; the scheduling fence keeps a group's four scalar rows from being hoisted above
+    // the previous group's FMAs (16 rows in flight = 256 SGPRs)
 #pragma unroll
-  for (int c = 0; c < LATENT_C; ++c) latent[((size_t)b * LATENT_C + c) * HW + p] = tanhf(acc[c]);
+    for (int q = 0; q < LATENT_C / 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = 4 * q + j;
+        const f32x2_t* row = reinterpret_cast<const f32x2_t*>(wt + ci * LATENT_C);
+        const f32x2_t a = (f32x2_t){in[ci], in[ci]};
+#pragma unroll
+        for (int co = 0; co < LATENT_C / 2; ++co) acc[co] = __builtin_elementwise_fma(row[co], a, acc[co]);
+      }
+      DD_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nx[q];
+    cur_in = nx_in;
+  }
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < LATENT_C; ++c) latent[((size_t)b * LATENT_C + c) * HW + p] = tanhf(acc[c >> 1][c & 1]);
+  }
 }
 
 hipError_t launch_encode(const CodecWeights& cw, const float* depth, float* tmp_nhwc, float* latent_nchw,
@@ -840,7 +872,7 @@ hipError_t launch_encode(const CodecWeights& cw, const float* depth, float* tmp_
   const int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
   dim3 grid((unsigned)(((long long)h * w + 255) / 256), (unsigned)B);
   hipLaunchKernelGGL(enc0_kernel, grid, dim3(256), 0, s, depth, cw.enc_w0, cw.enc_b0, tmp_nhwc, H, W, h, w);
-  hipLaunchKernelGGL(enc1_kernel, grid, dim3(256), 0, s, tmp_nhwc, cw.enc_w1, cw.enc_b1, latent_nchw, h, w);
+  hipLaunchKernelGGL(enc1_kernel, grid, dim3(256), 0, s, tmp_nhwc, cw.enc_w1t, cw.enc_b1, latent_nchw, h, w);
   return hipGetLastError();
 }
 
@@ -955,9 +987,11 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
   for (int idx = lane; idx < NR * NC; idx += 128) {
     const int rr = idx / NC, cc = idx - rr * NC;
     const int r = 2 * rr + pr, c = 2 * cc + pc;                 // second pixel: (r + 2 RSTEP, c)
-    float acc[2][LATENT_C];
+    // accumulators as cout PAIRS: v_pk_fma_f32 does two fp32 FMAs per lane and issue slot (the plain v_fma_f32 runs at half the vector unit's rate);
+    // weights = an SGPR pair of the scalar row, the pixel value broadcast to both halves (op_sel).  Two IEEE FMAs: the same bits as fmaf.
+    f32x2_t acc[2][LATENT_C / 2];
 #pragma unroll
-    for (int co = 0; co < LATENT_C; ++co) acc[0][co] = acc[1][co] = b0[co];
+    for (int co = 0; co < LATENT_C / 2; ++co) acc[0][co] = acc[1][co] = (f32x2_t){b0[2 * co], b0[2 * co + 1]};
     // (tap and channel loops stay rolled: each (tap, ci) row of 16 weights is one s_load_dwordx16; unrolling them made the
     //  compiler hold 256 scalar weights and spill SGPRs through v_readlane / v_writelane)
 #pragma unroll 1
@@ -972,11 +1006,12 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
 #pragma unroll 4
         for (int ci = 0; ci < LATENT_C; ++ci) {
           const float v0 = s_lat[ci][lr][lc], v1 = s_lat[ci][lr + RSTEP][lc];
+          const f32x2_t* row = reinterpret_cast<const f32x2_t*>(wt + ci * LATENT_C);
 #pragma unroll
-          for (int co = 0; co < LATENT_C; ++co) {
-            const float wv = wt[ci * LATENT_C + co];
-            acc[0][co] = fmaf(wv, v0, acc[0][co]);
-            acc[1][co] = fmaf(wv, v1, acc[1][co]);
+          for (int co = 0; co < LATENT_C / 2; ++co) {
+            const f32x2_t wv = row[co];
+            acc[0][co] = __builtin_elementwise_fma(wv, (f32x2_t){v0, v0}, acc[0][co]);
+            acc[1][co] = __builtin_elementwise_fma(wv, (f32x2_t){v1, v1}, acc[1][co]);
           }
         }
       }
@@ -989,7 +1024,7 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
       float4* dst = reinterpret_cast<float4*>(&s_mid[rk][c][0]);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        dst[q] = inside ? make_float4(fmaxf(acc[k][4 * q], 0.f), fmaxf(acc[k][4 * q + 1], 0.f), fmaxf(acc[k][4 * q + 2], 0.f), fmaxf(acc[k][4 * q + 3], 0.f))
+        dst[q] = inside ? make_float4(fmaxf(acc[k][2 * q][0], 0.f), fmaxf(acc[k][2 * q][1], 0.f), fmaxf(acc[k][2 * q + 1][0], 0.f), fmaxf(acc[k][2 * q + 1][1], 0.f))
                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
