@@ -13,7 +13,7 @@
 //   * rolling prefetch: the raw input of a whole tile (four 16-channel chunks) lives in registers; a chunk's registers are reloaded with the
 //     NEXT tile's chunk as soon as the chunk has been normalised into LDS, so every load has a full tile period to land and ~43 KB per
 //     workgroup are in flight all the time (Little: two workgroups per CU x 256 CUs x 43 KB = 22 MB against 8 TB/s x ~2.5 us);
-//   * no LDS-DMA, no counted waits: all loads are ordinary loads tracked by the compiler; workgroup barriers are raw `s_barrier`s behind an
+//   * no counted waits: the input loads are ordinary loads tracked by the compiler (only the one-time weight copy is an LDS-DMA, waited for with vmcnt(0)); workgroup barriers are raw `s_barrier`s behind an
 //     explicit `s_waitcnt lgkmcnt(0)` (a __syncthreads() would drain the prefetched loads: vmcnt(0)).
 // Round 4, the refined-f16 mode (EK_F16R, dd_kernels.h) -- three template switches on the same pipeline:
 //   STACK   the packed weight image carries an f16 PAIR per weight in ONE MFMA: the 32x32x16 instruction has 32 cout rows, conv4 has 16 couts, so rows
@@ -79,17 +79,26 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   int tl = wg / p.B;
 
   // ---- once per workgroup: weights -> LDS (the packed image IS the LDS image), bias, GroupNorm table of image b ----
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(p.wpack);
-    uint4* dst = reinterpret_cast<uint4*>(smem);
-    if (!(abl & 128)) for (int i = tid; i < W_BYTES / 16; i += THREADS) dst[i] = src[i];
-    if (tid < NROW) tab_bias[tid] = p.bias[tid];
+  // Round 4: every load of the workgroup's start-up is ISSUED before anything waits -- the GroupNorm partial sums and gamma / beta (the fp64 table is
+  // the longest dependent chain), the 36 KB of weights (LDS-DMA: no registers, no wait until the first barrier), and the first tile's raw input --
+  // instead of three memory round trips one after the other (weights copied through registers, then the sums fetched, then the tile requested):
+  // a workgroup walks only one to four tiles, so its start-up is 20 .. 40 % of its life.
+  const double* st = p.stats_in + (size_t)b * STAT_SLOTS * STAT_STRIDE + (lane >> 1) * STAT_STRIDE + (lane & 1) * 4;
+  double2 sv0 = *reinterpret_cast<const double2*>(st), sv1 = *reinterpret_cast<const double2*>(st + 2);
+  const int ct = tid < CIN ? tid : 0;                   // (unconditional, clamped: no branch ties a wait to these loads)
+  const float my_gamma = p.gn_gamma[ct], my_beta = p.gn_beta[ct];
+  const float my_bias = p.bias[tid < NROW ? tid : 0];
+  if (!(abl & 128)) {
+    static_assert(W_BYTES % 1024 == 0, "whole 1-KiB DMA pieces");
+    const unsigned lds_base = DD_LDS_BASE(smem);
+    for (int kc = wave; kc < W_BYTES / 1024; kc += WAVES) {
+      const char* gsrc = reinterpret_cast<const char*>(p.wpack) + (size_t)kc * 1024 + lane * 16;
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(lds_base + kc * 1024);
+      DD_LDS_DMA16(smem, gsrc, ldst);
+    }
   }
-  {
-    const double* st = p.stats_in + (size_t)b * STAT_SLOTS * STAT_STRIDE + (lane >> 1) * STAT_STRIDE + (lane & 1) * 4;
-    double2 sv0 = *reinterpret_cast<const double2*>(st), sv1 = *reinterpret_cast<const double2*>(st + 2);
-    float my_gamma = 0.f, my_beta = 0.f;
-    if (tid < CIN) { my_gamma = p.gn_gamma[tid]; my_beta = p.gn_beta[tid]; }
+  auto finish_startup = [&]() {
+    if (tid < NROW) tab_bias[tid] = my_bias;
 #pragma unroll
     for (int off = 2; off <= 32; off <<= 1) {
       sv0.x += __shfl_xor(sv0.x, off, 64); sv0.y += __shfl_xor(sv0.y, off, 64);
@@ -111,7 +120,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
       tab_a[tid] = (float)a * PSC;
       tab_b[tid] = (float)((double)my_beta - mean * a) * PSC;
     }
-  }
+  };
 
   // ---- per-thread staging items (independent of tile and chunk): piece jfix of patch pixel pp(u) ----
   const int jfix = tid & (PPP - 1);
@@ -217,9 +226,12 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     }
   };
 
-  // first tile: all four chunks requested, chunk 0 staged
+  // first tile: all four chunks requested (behind the start-up loads, in front of their first use), then the table; the weight DMA (invisible to
+  // hipcc's vmcnt bookkeeping) has landed when nothing is outstanding any more -- the first tile's input is needed right behind the barrier anyway
 #pragma unroll
   for (int c = 0; c < NCH; ++c) load_chunk(c, po_cur);
+  finish_startup();
+  DD_WAIT_VM(0);
   DD_WAIT_LGKM0();
   __builtin_amdgcn_s_barrier();                          // table + weights + bias visible
   asm volatile("" ::: "memory");
