@@ -186,13 +186,13 @@ def test_refined_f16_mode_on_the_far_range_golden(lib, golden, cases):
         return float(np.sqrt((((d - dref) / dref) ** 2).mean()))
     try:
         e_wide = rel_rmse("f16r", f16r_wide=1, f16r_c1=1, f16r_p4=0)          # the defaults: block-scaled int16 hand-over, conv1's weights as a pair
-        e_p4 = rel_rmse("f16r", f16r_wide=1, f16r_c1=1, f16r_p4=1)
+        e_p4 = rel_rmse("f16r", f16r_wide=1, f16r_c1=1, f16r_p4=1) if FULL else None
         e_narrow = rel_rmse("f16r", f16r_wide=0, f16r_c1=1, f16r_p4=0)
         e_c0 = rel_rmse("f16r", f16r_wide=1, f16r_c1=0) if FULL else None
     finally:
         be.set_option("f16r_wide", 1); be.set_option("f16r_c1", 1); be.set_option("f16r_p4", 0)
     e_f16 = rel_rmse("f16")
-    assert e_p4 < e_wide < e_narrow < e_f16, (e_p4, e_wide, e_narrow, e_f16)
+    assert e_wide < e_narrow < e_f16 and (e_p4 is None or e_p4 < e_wide), (e_p4, e_wide, e_narrow, e_f16)
     # the GPU suite's bound for the mode; half the f16 mode's error (measured 1.012e-4 vs 2.08e-4; an fp32 hand-over of y3 / the hoisted term
     # measured 9.89e-5 before it was dropped: int16 with block scales carries what fp32 carried)
     assert e_wide < 2e-4 and e_wide < 0.6 * e_f16, (e_wide, e_f16)
@@ -211,7 +211,7 @@ def test_refined_f16_reads_an_explicit_condition_tensor_in_place(lib):
     be, sd = backend_for(lib, {"wseed": 7244})
     be.set_option("hoist_cond", -1)
     be.timing(order=1, dma_late=1)
-    for B, h, w, T in ((2, 11, 37, 2), (1, 17, 70, 1)):
+    for B, h, w, T in ((2, 11, 37, 2),) + (((1, 17, 70, 1),) if FULL else ()):
         inp = synth.make_inputs(300 + h, B, h, w)
         be.set_option("cond_direct", 1)
         be.denoise(inp["x_T"], inp["cond"], T, "f16r")             # (the plan of this shape: its one-time launches)
@@ -274,7 +274,7 @@ def test_res_loop_with_the_hoisted_condition_term(lib):
     assert maxabs(x0, ref) < LATENT_TOL["f16"] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16r"] + (["f16"] if FULL else []))
+@pytest.mark.parametrize("prec", ["f16r"] + (["bf16", "f16"] if FULL else []))
 def test_hoisted_conv3_with_one_patch_buffer(lib, prec):
     """Kernel id ONE_CONV3H (dd_kernels.h): the loop's hoisted conv3 on its 8x32 tiles with ONE patch buffer -- the next chunk's patch is written into the
     buffer the MFMAs just read, behind a second workgroup barrier per stage (52 KB of LDS: three workgroups per CU on the GPU).  Same tiles, same
@@ -296,7 +296,7 @@ def test_hoisted_conv3_with_one_patch_buffer(lib, prec):
     assert maxabs(outs[0], ref) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16r"] + (["f16"] if FULL else []))      # f16r: the split layer 8's fp32 term reformatted into the 16x32-tile order
+@pytest.mark.parametrize("prec", ["f16r"] + (["bf16", "f16"] if FULL else []))      # f16r: the split layer 8's fp32 term reformatted into the 16x32-tile order
 def test_hoisted_conv3_on_16x32_tiles(lib, prec):
     """Kernel ids 48 / 49 (dd_kernels.h): the hoisted conv3 pair -- conv3(cond) once per image, conv3 in the loop -- on 16x32-pixel tiles (four
     waves of 128 pixels x 64 couts, raw patch one chunk ahead), which the library picks when the 8x32 tiles exceed the resident workgroup
@@ -341,7 +341,7 @@ def test_streaming_conv4_walks_several_tiles_per_workgroup(lib, prec, B, slots):
     assert maxabs(outs[0], classic) < LATENT_TOL[prec] * np.abs(ref).max() and maxabs(one_tile_each, classic) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("wide,p4", [(1, 0), (0, 1)] + ([(1, 1), (0, 0)] if FULL else []))
+@pytest.mark.parametrize("wide,p4", [(1, 0)] + ([(0, 1), (1, 1), (0, 0)] if FULL else []))
 def test_refined_f16_conv4_walks_several_tiles_per_workgroup(lib, wide, p4):
     """The stacked-weight forms of the streaming conv4 (dd_thin.hip: STACK, INQ = y3 as int16 with a per-pixel scale, PSPLIT with the second patch
     plane) across tile boundaries: 17 x 70 latent = 3 x 3 tiles per image, 3 resident slots for 2 images -> one
