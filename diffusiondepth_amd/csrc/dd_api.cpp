@@ -120,7 +120,7 @@ struct Plan {
                                   // plan of one (B, h, w, element kind) so that dd_condition can write it in place
   const void* cond_alias = nullptr;   // lanes of a batch whose condition map dd_condition left in the whole batch's buffer: this lane's images inside it
   const void* graph_cond = nullptr;   // the condition pointer the captured graph holds
-  void* cond_ptr() const { return cond_alias ? const_cast<void*>(cond_alias) : cond->p; }
+  void* cond_ptr() const { return cond_alias ? const_cast<void*>(cond_alias) : (cond ? cond->p : nullptr); }      // (null: a refined-f16 Res plan that has only ever read the caller's tensor in place)
   DevBuf y1, y2, y3, y4;   // raw conv outputs
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
@@ -235,6 +235,7 @@ struct dd_handle_s {
   int thin_slots = 512;       // option "thin_slots": workgroups of that kernel (two per CU on the 256 CUs; the tests shrink it to make a workgroup walk several tiles)
   int big_tiles = -1;         // option "big_tiles": hoisted conv3 pair on 16x32 tiles: -1 = when the 8x32 tiles exceed the 512 resident slots, 0 / 1 = forced
   int one_buffer = 1;         // option "one_buffer": the hoisted conv3 on 8x32 tiles in its one-patch-buffer form when the tiles exceed the resident slots (A/B switch)
+  int thin_xcd = 1;           // option "thin_xcd": that kernel's workgroup -> tile map keeps each XCD on one contiguous block of tiles (halo rows out of its L2); 0 = interleaved (A/B switch)
   int thin_stream = 1;        // option "thin_stream": conv4 as the persistent streaming kernel of dd_thin.hip; 0 = the general kernel (A/B switch)
   int f16r_wide = 1;          // DD_PREC_F16R: y3 and the hoisted conv3(cond) term as block-scaled int16 (0 = as f16, like DD_PREC_F16)
   int f16r_c1 = 1;            // DD_PREC_F16R: conv1's weights as an f16 pair (two MFMAs; 0 = the plain f16 kernel)
@@ -585,7 +586,10 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   const bool swin = h->variant == DD_VARIANT_SWIN;
   // Swin: the condition map is bilinearly upsampled to the latent size once per call and kept at that size
   (void)swin;
-  { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond, key.lane); if (rc) return rc; }
+  // (refined f16, Res denoiser: hoisted forward-only plans whose loop never reads the condition map, and whose once-per-image conv3(cond) reads an
+  // explicit `cond` tensor in place (option "cond_direct"): the blocked fp32 buffer -- 219 MB at KITTI B = 4 -- is only allocated when a call needs
+  // it: a non-direct stage_condition, or dd_condition's resident map)
+  if (!(pl->ek == EK_F16R && !swin && key.hoist)) { int rc = get_cond_buf(h, key.B, key.h, key.w, key.prec, &pl->cond, key.lane); if (rc) return rc; }
   pl->slots = (key.keep == 2 && key.T > 0) ? key.T : 1;
   const size_t ns = (size_t)pl->slots;
   if (swin) {      // (refined f16: the once-per-image chain runs on split operands through fp32 tensors in these two buffers)
@@ -618,7 +622,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   DD_HIP(pl->y3.alloc(ns * px * HID_C * es));
   if (pl->ek == EK_F16R && h->f16r_wide) DD_HIP(pl->y3_scale.alloc(ns * px * 4));
   DD_HIP(pl->y4.alloc(ns * px * LATENT_C * 4));
-  if (key.keep == 2) pl->kept_bytes = pl->y1.bytes + pl->y2.bytes + pl->y3.bytes + pl->y4.bytes + pl->sa.bytes + pl->sf.bytes;
+  if (key.keep == 2) pl->kept_bytes = pl->y1.bytes + pl->y2.bytes + pl->y3.bytes + pl->y3_scale.bytes + pl->y4.bytes + pl->sa.bytes + pl->sf.bytes;
   if (naive) {
     DD_HIP(pl->a1.alloc(px * HID_C * 4));
     DD_HIP(pl->f.alloc(px * COND_C * 4));
@@ -678,8 +682,8 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     auto launch = [&](ConvParams q) {
       q.prof = (h->prof_buf && layer == h->prof_layer) ? h->prof_buf : nullptr;
       q.tiles_y = (k.h + conv_pack_geom2(kid, ek).th - 1) / conv_pack_geom2(kid, ek).th;
-      if (layer == 4 && rf) { q.persist_slots = h->thin_slots; q.cadd_scale = static_cast<const float*>(pl->slot(pl->y3_scale, step)); return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
-      if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; return launch_conv4_stream(tk, q, s); }
+      if (layer == 4 && rf) { q.persist_slots = h->thin_slots; q.xcd_map = h->thin_xcd; q.cadd_scale = static_cast<const float*>(pl->slot(pl->y3_scale, step)); return launch_conv4_stream(EK_F16, q, s, true, pl->wide, pl->p4); }
+      if (layer == 4 && stream4) { q.persist_slots = h->thin_slots; q.xcd_map = h->thin_xcd; return launch_conv4_stream(tk, q, s); }
       int lek = ek;
       if (rf && (layer == 9 || layer == 7) && !pl->wide) lek = EK_F16;      // hand-over of y3 / the hoisted term as f16: the f16 mode's conv3 / 5x5 form
       if (rf && layer == 1 && !pl->c1) lek = EK_F16;        // conv1 without the weight pair: the f16 mode's conv1
@@ -893,6 +897,7 @@ int stage_condition(dd_handle_t h, Plan* pl, const float* cond, int B, int lat_h
   // conv3(cond) does, and that kernel can read the caller's NCHW tensor in place (option "cond_direct", default on): no blocked copy is made.
   const bool direct = cond && h->cond_direct && h->variant != DD_VARIANT_SWIN && pl->ek == EK_F16R && pl->key.hoist;
   if (direct) return enqueue_cond_conv(h, pl, s, cond);     // (the plan's blocked buffer -- possibly dd_condition's resident map -- is left alone)
+  if (!pl->cond) { int rc = get_cond_buf(h, pl->key.B, pl->key.h, pl->key.w, pl->key.prec, &pl->cond, pl->key.lane); if (rc) return rc; }      // allocated on first need (get_plan)
   if (cond) {
     if (h->variant == DD_VARIANT_SWIN) DD_HIP(launch_upsample_to_blocked(cond, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, lat_h, lat_w, s));
     else DD_HIP(launch_nchw_to_nhwc(cond, pl->cond->p, cond_kind(pl->ek), B, COND_C, cond_h, cond_w, precision != DD_PREC_NAIVE_FP32, s));
@@ -1530,6 +1535,11 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: cond_split must be 0 or 1");
     h->cond_split = (int)value;
   }
+  else if (k == "thin_xcd") {
+    if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_xcd must be 0 or 1");
+    if (h->thin_xcd != (int)value) { DD_HIP(hipDeviceSynchronize()); h->plans.clear(); h->last_once_plan = nullptr; }      // kernel parameters are baked into captured graphs
+    h->thin_xcd = (int)value;
+  }
   else if (k == "thin_stream") {
     if (value < 0 || value > 1) return h->fail(DD_ERR_INVALID_ARG, "dd_set_option: thin_stream must be 0 or 1");
     if (h->thin_stream != (int)value) {          // the kernel choice is baked into captured graphs
@@ -1921,7 +1931,7 @@ int dd_denoise_trace(dd_handle_t h, const float* x_T, const float* cond, float* 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   DD_HIP(hipSetDevice(h->device));
   Plan* pl = nullptr;
-  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 0)}, &pl);    // the kernels dd_denoise runs: same bits
+  rc = get_plan(h, PlanKey{B, lat_h, lat_w, cond_h, cond_w, T, precision, want_hoist(h, precision, T, 0)}, &pl);    // the plan of a ONE-lane dd_denoise call: the same kernels -- a multi-lane dd_denoise at KITTI size takes the 16x32-tile form of the hoisted conv3 (plan_big_tiles), whose GroupNorm partial sums add up in another order
   if (rc) return rc;
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const size_t n16 = (size_t)B * lat_h * lat_w * LATENT_C;

@@ -1176,12 +1176,16 @@ __global__ void __launch_bounds__(256) cadd_reformat_kernel(const float4* __rest
     v = src[((((stile * 4 + swave) * 2 + n) * 2 + sm) * 4 + q) * 64 + lane];
   }
   if (out_kind == 2) {
-    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    // NaN-preserving maximum (fmaxf drops a NaN operand and v_cvt_pknorm_i16_f32(NaN) is 0: a NaN in the condition map would come out of the
+    // hoisted term as finite zeros -- the other modes propagate it).  A NaN anywhere in the block makes the block's SCALE NaN, and the
+    // consumer's int16 * scale reproduces it on the block's 32 pixels x 32 couts.
+    auto nmax = [](float a, float b) { return (b > a || b != b) ? b : a; };
+    float mx = nmax(nmax(fabsf(v.x), fabsf(v.y)), nmax(fabsf(v.z), fabsf(v.w)));
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    for (int off = 32; off >= 1; off >>= 1) mx = nmax(mx, __shfl_xor(mx, off, 64));
     if (lane == 0) s_max[q] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    mx = nmax(nmax(s_max[0], s_max[1]), nmax(s_max[2], s_max[3]));
     const float inv = mx > 0.f ? 1.f / mx : 0.f;
     if (threadIdx.x == 0) scales[blk] = mx * (1.f / Q15_ONE);
     reinterpret_cast<uint2*>(dst)[e] = make_uint2(DD_CVT_PKNORM_I16(v.x * inv, v.y * inv), DD_CVT_PKNORM_I16(v.z * inv, v.w * inv));

@@ -144,12 +144,17 @@ class OverlappedGradReducer:
     accumulate locally, nothing is sent) -- the last backward then reduces the accumulated sums, overlapped as usual.  Without
     ``no_sync()`` the result is still correct: a bucket whose parameters receive another gradient after its all-reduce was issued is
     marked stale and reduced AGAIN in finish() from the accumulated ``.grad`` (the first transfer is wasted, not the gradient).
-    Not distributed (world size 1): every method is a no-op."""
+    Not distributed (no process group, or one of a single rank without ``force_single_rank``): every method is a no-op."""
 
-    def __init__(self, params, bucket_bytes: int = 64 << 20, average: bool = True):
+    force_single_rank = False      # class-wide switch (tests), like SyncBatchNorm.force_sync
+
+    def __init__(self, params, bucket_bytes: int = 64 << 20, average: bool = True, force_single_rank: bool = False):
+        """force_single_rank: take the collective path with a process group of ONE rank too (hooks, async all-reduce on the collective's own
+        stream, finish()): a one-GPU box then executes exactly the code N ranks execute (bench.py --mode train-dp under a launcher,
+        tests/test_zz_gpu_dist.py); the sums over one rank are the identity."""
         self.params = [p for p in params if p.requires_grad]
         self.average = average
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_single_rank or self.force_single_rank)
         self.buckets: List[List[int]] = []
         cur, nbytes = [], 0
         for i in reversed(range(len(self.params))):

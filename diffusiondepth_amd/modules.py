@@ -286,6 +286,16 @@ class ScheduledCNNRefine(nn.Module):
             raise ValueError("HipBound variant does not match the module variant")
         self.bound.register("model.", self)
 
+    @property
+    def single_call_precision(self) -> str:
+        """The precision ONE epsilon-network call (this module's forward: the heads' ddim_loss evaluation, …res.py:211) really runs in.  It is
+        ``self.precision`` except for the Swin / MPViT denoiser in the refined f16 mode: there "f16r" exists as hoisted forward-only plans of
+        the T-step loop only (dd_denoise; dd_denoise_once refuses it), so the single call runs this denoiser's plain f16 kernels.  `pred` comes
+        from the loop and is unaffected; `ddim_loss` of such a head is an f16-mode value ("Profiles and precisions")."""
+        if self.variant == "swin" and str(self.precision).lower() in ("f16r", "refined_f16"):
+            return "f16"
+        return self.precision
+
     def forward(self, noisy_image, t, *args):
         """forward(noisy_image, t, feat, blur_depth, sparse_depth, sparse_mask) -> eps (…res.py:324-344)."""
         feat = args[0]
@@ -293,9 +303,7 @@ class ScheduledCNNRefine(nn.Module):
             return self._eager_forward(noisy_image, t, feat)
         be = self.bound.ensure(noisy_image.device, need=("model",))
         t = torch.as_tensor(t, device=noisy_image.device)
-        # the refined f16 mode exists as hoisted forward-only plans: for the Swin / MPViT denoiser that is the T-step loop; a single call (the
-        # ddim_loss evaluation of the heads) runs this denoiser's f16 kernels
-        prec = "f16" if (self.variant == "swin" and str(self.precision).lower() in ("f16r", "refined_f16")) else self.precision
+        prec = self.single_call_precision
         if _wants_grad(self, noisy_image, feat):
             tt = t.to(torch.int64).reshape(-1)
             if tt.numel() == 1 and noisy_image.shape[0] > 1:

@@ -225,14 +225,15 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
- * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent, the result is bit-identical;
+ * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent and every image's result is bit-identical to the one-lane call's as long as both take the same tile form -- the hoisted conv3 pair of the 2-byte modes runs on 16x32 tiles in a multi-lane call with more tiles than resident slots and on 8x32 tiles otherwise (another GroupNorm partial-sum order: equal to fp32 round-off of the statistics, option "big_tiles" forces one form);
  * dd_denoise_backward splits the same way, with one parameter-gradient set per lane summed into the caller-visible one at the join;
  * default 1), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
  * "keep_activations_mb" (budget of the per-step activation slots kept by "keep_trajectory" forwards, default 65536: ONE figure for the
  * handle -- all lanes and shapes -- also held against the free device memory; stale sets are dropped first, and a forward that cannot
  * keep its activations keeps the states only), "thin_stream" (1 [default] = conv4 runs as the persistent streaming kernel of
  * csrc/dd_thin.hip in the 16-bit modes, 0 = as an instance of the general kernel: A/B switch), "thin_slots" (workgroups of that kernel,
- * default 512 = two per CU), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
+ * default 512 = two per CU), "thin_xcd" (1 [default] = that kernel's workgroup -> tile map keeps every XCD on one contiguous block of tiles, so that
+ * neighbouring tiles share their halo rows through that XCD's L2; 0 = the interleaved map of rounds 3-4: A/B switch), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
  * "f16r_wide" (DD_PREC_F16R: 1 [default] = y3 and the hoisted conv3(cond) term travel as int16 with block scales -- one fp32 scale per pixel of y3, per
  * 32-pixel x 32-cout accumulator block of the hoisted term: f16's bytes at ~15 bits --, 0 = as f16 like in DD_PREC_F16), "f16r_c1" (DD_PREC_F16R:
  * 1 [default] = conv1's weights as an f16 pair (two MFMAs), 0 = the plain f16 kernel), "one_buffer" (1 [default] = the loop's hoisted conv3 on

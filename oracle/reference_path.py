@@ -24,11 +24,29 @@ def _shim():
     return ref_import
 
 
+_usable = None
+
+
 def available() -> bool:
-    try:
-        return _shim().reference_available()
-    except Exception:  # noqa: BLE001
-        return False
+    """True when the reference's classes can really be IMPORTED here -- not merely when a directory exists: the staged bytecode is only good for
+    the interpreter version that compiled it (STAGED.json records it; a .pyc magic mismatch would otherwise surface as an ImportError in the
+    middle of bench.py's cpu_baseline leg), and an import of the tree itself can fail for its own reasons.  One trial import, cached; any
+    failure means "not available" and the callers fall back to the port (kind "port")."""
+    global _usable
+    if _usable is None:
+        try:
+            R = _shim()
+            ok = bool(R.reference_available())
+            if ok and R.reference_kind().startswith("staged"):
+                import json
+                with open(os.path.join(R.STAGED_SRC, "STAGED.json")) as f:
+                    ok = json.load(f).get("python") == list(sys.version_info[:2])
+            if ok:
+                R.load_reference()
+            _usable = ok
+        except Exception:  # noqa: BLE001
+            _usable = False
+    return _usable
 
 
 def kind() -> str:

@@ -213,8 +213,12 @@ def test_refined_f16_reads_an_explicit_condition_tensor_in_place(lib):
     be.timing(order=1, dma_late=1)
     for B, h, w, T in ((2, 11, 37, 2),) + (((1, 17, 70, 1),) if FULL else ()):
         inp = synth.make_inputs(300 + h, B, h, w)
+        # (the plan of this shape and its one-time launches, both routes: the blocked condition buffer of a refined-f16 Res plan is allocated by the
+        # first NON-direct call -- round 5 -- and the graph is then captured again around the new pointer)
+        be.set_option("cond_direct", 0)
+        be.denoise(inp["x_T"], inp["cond"], T, "f16r")
         be.set_option("cond_direct", 1)
-        be.denoise(inp["x_T"], inp["cond"], T, "f16r")             # (the plan of this shape: its one-time launches)
+        be.denoise(inp["x_T"], inp["cond"], T, "f16r")
         l0 = lib.emu_launch_count()
         a = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
         l1 = lib.emu_launch_count()
@@ -339,6 +343,30 @@ def test_streaming_conv4_walks_several_tiles_per_workgroup(lib, prec, B, slots):
     assert maxabs(outs[0], ref) < LATENT_TOL[prec] * np.abs(ref).max()
     # (16-bit rounding class, not closer: the next GroupNorm's partial sums are taken in another order)
     assert maxabs(outs[0], classic) < LATENT_TOL[prec] * np.abs(ref).max() and maxabs(one_tile_each, classic) < LATENT_TOL[prec] * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("prec,slots", [("f16r", 6), ("bf16", 512)])
+def test_streaming_conv4_xcd_aware_tile_map(lib, prec, slots):
+    """Round 5, option "thin_xcd" (default 1): the streaming conv4's workgroup -> tile map gives every XCD (block index % 8) one contiguous run of
+    (image, ordinal) ranks and enumerates an image's tiles in column strips of four -- 12 x 150 latent = 2 x 5 tiles: one full strip and a last strip
+    of width one; with 6 slots for 2 images a workgroup walks 3 or 4 tiles across both strips, with 512 one tile each.  Every tile is visited exactly
+    once: against the oracle and against the interleaved map of rounds 3-4 (same accumulation order per output; only the GroupNorm partial
+    sums regroup), bit-identical across the adversarial wave orders."""
+    be, inp, ref, T = _loop_case(lib, B=2, h=12, w=150)
+    try:
+        be.set_option("thin_slots", slots)
+        be.set_option("thin_xcd", 0)
+        old = be.denoise(inp["x_T"], inp["cond"], T, prec)
+        be.set_option("thin_xcd", 1)
+        outs = []
+        for order, late in ((0, 0), (1, 1)):
+            be.timing(order=order, dma_late=late)
+            outs.append(be.denoise(inp["x_T"], inp["cond"], T, prec))
+    finally:
+        be.set_option("thin_slots", 512); be.set_option("thin_xcd", 1)
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
+    assert maxabs(outs[0], ref) < LATENT_TOL[prec] * np.abs(ref).max()
+    assert maxabs(outs[0], old) < LATENT_TOL[prec] * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("wide,p4", [(1, 0)] + ([(0, 1), (1, 1), (0, 0)] if FULL else []))

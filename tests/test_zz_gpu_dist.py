@@ -49,3 +49,61 @@ def test_rccl_process_group_gradient_allreduce_and_sync_batchnorm_on_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", DD_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+# ---- bench.py's own multi-rank paths on the one GPU a box offers: every line below is the code N ranks run -------------------
+def _bench(argv, launcher, timeout=600):
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable]
+    if launcher:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    r = subprocess.run(cmd + [os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+QUICK = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--size", "nyu", "--batch", "2", "--no-cpu-baseline", "--no-train-extra", "--no-nlspn-extra",
+         "--no-head-extra", "--no-latency-b1", "--no-streams-extra"]
+
+
+def test_bench_line_under_the_launcher_runs_its_collectives_on_rccl_with_one_rank():
+    """`python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` (how the driver starts every rank of an N-GPU run): process group on
+    nccl = RCCL, barriers, the MAX all-reduce of the timed region, the rank census -- and the same line started plainly has no process group."""
+    r, d = _bench(["--gpus", "1"] + QUICK, launcher=True)
+    assert r.returncode == 0 and d is not None, r.stdout[-1500:] + r.stderr[-3000:]
+    assert d["n_gpus"] == 1 and d["config"]["ranks_seen"] == 1 and d["config"]["parallelism"].startswith("dp1 ")
+    assert d["config"]["process_group"] == "nccl (RCCL), world size 1" and "RCCL process group up: world size 1" in r.stderr
+    assert d["config"]["global_batch"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    r2, d2 = _bench(["--gpus", "1"] + QUICK, launcher=False)
+    assert r2.returncode == 0 and d2["config"]["process_group"] is None and d2["n_gpus"] == 1, r2.stderr[-2000:]
+
+
+def test_asking_for_more_gpus_than_the_box_has_fails_at_once_with_the_stated_message():
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box runs the real thing")
+    t0 = time.time()
+    r, d = _bench(["--gpus", "2"] + QUICK, launcher=False, timeout=180)
+    assert r.returncode != 0 and d is None and time.time() - t0 < 120
+    assert "only 1 HIP device(s) visible" in r.stderr + r.stdout and "no CPU fallback" in r.stderr + r.stdout
+    # ... and a launcher world size that contradicts --gpus is refused by every rank, not hung on
+    env = {k: v for k, v in os.environ.items()}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29599")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + QUICK, env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr + r.stdout
+
+
+def test_train_dp_under_the_launcher_takes_the_collective_path_with_one_rank():
+    """`--mode train-dp` under the launcher on one GPU: the overlapped gradient reducer is ACTIVE (post-accumulate hooks, async all-reduce on RCCL's
+    stream issued from inside backward, finish()) and SyncBatchNorm exchanges its statistics -- one rank, identity sums."""
+    r, d = _bench(["--gpus", "1", "--mode", "train-dp", "--variant", "res", "--size", "nyu", "--batch", "2", "--steps", "2", "--warmup", "1"], launcher=True)
+    assert r.returncode == 0 and d is not None, r.stdout[-1500:] + r.stderr[-3000:]
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["process_group"] == "nccl (RCCL), world size 1" and c["reducer_active"] and c["sync_batchnorm"]
+    assert d["collectives_launched_in_backward"] >= 1 and d["backward_reads_kept_states"] and d["value"] > 0
+    r2, d2 = _bench(["--gpus", "1", "--mode", "train-dp", "--variant", "res", "--size", "nyu", "--batch", "2", "--steps", "2", "--warmup", "1"], launcher=False)
+    assert r2.returncode == 0 and not d2["config"]["reducer_active"] and d2["config"]["process_group"] is None

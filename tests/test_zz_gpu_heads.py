@@ -39,6 +39,35 @@ def _load(head, sd):
     return head.cuda()
 
 
+HEADLINE_TOL = 1e-3 / 1.5          # the shipped ("fast" profile) mode f16r: depth RMSE vs the reference golden, with bench.py's margin
+
+
+def _check_fast_profile(dda, cls, chans, c, sd, fp, gt, inp, g, U, case, swin):
+    """The head as `profile="fast"` builds it (precision f16r, loss noise on the device) -- the configuration bench.py's headline and `head_forward`
+    time -- against the golden minted from the reference head: depth RMSE <= 1e-3 / 1.5 asserted, max-abs recorded (VERDICT r4 next #1a)."""
+    kw = dict(in_channels=list(chans)) if chans is not None else dict(in_channels=[64, 128, 256, 512])
+    hf = _load(getattr(dda, cls)(inference_steps=c["T"], num_train_timesteps=1000, depth_feature_dim=16, loss_cfgs=[], profile="fast", **kw).eval(), sd)
+    assert hf.model.precision == "f16r" and hf.loss_noise_device == "device" and hf.profile == "fast"
+    # the ONE extra denoiser call of ddim_loss: f16r for the Res denoiser, plain f16 for the Swin / MPViT one (forward-only hoisted plans are loop-only)
+    assert hf.model.single_call_precision == ("f16" if swin else "f16r")
+    out = _run(hf, fp, gt, inp, U)
+    pred = out["pred"].cpu().numpy()
+    rmse, mx = U.rms(pred, g["pred"]), U.maxabs(pred, g["pred"])
+    e_loss = abs(float(out["ddim_loss"]) - float(g["ddim_loss"][0])) / max(1.0, abs(float(g["ddim_loss"][0])))
+    U.record(case + "_f16r", depth_rmse=rmse, pred_maxabs=mx, ddim_loss_rel=e_loss, pred_max=float(g["pred"].max()),
+             ddim_loss_call_precision=hf.model.single_call_precision)
+    assert rmse <= HEADLINE_TOL, (case, rmse, mx)
+    assert e_loss < 2e-2, (case, e_loss)                      # a 16-bit-mode value of the same loss (fp32 heads: 1e-4)
+    be = hf._bound.backend
+    assert be.counter("graph_launches") >= 1
+    if swin:
+        # ... and the library itself refuses a single f16r call of this denoiser: the module's f16 substitution is the only way it runs
+        h, w = inp["x_T"].shape[-2:]
+        with pytest.raises(RuntimeError, match="hoisted forward-only"):
+            be.denoise_once(U.cu(inp["x_T"]), torch.tensor(500, device="cuda"), U.cu(inp["cond"]), "f16r")
+    return rmse, mx
+
+
 @pytest.mark.parametrize("case,cls,chans", [("head_swin_hahi", "DDIMDepthEstimate_Swin_ADDHAHI", (192, 384, 768, 1536)),
                                             ("head_mpvit_hahi", "DDIMDepthEstimate_MPVIT_ADDHAHI", (128, 216, 288, 288))], ids=["swin", "mpvit"])
 def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls, chans):
@@ -98,6 +127,7 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
         e_split = U.maxabs(_run(hs, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
         U.record(case + "_f16x3", pred_maxabs=e_split)
         assert e_split < 1e-3
+        _check_fast_profile(dda, cls, chans, c, sd, fp, gt, inp, g, U, case, swin=True)
     if case == "head_swin_hahi":
         # the neck's 1x1 / 3x3 convolutions ran in the library (dd_neck_condition), not in MIOpen: 3 launches per
         # pyramid level per forward -- and they equal the PyTorch neck + library FPN on the same features
@@ -131,6 +161,75 @@ def test_hahi_head_forward_matches_reference_golden(U, golden, cases, case, cls,
         e_split = U.maxabs(_run(hs, fp, gt, inp, U)["pred"].cpu().numpy(), g["pred"])
         U.record(case + "_f16x3", pred_maxabs=e_split)
         assert e_split < 1e-3
+        _check_fast_profile(dda, cls, chans, c, sd, fp, gt, inp, g, U, case, swin=True)
+
+
+def test_res_heads_in_the_fast_profile_match_the_reference_goldens(U, golden, cases):
+    """`profile="fast"` (f16r + device loss noise) for the Res heads: DDIMDepthEstimate_Res against `head_res`, DDIMDepthEstimate_ResVis against
+    `head_res_vis` (every intermediate sample through dd_denoise_trace in f16r)."""
+    import diffusiondepth_amd as dda
+    for case, cls in (("head_res", "DDIMDepthEstimate_Res"), ("head_res_vis", "DDIMDepthEstimate_ResVis")):
+        c, g = cases[case], golden(case)
+        sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+        sd.update(synth.make_fpn_state_dict(c["fseed"]))
+        B, H, W = c["B"], c["H"], c["W"]
+        fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+        gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+        h, w = synth.latent_hw(H, W)
+        inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
+        _check_fast_profile(dda, cls, None, c, sd, fp, gt, inp, g, U, case, swin=False)
+        if case == "head_res_vis":
+            hv = _load(dda.DDIMDepthEstimate_ResVis(in_channels=[64, 128, 256, 512], inference_steps=c["T"], num_train_timesteps=1000,
+                                                    depth_feature_dim=16, loss_cfgs=[], profile="fast").eval(), sd)
+            ov = _run(hv, fp, gt, inp, U)
+            inter = torch.stack(ov["pred_inter"]).cpu().numpy()
+            assert len(ov["pred_inter"]) == c["T"] and torch.equal(ov["pred_inter"][-1], ov["pred"])
+            U.record("head_res_vis_f16r", pred_inter_rmse=U.rms(inter, g["pred_inter"]), pred_inter_maxabs=U.maxabs(inter, g["pred_inter"]))
+            assert U.rms(inter, g["pred_inter"]) <= HEADLINE_TOL
+
+
+def test_head_defaults_are_the_reference_profile(U, cases):
+    """A head built with the reference's keywords alone: fp32, loss noise on the HOST generator (the reference's RNG streams: …res.py:203,207,277) --
+    two consecutive seeded forwards reproduce, draw for draw, what torch's generators hand the reference; the "fast" profile's private device
+    generator leaves the global device stream where the reference's draws expect it (same x_T on the second forward)."""
+    import diffusiondepth_amd as dda
+    c = cases["head_res"]
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    h, w = synth.latent_hw(H, W)
+    head = _load(dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=3, num_train_timesteps=1000, depth_feature_dim=16,
+                                           loss_cfgs=[]).eval(), sd)
+    assert head.profile == "reference" and head.model.precision == "fp32" and head.loss_noise_device == "cpu"
+    # what the reference's three draws per forward are, for two forwards, from the same seeds
+    torch.manual_seed(7240)
+    want = []
+    for _ in range(2):
+        x_T = torch.randn((B, 16, h, w), device="cuda")                 # …res.py:277 (device generator)
+        noise = torch.randn((B, 16, h, w))                              # …res.py:203 (HOST generator)
+        ts = torch.randint(0, 1000, (B,), device="cuda").long()         # …res.py:207 (device generator)
+        want.append((x_T, noise, ts))
+    outs = {}
+    for name, kw in (("reference", {}), ("fast", dict(profile="fast", precision="fp32"))):
+        hd = head if name == "reference" else _load(dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=3, num_train_timesteps=1000,
+                                                                                depth_feature_dim=16, loss_cfgs=[], **kw).eval(), sd)
+        torch.manual_seed(7240)
+        with torch.no_grad():
+            outs[name] = [hd(fp, gt, gt > 0, gt_depth_map=gt) for _ in range(2)]
+    be = head._bound.backend
+    for i, (x_T, noise, ts) in enumerate(want):
+        with torch.no_grad():
+            cond = head.aggregate_condition(fp)
+            x0 = be.denoise(x_T, cond, 3, "fp32")
+            pred = be.decode(x0)
+            eps = be.denoise_once(be.add_noise(x0, noise.cuda(), ts), ts, cond, "fp32")
+            loss = torch.nn.functional.mse_loss(eps, noise.cuda())
+        assert torch.equal(outs["reference"][i]["pred"], pred), i              # same x_T on forward 0 AND 1: the streams are the reference's
+        assert abs(float(outs["reference"][i]["ddim_loss"]) - float(loss)) <= 1e-6 * max(1.0, float(loss)), i
+        assert torch.equal(outs["fast"][i]["pred"], pred), i                   # the private generator did not advance the global device stream
+        assert np.isfinite(float(outs["fast"][i]["ddim_loss"]))
 
 
 def test_res_vis_head_returns_every_intermediate_sample(U, golden, cases):
@@ -174,7 +273,7 @@ def test_head_inference_switches(U, cases):
     h, w = synth.latent_hw(H, W)
     inp = synth.make_inputs(c["iseed"] + 2, B, h, w)
     outs = {}
-    for name, kw in (("ref", dict(loss_noise_device="cpu")), ("inf", dict(eval_ddim_loss=False)), ("dev", {})):      # (the default draws on the device in eval)
+    for name, kw in (("ref", {}), ("inf", dict(eval_ddim_loss=False)), ("dev", dict(loss_noise_device="device"))):      # (the default is the reference's host draw)
         head = _load(dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=5, num_train_timesteps=1000,
                                                depth_feature_dim=16, loss_cfgs=[], precision="fp32", **kw).eval(), sd)
         x_T = U.cu(inp["x_T"])
