@@ -429,6 +429,16 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     const double2 ov1 = make_double2(__shfl_xor(sv1.x, 1, 64), __shfl_xor(sv1.y, 1, 64));
     const bool hi = lane & 1;                  // this lane reduced groups 2,3 (hi) or 0,1
     const double2 g0 = hi ? ov0 : sv0, g1 = hi ? ov1 : sv1, g2 = hi ? sv0 : ov0, g3 = hi ? sv1 : ov1;
+    // Non-finite statistics (a NaN / Inf anywhere in the producing layer's output of this image -- e.g. a NaN in the caller's condition map): the
+    // reference's GroupNorm then returns NaN for the whole image and its ReLU keeps it (torch.relu(NaN) = NaN).  Here the ReLU is v_max_f32, which
+    // DROPS a NaN operand, so without help the image would come out finite and wrong.  Every thread holds all four groups' sums (the butterfly is
+    // redundant per wave), so each decides locally: poisoned -> this layer's bias (conv1: also c2 of the DDIM update) becomes NaN, every output of
+    // the image and its statistics are NaN, and the next layer does the same -- down to the final kernel, which writes the NaN image (dd_misc.hip).
+    const bool poisoned = !(((g0.x - g0.x) + (g0.y - g0.y)) + ((g1.x - g1.x) + (g1.y - g1.y)) + ((g2.x - g2.x) + (g2.y - g2.y)) + ((g3.x - g3.x) + (g3.y - g3.y)) == 0.0);
+    if (poisoned) {
+      if (tid < C::NT * C::SPW) tab_bias[tid] = __builtin_nanf("");      // (program-ordered behind this thread's own bias store above; read after the barrier below)
+      if constexpr (C::PRO == PRO_X) c2 = __builtin_nanf("");
+    }
     static_assert(C::PRO == PRO_RAW || C::CTAB <= C::THREADS, "one table channel per thread");
     if (tid < C::CTAB) {
       constexpr int CG = (C::CTAB > 0) ? C::CTAB / GN_GROUPS : 1;
@@ -706,7 +716,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
         if constexpr (C::RELU_OUT) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+          for (int i = 0; i < 4; ++i) v[i] = (v[i] < 0.f) ? 0.f : v[i];      // (once-per-image layers: torch.relu keeps a NaN, v_max_f32 drops it)
           if constexpr (C::IS_LAT) {
             // FPN top-down term: x = relu(bn(conv(f))) + pooled(up(pre_x))  (reference ...res.py:113-116)
             if (p.addend != nullptr && pvalid) {

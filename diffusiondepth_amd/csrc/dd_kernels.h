@@ -119,7 +119,6 @@ struct ConvParams {
   unsigned long long* prof; // -DDD_PHASE_PROF=1 builds only (tools/phase_prof.py): 8 x u64 per workgroup: wall-clock (100 MHz) at kernel entry,
                             // GroupNorm table done, first patch + weights in LDS, main loop done, stores issued, exit; [6] = HW_ID, [7] = XCC_ID
   int persist_slots;        // persistent kernels (dd_thin.hip): resident workgroup slots to fill (0 = 512: two per CU on the 256 CUs)
-  int xcd_map;              // persistent kernels (dd_thin.hip): 1 = XCD-aware workgroup -> tile map (contiguous tile blocks per XCD; option "thin_xcd"), 0 = round-3 map
   int ablate;               // TIMING EXPERIMENTS ONLY (results are wrong when non-zero): bit0 skip in-loop patch transform,
                             // bit1 skip in-loop patch loads, bit2 skip in-loop weight DMA, bit3 skip MFMAs, bit4 skip output
                             // stores, bit5 skip GroupNorm statistics, bit6 skip the per-stage barrier

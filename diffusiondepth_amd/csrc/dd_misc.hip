@@ -7,6 +7,9 @@
 #include "dd_gcn.h"
 
 namespace dd {
+// torch.relu / torch.clamp keep a NaN; fmaxf (v_max_f32) returns the other operand.  The once-per-image kernels of this file follow torch.
+__device__ __forceinline__ float relu_keep_nan(float v) { return (v < 0.f) ? 0.f : v; }
+
 
 __device__ __forceinline__ uint32_t cvt_bf16(float f) {
   uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -385,6 +388,7 @@ __global__ void __launch_bounds__(256) final_kernel(const float* __restrict__ x,
                                                     int step, int mode, float* __restrict__ out, long long HW) {
   __shared__ double s_sum[8];
   __shared__ float s_a[LATENT_C], s_b[LATENT_C];
+  __shared__ float s_poison;      // 0, or NaN when y4's statistics are not finite: the image is poisoned (dd_igemm2.hip) and comes out as NaN, as from the reference
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   if (tid < 8) {
@@ -404,9 +408,15 @@ __global__ void __launch_bounds__(256) final_kernel(const float* __restrict__ x,
     s_a[tid] = (float)a;
     s_b[tid] = (float)((double)beta[tid] - mean * a);
   }
+  if (tid == 0) {
+    double z = 0.0;
+    for (int k = 0; k < 8; ++k) z += s_sum[k] - s_sum[k];
+    s_poison = (z == 0.0) ? 0.f : __builtin_nanf("");
+  }
   __syncthreads();
   const long long p = (long long)blockIdx.x * blockDim.x + tid;
   if (p >= HW) return;
+  const float poison = s_poison;
   float c1 = 0.f, c2 = 1.f;
   if (mode == 0) { c1 = c1c2[2 * step]; c2 = c1c2[2 * step + 1]; }
   const float4* yv = reinterpret_cast<const float4*>(y4 + ((size_t)b * HW + p) * LATENT_C);
@@ -422,7 +432,7 @@ __global__ void __launch_bounds__(256) final_kernel(const float* __restrict__ x,
     for (int i = 0; i < 4; ++i) {
       const int c = q * 4 + i;
       const float e = fmaxf(fmaf(s_a[c], ys[i], s_b[c]), 0.f);
-      out[((size_t)b * LATENT_C + c) * HW + p] = (mode == 0) ? (c1 * xs[i] + c2 * e) : e;
+      out[((size_t)b * LATENT_C + c) * HW + p] = ((mode == 0) ? (c1 * xs[i] + c2 * e) : e) + poison;
     }
   }
 }
@@ -915,7 +925,7 @@ __global__ void __launch_bounds__(256) dec0_kernel(const float* __restrict__ lat
   float4* dst = reinterpret_cast<float4*>(tmp + ((size_t)b * H * W + p) * LATENT_C);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    dst[q] = make_float4(fmaxf(acc[4 * q], 0.f), fmaxf(acc[4 * q + 1], 0.f), fmaxf(acc[4 * q + 2], 0.f), fmaxf(acc[4 * q + 3], 0.f));
+    dst[q] = make_float4(relu_keep_nan(acc[4 * q]), relu_keep_nan(acc[4 * q + 1]), relu_keep_nan(acc[4 * q + 2]), relu_keep_nan(acc[4 * q + 3]));
 }
 
 __global__ void __launch_bounds__(256) dec1_kernel(const float* __restrict__ tmp, const float* __restrict__ w1, float b1,
@@ -941,7 +951,7 @@ __global__ void __launch_bounds__(256) dec1_kernel(const float* __restrict__ tmp
     }
   }
   const float sg = 1.f / (1.f + expf(-z));
-  depth[(size_t)b * H * W + p] = 1.f / fmaxf(sg, 1e-6f) - 1.f;
+  depth[(size_t)b * H * W + p] = 1.f / ((sg < 1e-6f) ? 1e-6f : sg) - 1.f;
 }
 
 // Fused decoder: one workgroup produces a 14x30 tile of the depth map.  The (7+2)x(15+2) latent patch and the ReLU'd
@@ -1024,7 +1034,7 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
       float4* dst = reinterpret_cast<float4*>(&s_mid[rk][c][0]);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        dst[q] = inside ? make_float4(fmaxf(acc[k][2 * q][0], 0.f), fmaxf(acc[k][2 * q][1], 0.f), fmaxf(acc[k][2 * q + 1][0], 0.f), fmaxf(acc[k][2 * q + 1][1], 0.f))
+        dst[q] = inside ? make_float4(relu_keep_nan(acc[k][2 * q][0]), relu_keep_nan(acc[k][2 * q][1]), relu_keep_nan(acc[k][2 * q + 1][0]), relu_keep_nan(acc[k][2 * q + 1][1]))
                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
@@ -1048,7 +1058,7 @@ __global__ void __launch_bounds__(256) dec_fused_kernel(const float* __restrict_
         }
       }
     const float sg = 1.f / (1.f + expf(-z));
-    depth[(size_t)b * H * W + (size_t)oy * W + ox] = 1.f / fmaxf(sg, 1e-6f) - 1.f;
+    depth[(size_t)b * H * W + (size_t)oy * W + ox] = 1.f / ((sg < 1e-6f) ? 1e-6f : sg) - 1.f;
   }
 }
 

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) naive_gn_apply_kernel(const float* __rest
   var = var > 0.0 ? var : 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)GN_EPS));
   float v = (y[i] - (float)mean) * rstd * gamma[c] + beta[c];
-  v = fmaxf(v, 0.f);
+  v = (v < 0.f) ? 0.f : v;      // torch.relu: keeps a NaN (fmaxf / v_max_f32 would drop it)
   if (cond) {
     const long long t = clamp_t(tvec[t_base + b * t_bstride]);
     v = (cond[i] + emb[(size_t)t * C + c]) + v;        // feat = feat + E[t]; feat = feat + NE(x)

@@ -73,32 +73,13 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   // timing experiments (-DDD_ABLATE=1 builds only; results are wrong): bit0 no patch transform / LDS writes, bit1 no prefetch loads, bit3 no fragment
   // reads / MFMAs, bit4 no output stores, bit5 no statistics atomics, bit6 no per-stage barrier, bit7 no weight copy
   const int abl = DD_ABLATE ? p.ablate : 0;
-  // workgroup -> (image, first tile ordinal, stride): persist_grid() launches B * n workgroups.  Round 5, XCD-aware: the dispatcher places block i on
-  // XCD i % 8 and every XCD has its own L2.  With b = i % B, tile = i / B (rounds 3-4) the tiles an XCD worked on at one time were spread over
-  // the whole image with ALL their neighbours on other XCDs -- every halo row / column came from HBM twice (PMC: 76.9 MB fetched for 56.5 MB of
-  // y3, profiles/pmc_traffic.json r04).  Now XCD x owns one contiguous run of ranks (the bijection of dd_igemm2.hip), a rank is (image, ordinal
-  // position) and ordinals enumerate the tiles in column strips of four (4 x 16-tile blocks: the 64 workgroups of an XCD that run at the same time
-  // share their halos through that XCD's L2; vertical neighbours -- two of ten patch rows -- matter most).  option "thin_xcd" = 0: the old map.
+  // workgroup -> (image, first tile, stride): persist_grid() launches B * n workgroups.  (Round 5 measured an XCD-aware map here -- every XCD one
+  // contiguous 4 x 16-tile block of an image, so that halo rows come out of its L2 instead of HBM twice: conv4 32.3 -> 34.3 us at KITTI B=4, i.e.
+  // SLOWER, A/B/A/B on one box; the interleaved map spreads every moment's loads over all HBM channels and that matters more than the 20 MB of
+  // halo re-reads: profiles/r05_experiments.md section 1.  Not kept.)
   const int wg = blockIdx.x, n_per_img = (int)gridDim.x / p.B;
-  int b, tl;
-  if (p.xcd_map) {
-    const int nwg = (int)gridDim.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-    const int rank = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);     // bijective for any nwg
-    b = rank / n_per_img;
-    tl = rank - b * n_per_img;
-  } else {
-    b = wg % p.B;
-    tl = wg / p.B;
-  }
-  // tile ordinal -> tile coordinates: column strips of SW tiles, row-major inside a strip (the last strip may be narrower)
-  constexpr int SW = 4;
-  const int strips_full = p.tiles_x / SW, per_strip = SW * p.tiles_y, w_last = p.tiles_x - strips_full * SW;
-  auto tile_yx = [&](int o, int& ty, int& tx) {
-    if (!p.xcd_map) { ty = o / p.tiles_x; tx = o - ty * p.tiles_x; return; }
-    const int s_ = o / per_strip;
-    if (s_ < strips_full) { const int rr = o - s_ * per_strip; ty = rr / SW; tx = s_ * SW + (rr - ty * SW); }
-    else { const int rr = o - strips_full * per_strip; ty = rr / w_last; tx = strips_full * SW + (rr - ty * w_last); }
-  };
+  const int b = wg % p.B;
+  int tl = wg / p.B;
 
   // ---- once per workgroup: weights -> LDS (the packed image IS the LDS image), bias, GroupNorm table of image b ----
   // Round 4: every load of the workgroup's start-up is ISSUED before anything waits -- the GroupNorm partial sums and gamma / beta (the fp64 table is
@@ -130,6 +111,9 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     const double2 ov1 = make_double2(__shfl_xor(sv1.x, 1, 64), __shfl_xor(sv1.y, 1, 64));
     const bool hi = lane & 1;
     const double2 g0 = hi ? ov0 : sv0, g1 = hi ? ov1 : sv1, g2 = hi ? sv0 : ov0, g3 = hi ? sv1 : ov1;
+    // non-finite statistics of y3: the image is poisoned (dd_igemm2.hip, same rule) -- conv4's bias becomes NaN, y4 and its statistics with it
+    const bool poisoned = !(((g0.x - g0.x) + (g0.y - g0.y)) + ((g1.x - g1.x) + (g1.y - g1.y)) + ((g2.x - g2.x) + (g2.y - g2.y)) + ((g3.x - g3.x) + (g3.y - g3.y)) == 0.0);
+    if (poisoned && tid < NROW) tab_bias[tid] = __builtin_nanf("");
     if (tid < CIN) {
       constexpr int CG = CIN / GN_GROUPS;
       const int grp = tid / CG;
@@ -160,8 +144,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
   const char* in_b = reinterpret_cast<const char*>(p.in) + (size_t)b * h * w * CIN * 2;
   // geometry of a tile: clamped pixel offsets of this thread's items and their inside-the-image mask
   auto geometry = [&](int t_local, int* po, unsigned& mi) {
-    int ty, tx;
-    tile_yx(t_local, ty, tx);
+    const int ty = t_local / p.tiles_x, tx = t_local - ty * p.tiles_x;
     mi = 0;
 #pragma unroll
     for (int u = 0; u < NIT; ++u) {
@@ -304,8 +287,7 @@ __global__ void __launch_bounds__(thin::THREADS, 4) conv4_stream_kernel(ConvPara
     }
     // ---- epilogue of this tile: bias, statistics, fp32 NHWC store (lane: pixel (wave, li), couts 4g..4g+3 and 8+4g..8+4g+3) ----
     {
-      int ty, tx;
-      tile_yx(tl, ty, tx);
+      const int ty = tl / p.tiles_x, tx = tl - ty * p.tiles_x;
       const int gy = ty * TH + wave, gx = tx * TW + li;
       if (gy < h && gx < w) {
 #pragma unroll

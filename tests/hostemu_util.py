@@ -62,7 +62,7 @@ def ptr(a):
 
 
 # ---- the whole library for the host: every csrc source + the harness units of tests/host_emul ------------------------------------------------------
-LIB_SOURCES = ("dd_api.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_wgrad2.hip", "dd_dcn.hip", "dd_thin.hip")
+LIB_SOURCES = ("dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_wgrad2.hip", "dd_dcn.hip", "dd_thin.hip")
 HARNESS_UNITS = ("ddepth_host.cpp", "igemm2_host.cpp")
 _FLAGS = ["-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-fPIC", "-c"]
 

@@ -59,7 +59,7 @@ def _check_fast_profile(dda, cls, chans, c, sd, fp, gt, inp, g, U, case, swin):
     assert rmse <= HEADLINE_TOL, (case, rmse, mx)
     assert e_loss < 2e-2, (case, e_loss)                      # a 16-bit-mode value of the same loss (fp32 heads: 1e-4)
     be = hf._bound.backend
-    assert be.counter("graph_launches") >= 1
+    assert be.counter("graph_launches") >= 1 or hf._VIS          # (the *Vis heads run dd_denoise_trace: eager launches, every state kept)
     if swin:
         # ... and the library itself refuses a single f16r call of this denoiser: the module's f16 substitution is the only way it runs
         h, w = inp["x_T"].shape[-2:]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Builds a variant of the library with extra compile flags into build_variants/libddepth_<name>.so (git-ignored; travels to the GPU box).
-Only dd_igemm2.hip (and dd_api.cpp when --api is given) are recompiled; the other objects come from the default build.
+Only dd_igemm2.hip (and the dd_api*.cpp units when --api is given) are recompiled; the other objects come from the default build.
 
     python tools/build_variant.py c3_2 -DDD_C3=2
 Use with DDEPTH_LIBRARY=build_variants/libddepth_<name>.so (tools/variant_bench.py)."""
@@ -14,7 +14,7 @@ def main():
     b.build()                                             # default objects up to date
     outdir = os.path.join(ROOT, "build_variants"); os.makedirs(outdir, exist_ok=True)
     hipcc = b.find_hipcc()
-    redo = ["dd_igemm2.hip", "dd_thin.hip"] + (["dd_api.cpp"] if "--api" in sys.argv else [])
+    redo = ["dd_igemm2.hip", "dd_thin.hip"] + (["dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp"] if "--api" in sys.argv else [])
     objs = []
     for src in b.SOURCES:
         base = os.path.splitext(src)[0]

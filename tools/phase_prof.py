@@ -22,7 +22,7 @@ def build():
     for src in b.SOURCES:
         obj = os.path.join(ROOT, "build_variants", "prof_" + os.path.splitext(src)[0] + ".o")
         cmd = [hipcc] + [f for f in b.FLAGS if f != "-shared"] + ["-DDD_PHASE_PROF=1"] + os.environ.get("DDEPTH_CFLAGS", "").split() + ["-x", "hip", "-c", os.path.join(b.CSRC, src), "-o", obj]
-        if src not in ("dd_api.cpp", "dd_igemm2.hip") and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(os.path.join(b.CSRC, src)):
+        if src not in ("dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp", "dd_igemm2.hip") and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(os.path.join(b.CSRC, src)):
             objs.append(obj); continue
         print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
