@@ -164,7 +164,7 @@ def head_extra(dev, B, H, W, precision, T, variant="res"):
 
     def timed(head, n=7):
         # median of per-forward times: one host-side pause (a 25-ms stall between two library calls was traced in a 5-forward average:
-        # profiles/r02_run29_lanes_head_trace.md) must not pass for the forward's cost
+        # profiles/history/r02_run29_lanes_head_trace.md) must not pass for the forward's cost
         ts = []
         with torch.no_grad():
             for _ in range(2):
@@ -484,7 +484,7 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     # the interpreter's cyclic collector stays out of the timed regions of this file (a 25-ms host pause between two library calls was
-    # traced in a head-forward average: profiles/r02_run29_lanes_head_trace.md); nothing of the step is skipped by that
+    # traced in a head-forward average: profiles/history/r02_run29_lanes_head_trace.md); nothing of the step is skipped by that
     gc.collect()
     gc.disable()
     # The timed region of the contract -- EXACTLY K steps between barrier + synchronize on both sides, MAX over ranks -- is measured `--repeats`

@@ -148,7 +148,7 @@ class HipDenoiser:
         # (dd_set_option "streams": +6..13 % throughput on MI355X, per-image results bit-identical).  The C library's default is 1; this
         # binding's is 2 (the whole GPU suite passes either way; DDEPTH_STREAMS=1 turns it off); bench.py pins 1 for its headline line,
         # whose roofline object is defined per launch on one stream.  (An apparent instability of the head forward under it was a host-side
-        # pause in a short average: profiles/r02_run29_lanes_head_trace.md.)
+        # pause in a short average: profiles/history/r02_run29_lanes_head_trace.md.)
         self.n_streams = max(1, int(os.environ.get("DDEPTH_STREAMS", "2") or 2))
         if self.n_streams > 1:
             self.set_option("streams", self.n_streams)
@@ -298,7 +298,7 @@ class HipDenoiser:
         test() feeds one image at a time): a launch of the two large convolutions has ceil(h / 8) * ceil(w / 32) workgroups per image
         and the chip holds `resident_slots` of them (two per CU), so a lane needs about two rounds of them for the tail of one
         round to disappear under the next -- lanes x ceil(2 * slots / tiles per image).  KITTI 176x608: 6; NYU 114x152: 28
-        (measured: KITTI B=4 -> 16 +5 %; NYU B=4 -> 16 +48 %, profiles/r03_*, r04_*)."""
+        (measured: KITTI B=4 -> 16 +5 %; NYU B=4 -> 16 +48 %, profiles/history/r03_*, r04_*)."""
         tiles = ((int(lat_h) + 7) // 8) * ((int(lat_w) + 31) // 32)
         slots = self.counter("resident_slots")
         return self.n_streams * max(1, -(-2 * slots // tiles))

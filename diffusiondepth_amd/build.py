@@ -20,7 +20,7 @@ HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + \
           [os.path.join("..", "..", "include", f) for f in sorted(os.listdir(os.path.join(HERE, "..", "include"))) if f.endswith(".h")]
 # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar fp32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32, and packed fp32 VALU beside
 # running MFMAs costs ~22 cycles more per instruction than its two scalar halves (MI355X_MICROARCH.md; measured here: the 20-step loop 7.38 ->
-# 6.90 ms with this flag and scalar FMAs in the prologue, profiles/r02_run14_no_packed_fp32.md)
+# 6.90 ms with this flag and scalar FMAs in the prologue, profiles/history/r02_run14_no_packed_fp32.md)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 

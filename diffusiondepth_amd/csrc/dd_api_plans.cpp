@@ -119,7 +119,7 @@ bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
   if (h->big_tiles >= 0) return h->big_tiles != 0;
   // more 8x32 tiles than resident slots: 16x32 tiles under concurrent lanes (half the weight stream and 0.75 LDS reads per MFMA: what counts when
   // the other lane keeps the chip full anyway); a call that runs as ONE lane keeps the 8x32 tiles in their one-patch-buffer form (three workgroups
-  // per CU: conv3 140 -> 132 us at KITTI B=4, profiles/r04_call3_*) -- the Res denoiser's conv3; the Swin 5x5 form has no such kernel
+  // per CU: conv3 140 -> 132 us at KITTI B=4, profiles/history/r04_call3_*) -- the Res denoiser's conv3; the Swin 5x5 form has no such kernel
   const bool many = (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > h->resident_slots;
   return many && (key.lanes > 1 || h->variant == DD_VARIANT_SWIN);
 }

@@ -719,7 +719,7 @@ int launch_prop(const float* fin, const float* offset, const float* aff, const f
   const bool can_vec4 = KF == 3 && (W % 4 == 0) && aligned16(fin) && aligned16(offset) && aligned16(aff) && aligned16(out) &&
                         (blend == nullptr || (aligned16(fix) && aligned16(blend)));
   const bool can_pair = W >= 2;
-  // default (measured on MI355X, profiles/r01_run35_nlspn.md): LDS window, 16-row tiles, pair-load fallback
+  // default (measured on MI355X, profiles/history/r01_run35_nlspn.md): LDS window, 16-row tiles, pair-load fallback
   PropChoice c{16, 1, can_pair, false};
   if (const char* e = getenv("DD_NLSPN_KERNEL")) {
     const std::string m(e);

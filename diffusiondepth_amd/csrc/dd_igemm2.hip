@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   if constexpr (C::ADD_T) my_bias += p.ttab[tid < HID_C ? tid : 0];        // hoisted Swin form: + the E[t] term of the reference border class
   // hoisted condition term: this thread's entries of the E[t] tap-sum row.  Only the LOADS are issued here (into registers): the LDS
   // image is written behind the GroupNorm butterfly and read in the epilogue, so the timestep -> etab row -> LDS dependency does
-  // not sit in front of the partial-sum / patch / accumulator loads (it cost ~4 us of every workgroup: profiles/r02_run3_phase_profile.md)
+  // not sit in front of the partial-sum / patch / accumulator loads (it cost ~4 us of every workgroup: profiles/history/r02_run3_phase_profile.md)
   constexpr int NET = C::ADD_C ? (10 * HID_C + C::THREADS - 1) / C::THREADS : 1;
   float et_r[NET];
   if constexpr (C::ADD_C) {

@@ -1,8 +1,8 @@
 // dd_igemm2_cfg.h -- per-layer tiling constants of the fused convolution kernels (dd_igemm2.hip).
-// Variants that were measured slower on MI355X and removed in round 2 (profiles/r01_run30_power_and_variants.md,
-// profiles/r02_run1_ddimloss_and_winograd.md): wave-specialised staging waves, a 16x32 / 8-wave / 9-taps-per-stage conv3 tile with
+// Variants that were measured slower on MI355X and removed in round 2 (profiles/history/r01_run30_power_and_variants.md,
+// profiles/history/r02_run1_ddimloss_and_winograd.md): wave-specialised staging waves, a 16x32 / 8-wave / 9-taps-per-stage conv3 tile with
 // and without ping-pong halves, persistent conv1 / conv4 workgroups, in-loop interleaving of the prologue, Winograd F(2x2,3x3).
-// Round 3 (profiles/r03_run2_variants.md): the next stage's weight DMA issued between the tap groups of the MFMA block, conv1 at eight
+// Round 3 (profiles/history/r03_run2_variants.md): the next stage's weight DMA issued between the tap groups of the MFMA block, conv1 at eight
 // waves per SIMD, eight-wave "latency variants" of conv2 / conv3, a persistent conv3.
 #pragma once
 #include "dd_elem.h"
@@ -23,7 +23,7 @@
 //   1 = 8x32 pixels, 16-channel chunks, 9 taps per stage (36 MFMAs per wave between barriers)
 //   2 = 16x32 pixels, 4 waves x (128 pixels x 64 couts), 16-channel chunks, 9 taps per stage (72 MFMAs between barriers, 0.75 LDS reads per MFMA)
 // Round 3: tiling 2 is ALSO instantiated beside the default as the kernel ids BIG_CONV3C / BIG_CONV3H (layers 8 / 9) and picked per launch when
-// the tiles do not fit the chip at once -- under the two concurrent lanes it is worth +1.8 % at B=4 and +4 % at B=8 (profiles/r03_run2_variants.md).
+// the tiles do not fit the chip at once -- under the two concurrent lanes it is worth +1.8 % at B=4 and +4 % at B=8 (profiles/history/r03_run2_variants.md).
 #ifndef DD_C3
 #define DD_C3 1
 #endif
@@ -196,7 +196,7 @@ template <int EKM_, int LAYER_ID_> struct Cfg2 {
   // read, behind a second workgroup barrier per stage, instead of into a twin buffer under the running stage.  63 -> 52 KB of LDS = THREE
   // workgroups per CU (12 waves, three per SIMD; the kernel needs 160 VGPRs) where the two-buffer form has two: a wave spends ~20 % of a stage in
   // its MFMA block and the rest waiting for memory, the weight DMA or a barrier -- it lacks co-resident waves, not issue slots.  Measured
-  // (round 4, profiles/r04_call3_*): conv3 at KITTI B=4 on one stream 140 -> 132 us (bf16), 147 -> 137 (f16r); neutral under two lanes and at B=1
+  // (round 4, profiles/history/r04_call3_*): conv3 at KITTI B=4 on one stream 140 -> 132 us (bf16), 147 -> 137 (f16r); neutral under two lanes and at B=1
   static constexpr bool ONEBUF = LAYER_ID_ == ONE_CONV3H;
   static_assert(!ONEBUF || (C3 == 1 && NCHUNK > 1), "one-buffer form: the 8x32 tiling of the 2-byte kinds");
   static constexpr int NPB = (NCHUNK > 1 && !ONEBUF) ? 2 : 1;       // patch buffers

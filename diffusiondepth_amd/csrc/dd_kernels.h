@@ -41,7 +41,7 @@ constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2
 // behind a GroupNorm, whose output is bounded -- the unbounded inputs, the state x of conv1 and the raw tensors the Swin convB / pred.0 read,
 // are carried unscaled: f16 overflows only beyond |v| = 65504) so that the lo halves of ordinary values stay in f16's normal range, and the
 // epilogue multiplies the accumulators by the exact inverse.  (gfx950's f16 MFMA honours subnormal inputs -- tools/micro/f16_denorm_probe.hip,
-// profiles/r03_run1_f16_denorm_probe.txt -- so the scaling buys bits for small values, it is not needed for correctness.)  It is the
+// profiles/history/r03_run1_f16_denorm_probe.txt -- so the scaling buys bits for small values, it is not needed for correctness.)  It is the
 // abs-1e-3-on-depth mode at ~1/3 of the 16-bit MFMA rate (5x the fp32-operand MFMA rate): DESIGN.md section 4.
 // EK_F16R is the third MODE: "refined f16" (DD_PREC_F16R; round 4) -- the 16-bit mode that holds the depth tolerance at KITTI's depth range.
 // tools/bf16_error_budget.py --log-scale 1.8 shows that the f16 mode's depth error (1.0e-3 RMSE at 0.5..60 m) is NOT made by the two large
@@ -56,7 +56,7 @@ constexpr int STAT_STRIDE = 16;   // doubles per slot (128 B): [g*2+0]=sum, [g*2
 //                    staging item is 8 channels of one pixel), the hoisted term as int16 with one scale per accumulator block (32 pixels x 32
 //                    couts: a wave-uniform scalar in conv3's accumulator initialisation).  f16's bytes at ~15 bits relative to the block's largest
 //                    value: 4e-5 instead of f16's 3.5e-4 depth RMSE per tensor (the emulator; an fp32 hand-over measured the same error at
-//                    conv3 +26 us / conv4 +15 us per step and was dropped: profiles/r04_call1_*, r04_call2_*)
+//                    conv3 +26 us / conv4 +15 us per step and was dropped: profiles/history/r04_call1_*, r04_call2_*)
 //   conv4            weights as an f16 pair hi + lo IN ONE MFMA: the 32 x 32 x 16 instruction has 32 cout rows and conv4 16 couts, so rows
 //                    16..31 of the A operand -- zero padding until now -- carry lo * 2^11 and the epilogue adds the two accumulator halves
 //                    (lane-local: register quads q and q + 2); option "f16r_p4": the operand relu(gn3(y3)) as a pair as well (two MFMAs)

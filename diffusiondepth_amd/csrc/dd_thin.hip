@@ -1,6 +1,6 @@
 // dd_thin.hip -- conv4 of the denoiser (64 -> 16, `model.pred.3`; reference src/model/head/ddim_depth_estimate_res.py:319-321) as a PERSISTENT
 // STREAMING kernel.  (conv1 -- 16 -> 64 with the fused DDIM update -- was built the same way in round 3 and measured: 40.3 -> 38.8 us at
-// B=4, 70.9 -> 66.2 at B=8, 15.8 -> 17.3 at B=1; not kept: profiles/r03_run2_variants.md.)
+// B=4, 70.9 -> 66.2 at B=8, 15.8 -> 17.3 at B=1; not kept: profiles/history/r03_run2_variants.md.)
 //
 // conv4 carries 3 % of the step's FLOPs and is bound by memory: 192 algorithmic bytes per latent pixel (y3 in, y4 out) against 18 kFLOP.  As an
 // instance of the general convolution kernel (dd_igemm2.hip, one workgroup per tile) it ran at 0.27-0.29 of the HBM rate: a workgroup's life
@@ -21,7 +21,7 @@
 //           Same MFMA count, same LDS traffic; conv4's weight rounding -- the largest single term of the f16 mode's depth error -- is gone.
 //   INQ     y3 arrives as int16 with one fp32 scale per pixel (EK_F16R, dd_kernels.h: f16's bytes, ~15 bits relative to the pixel's largest channel)
 //           instead of the 2-byte kind: one more 4-byte load per staging item.  (An fp32 y3 -- two 16-byte loads per item, a two-slot register ring
-//           to stay inside 128 VGPRs -- was built first and measured: same depth error, conv4 30 -> 45 us; removed: profiles/r04_call1_*.)
+//           to stay inside 128 VGPRs -- was built first and measured: same depth error, conv4 30 -> 45 us; removed: profiles/history/r04_call1_*.)
 //   PSPLIT  the operand relu(gn3(y3)) as an f16 pair as well (scaled by 2^4 so that lo halves stay normal): a second LDS plane per patch buffer and
 //           a second MFMA per tap against the same stacked weight fragment -- [Whi; Wlo] . (Phi + Plo) = all four partial products
 // Same arithmetic as layer 4 of dd_igemm2.hip: the packed weight image of that layer (16-channel chunks, nine taps per stage, 32 cout rows,

@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = {"naive_fp32": 1e-4, "fp32": 1e-4, "f16": 6e-2, "bf16": 2e-1}
 # K-step SGD trajectory, bf16 mode against fp32 (test_bf16_training_tracks_the_fp32_trajectory_over_sgd_steps): bounds = 2x measured
-# (measured, profiles/r03_run2_parity_report.jsonl: loss 1.9e-3 / 7.1e-3, step-0 gradients 0.060 / 0.091 worst tensor (the first conv's weight;
+# (measured, profiles/history/r03_run2_parity_report.jsonl: loss 1.9e-3 / 7.1e-3, step-0 gradients 0.060 / 0.091 worst tensor (the first conv's weight;
 #  most tensors 0.01-0.03), accumulated parameter change 0.062 / 0.199 worst tensor, cosine 0.998 / 0.980)
 SGD_LOSS_REL = {"res": 4e-3, "swin": 1.5e-2}
 SGD_GRAD0_REL = {"res": 0.12, "swin": 0.18}

@@ -1,7 +1,7 @@
 """GPU (`-m gpu`), last in collection order on purpose: the device route of the denoiser parameters (dd_set_weight_device -> pack kernels of
 dd_misc.hip; include/ddepth.h).  It is what keeps a training iteration's parameter refresh in HBM after optimizer.step(); it has been
 validated bit for bit against the host packer under host emulation (tests/test_library_host_emulation.py); this file passed on an
-MI355X in round 2 (profiles/r02_run10_pytest_gpu.txt), since when the route is the default (DDEPTH_DEVICE_WEIGHTS=1)."""
+MI355X in round 2 (profiles/history/r02_run10_pytest_gpu.txt), since when the route is the default (DDEPTH_DEVICE_WEIGHTS=1)."""
 import numpy as np
 import pytest
 import torch

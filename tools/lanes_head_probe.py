@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py's default run once showed the head forward (second handle, two lanes) at 14.8 instead of 9.2 ms after the bench's own handle
 had run lanes, a B=1 plan and a training pass.  Replays that order and prints per-forward times and the head backend's counters.  Finding
-(profiles/r02_run29_lanes_head_trace.md): ONE forward of the five stalls ~25 ms on the host between two library calls; the others take 8.5 ms."""
+(profiles/history/r02_run29_lanes_head_trace.md): ONE forward of the five stalls ~25 ms on the host between two library calls; the others take 8.5 ms."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ["DDEPTH_STREAMS"] = sys.argv[1] if len(sys.argv) > 1 else "2"

@@ -16,7 +16,7 @@ constexpr unsigned SPIN_MAX = 1u << 17;      // ~20 ms: a barrier that does not 
 // Agent scope: an sc1 load (misses the CU's vector L1, coherent across XCDs).  "Workgroup" scope is used here for the counters that live in ONE
 // XCD's L2: a workgroup-scope LOAD may hit the CU's own L1 (the scope only promises coherence inside a workgroup), so the poll is an atomic
 // read-modify-write of zero -- atomics always execute at the L2, which is shared by the XCD's CUs (first version of this probe polled with
-// sc0 loads and timed out: profiles/r04_call2_grid_sync_probe2.txt).
+// sc0 loads and timed out: profiles/history/r04_call2_grid_sync_probe2.txt).
 template <int SCOPE> __device__ __forceinline__ bool spin_until(unsigned* ctr, unsigned target) {
   for (unsigned s = 0; s < SPIN_MAX; ++s) {
     const unsigned v = SCOPE == __HIP_MEMORY_SCOPE_WORKGROUP ? __hip_atomic_fetch_add(ctr, 0u, __ATOMIC_RELAXED, SCOPE) : __hip_atomic_load(ctr, __ATOMIC_RELAXED, SCOPE);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite database (what `rocprofv3 --kernel-trace --stats` writes on ROCm 7.2)
 into the per-kernel statistics table that is committed under profiles/.
-    python tools/rocpd_stats.py gpurun_out/prof/bench_results.db > profiles/r01_kernel_stats.md"""
+    python tools/rocpd_stats.py gpurun_out/prof/bench_results.db > profiles/history/r01_kernel_stats.md"""
 import sqlite3
 import sys
 
