@@ -21,6 +21,14 @@ Extra objects in the line (tier contract):
   roofline      dominant kernel (conv3x3 implicit GEMM) measured live with hipEvents on the launch
                 stream (library option "layer_timing"): achieved TFLOP/s = algorithmic FLOPs per launch
                 (2*9*Cin*Cout*B*h*w) / mean launch duration, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+                When profiles/kernel_stats.json (the committed rocprofv3 --kernel-trace --stats summary) carries the stamp of THESE library sources and
+                this configuration, the top-level achieved / frac / avg_launch_us use ITS clock (the figure anybody can recompute from profiles/) and
+                the live measurement sits beside it as `live_events`; otherwise the live figure is on top and `clock_of_achieved` says so.
+  spread        the contract's timed region -- exactly K steps between barrier + synchronize -- is measured `--repeats` (3) times; `value` is the MEDIAN
+                region, every region and the min / median / max of the individual steps (one event per step) are listed.
+  named_dtype / abs_clean (+ flat named_dtype_bf16_* / abs_clean_f16x3_* scalars)   the same step in BASELINE.json's named dtype (bf16 operands) and in
+                the abs-clean split-f16 mode, with their depth errors at KITTI's range -- at the line's FIRST level.
+  head_forward  the drop-in head's forward() in its DEFAULT profile ("reference": fp32, host-side loss noise) and in profile "fast" (this line's precision).
   cpu_baseline  the reference's OWN classes (staged as bytecode under oracle/_ref/py by oracle/ref_py/build_ref.py; kind "reference") or, when
                 that staging is absent, the torch-CPU port of the reference path (oracle/torch_cpu_port.py; kind "port"), timed on this
                 host's cores for ONE map of the same workload (N = 1, rank 0 only).

@@ -88,6 +88,8 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   if (k == "graph") h->use_graph = value != 0;
   else if (k == "timing") h->timing = value != 0;
   else if (k == "debug_sync") h->debug_sync = value != 0;
+  else if (k == "check_finite") h->check_finite = (int)value;
+  else if (k == "train_graphs") h->train_graphs = value != 0;
   else if (k == "ablate") {
     if (h->ablate != (int)value) {            // kernel parameters are baked into captured graphs
       DD_HIP(hipDeviceSynchronize());
@@ -414,7 +416,15 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
     return DD_OK;
   }
 
-  const bool want_graph = h->use_graph && !h->layer_timing && !h->debug_sync && !pl->capture_failed;
+  // A plan that KEEPS its trajectory -- the forward of a training step -- is enqueued eagerly (option "train_graphs" = 1 restores the graph).  Round 5
+  // found 16-bit training steps producing non-finite values intermittently (3 of 8 processes within 40 iterations, always in iterations 20..34 of
+  // a process; never with fp32 operands, never forward-only, never with ANY host synchronisation, extra kernel or serialisation added between
+  // the stages -- every observation made the symptom go away) and the one switch that separates clean from failing runs with no other change is
+  // whether this forward is a replayed hipGraph: 0 of 12 processes fail with eager launches, 9 of 21 with the graph (A/B alternating on one
+  // box: profiles/r05_experiments.md section 4).  The cause inside the graph replay next to the backward's ~600-launch eager bursts was not
+  // established; the eager form costs the 59-ms training step nothing measurable and the inference plans (hundreds of replays per bench run,
+  // parity-checked) are not affected.
+  const bool want_graph = h->use_graph && !h->layer_timing && !h->debug_sync && !pl->capture_failed && (!keep || h->train_graphs);
   bool launched = false;
   if (want_graph) {
     if (!pl->exec) {

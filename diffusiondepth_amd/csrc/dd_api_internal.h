@@ -232,6 +232,9 @@ struct dd_handle_s {
   DevBuf d_acp;
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
+  bool train_graphs = false;          // option "train_graphs": 1 = the trajectory-keeping forward of a training step replays a hipGraph too (A/B; default eager)
+  int check_finite = 0;        // 1 = synchronise after every stage; 2 = count asynchronously, report at the end of the call (no host synchronisation in between)
+  DevBuf chk_buf; std::vector<std::string> chk_labels;      // check_finite == 2: one counter per checked stage of the running call   // option "check_finite" (debug): the backward synchronises after every stage and fails with the name of the first tensor holding a NaN / Inf
   int ablate = 0;             // timing experiments only (ConvParams::ablate)
   unsigned long long* prof_buf = nullptr;   // tools/phase_prof.py (-DDD_PHASE_PROF=1 builds): caller-owned device buffer, 8 x u64 per workgroup
   int prof_layer = 0;         // the kernel layer id whose launches write it

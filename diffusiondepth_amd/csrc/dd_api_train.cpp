@@ -75,6 +75,26 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   const int ek = opnd_kind(mode);           // gradients, materialised activations, weight-gradient operands: bf16 in the mode EK_BF16M
   const int yk = store_kind(mode);          // the stored conv outputs y1..y3 and the condition map (f16 in that mode)
   int rc = DD_OK;
+  // option "check_finite" (debug): after a stage, count the non-finite elements of what it wrote; the first hit fails the call by name
+  auto chk = [&](const char* what, int l, const void* ptr, long long n, int kind) -> int {
+    if (!h->check_finite) return DD_OK;
+    if (h->check_finite == 2) {      // asynchronous: one counter per stage, read by check_finite_report at the end of the call
+      if (!h->chk_buf.p || h->chk_labels.size() >= 16384) return DD_OK;      // (a multi-lane call does not open a report: counters are per call, not per lane)
+      DD_HIP(launch_count_nonfinite(ptr, n, kind, h->chk_buf.as<unsigned>() + h->chk_labels.size(), s));
+      h->chk_labels.push_back(std::string(what) + " of layer " + std::to_string(l) + " (step slot " + std::to_string(sstep) + ", lane " + std::to_string(lane) + ")");
+      return DD_OK;
+    }
+    if (!h->wmax.p) DD_HIP(h->wmax.alloc(sizeof(unsigned)));
+    DD_HIP(hipMemsetAsync(h->wmax.p, 0, sizeof(unsigned), s));
+    DD_HIP(launch_count_nonfinite(ptr, n, kind, h->wmax.as<unsigned>(), s));
+    unsigned c = 0;
+    DD_HIP(hipMemcpyAsync(&c, h->wmax.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    DD_HIP(hipStreamSynchronize(s));
+    if (c) return h->fail(DD_ERR_HIP, std::string("check_finite: ") + what + " of layer " + std::to_string(l) + " (step slot " + std::to_string(sstep) + ", lane " +
+                                      std::to_string(lane) + ") holds " + std::to_string(c) + " non-finite values of " + std::to_string(n));
+    return DD_OK;
+  };
+  const int kk = (opnd_kind(pl->ek) == EK_F32) ? 0 : (opnd_kind(pl->ek) == EK_BF16 ? 1 : 2);
   if (!kept) DD_HIP(hipMemsetAsync(pl->stat_ptr(0, 0), 0, (size_t)4 * B * STAT_SLOTS * STAT_STRIDE * sizeof(double), s));
   const int lay = naive ? 0 : 1;                    // activation layout flag of the views: plain NHWC fp32 / channel-blocked
   const ActView nothing{nullptr, EK_F32, 0, 1, HW};
@@ -139,6 +159,9 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       DD_HIP(launch_gn_param_grad(pl->dgb.as<double>(), dgam, dbet, B, C, s));
       DD_HIP(launch_channel_sum(gyv, dbias, nullptr, 0, 0, B, s));
     }
+    rc = chk("GroupNorm-backward sums (dgb)", l, pl->dgb.p, (long long)B * C * (vec ? 4 : 2), 3); if (rc) return rc;
+    rc = chk("dLoss/dy (gY)", l, pl->gY.p, (long long)B * C * HW, naive ? 0 : kk); if (rc) return rc;
+    rc = chk("the conv's input activation", l, inbuf[l], (long long)B * CI * HW, naive ? 0 : kk); if (rc) return rc;
     float* dw = grad_buf(h, std::string(kConvNames[l]) + ".weight", (size_t)C * CI * 9, s, &e, lane); DD_HIP(e);
     const ActView inv{inbuf[l], ek_g, lay, CI, HW};
     if (!naive && ek != EK_F32 && !h->naive_wgrad) {
@@ -160,6 +183,8 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
       q.in = pl->gY.p; q.wpack = h->L[l].wpackT[ek].p; q.bias = h->zero_bias.as<float>(); q.out = pl->gA.p;
       DD_HIP(launch_conv_igemm2(layer, ek, q, s));          // data gradients: plain kinds (bf16 in the mode EK_BF16M)
     }
+    rc = chk("weight gradient (dw, accumulated)", l, dw, (long long)C * CI * 9, 0); if (rc) return rc;
+    rc = chk("dLoss/d(input) out of the data-gradient convolution (gA)", l, pl->gA.p, (long long)B * CI * HW, (naive || l == 0) ? 0 : kk); if (rc) return rc;
     if (l == 2 && swin) {
       // Swin fuse (reference ...swin_addHAHI.py:321-333,378): sf = convB(sa), sa = convA(u), u = relu(gn2(y2)) + up(cond) + E[t];
       // no norm / activation in between.  gA = dLoss/dsf on entry, dLoss/du on exit (gY is the scratch in between).
@@ -208,6 +233,25 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   return DD_OK;
 }
 
+// option "check_finite" = 2: counters of the running backward call
+int check_finite_begin(dd_handle_t h, hipStream_t s) {
+  if (h->check_finite != 2) return DD_OK;
+  if (!h->chk_buf.p) DD_HIP(h->chk_buf.alloc(16384 * sizeof(unsigned)));
+  DD_HIP(hipMemsetAsync(h->chk_buf.p, 0, 16384 * sizeof(unsigned), s));
+  h->chk_labels.clear();
+  return DD_OK;
+}
+int check_finite_report(dd_handle_t h, hipStream_t s) {
+  if (h->check_finite != 2 || h->chk_labels.empty()) return DD_OK;
+  std::vector<unsigned> c(h->chk_labels.size());
+  DD_HIP(hipMemcpyAsync(c.data(), h->chk_buf.p, c.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  DD_HIP(hipStreamSynchronize(s));
+  for (size_t i = 0; i < c.size(); ++i)
+    if (c[i]) return h->fail(DD_ERR_HIP, "check_finite: first non-finite tensor of this backward (stage " + std::to_string(i) + " of " + std::to_string(c.size()) + "): " +
+                                          h->chk_labels[i] + ": " + std::to_string(c[i]) + " values");
+  return DD_OK;
+}
+
 int check_bwd(dd_handle_t h, int precision, const char* who) {
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_SWIN has no unfused path (use fp32 / bf16 / f16)");
@@ -250,11 +294,12 @@ int dd_denoise_once_backward(dd_handle_t h, const float* x_t, const int64_t* t, 
       kept = it->second.get();
   }
   if (kept) h->n_traj_reuse++;
+  rc = check_finite_begin(h, s); if (rc) return rc;
   rc = bwd_core(h, pl, pl->x[0].as<float>(), reinterpret_cast<const long long*>(t), 0, 1, grad_cond, 0, s, kept, 0);
   if (rc) return rc;
   if (grad_x) DD_HIP(launch_nhwc_to_nchw_f32(pl->gA.p, EK_F32, grad_x, B, LATENT_C, lat_h, lat_w, 0, s));
   h->last_once_plan = pl;
-  return DD_OK;
+  return check_finite_report(h, s);
 }
 
 }  // extern "C"
@@ -344,9 +389,10 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
   const int S = lane_count(h, B, precision);
   bool reused = false;
   if (S <= 1) {
+    rc = check_finite_begin(h, s); if (rc) return rc;
     rc = denoise_backward_lane(h, x_T, cond, grad_x0, grad_xT, grad_cond, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, &reused, 1);
     if (rc == DD_OK && reused) h->n_traj_reuse++;
-    return rc;
+    return rc ? rc : check_finite_report(h, s);
   }
   for (int l = 1; l < S; ++l) {
     if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));

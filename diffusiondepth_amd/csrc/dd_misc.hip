@@ -1151,6 +1151,24 @@ __global__ void __launch_bounds__(256) max_abs_kernel(const float* __restrict__ 
   for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(m, off, 64); m = (o > m || o != o) ? o : m; }
   if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, m));
 }
+// debug (option "check_finite"): number of non-finite elements of a tensor (kind 0 fp32, 1 bf16, 2 f16, 3 fp64) added to *out
+__global__ void __launch_bounds__(256) count_nonfinite_kernel(const void* __restrict__ p, long long n, int kind, unsigned* __restrict__ out) {
+  unsigned c = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float v;
+    if (kind == 0) v = static_cast<const float*>(p)[i];
+    else if (kind == 1) v = bf16_to_f32(static_cast<const uint16_t*>(p)[i]);
+    else if (kind == 2) v = f16_to_f32(static_cast<const uint16_t*>(p)[i]);
+    else { const double d = static_cast<const double*>(p)[i]; v = (d - d == 0.0) ? 0.f : __builtin_nanf(""); }
+    if (!(v - v == 0.f)) ++c;
+  }
+  if (c) atomicAdd(out, c);
+}
+hipError_t launch_count_nonfinite(const void* p, long long n, int kind, unsigned* out, hipStream_t s) {
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb)), dim3(256), 0, s, p, n, kind, out);
+  return hipGetLastError();
+}
 hipError_t launch_max_abs(const float* w, long long n, unsigned* out_bits, hipStream_t s) {
   const unsigned nb = (unsigned)((n + 256 * 8 - 1) / (256 * 8));
   hipLaunchKernelGGL(max_abs_kernel, dim3(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb)), dim3(256), 0, s, w, n, out_bits);

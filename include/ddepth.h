@@ -232,7 +232,11 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * handle -- all lanes and shapes -- also held against the free device memory; stale sets are dropped first, and a forward that cannot
  * keep its activations keeps the states only), "thin_stream" (1 [default] = conv4 runs as the persistent streaming kernel of
  * csrc/dd_thin.hip in the 16-bit modes, 0 = as an instance of the general kernel: A/B switch), "thin_slots" (workgroups of that kernel,
- * default 512 = two per CU), "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
+ * default 512 = two per CU), "train_graphs" (0 [default] = a forward that keeps its trajectory -- a training step -- is
+ * enqueued eagerly, 1 = it replays a captured hipGraph like the inference plans: round 5 measured intermittent non-finite values in 16-bit training
+ * steps only with the graph), "check_finite" (debug: the backward counts the non-finite values of every tensor it writes and fails
+ * with the name of the first one; 1 = synchronising after every stage, 2 = asynchronously, reported at the end of the call),
+ * "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
  * "f16r_wide" (DD_PREC_F16R: 1 [default] = y3 and the hoisted conv3(cond) term travel as int16 with block scales -- one fp32 scale per pixel of y3, per
  * 32-pixel x 32-cout accumulator block of the hoisted term: f16's bytes at ~15 bits --, 0 = as f16 like in DD_PREC_F16), "f16r_c1" (DD_PREC_F16R:
  * 1 [default] = conv1's weights as an f16 pair (two MFMAs), 0 = the plain f16 kernel), "one_buffer" (1 [default] = the loop's hoisted conv3 on

@@ -358,6 +358,37 @@ def test_refined_f16_reads_an_explicit_condition_tensor_in_place(U):
         assert np.isfinite(b).all() and np.array_equal(a, b) and np.array_equal(ea, eb), (B, h, w)
 
 
+@pytest.mark.parametrize("variant", ["res", "swin"])
+def test_a_nan_in_the_inputs_poisons_that_image_and_only_that_image(U, variant):
+    """The reference turns ONE NaN / Inf of an image's condition map or x_T into an all-NaN prediction for that image (GroupNorm spreads it, torch.relu keeps
+    it).  The kernels' ReLU (v_max_f32) drops a NaN operand, so the library carries it through the GroupNorm statistics instead:
+    every precision, the loop at KITTI size (two lanes, 16x32 tiles) and on a ragged size, single calls, and the decoder; the clean image of the batch is
+    bit-identical to its clean run."""
+    c = {"wseed": 7240, "variant": variant}
+    be = U.backend_for(c)
+    for (B, h, w, T) in ((2, 176, 608, 3), (2, 9, 33, 2)):
+        chw = None if variant == "res" else ((h + 1) // 2, (w + 1) // 2)
+        inp = synth.make_inputs(321 + h, B, h, w, chw)
+        x, cond = U.cu(inp["x_T"]), U.cu(inp["cond"])
+        bad_c = cond.clone()
+        bad_c[1, 7, bad_c.shape[2] // 2, 5] = float("nan")
+        bad_x = x.clone()
+        bad_x[0, 3, h // 2, w // 3] = float("inf")
+        for prec in ("f16r", "f16", "bf16", "f16x3", "fp32"):
+            clean = be.denoise(x, cond, T, prec)
+            assert torch.isfinite(clean).all(), prec
+            out = be.denoise(x, bad_c, T, prec)
+            assert torch.isnan(out[1]).all(), (variant, prec, h, "a NaN of the condition map was lost", int(torch.isnan(out[1]).sum()))
+            assert torch.equal(out[0], clean[0]), (variant, prec, h, "the clean image of the batch changed")
+            out = be.denoise(bad_x, cond, T, prec)
+            assert torch.isnan(out[0]).all() and torch.equal(out[1], clean[1]), (variant, prec, h, "an Inf of x_T was lost")
+            if not (variant == "swin" and prec == "f16r"):
+                eps = be.denoise_once(x, torch.full((B,), 321, device="cuda", dtype=torch.long), bad_c, prec)
+                assert torch.isnan(eps[1]).all() and torch.isfinite(eps[0]).all(), (variant, prec, h, "single call")
+        d = be.decode(out)
+        assert torch.isnan(d[0]).all() and torch.isfinite(d[1]).all()
+
+
 # ---- Swin / MPViT variant of the denoiser (SURVEY.md 8a row a3): UpSample_add fuse, stride-4 condition map ----
 @pytest.mark.parametrize("prec", ["fp32", "f16x3", "bf16", "f16"])
 def test_swin_variant_single_call_and_loop_vs_reference(U, golden, cases, prec):
