@@ -359,6 +359,13 @@ class CNNDDIMPipiline:
                 image = _DenoiseLoopFn.apply(be, self.model.precision, int(num_inference_steps), image.float().contiguous(),
                                              input_args[0].float().contiguous(), *_ordered_params(self.model)).to(dtype)
             else:
+                if self.model.variant == "swin" and str(self.model.precision).lower() == "bf16" and not getattr(self.model, "_warned_bf16_inference", False):
+                    # bf16 operands are this denoiser's TRAINING precision: its inference depth RMSE is 1.3e-3 at the near range and 7.6e-3 at KITTI's
+                    # range with the synthetic weights -- outside the 1e-3 tolerance; the in-tolerance modes are f16r / f16x3 / fp32
+                    import warnings
+                    warnings.warn("diffusiondepth_amd: precision='bf16' on the Swin / MPViT denoiser is its training precision; for inference it is outside "
+                                  "the 1e-3 depth tolerance (use precision='f16r', or 'f16x3' / 'fp32' for the absolute bound)", stacklevel=3)
+                    self.model._warned_bf16_inference = True
                 image = be.denoise(image.float(), input_args[0].float(), num_inference_steps, self.model.precision).to(dtype)
         else:
             for t in self.scheduler.timesteps:
