@@ -78,8 +78,21 @@ def _cc(cxx, src, obj, incs):
     return subprocess.run(cmd, capture_output=True, text=True)
 
 
+class _BuildLock:
+    """One host build at a time across processes (pytest-xdist workers share build/host_emul): the first worker compiles, the others find its cache."""
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(OUT, exist_ok=True)
+        self.f = open(os.path.join(OUT, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+
+    def __exit__(self, *a):
+        self.f.close()
+
+
 def _objects():
-    """Compile (in parallel, cached by the hash of every input) all translation units; -> (cxx, {unit: object path})."""
+    """Compile (in parallel, cached by the hash of every input) all translation units; -> (cxx, {unit: object path}).  Call under _BuildLock."""
     from concurrent.futures import ThreadPoolExecutor
     cxx = _clangxx()
     if cxx is None:
@@ -129,17 +142,19 @@ def build_library():
     (emu_*) executing on the CPU.  DD_EMU_LIB=<path> substitutes a hand-built variant."""
     if os.environ.get("DD_EMU_LIB"):
         return ctypes.CDLL(os.environ["DD_EMU_LIB"])
-    cxx, objs, objdir = _objects()
-    so = os.path.join(objdir, "libddepth_hostemu.so")
-    if not os.path.exists(so):
-        _link(cxx, objs.values(), so)
+    with _BuildLock():
+        cxx, objs, objdir = _objects()
+        so = os.path.join(objdir, "libddepth_hostemu.so")
+        if not os.path.exists(so):
+            _link(cxx, objs.values(), so)
     return ctypes.CDLL(so)
 
 
 def build_mutant(unit, old, new, tmp_path, count=None):
     """The library with ONE source file textually changed (old -> new): only that unit is recompiled.  For the tests that check that the
     emulation notices a broken kernel."""
-    cxx, objs, _ = _objects()
+    with _BuildLock():
+        cxx, objs, _ = _objects()
     src = open(os.path.join(CSRC, unit)).read()
     n = src.count(old)
     assert n >= 1 and (count is None or n == count), "mutation anchor not found %d times in %s: the source changed, update the test" % (n, unit)
