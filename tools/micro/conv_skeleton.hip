@@ -1,0 +1,132 @@
+// conv_skeleton.hip -- the MAIN LOOP of conv2 (64 -> 256, csrc/dd_igemm2.hip, Cfg2<EK_F16, 2>) as a skeleton: which part of the gap between the kernel
+// (0.35 of the f16 MFMA peak) and the power-capped ceiling of its instruction mix (0.52-0.54: tools/micro/mfma_mix.hip) is the STAGE STRUCTURE -- weight
+// stage by LDS-DMA one stage ahead, counted wait, workgroup barrier, 32 MFMAs + 24 fragment reads per wave and stage -- and which part is everything
+// around the loop (prologue / epilogue of a workgroup's life, occupancy, tails)?
+// A persistent workgroup (4 waves, 78 KB of LDS: two per CU, as conv2) owns a 10 x 34 x 64-channel patch image in LDS (random f16, written once) and
+// runs `tiles` x 18 stages; a stage = [issue the next stage's 16 KB of weights global -> LDS ring by LDS-DMA] [32 MFMAs (4 k-steps x 4 cout blocks x 2 pixel
+// blocks) with 16 weight-fragment + 8 patch-fragment ds_read_b128, fragments double-buffered by k-step] [s_waitcnt vmcnt(0)] [s_barrier].  No prologue,
+// no epilogue, no global stores: the loop alone.  The 295-KB weight image is shared by all workgroups (L2 / MALL resident, as in the kernel).
+// Variants (template MODE bits): 1 = no weight DMA (the ring keeps its first contents), 2 = no barrier, 4 = the DMA of stage s + 2 instead of s + 1
+// into a 3-slot ring of 8-KB HALF stages (16 MFMAs between barriers, the same 32 KB of ring: the DMA gets two half stages = the same time to land,
+// but the barrier count doubles -- the structure round 3 measured inside the kernel), 8 = one workgroup per CU (LDS padded to 100 KB).
+//   hipcc --offload-arch=gfx950 -O3 -I diffusiondepth_amd/csrc -o build_variants/conv_skeleton tools/micro/conv_skeleton.hip && build_variants/conv_skeleton
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "dd_gcn.h"
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int PATCH_BYTES = 10 * 34 * 64 * 2;          // 43 520
+constexpr int STAGE_BYTES = 128 * 64 * 2;              // one tap x 128 couts x 64 channels: 16 384
+constexpr int NSTAGE = 18;                             // 9 taps x 2 cout splits
+constexpr int WIMG_BYTES = NSTAGE * STAGE_BYTES;       // 294 912
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, float* out, int tiles, unsigned seed) {
+  constexpr bool NO_DMA = MODE & 1, NO_BAR = MODE & 2, HALF = MODE & 4;
+  constexpr int SLOT = HALF ? STAGE_BYTES / 2 : STAGE_BYTES, NSLOT = HALF ? 4 : 2, AHEAD = HALF ? 3 : 1;
+  constexpr int KSTEPS = HALF ? 2 : 4;                 // k-steps (16 channels) per stage
+  constexpr int NST = HALF ? 2 * NSTAGE : NSTAGE;
+  DD_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned s = seed ^ (tid * 2654435761u) ^ (blockIdx.x * 40503u);
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) | 0x38003800u) & 0x3bff3bffu; };
+  uint4* l4 = reinterpret_cast<uint4*>(smem);
+  for (int i = tid; i < (PATCH_BYTES + NSLOT * SLOT) / 16; i += 256) l4[i] = make_uint4(rnd(), rnd(), rnd(), rnd());
+  __syncthreads();
+  const unsigned lds_base = DD_LDS_BASE(smem);
+  auto issue = [&](int st) {                           // stage st (mod NST) -> ring slot st % NSLOT: this wave's share, 1 KiB per instruction
+    if (NO_DMA) return;
+    const int sl = st % NSLOT, sg = st % NST;
+#pragma unroll
+    for (int kc = 0; kc < SLOT / 1024 / 4; ++kc) {
+      const int piece = kc * 4 + wave;
+      const char* src = wimg + (size_t)sg * SLOT + piece * 1024 + lane * 16;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + PATCH_BYTES + sl * SLOT + piece * 1024);
+      DD_LDS_DMA16(smem, src, dst);
+    }
+  };
+  f32x16_t acc[4][2];
+  for (int n = 0; n < 4; ++n) for (int m = 0; m < 2; ++m) for (int j = 0; j < 16; ++j) acc[n][m][j] = 0.f;
+  // per-lane fragment addresses: a weight fragment = 16 B of row (cout block n, lane & 31), k-half lane >> 5; a patch fragment = 16 B of pixel
+  const int wrow = (lane & 31) * 32 + (lane >> 5) * 16;                       // inside a (32 couts x 16 channels) block of 1 KiB
+  // patch fragment of pixel (row, col): 16-B piece (2 * k-step + k-half) of its 128-B row, XOR-swizzled by the column (conflict-free b128 reads, as the kernel's image)
+  const int g = lane >> 5, li = lane & 31;
+#pragma unroll 1
+  for (int a = 0; a < AHEAD; ++a) issue(a);
+  if (!NO_DMA) DD_WAIT_VM(0);
+  __syncthreads();
+  int st = 0;
+#pragma unroll 1
+  for (int t = 0; t < tiles; ++t) {
+#pragma unroll 1
+    for (int sg = 0; sg < NST; ++sg, ++st) {
+      issue(st + AHEAD);
+      const int wbase = PATCH_BYTES + (st % NSLOT) * SLOT;
+      const int tap = (HALF ? sg / 2 : sg) % 9, dy = tap / 3, dx = tap % 3;
+      const int col = li + dx, pk = g ^ (col & 7);
+      const int pbase = ((wave * 2 + dy) * 34 + col) * 128;
+      const int kofs = HALF ? (sg & 1) * 2 : 0;
+#pragma unroll
+      for (int k = 0; k < KSTEPS; ++k) {
+        uint4 wf[4], pf[2];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) wf[n] = *reinterpret_cast<const uint4*>(smem + wbase + (k * 4 + n) * 1024 + wrow);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) pf[m] = *reinterpret_cast<const uint4*>(smem + pbase + m * 34 * 128 + ((((k + kofs) * 2) ^ pk) << 4));
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            acc[n][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, wf[n]), __builtin_bit_cast(f16x8_t, pf[m]), acc[n][m], 0, 0, 0);
+      }
+      if (NO_DMA) DD_WAIT_LGKM0(); else if (HALF) DD_WAIT_VM_LGKM0(4) ; else DD_WAIT_VM_LGKM0(0);
+      if (!NO_BAR) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if ((t & 7) == 7) for (int n = 0; n < 4; ++n) for (int m = 0; m < 2; ++m) for (int j = 0; j < 16; ++j) acc[n][m][j] *= 1e-30f;
+  }
+  if (!NO_DMA) DD_WAIT_VM(0);
+  float r = 0.f;
+  for (int n = 0; n < 4; ++n) for (int m = 0; m < 2; ++m) for (int j = 0; j < 16; ++j) r += acc[n][m][j];
+  if (r == 123.456f) out[0] = r;
+}
+
+template <int MODE> static double run(const char* wimg, float* out, double secs) {
+  const int lds = (MODE & 8) ? 100 * 1024 : PATCH_BYTES + 2 * STAGE_BYTES + 2048;     // 78 336 B: two workgroups per CU
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int blocks = 256 * ((MODE & 8) ? 1 : 2), tiles = 64;
+  hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u);
+  (void)hipDeviceSynchronize();
+  auto t0 = std::chrono::steady_clock::now();
+  int n = 0; double el = 0;
+  while (el < secs) { hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u); (void)hipDeviceSynchronize(); ++n;
+                      el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+  // per wave and tile: 18 stages x 32 MFMAs (in every variant)
+  return (double)n * blocks * 4 * tiles * 18.0 * 32.0 * 32768.0 / el * 1e-12;
+}
+
+int main(int argc, char** argv) {
+  const double secs = argc > 1 ? atof(argv[1]) : 1.0;
+  std::vector<unsigned> hw(WIMG_BYTES / 4);
+  unsigned s = 99u;
+  for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = ((s >> 9) | 0x38003800u) & 0x3bff3bffu; }
+  char* wimg; float* out;
+  (void)hipMalloc(&wimg, WIMG_BYTES); (void)hipMalloc(&out, 4);
+  (void)hipMemcpy(wimg, hw.data(), WIMG_BYTES, hipMemcpyHostToDevice);
+  printf("conv2 main-loop skeleton: 4-wave workgroups, 0.75 ds_read_b128 per MFMA, ~0.1 VALU per MFMA; TFLOP/s (fraction of 2500)\n");
+#define ROW(MODE, label) { double a = run<MODE>(wimg, out, secs); printf("%-92s %8.0f (%.3f)\n", label, a, a / 2500); fflush(stdout); }
+  ROW(0, "weight DMA one stage ahead + wait + barrier per 32 MFMAs, 2 WG/CU (the kernel's loop)")
+  ROW(1, "no weight DMA (barrier kept)")
+  ROW(2, "weight DMA + wait, no barrier")
+  ROW(3, "neither (fragment reads + MFMAs only: the mix microbenchmark's row 0.75 / 0)")
+  ROW(4, "8-KB half stages, 4-slot ring, DMA three half stages ahead, barrier per 16 MFMAs")
+  ROW(8, "the kernel's loop, ONE workgroup per CU")
+  ROW(9, "no weight DMA, ONE workgroup per CU")
+  ROW(0, "the kernel's loop, 2 WG/CU (again: drift check)")
+  return 0;
+}

@@ -12,8 +12,17 @@ from oracle import ddim_oracle as O
 name = os.path.basename(os.environ.get("DDEPTH_LIBRARY", "default"))
 sd = synth.make_state_dict(7240)
 be = dda.HipDenoiser(); be.load_state_dict(sd); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+# with DD_CMP=1: the full-size result under the library's default options, to compare the optioned run against (same process, same inputs)
+cmp_ref = None
+if os.environ.get("DD_CMP"):
+    _i = synth.make_inputs(7240, 4, 176, 608)
+    _prec = os.environ.get("DD_PRECS", "bf16").split(",")[0]
+    cmp_ref = be.denoise(torch.from_numpy(_i["x_T"]).cuda(), torch.from_numpy(_i["cond"]).cuda(), 20, _prec).cpu().numpy()
 for kv in filter(None, os.environ.get("DD_OPTS", "").split(",")):      # e.g. DD_OPTS=gn_table=0,hoist_cond=0
     k, v = kv.split("="); be.set_option(k, int(v)); name += f" {k}={v}"
+if cmp_ref is not None:
+    got = be.denoise(torch.from_numpy(_i["x_T"]).cuda(), torch.from_numpy(_i["cond"]).cuda(), 20, _prec).cpu().numpy()
+    print(f"[{name}] KITTI B=4 {_prec} vs default options: max |diff| / max |x_0| = {float(np.abs(got - cmp_ref).max()) / float(np.abs(cmp_ref).max()):.3e}, finite {bool(np.isfinite(got).all())}", flush=True)
 ok = True
 for (B, h, w, T) in [(2, 9, 33, 3), (1, 24, 40, 5), (2, 17, 70, 2)]:
     inp = synth.make_inputs(50 + h, B, h, w)
