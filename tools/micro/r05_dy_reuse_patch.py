@@ -1,3 +1,8 @@
+# Applies the row-reuse MFMA block of profiles/r05_experiments.md section 2 to dd_igemm2.hip / dd_igemm2_cfg.h IN PLACE (the sources of the commit it was cut from;
+# every anchor is asserted).  Run it as `python tools/micro/r05_dy_reuse_patch.py apply` -- without the word it does nothing; undo with `git checkout -- diffusiondepth_amd/csrc`.
+import sys
+if sys.argv[1:] != ["apply"]:
+    sys.exit("usage: python tools/micro/r05_dy_reuse_patch.py apply   (edits diffusiondepth_amd/csrc in place)")
 p='/root/repo/diffusiondepth_amd/csrc/dd_igemm2.hip'
 s=open(p).read()
 old='''    int wa[NKQ];
