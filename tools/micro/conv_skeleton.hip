@@ -9,12 +9,17 @@
 // Variants (template MODE bits): 1 = no weight DMA (the ring keeps its first contents), 2 = no barrier, 4 = the DMA of stage s + 2 instead of s + 1
 // into a 3-slot ring of 8-KB HALF stages (16 MFMAs between barriers, the same 32 KB of ring: the DMA gets two half stages = the same time to land,
 // but the barrier count doubles -- the structure round 3 measured inside the kernel), 8 = one workgroup per CU (LDS padded to 100 KB).
+// The phases AROUND the loop, added one at a time (second part of the table): 16 = behind each cout split (stages 8 and 17) every lane stores its 128 f16 outputs
+// of the split as 16 x 16 bytes to its own region of a 1-GB buffer (the kernel's 64 KB per split and workgroup), 32 = in front of each tile the workgroup fetches a
+// 43.5-KB patch from global memory (11 x 16 bytes per thread), runs ~30 VALU per item on it and writes it into the LDS patch image behind a barrier, 64 = the
+// stores of bit 16 not in one burst but two per stage over the FOLLOWING split's nine stages (what parking a split's packed outputs in registers would buy).
 //   hipcc --offload-arch=gfx950 -O3 -I diffusiondepth_amd/csrc -o build_variants/conv_skeleton tools/micro/conv_skeleton.hip && build_variants/conv_skeleton
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 #include "dd_gcn.h"
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -25,8 +30,9 @@ constexpr int NSTAGE = 18;                             // 9 taps x 2 cout splits
 constexpr int WIMG_BYTES = NSTAGE * STAGE_BYTES;       // 294 912
 
 template <int MODE>
-__global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, float* out, int tiles, unsigned seed) {
-  constexpr bool NO_DMA = MODE & 1, NO_BAR = MODE & 2, HALF = MODE & 4;
+__global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, float* out, int tiles, unsigned seed, char* gbuf) {
+  constexpr bool NO_DMA = MODE & 1, NO_BAR = MODE & 2, HALF = MODE & 4, STORES = MODE & 16, PATCH = MODE & 32, SPREAD = MODE & 64;
+  static_assert(!(HALF && (STORES || PATCH)), "the phase models are written for full stages");
   constexpr int SLOT = HALF ? STAGE_BYTES / 2 : STAGE_BYTES, NSLOT = HALF ? 4 : 2, AHEAD = HALF ? 3 : 1;
   constexpr int KSTEPS = HALF ? 2 : 4;                 // k-steps (16 channels) per stage
   constexpr int NST = HALF ? 2 * NSTAGE : NSTAGE;
@@ -61,11 +67,48 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
   if (!NO_DMA) DD_WAIT_VM(0);
   __syncthreads();
   int st = 0;
+  // this workgroup's region of the global buffer: 16 tile slots x (128 KB of outputs + 64 KB to fetch patches from)
+  char* my = gbuf + (size_t)blockIdx.x * (16 * 192 * 1024);
+  uint4 keep[16];                                    // SPREAD: the packed outputs of the split that just finished
+  for (int i = 0; i < 16; ++i) keep[i] = make_uint4(0u, 0u, 0u, 0u);
+  int pending = 0;                                   // SPREAD: stores of `keep` still to issue
+  char* pend_dst = my;
 #pragma unroll 1
   for (int t = 0; t < tiles; ++t) {
-#pragma unroll 1
-    for (int sg = 0; sg < NST; ++sg, ++st) {
+    char* tslot = my + (size_t)(t & 15) * (192 * 1024);
+    if constexpr (PATCH) {
+      // prologue model: 680 x 4 = 2720 sixteen-byte items of the patch image, 11 per thread (clamped), a GroupNorm-apply's worth of VALU, LDS write, barrier
+      uint4 raw[11];
+#pragma unroll
+      for (int u = 0; u < 11; ++u) { const int it = u * 256 + tid; raw[u] = *reinterpret_cast<const uint4*>(tslot + 128 * 1024 + (size_t)(it < 2720 ? it : 2719) * 16); }
+#pragma unroll
+      for (int u = 0; u < 11; ++u) {
+        float f[4] = {__builtin_bit_cast(float, raw[u].x), __builtin_bit_cast(float, raw[u].y), __builtin_bit_cast(float, raw[u].z), __builtin_bit_cast(float, raw[u].w)};
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(0.9999f), "v"(1e-4f));
+        const int it = u * 256 + tid;
+        if (it < 2720) *reinterpret_cast<uint4*>(smem + it * 16) = make_uint4(((__builtin_bit_cast(unsigned, f[0]) >> 9) | 0x38003800u) & 0x3bff3bffu, ((__builtin_bit_cast(unsigned, f[1]) >> 9) | 0x38003800u) & 0x3bff3bffu,
+                                                                            ((__builtin_bit_cast(unsigned, f[2]) >> 9) | 0x38003800u) & 0x3bff3bffu, ((__builtin_bit_cast(unsigned, f[3]) >> 9) | 0x38003800u) & 0x3bff3bffu);
+      }
+      DD_WAIT_LGKM0();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    auto stage = [&](int sg, auto kic) {
+      constexpr int KI = decltype(kic)::value;     // the stage's index inside its cout split (0..8), or -1 in the half-stage form
       issue(st + AHEAD);
+      if constexpr (SPREAD && KI >= 0) {
+        if constexpr (KI < 8) {
+          if (pending > 0) {                         // two of the parked stores per stage: keep[2 KI], keep[2 KI + 1] (compile-time indices: registers, not scratch)
+            DD_GLOBAL_STORE16_UNTRACKED(pend_dst + ((size_t)(2 * KI) * 256 + tid) * 16, make_float4(__builtin_bit_cast(float, keep[2 * KI].x), __builtin_bit_cast(float, keep[2 * KI].y), __builtin_bit_cast(float, keep[2 * KI].z), __builtin_bit_cast(float, keep[2 * KI].w)));
+            DD_GLOBAL_STORE16_UNTRACKED(pend_dst + ((size_t)(2 * KI + 1) * 256 + tid) * 16, make_float4(__builtin_bit_cast(float, keep[2 * KI + 1].x), __builtin_bit_cast(float, keep[2 * KI + 1].y), __builtin_bit_cast(float, keep[2 * KI + 1].z), __builtin_bit_cast(float, keep[2 * KI + 1].w)));
+          }
+        } else {
+          pending = 0;
+        }
+      }
       const int wbase = PATCH_BYTES + (st % NSLOT) * SLOT;
       const int tap = (HALF ? sg / 2 : sg) % 9, dy = tap / 3, dx = tap % 3;
       const int col = li + dx, pk = g ^ (col & 7);
@@ -87,6 +130,37 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
       if (NO_DMA) DD_WAIT_LGKM0(); else if (HALF) DD_WAIT_VM_LGKM0(4) ; else DD_WAIT_VM_LGKM0(0);
       if (!NO_BAR) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (STORES) {
+        if (KI == 8) {
+          // epilogue model of one cout split: the wave's 64 pixels x 128 couts as f16 = 16 x 16 bytes per lane, ~6 VALU per output in front of them
+          char* dst = tslot + (sg == 17 ? 64 * 1024 : 0);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            f32x16_t& a = acc[i & 3][(i >> 2) & 1];
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f[j] = a[(i >> 3) * 8 + j]; 
+#pragma unroll
+              for (int r = 0; r < 5; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j]) : "v"(0.9999f), "v"(1e-4f)); }
+            const uint4 v = make_uint4(__builtin_bit_cast(unsigned, f[0]) ^ __builtin_bit_cast(unsigned, f[1]), __builtin_bit_cast(unsigned, f[2]) ^ __builtin_bit_cast(unsigned, f[3]),
+                                       __builtin_bit_cast(unsigned, f[4]) ^ __builtin_bit_cast(unsigned, f[5]), __builtin_bit_cast(unsigned, f[6]) ^ __builtin_bit_cast(unsigned, f[7]));
+            if constexpr (SPREAD) keep[i] = v;
+            else DD_GLOBAL_STORE16_UNTRACKED(dst + ((size_t)i * 256 + tid) * 16, make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w)));
+          }
+          if constexpr (SPREAD) { pending = 16; pend_dst = dst; }
+        }
+      }
+    };
+    if constexpr (HALF) {
+#pragma unroll 1
+      for (int sg = 0; sg < NST; ++sg, ++st) stage(sg, std::integral_constant<int, -1>{});
+    } else {
+#pragma unroll 1
+      for (int sp = 0; sp < 2; ++sp) {
+        stage(sp * 9 + 0, std::integral_constant<int, 0>{}); ++st; stage(sp * 9 + 1, std::integral_constant<int, 1>{}); ++st; stage(sp * 9 + 2, std::integral_constant<int, 2>{}); ++st;
+        stage(sp * 9 + 3, std::integral_constant<int, 3>{}); ++st; stage(sp * 9 + 4, std::integral_constant<int, 4>{}); ++st; stage(sp * 9 + 5, std::integral_constant<int, 5>{}); ++st;
+        stage(sp * 9 + 6, std::integral_constant<int, 6>{}); ++st; stage(sp * 9 + 7, std::integral_constant<int, 7>{}); ++st; stage(sp * 9 + 8, std::integral_constant<int, 8>{}); ++st;
+      }
     }
     if ((t & 7) == 7) for (int n = 0; n < 4; ++n) for (int m = 0; m < 2; ++m) for (int j = 0; j < 16; ++j) acc[n][m][j] *= 1e-30f;
   }
@@ -96,15 +170,16 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
   if (r == 123.456f) out[0] = r;
 }
 
+static char* g_buf = nullptr;
 template <int MODE> static double run(const char* wimg, float* out, double secs) {
   const int lds = (MODE & 8) ? 100 * 1024 : PATCH_BYTES + 2 * STAGE_BYTES + 2048;     // 78 336 B: two workgroups per CU
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int blocks = 256 * ((MODE & 8) ? 1 : 2), tiles = 64;
-  hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u);
+  hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u, g_buf);
   (void)hipDeviceSynchronize();
   auto t0 = std::chrono::steady_clock::now();
   int n = 0; double el = 0;
-  while (el < secs) { hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u); (void)hipDeviceSynchronize(); ++n;
+  while (el < secs) { hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u, g_buf); (void)hipDeviceSynchronize(); ++n;
                       el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   // per wave and tile: 18 stages x 32 MFMAs (in every variant)
   return (double)n * blocks * 4 * tiles * 18.0 * 32.0 * 32768.0 / el * 1e-12;
@@ -118,6 +193,8 @@ int main(int argc, char** argv) {
   char* wimg; float* out;
   (void)hipMalloc(&wimg, WIMG_BYTES); (void)hipMalloc(&out, 4);
   (void)hipMemcpy(wimg, hw.data(), WIMG_BYTES, hipMemcpyHostToDevice);
+  (void)hipMalloc(&g_buf, (size_t)512 * 16 * 192 * 1024);      // 1.5 GB: 512 workgroups x 16 tile slots x (128 KB outputs + 64 KB patch source)
+  (void)hipMemset(g_buf, 0x3a, (size_t)512 * 16 * 192 * 1024);
   printf("conv2 main-loop skeleton: 4-wave workgroups, 0.75 ds_read_b128 per MFMA, ~0.1 VALU per MFMA; TFLOP/s (fraction of 2500)\n");
 #define ROW(MODE, label) { double a = run<MODE>(wimg, out, secs); printf("%-92s %8.0f (%.3f)\n", label, a, a / 2500); fflush(stdout); }
   ROW(0, "weight DMA one stage ahead + wait + barrier per 32 MFMAs, 2 WG/CU (the kernel's loop)")
@@ -128,5 +205,14 @@ int main(int argc, char** argv) {
   ROW(8, "the kernel's loop, ONE workgroup per CU")
   ROW(9, "no weight DMA, ONE workgroup per CU")
   ROW(0, "the kernel's loop, 2 WG/CU (again: drift check)")
+  printf("the phases around the loop, per 18-stage tile (2 WG/CU)\n");
+  ROW(16, "+ 2 x 64 KB of output stores per workgroup and tile, each split's in one burst behind its loop")
+  ROW(32, "+ a 43.5-KB patch fetched from global memory, transformed and written to LDS in front of each tile")
+  ROW(48, "+ both (a workgroup's life without its GroupNorm table)")
+  ROW(80, "+ stores spread two per stage over the following split's loop instead of the burst")
+  ROW(112, "+ both, stores spread")
+  ROW(17, "+ the output stores, NO weight DMA: no stage ever waits on vmcnt (is it the bytes, or the stores sitting in the DMA's counter?)")
+  ROW(1, "no weight DMA, no stores (again)")
+  ROW(0, "the kernel's loop, 2 WG/CU (third run)")
   return 0;
 }
