@@ -32,6 +32,7 @@ constexpr int WIMG_BYTES = NSTAGE * STAGE_BYTES;       // 294 912
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, float* out, int tiles, unsigned seed, char* gbuf) {
   constexpr bool NO_DMA = MODE & 1, NO_BAR = MODE & 2, HALF = MODE & 4, STORES = MODE & 16, PATCH = MODE & 32, SPREAD = MODE & 64;
+  constexpr bool NO_EVALU = MODE & 128, NO_ESTORE = MODE & 256;      // the output phase without its VALU model / without its store instructions
   static_assert(!(HALF && (STORES || PATCH)), "the phase models are written for full stages");
   constexpr int SLOT = HALF ? STAGE_BYTES / 2 : STAGE_BYTES, NSLOT = HALF ? 4 : 2, AHEAD = HALF ? 3 : 1;
   constexpr int KSTEPS = HALF ? 2 : 4;                 // k-steps (16 channels) per stage
@@ -141,10 +142,11 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
 #pragma unroll
             for (int j = 0; j < 8; ++j) { f[j] = a[(i >> 3) * 8 + j]; 
 #pragma unroll
-              for (int r = 0; r < 5; ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j]) : "v"(0.9999f), "v"(1e-4f)); }
+              for (int r = 0; r < (NO_EVALU ? 0 : 5); ++r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j]) : "v"(0.9999f), "v"(1e-4f)); }
             const uint4 v = make_uint4(__builtin_bit_cast(unsigned, f[0]) ^ __builtin_bit_cast(unsigned, f[1]), __builtin_bit_cast(unsigned, f[2]) ^ __builtin_bit_cast(unsigned, f[3]),
                                        __builtin_bit_cast(unsigned, f[4]) ^ __builtin_bit_cast(unsigned, f[5]), __builtin_bit_cast(unsigned, f[6]) ^ __builtin_bit_cast(unsigned, f[7]));
             if constexpr (SPREAD) keep[i] = v;
+            else if constexpr (NO_ESTORE) { if (v.x == 0x12345678u && v.y == v.z) out[1] = 1.f; }
             else DD_GLOBAL_STORE16_UNTRACKED(dst + ((size_t)i * 256 + tid) * 16, make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w)));
           }
           if constexpr (SPREAD) { pending = 16; pend_dst = dst; }
@@ -211,6 +213,8 @@ int main(int argc, char** argv) {
   ROW(48, "+ both (a workgroup's life without its GroupNorm table)")
   ROW(80, "+ stores spread two per stage over the following split's loop instead of the burst")
   ROW(112, "+ both, stores spread")
+  ROW(16 | 128, "+ the output phase WITHOUT its VALU (16 store instructions per lane and split only)")
+  ROW(16 | 256, "+ the output phase WITHOUT its stores (~640 VALU per wave and split only)")
   ROW(17, "+ the output stores, NO weight DMA: no stage ever waits on vmcnt (is it the bytes, or the stores sitting in the DMA's counter?)")
   ROW(1, "no weight DMA, no stores (again)")
   ROW(0, "the kernel's loop, 2 WG/CU (third run)")
