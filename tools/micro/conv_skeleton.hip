@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
   // 512: the KERNEL's store addresses instead of lane-contiguous ones -- channel-blocked y2 ([C/32][h][w][32] f16: 64 bytes per pixel and block), lane (li, g) writes the
   // 16 bytes of channels 16 k + 8 g .. + 7 of pixel li: one instruction = 32 x 2 pieces of 16 bytes, 64 bytes apart (half of every 64-byte pixel row, the other half by the next instruction)
   constexpr bool KADDR = MODE & 512;
+  constexpr int NSTORE = (MODE & 1024) ? 8 : 16;      // 1024: half the output bytes (what a one-byte y2 with a per-pixel scale would write), the same VALU
   static_assert(!(HALF && (STORES || PATCH)), "the phase models are written for full stages");
   constexpr int SLOT = HALF ? STAGE_BYTES / 2 : STAGE_BYTES, NSLOT = HALF ? 4 : 2, AHEAD = HALF ? 3 : 1;
   constexpr int KSTEPS = HALF ? 2 : 4;                 // k-steps (16 channels) per stage
@@ -149,6 +150,7 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
             const uint4 v = make_uint4(__builtin_bit_cast(unsigned, f[0]) ^ __builtin_bit_cast(unsigned, f[1]), __builtin_bit_cast(unsigned, f[2]) ^ __builtin_bit_cast(unsigned, f[3]),
                                        __builtin_bit_cast(unsigned, f[4]) ^ __builtin_bit_cast(unsigned, f[5]), __builtin_bit_cast(unsigned, f[6]) ^ __builtin_bit_cast(unsigned, f[7]));
             if constexpr (SPREAD) keep[i] = v;
+            else if (i >= NSTORE) { if (v.x == 0x12345678u && v.y == v.z) out[1] = 1.f; }
             else if constexpr (NO_ESTORE) { if (v.x == 0x12345678u && v.y == v.z) out[1] = 1.f; }
             else if constexpr (KADDR) DD_GLOBAL_STORE16_UNTRACKED(dst + (size_t)wave * 16384 + (size_t)(i >> 1) * 2048 + (lane & 31) * 64 + (lane >> 5) * 16 + (i & 1) * 32, make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w)));
             else DD_GLOBAL_STORE16_UNTRACKED(dst + ((size_t)i * 256 + tid) * 16, make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w)));
@@ -219,6 +221,7 @@ int main(int argc, char** argv) {
   ROW(112, "+ both, stores spread")
   ROW(16 | 512, "+ the output phase with the KERNEL's store addresses (16-byte pieces 64 bytes apart) instead of lane-contiguous ones")
   ROW(16 | 128 | 512, "+ the kernel's store addresses, stores only (no VALU)")
+  ROW(16 | 1024, "+ the output phase with HALF the store instructions (a one-byte y2): same VALU, 64 KB per tile")
   ROW(16 | 128, "+ the output phase WITHOUT its VALU (16 store instructions per lane and split only)")
   ROW(16 | 256, "+ the output phase WITHOUT its stores (~640 VALU per wave and split only)")
   ROW(17, "+ the output stores, NO weight DMA: no stage ever waits on vmcnt (is it the bytes, or the stores sitting in the DMA's counter?)")
