@@ -391,7 +391,11 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
   DD_HIP(launch_nchw_to_nhwc(x_T, x_first, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s, img0, whole_B);
   if (rc) return rc;
-  if (pl->exec && pl->graph_cond != pl->cond_ptr()) {      // the graph holds another condition pointer (the whole batch's buffer moved)
+  // the graph holds another condition pointer (the whole batch's buffer moved).  Only plans whose LOOP reads the condition map care: the hoisted
+  // plans (Res: conv3(cond) runs once per image in stage_condition, in front of the graph; Swin: the whole step-invariant chain does) pass the
+  // pointer to kernels that never dereference it -- a refined-f16 lane that alternates between dd_condition's buffer and a direct tensor used to
+  // re-capture on every switch
+  if (pl->exec && !pl->key.hoist && pl->graph_cond != pl->cond_ptr()) {
     DD_HIP(hipStreamSynchronize(s));
     (void)hipGraphExecDestroy(pl->exec);
     pl->exec = nullptr;

@@ -24,7 +24,7 @@ int lane_count(dd_handle_t h, int B, int precision) {
   int S = h->n_streams;
   if (S > B) S = B;
   if (S > dd_handle_s::MAX_LANES) S = dd_handle_s::MAX_LANES;
-  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->prof_buf) S = 1;
+  if (precision == DD_PREC_NAIVE_FP32 || h->layer_timing || h->debug_sync || h->prof_buf || h->check_finite) S = 1;      // (check_finite: its counters and its report are per call, not per lane)
   return S < 1 ? 1 : S;
 }
 
@@ -117,11 +117,12 @@ bool plan_big_tiles(dd_handle_t h, const PlanKey& key) {
   const int ek = ek_of_precision(key.prec, h->bf16_pure);
   if (ek == EK_F32 || ek == EK_F16S) return false;
   if (h->big_tiles >= 0) return h->big_tiles != 0;
-  // more 8x32 tiles than resident slots: 16x32 tiles under concurrent lanes (half the weight stream and 0.75 LDS reads per MFMA: what counts when
-  // the other lane keeps the chip full anyway); a call that runs as ONE lane keeps the 8x32 tiles in their one-patch-buffer form (three workgroups
-  // per CU: conv3 140 -> 132 us at KITTI B=4, profiles/history/r04_call3_*) -- the Res denoiser's conv3; the Swin 5x5 form has no such kernel
+  // Round 6: the Res denoiser keeps its 8x32 tiles -- in their one-patch-buffer form, three workgroups per CU (conv3h_kid) -- under concurrent lanes as
+  // well.  Round 3 had picked the 16x32 tiles there (+1.8 % on that round's kernels); on every box since round 5's call 26 the one-buffer form is ahead
+  // under two lanes: 556.7 vs 527.1 and 542.4 vs 522.4 maps/s at KITTI B = 4 f16r (profiles/r06_experiments.md section 2).  The Swin 5x5 form has no
+  // one-buffer kernel and keeps the 16x32 tiles when its 8x32 tiles exceed the resident slots.
   const bool many = (long long)key.B * ((key.h + 7) / 8) * ((key.w + 31) / 32) > h->resident_slots;
-  return many && (key.lanes > 1 || h->variant == DD_VARIANT_SWIN);
+  return many && h->variant == DD_VARIANT_SWIN;
 }
 inline int conv3c_kid(dd_handle_t h, const PlanKey& key) { return plan_big_tiles(h, key) ? (int)BIG_CONV3C : 8; }
 // the loop's hoisted conv3: 16x32 tiles, or 8x32 tiles -- with ONE patch buffer (kernel id ONE_CONV3H: same tiles, same fragment order, 52 KB

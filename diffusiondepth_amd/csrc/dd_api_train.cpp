@@ -79,16 +79,18 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   auto chk = [&](const char* what, int l, const void* ptr, long long n, int kind) -> int {
     if (!h->check_finite) return DD_OK;
     if (h->check_finite == 2) {      // asynchronous: one counter per stage, read by check_finite_report at the end of the call
-      if (!h->chk_buf.p || h->chk_labels.size() >= 16384) return DD_OK;      // (a multi-lane call does not open a report: counters are per call, not per lane)
+      if (!h->chk_buf.p || h->chk_labels.size() >= 16383) return DD_OK;      // (calls with the option set run as one lane -- lane_count -- so a report is always open; entry 16383 is mode 1's counter)
       DD_HIP(launch_count_nonfinite(ptr, n, kind, h->chk_buf.as<unsigned>() + h->chk_labels.size(), s));
       h->chk_labels.push_back(std::string(what) + " of layer " + std::to_string(l) + " (step slot " + std::to_string(sstep) + ", lane " + std::to_string(lane) + ")");
       return DD_OK;
     }
-    if (!h->wmax.p) DD_HIP(h->wmax.alloc(sizeof(unsigned)));
-    DD_HIP(hipMemsetAsync(h->wmax.p, 0, sizeof(unsigned), s));
-    DD_HIP(launch_count_nonfinite(ptr, n, kind, h->wmax.as<unsigned>(), s));
+    // (mode 1 counts into the LAST entry of the option's own buffer: h->wmax is the weight-range scratch of the device weight route)
+    if (!h->chk_buf.p) DD_HIP(h->chk_buf.alloc(16384 * sizeof(unsigned)));
+    unsigned* cnt = h->chk_buf.as<unsigned>() + 16383;
+    DD_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned), s));
+    DD_HIP(launch_count_nonfinite(ptr, n, kind, cnt, s));
     unsigned c = 0;
-    DD_HIP(hipMemcpyAsync(&c, h->wmax.p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    DD_HIP(hipMemcpyAsync(&c, cnt, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     DD_HIP(hipStreamSynchronize(s));
     if (c) return h->fail(DD_ERR_HIP, std::string("check_finite: ") + what + " of layer " + std::to_string(l) + " (step slot " + std::to_string(sstep) + ", lane " +
                                       std::to_string(lane) + ") holds " + std::to_string(c) + " non-finite values of " + std::to_string(n));

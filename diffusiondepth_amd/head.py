@@ -70,7 +70,7 @@ class DDIMDepthEstimate_Res(nn.Module):
                            distribution; saves the 6.8 MB-per-KITTI-map host RNG + H2D copy per forward: 15.6 -> 8.0 ms per KITTI eval
                            forward); "auto" = "cpu" in .train() -- the reference's training RNG stream -- and "device" in eval."""
         super().__init__()
-        profile = profile or os.environ.get("DDEPTH_PROFILE", "reference")
+        profile = profile or os.environ.get("DDEPTH_PROFILE") or "reference"      # (an empty DDEPTH_PROFILE means "not set")
         if profile not in PROFILES:
             raise ValueError(f"profile must be one of {sorted(PROFILES)}")
         self.profile = profile
@@ -81,6 +81,7 @@ class DDIMDepthEstimate_Res(nn.Module):
         if loss_noise_device not in ("cpu", "device", "auto"):
             raise ValueError("loss_noise_device must be 'cpu', 'device' or 'auto'")
         self._loss_noise_gen = None       # private device generator of the "device" route (created on first use)
+        self._loss_noise_seed = None      # torch.initial_seed() it was seeded from
         # HAHI heads only: True runs the PyTorch neck under autocast in the kernels' 16-bit type.  Default False = the reference's fp32
         # arithmetic (the reference never autocasts the neck)
         self.neck_autocast = bool(kwargs.pop("neck_autocast", False))
@@ -211,10 +212,16 @@ class DDIMDepthEstimate_Res(nn.Module):
         else:
             # a PRIVATE generator: the global device stream -- x_T (…res.py:277) and `timesteps` (:207) are drawn from it -- is not advanced, so the
             # reference's draws of this and every later forward stay what they are.  Seeded from torch's seed: reproducible runs.
+            # (Re-)seeded whenever torch's seed changed since it was built -- a later torch.manual_seed() makes the loss reproducible again -- with the
+            # process-group rank mixed in (data-parallel ranks that share a seed draw different noise, as ranks that call torch.randn on different
+            # shards would).  The generator's state is not part of state_dict(): a resumed run restarts this stream.
             gen = self._loss_noise_gen
-            if gen is None or gen.device != blur_depth_t.device:
+            seed_now = torch.initial_seed()
+            if gen is None or gen.device != blur_depth_t.device or self._loss_noise_seed != seed_now:
+                rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
                 gen = self._loss_noise_gen = torch.Generator(device=blur_depth_t.device)
-                gen.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF)
+                gen.manual_seed((seed_now + 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019 * rank) & 0x7FFFFFFFFFFFFFFF)
+                self._loss_noise_seed = seed_now
             noise = torch.randn(blur_depth_t.shape, device=blur_depth_t.device, generator=gen).to(blur_depth_t.device)     # (.to: a no-op unless a test injects its own draw)
         bs = blur_depth_t.shape[0]
         timesteps = torch.randint(0, self.scheduler.num_train_timesteps, (bs,), device=gt_depth.device).long()

@@ -148,6 +148,8 @@ class HipBound:
             sig = self._signature(group)
             # .train(): never trust the version counter (see the class docstring); once per hold() scope / per call
             if sig != self._sig.get(group) or self._any_training(group):
+                if group == "model":
+                    self.check_grad_guard()
                 sd = {}
                 for prefix, ref in self._modules:
                     if self._group_of(prefix) == group:
@@ -162,6 +164,19 @@ class HipBound:
                 self.backend.set_schedule(scheduler._acp_host)
                 self._sched_sig = ssig
         return self.backend
+
+    def check_grad_guard(self):
+        """Raise if a backward of the library returned a non-finite value since the last check (``_note_grads``).  Called in front of every refresh of
+        the denoiser's parameters (i.e. once per training iteration); callable by hand after ``loss.backward()``."""
+        be = self.backend
+        flag = getattr(be, "_grad_guard", None) if be is not None else None
+        if flag is None:
+            return
+        be._grad_guard = None
+        if not bool(torch.isfinite(flag)):
+            raise FloatingPointError("diffusiondepth_amd: a backward pass of the HIP denoiser returned non-finite gradients (NaN / Inf) since the last "
+                                     "parameter refresh; refusing to continue training on parameters built from them (DDEPTH_GRAD_GUARD=0 disables this check; "
+                                     "dd_set_option('check_finite', 2) names the first non-finite tensor)")
 
     @staticmethod
     def _hip_device(device) -> torch.device:
@@ -204,6 +219,25 @@ def _ordered_params(model: nn.Module):
     return [named[n[len("model."):]] for n in _param_order(model.variant)]
 
 
+GRAD_GUARD = os.environ.get("DDEPTH_GRAD_GUARD", "1") != "0"
+
+
+def _note_grads(be, tensors):
+    """Always-on guard of the training path (round 6; ADVICE r5 medium: the 16-bit training steps once continued silently on NaN parameters): every
+    backward of the library folds the sum of everything it returns -- parameter gradients, grad_x, grad_cond -- into ONE device scalar on the backend
+    (asynchronous: a handful of reduction kernels, no host synchronisation here).  A NaN / Inf anywhere makes that scalar non-finite, and it stays so.
+    ``HipBound.ensure`` reads it when the NEXT training forward refreshes the parameters (by then the previous step is long complete: the read costs one
+    round trip per iteration) and raises FloatingPointError instead of uploading parameters that an optimizer built from non-finite gradients.
+    DDEPTH_GRAD_GUARD=0 switches it off."""
+    if not GRAD_GUARD:
+        return
+    parts = [t.sum() for t in tensors if t is not None]
+    if not parts:
+        return
+    s = torch.stack(parts).sum()
+    be._grad_guard = s if getattr(be, "_grad_guard", None) is None else be._grad_guard + s
+
+
 class _DenoiseOnceFn(torch.autograd.Function):
     """autograd node of one epsilon-network call: forward dd_denoise_once, backward dd_denoise_once_backward (what
     loss.backward() sends through ``self.model(...)`` in the reference's training step, …res.py:211, src/main.py:232-241)."""
@@ -225,6 +259,7 @@ class _DenoiseOnceFn(torch.autograd.Function):
                                           need_grad_x=ctx.needs_input_grad[2], need_grad_cond=ctx.needs_input_grad[4],
                                           trajectory_ticket=ctx.ticket)
         grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_param_order(be.variant))]
+        _note_grads(be, [gx, gc, *grads])
         return (None, None, gx, None, gc, *grads)
 
 
@@ -249,6 +284,7 @@ class _DenoiseLoopFn(torch.autograd.Function):
                                      need_grad_xT=ctx.needs_input_grad[3], need_grad_cond=ctx.needs_input_grad[4],
                                      trajectory_ticket=ctx.ticket)
         grads = [be.grad(n) if ctx.needs_input_grad[5 + i] else None for i, n in enumerate(_param_order(be.variant))]
+        _note_grads(be, [gx, gc, *grads])
         return (None, None, None, gx, gc, *grads)
 
 

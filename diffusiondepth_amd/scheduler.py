@@ -12,6 +12,8 @@ from __future__ import annotations
 from types import SimpleNamespace
 from typing import Optional
 
+import math
+
 import numpy as np
 import torch
 
@@ -30,6 +32,12 @@ class DDIMScheduler:
             betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
         elif beta_schedule == "scaled_linear":                            # :132-136
             betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif beta_schedule == "squaredcos_cap_v2":                        # :137-139, betas_for_alpha_bar :67-94 (the Glide cosine schedule)
+            # beta_i = min(1 - abar((i + 1) / N) / abar(i / N), 0.999), abar(u) = cos^2((u + 0.008) / 1.008 * pi / 2): host double arithmetic per
+            # entry with the libm cosine, then ONE rounding to fp32 -- the reference's order of operations, so the table is bit-identical
+            abar = lambda u: math.cos((u + 0.008) / 1.008 * math.pi / 2) ** 2
+            n = num_train_timesteps
+            betas = torch.tensor([min(1 - abar((i + 1) / n) / abar(i / n), 0.999) for i in range(n)])
         else:
             raise NotImplementedError(f"{beta_schedule} is not implemented for {self.__class__.__name__}")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,

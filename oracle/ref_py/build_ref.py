@@ -5,9 +5,10 @@
 
 Why: BASELINE.md section 3 plans the `cpu_baseline` of bench.py as the reference's own classes timed on the bench host, but /root/reference does
 not exist on the GPU box.  The DCN leg solved that by compiling the reference's device code into oracle/_ref/libref_dcn.so; this is the same
-move for a Python reference: every module the import shim (tests/golden/ref_import.py) pulls from /root/reference/src -- scheduling_ddim.py,
-ddim_depth_estimate_res.py, ddim_depth_estimate_res_swin_add.py, mmbev_base_depth_refine.py, depth_transform.py, common.py and the package
-__init__ files they import through -- is COMPILED where it lies (py_compile, unchecked-hash .pyc, no source text) into the mirrored path
+move for a Python reference: every module the import shim (tests/golden/ref_import.py, make_golden_hahi.py) pulls from /root/reference/src --
+scheduling_ddim.py, ddim_depth_estimate_res.py, ddim_depth_estimate_res_swin_add.py, mmbev_base_depth_refine.py, depth_transform.py, common.py, the
+package __init__ files they import through and (round 6, for tests/test_reference_facade.py) the model facade diffusion_dcbase_model.py, the HAHI neck
+hahi.py and the HAHI / Vis head modules -- is COMPILED where it lies (py_compile, unchecked-hash .pyc, no source text) into the mirrored path
 under oracle/_ref/py/.  oracle/_ref/ is git-ignored (nothing of the reference enters the history) and travels to the GPU box with the
 snapshot like the built .so files; there the shim imports the sourceless modules, so what bench.py times as `cpu_baseline.kind =
 "reference"` is the reference's code object for code object.  Without /root/reference the staged tree is used as it is; build() returns
@@ -40,10 +41,10 @@ def staged() -> bool:
 
 def _modules_the_shim_loads():
     """{module name: source file} of everything ref_import.load_reference() imports from the reference tree (in a child interpreter)."""
-    code = ("import json, os, sys; sys.path.insert(0, %r); os.environ['DD_REFERENCE_ROOT'] = %r; import ref_import; ref_import.load_reference(); "
+    code = ("import json, os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); os.environ['DD_REFERENCE_ROOT'] = %r; import ref_import; ref_import.load_reference(); ref_import.load_reference_facade(); import make_golden_hahi; make_golden_hahi.load_hahi_reference(); "
             "src = os.path.realpath(%r) + os.sep; "
             "print(json.dumps({n: m.__file__ for n, m in sys.modules.items() if getattr(m, '__file__', None) and os.path.realpath(m.__file__).startswith(src)}))"
-            % (SHIM_DIR, REF_ROOT, REF_SRC))
+            % (SHIM_DIR, ROOT, REF_ROOT, REF_SRC))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("importing the reference through tests/golden/ref_import.py failed:\n" + r.stderr[-3000:])

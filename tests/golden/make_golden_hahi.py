@@ -81,7 +81,7 @@ class _ZeroPos(nn.Module):
 
     def forward(self, mask):
         B, H, W = mask.shape
-        return torch.zeros(B, 2 * self.num_feats, H, W)
+        return torch.zeros(B, 2 * self.num_feats, H, W, device=mask.device)
 
 
 def load_hahi_reference():

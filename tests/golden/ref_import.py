@@ -191,3 +191,47 @@ def load_weights(module: nn.Module, sd: dict, prefix: str):
     assert not missing and not extra, (missing, extra)
     module.load_state_dict(sub, strict=True)
     return module
+
+
+# ---- the reference's own model FACADE (src/model/diffusion_dcbase_model.py:26-224), for the drop-in test tests/test_reference_facade.py ----------
+_FACADE = {}
+
+
+def load_reference_facade():
+    """The reference's unmodified ``Diffusion_DCbase_Model`` class, imported from the reference tree (or its staged bytecode) behind stand-ins for the
+    CONTAINER names its module imports at the top (diffusion_dcbase_model.py:11-21):
+      mmdet.models.DETECTORS / BACKBONES, mmdet3d.models.builder, mmdet3d.core.bbox3d2result, mmdet3d.utils.collect_env / get_root_logger
+                                  registries and helpers the class only names (a decorator and unused imports)
+      model.ops.ip_basic          classical depth completion (cv2): reached only with ip_basic=True, which no configuration sets
+      model.backbone.get          the reference's rule `getattr(import_module('model.backbone.' + module), name)` needs mmdet's ResNet blocks; the stand-in
+                                  serves the zero-argument factories the TEST registers in ``BACKBONE_FACTORIES`` (the same backbone on both sides of a comparison)
+      model.head.get              named, never called (the head comes from HEADS.build, :91)
+    Returns the loaded module; its global ``HEADS`` is the registry ``Diffusion_DCbase_Model.__init__`` builds the head from (:91) -- the test rebinds it to a
+    registry holding either the reference's head classes or diffusiondepth_amd's."""
+    if _FACADE:
+        return _FACADE["mod"]
+    load_reference()
+    m = sys.modules
+
+    def mod(name, **attrs):
+        mm = m.get(name) or types.ModuleType(name)
+        mm.__dict__.update(attrs)
+        m[name] = mm
+        return mm
+    mod("mmdet")
+    mod("mmdet.models", DETECTORS=_Registry("detectors"), BACKBONES=_Registry("backbones"))
+    mod("mmdet3d.models", builder=m["mmdet3d.models.builder"])
+    mod("mmdet3d.core", bbox3d2result=None)
+    mod("mmdet3d.utils", collect_env=None, get_root_logger=None)
+    mod("model.ops.ip_basic")
+    m["model.ops"].ip_basic = m["model.ops.ip_basic"]
+    bb = mod("model.backbone", BACKBONE_FACTORIES={})
+    bb.get = lambda args: bb.BACKBONE_FACTORIES[args.backbone_name]
+    m["model.head"].get = lambda args: None
+    fac = _load_as("model.diffusion_dcbase_model", "model/diffusion_dcbase_model.py")
+    _FACADE["mod"] = fac
+    return fac
+
+
+def new_registry(name="heads"):
+    return _Registry(name)

@@ -52,6 +52,23 @@ def test_scheduler_matches_reference_tables(golden):
     assert s.hip_supported(0.0) is None and s.hip_supported(0.5) is not None
 
 
+def test_scheduler_cosine_schedule_matches_the_reference_class():
+    """beta_schedule="squaredcos_cap_v2" (reference scheduling_ddim.py:137-139, betas_for_alpha_bar :67-94): no head uses it, the mirror carries it so
+    that the scheduler interface has no hole.  Compared with the reference's own class (tree or staged bytecode), bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_import
+    if not ref_import.reference_available():
+        pytest.skip("needs the reference tree or its staged bytecode")
+    ref = ref_import.load_reference()
+    for n in (1000, 250):
+        r = ref.DDIMScheduler(num_train_timesteps=n, beta_schedule="squaredcos_cap_v2", clip_sample=False)
+        s = dda.DDIMScheduler(num_train_timesteps=n, beta_schedule="squaredcos_cap_v2", clip_sample=False)
+        assert torch.equal(s.betas, r.betas) and torch.equal(s.alphas_cumprod, r.alphas_cumprod)
+        r.set_timesteps(20); s.set_timesteps(20)
+        assert np.array_equal(np.asarray(s.timesteps), np.asarray(r.timesteps))
+
+
 def test_scheduler_step_and_add_noise_match_reference(golden, cases):
     c, g = cases["sched"], golden("sched")
     rs = np.random.RandomState(c["seed"])

@@ -320,6 +320,36 @@ def test_the_host_never_blocks_in_steady_state(on_host, lib, monkeypatch):
     assert per_route["0"][1] == 0 and per_route["0"][0] > 20, per_route
 
 
+def test_training_refuses_to_continue_on_non_finite_gradients(on_host, monkeypatch):
+    """The always-on guard of the training path (modules._note_grads / HipBound.check_grad_guard; ADVICE r5: round 4's library trained on NaN
+    parameters silently): a backward of the library that returns a NaN makes the NEXT training forward raise before it uploads parameters; a clean
+    step passes, and DDEPTH_GRAD_GUARD=0 (module switch GRAD_GUARD) restores the old behaviour."""
+    from diffusiondepth_amd import modules as M
+    sd = synth.make_state_dict(7240)
+    sd.update(synth.make_fpn_state_dict(7241))
+    Bn, H, W = 1, 16, 48
+    fp = [torch.from_numpy(f) for f in synth.make_backbone_features(1, Bn, H, W)]
+    gt = torch.from_numpy(synth.make_gt_depth(2, Bn, H, W))
+    head = dda.DDIMDepthEstimate_Res(precision="naive_fp32", inference_steps=2).train()
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    monkeypatch.setattr(type(head), "_on_hip", staticmethod(lambda tensors: True))
+
+    def step(poison):
+        out = head([f.clone() for f in fp], gt, gt > 0, gt_depth_map=gt)
+        loss = (out["pred"] - gt).abs().mean() + out["ddim_loss"]
+        (loss * float("nan") if poison else loss).backward()
+        head.zero_grad()
+    step(False)
+    step(False)                     # a clean step's flag is consumed by the next forward without complaint
+    step(True)                      # NaN gradients come back from dd_denoise_backward / dd_denoise_once_backward ...
+    with pytest.raises(FloatingPointError, match="non-finite gradients"):
+        step(False)                 # ... and the next forward refuses to refresh the parameters
+    step(False)                     # (the flag is consumed by the raise: training can be resumed by whoever handles it)
+    monkeypatch.setattr(M, "GRAD_GUARD", False)
+    step(True)
+    step(False)
+
+
 def test_loop_backward_reads_the_states_the_forward_kept(on_host):
     """Training: dd_denoise with option keep_trajectory leaves the state entering every step behind and hands out a ticket;
     dd_denoise_backward given that ticket skips its second forward loop (counter trajectory_reuses) -- and, the activations of every step

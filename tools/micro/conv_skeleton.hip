@@ -30,13 +30,20 @@ constexpr int NSTAGE = 18;                             // 9 taps x 2 cout splits
 constexpr int WIMG_BYTES = NSTAGE * STAGE_BYTES;       // 294 912
 
 template <int MODE>
-__global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, float* out, int tiles, unsigned seed, char* gbuf) {
+__global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, float* out, int tiles, unsigned seed, char* gbuf, unsigned* cu_ctr, int skew_ticks) {
   constexpr bool NO_DMA = MODE & 1, NO_BAR = MODE & 2, HALF = MODE & 4, STORES = MODE & 16, PATCH = MODE & 32, SPREAD = MODE & 64;
   constexpr bool NO_EVALU = MODE & 128, NO_ESTORE = MODE & 256;      // the output phase without its VALU model / without its store instructions
   // 512: the KERNEL's store addresses instead of lane-contiguous ones -- channel-blocked y2 ([C/32][h][w][32] f16: 64 bytes per pixel and block), lane (li, g) writes the
   // 16 bytes of channels 16 k + 8 g .. + 7 of pixel li: one instruction = 32 x 2 pieces of 16 bytes, 64 bytes apart (half of every 64-byte pixel row, the other half by the next instruction)
   constexpr bool KADDR = MODE & 512;
   constexpr int NSTORE = (MODE & 1024) ? 8 : 16;      // 1024: half the output bytes (what a one-byte y2 with a per-pixel scale would write), the same VALU
+  // 2048 (round 6): the two workgroups of a CU OUT OF STEP by construction -- every workgroup takes a number from its CU's counter (key = XCC id + SE / SH / CU id
+  // of HW_ID); the odd one waits `skew_ticks` (100-MHz wall-clock ticks) before its first tile, so its output phases fall into its neighbour's MFMA loop
+  constexpr bool SKEW = MODE & 2048;
+  // 4096 (round 6): a LEAN issue sequence for the weight DMA -- `buffer_load_dwordx4 ... offen lds` on a buffer resource (scalar base + scalar stage / wave offset, one per-lane
+  // VGPR offset that never changes), every wave copying FOUR CONSECUTIVE KiB of a stage so that one M0 write serves its four instructions through the immediate offset:
+  // no per-piece address VALU, no branches (the kernel's sequence is ~12 instructions and two branches per 1-KiB piece)
+  constexpr bool LEAN = MODE & 4096;
   static_assert(!(HALF && (STORES || PATCH)), "the phase models are written for full stages");
   constexpr int SLOT = HALF ? STAGE_BYTES / 2 : STAGE_BYTES, NSLOT = HALF ? 4 : 2, AHEAD = HALF ? 3 : 1;
   constexpr int KSTEPS = HALF ? 2 : 4;                 // k-steps (16 channels) per stage
@@ -49,10 +56,43 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
   uint4* l4 = reinterpret_cast<uint4*>(smem);
   for (int i = tid; i < (PATCH_BYTES + NSLOT * SLOT) / 16; i += 256) l4[i] = make_uint4(rnd(), rnd(), rnd(), rnd());
   __syncthreads();
+  if constexpr (SKEW) {
+    if (tid == 0) {
+      unsigned hw_, xcc_;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));
+      const unsigned key = ((xcc_ & 15u) << 8) | ((hw_ >> 8) & 0xFFu);
+      const unsigned n = atomicAdd(&cu_ctr[key], 1u);
+      if (n & 1u) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < (unsigned long long)skew_ticks) __builtin_amdgcn_s_sleep(64);
+      }
+    }
+    __syncthreads();
+  }
   const unsigned lds_base = DD_LDS_BASE(smem);
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  u32x4_t rsrc;
+  {
+    const unsigned long long a = (unsigned long long)wimg;
+    rsrc.x = __builtin_amdgcn_readfirstlane((unsigned)a); rsrc.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+    rsrc.z = 0x7fffffffu; rsrc.w = 0x00020000u;
+  }
+  const unsigned lane16 = lane * 16;
   auto issue = [&](int st) {                           // stage st (mod NST) -> ring slot st % NSLOT: this wave's share, 1 KiB per instruction
     if (NO_DMA) return;
     const int sl = st % NSLOT, sg = st % NST;
+    if constexpr (LEAN) {
+      static_assert(!LEAN || SLOT == 16384, "lean issue: 16-KiB stages, four consecutive KiB per wave");
+      const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(sg * SLOT + wave * 4096));
+      const unsigned ldst = __builtin_amdgcn_readfirstlane(lds_base + PATCH_BYTES + sl * SLOT + wave * 4096);
+      unsigned keep_m0_;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                   "buffer_load_dwordx4 %2, %3, %4 offen offset:0 lds\n\tbuffer_load_dwordx4 %2, %3, %4 offen offset:1024 lds\n\t"
+                   "buffer_load_dwordx4 %2, %3, %4 offen offset:2048 lds\n\tbuffer_load_dwordx4 %2, %3, %4 offen offset:3072 lds\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep_m0_) : "s"(ldst), "v"(lane16), "s"(rsrc), "s"(soff) : "memory");
+      return;
+    }
 #pragma unroll
     for (int kc = 0; kc < SLOT / 1024 / 4; ++kc) {
       const int piece = kc * 4 + wave;
@@ -179,15 +219,16 @@ __global__ void __launch_bounds__(256, 2) skel(const char* __restrict__ wimg, fl
 }
 
 static char* g_buf = nullptr;
-template <int MODE> static double run(const char* wimg, float* out, double secs) {
+static unsigned* g_ctr = nullptr;
+template <int MODE> static double run(const char* wimg, float* out, double secs, int skew_ticks = 0) {
   const int lds = (MODE & 8) ? 100 * 1024 : PATCH_BYTES + 2 * STAGE_BYTES + 2048;     // 78 336 B: two workgroups per CU
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int blocks = 256 * ((MODE & 8) ? 1 : 2), tiles = 64;
-  hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u, g_buf);
+  hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u, g_buf, g_ctr, skew_ticks);
   (void)hipDeviceSynchronize();
   auto t0 = std::chrono::steady_clock::now();
   int n = 0; double el = 0;
-  while (el < secs) { hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u, g_buf); (void)hipDeviceSynchronize(); ++n;
+  while (el < secs) { hipLaunchKernelGGL((skel<MODE>), dim3(blocks), dim3(256), lds, 0, wimg, out, tiles, 1234u, g_buf, g_ctr, skew_ticks); (void)hipDeviceSynchronize(); ++n;
                       el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
   // per wave and tile: 18 stages x 32 MFMAs (in every variant)
   return (double)n * blocks * 4 * tiles * 18.0 * 32.0 * 32768.0 / el * 1e-12;
@@ -203,6 +244,7 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(wimg, hw.data(), WIMG_BYTES, hipMemcpyHostToDevice);
   (void)hipMalloc(&g_buf, (size_t)512 * 16 * 192 * 1024);      // 1.5 GB: 512 workgroups x 16 tile slots x (128 KB outputs + 64 KB patch source)
   (void)hipMemset(g_buf, 0x3a, (size_t)512 * 16 * 192 * 1024);
+  (void)hipMalloc(&g_ctr, 4096 * 4); (void)hipMemset(g_ctr, 0, 4096 * 4);
   printf("conv2 main-loop skeleton: 4-wave workgroups, 0.75 ds_read_b128 per MFMA, ~0.1 VALU per MFMA; TFLOP/s (fraction of 2500)\n");
 #define ROW(MODE, label) { double a = run<MODE>(wimg, out, secs); printf("%-92s %8.0f (%.3f)\n", label, a, a / 2500); fflush(stdout); }
   ROW(0, "weight DMA one stage ahead + wait + barrier per 32 MFMAs, 2 WG/CU (the kernel's loop)")
@@ -227,5 +269,27 @@ int main(int argc, char** argv) {
   ROW(17, "+ the output stores, NO weight DMA: no stage ever waits on vmcnt (is it the bytes, or the stores sitting in the DMA's counter?)")
   ROW(1, "no weight DMA, no stores (again)")
   ROW(0, "the kernel's loop, 2 WG/CU (third run)")
+  printf("round 6: the two workgroups of a CU out of step by construction (the odd one of each CU starts late; a tile is ~32 us, a cout split ~16 us)\n");
+#define SROW(MODE, us, label) { double a = run<(MODE) | 2048>(wimg, out, secs, (us) * 100); printf("%-72s skew %3d us %8.0f (%.3f)\n", label, us, a, a / 2500); fflush(stdout); }
+  SROW(16, 0, "output phase (stores + VALU), burst")
+  SROW(16, 4, "output phase (stores + VALU), burst")
+  SROW(16, 8, "output phase (stores + VALU), burst")
+  SROW(16, 12, "output phase (stores + VALU), burst")
+  SROW(16, 16, "output phase (stores + VALU), burst")
+  SROW(16, 24, "output phase (stores + VALU), burst")
+  SROW(48, 0, "patch fetch + output phase (a workgroup's life)")
+  SROW(48, 8, "patch fetch + output phase (a workgroup's life)")
+  SROW(48, 16, "patch fetch + output phase (a workgroup's life)")
+  SROW(16 | 512, 8, "output phase, the kernel's store addresses")
+  SROW(0, 8, "bare loop (control)")
+  SROW(16, 0, "output phase (stores + VALU), burst (again)")
+  SROW(16, 8, "output phase (stores + VALU), burst (again)")
+  printf("round 6: a lean weight-DMA issue sequence (buffer_load ... lds, scalar addressing, one M0 write per stage and wave)\n");
+  ROW(0, "the kernel's loop, global_load_lds per piece (as the kernel)")
+  ROW(4096, "the kernel's loop, lean buffer_load ... lds issue")
+  ROW(48, "loop + patch fetch + output phase, global_load_lds")
+  ROW(48 | 4096, "loop + patch fetch + output phase, lean issue")
+  ROW(0, "the kernel's loop, global_load_lds per piece (again)")
+  ROW(4096, "the kernel's loop, lean issue (again)")
   return 0;
 }
