@@ -90,6 +90,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
   else if (k == "debug_sync") h->debug_sync = value != 0;
   else if (k == "check_finite") h->check_finite = (int)value;
   else if (k == "train_graphs") h->train_graphs = value != 0;
+  else if (k == "graph_fence") h->graph_fence = (int)value;
   else if (k == "ablate") {
     if (h->ablate != (int)value) {            // kernel parameters are baked into captured graphs
       DD_HIP(hipDeviceSynchronize());
@@ -461,7 +462,19 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
       if (timed) DD_HIP(hipEventRecord(h->ev0, s));
     }
     if (pl->exec) {
+      if (h->graph_fence & 1) DD_HIP(hipStreamSynchronize(s));
+      if (h->graph_fence & 4) {
+        // the replay on a stream of the handle's own, ordered against the caller's stream by two events (what the lanes do for lane 1..)
+        if (!h->lane_fork) DD_HIP(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
+        if (!h->lane_done[0]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[0], hipEventDisableTiming));
+        DD_HIP(hipEventRecord(h->lane_fork, s));
+        DD_HIP(hipStreamWaitEvent(h->cap_stream, h->lane_fork, 0));
+        DD_HIP(hipGraphLaunch(pl->exec, h->cap_stream));
+        DD_HIP(hipEventRecord(h->lane_done[0], h->cap_stream));
+        DD_HIP(hipStreamWaitEvent(s, h->lane_done[0], 0));
+      } else
       DD_HIP(hipGraphLaunch(pl->exec, s));
+      if (h->graph_fence & 2) DD_HIP(hipStreamSynchronize(s));
       h->n_graph_launches++;
       launched = true;
     }
@@ -602,6 +615,12 @@ int dd_denoise_once(dd_handle_t h, const float* x_t, const int64_t* t, const flo
   DD_HIP(launch_nchw_to_nhwc(x_t, pl->x[0].p, EK_F32, B, LATENT_C, lat_h, lat_w, 0, s));
   rc = stage_condition(h, pl, cond, B, lat_h, lat_w, cond_h, cond_w, precision, s);
   if (rc) return rc;
+  if (h->variant == DD_VARIANT_SWIN && pl->key.hoist) {
+    // the hoisted single call (refined f16): one E[t] border table per image, from this call's timesteps (read and clamped on the device)
+    if (!h->LA.w_oihw.p || !h->LB.w_oihw.p || !h->L[2].w_oihw.p) return h->fail(DD_ERR_STATE, "hoisted Swin form: the fp32 weights of the fuse convolutions are not on the device");
+    DD_HIP(launch_swin_ttab(h->LA.w_oihw.as<float>(), h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->emb.as<float>(), tv, B, lat_h, lat_w,
+                            pl->tt_scratch.as<float>(), pl->ttab.as<float>(), s));
+  }
   DD_HIP(hipMemsetAsync(pl->stats.p, 0, pl->stats_bytes, s));
   if (precision == DD_PREC_NAIVE_FP32) {
     rc = enqueue_naive_eps(h, pl, 0, pl->x[0].as<float>(), tv, 0, 1, s);

@@ -232,6 +232,8 @@ struct dd_handle_s {
   DevBuf d_acp;
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
+  int graph_fence = 0;                // option "graph_fence" (diagnosis of the training-graph fault, profiles/r06_experiments.md section 5): bit 0 = hipStreamSynchronize in FRONT of every
+                                      // hipGraphLaunch, bit 1 = behind it, bit 2 = the graph is launched on the handle's own capture stream between two events instead of on the caller's stream
   bool train_graphs = false;          // option "train_graphs": 1 = the trajectory-keeping forward of a training step replays a hipGraph too (A/B; default eager)
   int check_finite = 0;        // 1 = synchronise after every stage; 2 = count asynchronously, report at the end of the call (no host synchronisation in between)
   DevBuf chk_buf; std::vector<std::string> chk_labels;      // check_finite == 2: one counter per checked stage of the running call   // option "check_finite" (debug): the backward synchronises after every stage and fails with the name of the first tensor holding a NaN / Inf

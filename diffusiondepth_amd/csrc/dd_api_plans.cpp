@@ -72,6 +72,10 @@ int want_hoist(dd_handle_t h, int precision, int T, int keep) {
   if (precision == DD_PREC_NAIVE_FP32) return 0;
   const int ek = ek_of_precision(precision, h->bf16_pure);
   if (h->variant == DD_VARIANT_SWIN) {
+    // (round 6) ONE refined-f16 call with per-sample timesteps (dd_denoise_once, T = 0: what a "fast" head's ddim_loss evaluates, ...swin_addHAHI.py:207-223)
+    // runs the hoisted form as well -- its E[t] border tables are then built per IMAGE from the call's own timesteps (ConvParams::ttab_bstride);
+    // every other precision keeps the reference's order for single calls
+    if (T <= 0 && keep == 0 && ek == EK_F16R && h->swin_w5 && h->hoist_cond != 0) return 1;
     if (T <= 0 || keep != 0 || h->hoist_cond == 0 || ((ek == EK_F16S || ek == EK_F16R) && !h->swin_w5)) return 0;      // (split / refined f16: the 5x5 form only)
     return (h->hoist_cond == 1 || ek != EK_F32) ? 1 : 0;
   }
@@ -157,8 +161,8 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
   const bool naive = key.prec == DD_PREC_NAIVE_FP32;
   pl->ek = naive ? EK_F32 : ek_of_precision(key.prec, h->bf16_pure);
   if (pl->ek == EK_F16R && !key.hoist)
-    return h->fail(DD_ERR_UNSUPPORTED, "DD_PREC_F16R runs the hoisted forward-only plans: for the Swin / MPViT denoiser that is the T-step loop (dd_denoise / "
-                                       "dd_denoise_trace) with option swin_w5 = 1; single calls (dd_denoise_once) and training plans: DD_PREC_F16");
+    return h->fail(DD_ERR_UNSUPPORTED, "DD_PREC_F16R runs the hoisted forward-only plans: for the Swin / MPViT denoiser those exist with option swin_w5 = 1 "
+                                       "(dd_denoise / dd_denoise_trace / dd_denoise_once); training plans: DD_PREC_F16");
   const size_t px = (size_t)key.B * key.h * key.w;
   const size_t es = ek_size(pl->ek);
   DD_HIP(pl->x[0].alloc(px * LATENT_C * 4));
@@ -188,7 +192,7 @@ int get_plan(dd_handle_t h, const PlanKey& key, Plan** out) {
     }
   }
   if (key.hoist && swin) {
-    const int T1 = key.T > 0 ? key.T : 1;
+    const int T1 = key.T > 0 ? key.T : key.B;      // (a single call: one table per image, built from that image's timestep)
     const int RH = key.h < SWIN_TT_AX ? key.h : SWIN_TT_AX, RW = key.w < SWIN_TT_AX ? key.w : SWIN_TT_AX;
     DD_HIP(pl->ttab.alloc((size_t)T1 * SWIN_TT_ROWS * HID_C * 4));
     DD_HIP(pl->tt_scratch.alloc((size_t)T1 * RH * RW * (2 * COND_C + HID_C) * 4));
@@ -305,6 +309,7 @@ int enqueue_fused_step(dd_handle_t h, Plan* pl, int step, const float* x_in, flo
     DD_HIP(timed_launch(5, p, SWIN_CONVA_H));
     p.stats_in = nullptr;
     p.cadd = pl->ccond.as<float>(); p.ttab = pl->ttab.as<float>() + (size_t)step * SWIN_TT_ROWS * HID_C;
+    p.ttab_bstride = k.T > 0 ? 0 : SWIN_TT_ROWS * HID_C;
     if (pl->bcorr.p) {
       // pred.0 o convB as one 5x5 convolution on convA's result; the border ring's correction first
       DD_HIP(launch_swin_bcorr(sa_, ek == EK_F16S ? (int)EK_F32 : opnd_kind(ek), h->pairp.as<float>(), h->kside.p, pl->bcorr.as<float>(), k.B, k.h, k.w, s));     // (kind convA' stored its result in)
@@ -430,7 +435,7 @@ int ensure_swin_w5(dd_handle_t h, hipStream_t s) {
 // condition map is in the plan's buffer; Plan::sa / sf are free until the loop starts.
 int enqueue_swin_hoist(dd_handle_t h, Plan* pl, hipStream_t s) {
   const PlanKey& k = pl->key;
-  if (pl->ttab_weights != h->weights_serial) {
+  if (k.T > 0 && pl->ttab_weights != h->weights_serial) {      // (a single call's tables depend on the call's timesteps: dd_denoise_once builds them)
     if (!h->LA.w_oihw.p || !h->LB.w_oihw.p || !h->L[2].w_oihw.p) return h->fail(DD_ERR_STATE, "hoisted Swin form: the fp32 weights of the fuse convolutions are not on the device");
     DD_HIP(launch_swin_ttab(h->LA.w_oihw.as<float>(), h->LB.w_oihw.as<float>(), h->L[2].w_oihw.as<float>(), h->emb.as<float>(),
                             pl->tsteps.as<long long>(), k.T, k.h, k.w, pl->tt_scratch.as<float>(), pl->ttab.as<float>(), s));

@@ -111,6 +111,7 @@ struct ConvParams {
   // Swin denoiser with the step-invariant part of pred.0(convB(convA(.))) hoisted (kernel id SWIN_PRED_H): this step's rows of the
   // time-embedding table [SWIN_TT_ROWS][64] fp32 -- row 0 is added to every pixel, row 1 + 7 r + c to the pixels of border class (r, c)
   const float* ttab;
+  int ttab_bstride;         // floats between the tables of consecutive images: 0 in the loop (one timestep for the whole batch), SWIN_TT_ROWS * 64 for a single call with per-sample timesteps
   const float* bcorr;       // SWIN_PRED5_H: [B][swin_ring_stride][64] fp32, subtracted at the pixels on the image border (corners: ring entry + corner entry)
   const void* addend;       // FPN lateral convs (layers 10..13): optional top-down term added after the ReLU (activation layout), or NULL
   // HAHI neck layers (30..41): the input / output tensor is a channel range of a wider channel-blocked buffer (the concatenation the

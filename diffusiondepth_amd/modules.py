@@ -324,12 +324,10 @@ class ScheduledCNNRefine(nn.Module):
 
     @property
     def single_call_precision(self) -> str:
-        """The precision ONE epsilon-network call (this module's forward: the heads' ddim_loss evaluation, …res.py:211) really runs in.  It is
-        ``self.precision`` except for the Swin / MPViT denoiser in the refined f16 mode: there "f16r" exists as hoisted forward-only plans of
-        the T-step loop only (dd_denoise; dd_denoise_once refuses it), so the single call runs this denoiser's plain f16 kernels.  `pred` comes
-        from the loop and is unaffected; `ddim_loss` of such a head is an f16-mode value ("Profiles and precisions")."""
-        if self.variant == "swin" and str(self.precision).lower() in ("f16r", "refined_f16"):
-            return "f16"
+        """The precision ONE epsilon-network call (this module's forward: the heads' ddim_loss evaluation, …res.py:211) really runs in: ``self.precision``.
+        (Until round 5 the Swin / MPViT denoiser in the refined f16 mode fell back to its plain f16 kernels here -- "f16r" existed for it as hoisted plans of
+        the T-step loop only.  Since round 6 dd_denoise_once runs the hoisted form for that denoiser as well, with one E[t] border table per image built
+        from the call's own timesteps: a "fast" Swin head's `ddim_loss` is an f16r value like its `pred`.)"""
         return self.precision
 
     def forward(self, noisy_image, t, *args):

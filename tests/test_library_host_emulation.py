@@ -468,15 +468,25 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
         assert np.isfinite(xs).all() and maxabs(xs, ref) < LATENT_TOL["f16x3"] * scale
         # refined f16 (DD_PREC_F16R): the once-per-image chain on split operands from the fp32 upsampled condition map, reformatted into the 5x5
         # kernel's accumulator order as block-scaled int16 (8x32 and 16x32 tiles); the 5x5 kernel writes y3 as int16 with a per-pixel scale; conv1 /
-        # conv4 in their weight-pair forms.  Closer to the oracle than the f16 mode; single calls are refused (no hoisted form)
+        # conv4 in their weight-pair forms.  Closer to the oracle than the f16 mode; a single call with per-sample timesteps runs the hoisted form too
+        # (round 6: one E[t] border table per image), and the library still refuses the mode when the 5x5 form is switched off
         xr = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
         be.set_option("big_tiles", 1)
         xrb = be.denoise(inp["x_T"], inp["cond"], T, "f16r")
         be.set_option("big_tiles", -1)
         for got in (xr, xrb):
             assert np.isfinite(got).all() and maxabs(got, ref) < LATENT_TOL["f16r"] * scale
-        with pytest.raises(RuntimeError, match="hoisted forward-only"):
-            be.denoise_once(inp["x_T"], 500, inp["cond"], "f16r")
+        tt = np.array([500, 33][:inp["x_T"].shape[0]], dtype=np.int64)
+        e_r = be.denoise_once(inp["x_T"], tt, inp["cond"], "f16r")
+        e_32 = be.denoise_once(inp["x_T"], tt, inp["cond"], "fp32")
+        e_16 = be.denoise_once(inp["x_T"], tt, inp["cond"], "f16")
+        assert np.isfinite(e_r).all() and maxabs(e_r, e_32) < EPS_TOL["f16r"] and maxabs(e_r, e_32) <= maxabs(e_16, e_32) * 1.05 + 1e-6, (maxabs(e_r, e_32), maxabs(e_16, e_32))
+        be.set_option("swin_w5", 0)
+        try:
+            with pytest.raises(RuntimeError, match="hoisted forward-only"):
+                be.denoise_once(inp["x_T"], tt, inp["cond"], "f16r")
+        finally:
+            be.set_option("swin_w5", 1)
 
 
 @full_only
