@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // load is a wait for every large one in front of it): small table inputs, then the patch, then the accumulators' start values.
   issue_weights(0);
   float my_bias = p.bias[n0 + (tid < C::NT * C::SPW ? tid : 0)];     // into tab_bias behind the loads below
-  if constexpr (C::ADD_T) my_bias += p.ttab[tid < HID_C ? tid : 0];        // hoisted Swin form: + the E[t] term of the reference border class
+  if constexpr (C::ADD_T) my_bias += p.ttab[(size_t)b * p.ttab_bstride + (tid < HID_C ? tid : 0)];        // hoisted Swin form: + the E[t] term of the reference border class
   // hoisted condition term: this thread's entries of the E[t] tap-sum row.  Only the LOADS are issued here (into registers): the LDS
   // image is written behind the GroupNorm butterfly and read in the epilogue, so the timestep -> etab row -> LDS dependency does
   // not sit in front of the partial-sum / patch / accumulator loads (it cost ~4 us of every workgroup: profiles/history/r02_run3_phase_profile.md)
@@ -690,7 +690,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
         }
         if constexpr (C::ADD_T) {
           if (trow >= 0) {
-            const float4 dv = *reinterpret_cast<const float4*>(p.ttab + trow * HID_C + n * 32 + 8 * q + 4 * g);
+            const float4 dv = *reinterpret_cast<const float4*>(p.ttab + (size_t)e_b * p.ttab_bstride + trow * HID_C + n * 32 + 8 * q + 4 * g);
             bv.x += dv.x; bv.y += dv.y; bv.z += dv.z; bv.w += dv.w;
           }
           if constexpr (C::PRED5) {

@@ -225,7 +225,7 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
  * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
- * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent and every image's result is bit-identical to the one-lane call's as long as both take the same tile form -- the hoisted conv3 pair of the 2-byte modes runs on 16x32 tiles in a multi-lane call with more tiles than resident slots and on 8x32 tiles otherwise (another GroupNorm partial-sum order: equal to fp32 round-off of the statistics, option "big_tiles" forces one form);
+ * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent and every image's result is bit-identical to the one-lane call's as long as both take the same tile form -- since round 6 the Res denoiser's hoisted conv3 pair keeps its 8x32 tiles for every lane count (the Swin 5x5 form moves to 16x32 tiles when its 8x32 tiles exceed the resident slots, whatever the lane count), so they do; option "big_tiles" forces one form;
  * dd_denoise_backward splits the same way, with one parameter-gradient set per lane summed into the caller-visible one at the join;
  * default 1), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
  * "keep_activations_mb" (budget of the per-step activation slots kept by "keep_trajectory" forwards, default 65536: ONE figure for the
@@ -234,7 +234,9 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * csrc/dd_thin.hip in the 16-bit modes, 0 = as an instance of the general kernel: A/B switch), "thin_slots" (workgroups of that kernel,
  * default 512 = two per CU), "train_graphs" (0 [default] = a forward that keeps its trajectory -- a training step -- is
  * enqueued eagerly, 1 = it replays a captured hipGraph like the inference plans: round 5 measured intermittent non-finite values in 16-bit training
- * steps only with the graph), "check_finite" (debug: the backward counts the non-finite values of every tensor it writes and fails
+ * steps only with the graph; round 6 traced them to the HIP runtime's graph packet capture next to MIOpen-launched kernels -- gone with
+ * DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment, profiles/r06_experiments.md section 5), "graph_fence" (diagnosis: bit 0 / 1 = a host
+ * synchronisation in front of / behind every graph launch, bit 2 = the graph on the handle's own stream between two events), "check_finite" (debug: the backward counts the non-finite values of every tensor it writes and fails
  * with the name of the first one; 1 = synchronising after every stage, 2 = asynchronously, reported at the end of the call),
  * "bf16_storage" (1 = all-bf16 tensors in DD_PREC_BF16; default 0 = f16 storage),
  * "f16r_wide" (DD_PREC_F16R: 1 [default] = y3 and the hoisted conv3(cond) term travel as int16 with block scales -- one fp32 scale per pixel of y3, per

@@ -476,15 +476,21 @@ def test_swin_loop_with_the_step_invariant_terms_hoisted(lib, h, w, T):
         be.set_option("big_tiles", -1)
         for got in (xr, xrb):
             assert np.isfinite(got).all() and maxabs(got, ref) < LATENT_TOL["f16r"] * scale
-        tt = np.array([500, 33][:inp["x_T"].shape[0]], dtype=np.int64)
-        e_r = be.denoise_once(inp["x_T"], tt, inp["cond"], "f16r")
-        e_32 = be.denoise_once(inp["x_T"], tt, inp["cond"], "fp32")
-        e_16 = be.denoise_once(inp["x_T"], tt, inp["cond"], "f16")
-        assert np.isfinite(e_r).all() and maxabs(e_r, e_32) < EPS_TOL["f16r"] and maxabs(e_r, e_32) <= maxabs(e_16, e_32) * 1.05 + 1e-6, (maxabs(e_r, e_32), maxabs(e_16, e_32))
+        # (TWO images with DIFFERENT timesteps: each takes its own E[t] border table -- ConvParams::ttab_bstride; against the fp64 oracle, both tile forms)
+        i2 = synth.make_inputs(411, 2, h, w, (3, 5))
+        tt = np.array([500, 33], dtype=np.int64)
+        _, sd2 = backend_for(lib, {"wseed": 7245, "variant": "swin"})
+        be.set_option("hoist_cond", -1)
+        ref_eps = O.denoiser_forward(sd2, i2["x_T"], tt, i2["cond"], "swin")
+        for big in (0, 1):
+            be.set_option("big_tiles", big)
+            e_r = be.denoise_once(i2["x_T"], tt, i2["cond"], "f16r")
+            assert np.isfinite(e_r).all() and max(maxabs(e_r[b], ref_eps[b]) for b in range(2)) < EPS_TOL["f16r"], [maxabs(e_r[b], ref_eps[b]) for b in range(2)]
+        be.set_option("big_tiles", -1)
         be.set_option("swin_w5", 0)
         try:
             with pytest.raises(RuntimeError, match="hoisted forward-only"):
-                be.denoise_once(inp["x_T"], tt, inp["cond"], "f16r")
+                be.denoise_once(i2["x_T"], tt, i2["cond"], "f16r")
         finally:
             be.set_option("swin_w5", 1)
 
