@@ -87,7 +87,14 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   constexpr int NSPLIT_G = NSPLIT / C::SPW;
   const int nsplit = (wgid % NSPLIT_G) * C::SPW;      // first split of this workgroup
   const int tiles_per_img = p.tiles_x * p.tiles_y;
-  int n0 = nsplit * C::NT;                            // first cout of the split being computed
+#ifndef DD_SPLIT_FLIP
+#define DD_SPLIT_FLIP 1
+#endif
+  // DD_SPLIT_FLIP (round 6): workgroups of odd tiles walk their two cout splits in the opposite order, so that at any moment half the workgroups stream the first
+  // split's weight stages and half the second's (otherwise every workgroup of an XCD reads the same L2 lines at the same time).  Bit-identical outputs; conv2 130.7 /
+  // 131.4 -> 129.4 / 129.0 us at KITTI B = 4 (A/B/A/B on one box, profiles/r06_call19_split_flip.txt): -1 %.
+  const int flip = (DD_SPLIT_FLIP && C::SPW == 2) ? ((wgid / NSPLIT_G) & 1) : 0;
+  int n0 = (nsplit + flip) * C::NT;                   // first cout of the split being computed
   int sbase = 0;                                      // weight stages consumed by the splits already done (ring slots run on across splits)
   const int h = p.h, w = p.w;
   const bool have_norm = (C::PRO == PRO_X) ? (p.step > 0) : (C::PRO != PRO_RAW);
@@ -124,7 +131,8 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   const unsigned lds_base = DD_LDS_BASE(smem);
   constexpr int NWPIECE = (C::W_BYTES / 1024 + C::WAVES - 1) / C::WAVES;      // 1-KiB DMA instructions per wave and stage
   auto issue_weight_piece = [&](int s, int c) {
-    const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)nsplit * C::NSTAGE + s) * (size_t)C::W_BYTES + lane * 16;
+    const int si = flip ? (s < C::NSTAGE ? s + C::NSTAGE : s - C::NSTAGE) : s;      // (DD_SPLIT_FLIP: the stage's place in the packed image)
+    const char* src = reinterpret_cast<const char*>(p.wpack) + ((size_t)nsplit * C::NSTAGE + si) * (size_t)C::W_BYTES + lane * 16;
     const unsigned dst = lds_base + C::W_OFF + (s & (C::NWB - 1)) * C::W_BYTES;
     const int kc = c * C::WAVES + wave;
     if (kc < C::W_BYTES / 1024) {
@@ -322,7 +330,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   // Loads only, in the order they are needed, and nothing that waits in between (VMEM returns in issue order: a wait for a late small
   // load is a wait for every large one in front of it): small table inputs, then the patch, then the accumulators' start values.
   issue_weights(0);
-  float my_bias = p.bias[n0 + (tid < C::NT * C::SPW ? tid : 0)];     // into tab_bias behind the loads below
+  float my_bias = p.bias[nsplit * C::NT + (tid < C::NT * C::SPW ? tid : 0)];     // into tab_bias behind the loads below (the table holds the splits in their natural order)
   if constexpr (C::ADD_T) my_bias += p.ttab[(size_t)b * p.ttab_bstride + (tid < HID_C ? tid : 0)];        // hoisted Swin form: + the E[t] term of the reference border class
   // hoisted condition term: this thread's entries of the E[t] tap-sum row.  Only the LOADS are issued here (into registers): the LDS
   // image is written behind the GroupNorm butterfly and read in the epilogue, so the timestep -> etab row -> LDS dependency does
@@ -674,7 +682,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
     auto value_of = [&](int n, int q, float (&v)[4]) {
       const int co = n0 + n * 32 + 8 * q + 4 * g;
       (void)co;
-        float4 bv = *reinterpret_cast<const float4*>(tab_bias + sp * C::NT + n * 32 + 8 * q + 4 * g);
+        float4 bv = *reinterpret_cast<const float4*>(tab_bias + (sp ^ flip) * C::NT + n * 32 + 8 * q + 4 * g);
         if constexpr (C::ADD_C) {
           // tab_bias already holds bias + the full 9-tap E[t] sum; pixels on the image border take the missing taps out
           if (tapmask != 0x1FFu) {
@@ -872,7 +880,7 @@ __global__ void __launch_bounds__(C::THREADS, C::MIN_WAVES_PER_SIMD) conv_igemm2
   DD_PROF_MARK(5);
   if (sp + 1 >= C::SPW) break;
   // next cout split over the same patch: its first weight stage was requested during this split's last stage and has landed
-  n0 += C::NT;
+  n0 = (nsplit + ((sp + 1) ^ flip)) * C::NT;
   sbase += C::NSTAGE;
   init_acc();
   }
