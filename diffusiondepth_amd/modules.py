@@ -165,18 +165,26 @@ class HipBound:
                 self._sched_sig = ssig
         return self.backend
 
-    def check_grad_guard(self):
-        """Raise if a backward of the library returned a non-finite value since the last check (``_note_grads``).  Called in front of every refresh of
-        the denoiser's parameters (i.e. once per training iteration); callable by hand after ``loss.backward()``."""
+    def check_grad_guard(self, wait: bool = False):
+        """Raise if a backward of the library returned a non-finite value (``_note_grads``).  Called in front of every refresh of the denoiser's
+        parameters (once per training iteration) without blocking: only entries whose event has completed are read; ``wait=True`` (callable by hand
+        after ``loss.backward()``) reads them all."""
         be = self.backend
-        flag = getattr(be, "_grad_guard", None) if be is not None else None
-        if flag is None:
+        q = getattr(be, "_grad_guard", None) if be is not None else None
+        if not q:
             return
-        be._grad_guard = None
-        if not bool(torch.isfinite(flag)):
-            raise FloatingPointError("diffusiondepth_amd: a backward pass of the HIP denoiser returned non-finite gradients (NaN / Inf) since the last "
-                                     "parameter refresh; refusing to continue training on parameters built from them (DDEPTH_GRAD_GUARD=0 disables this check; "
-                                     "dd_set_option('check_finite', 2) names the first non-finite tensor)")
+        bad = False
+        while q:
+            flag, ev = q[0]
+            if not wait and ev is not None and len(q) <= 4 and not ev.query():
+                break
+            q.pop(0)
+            bad = bad or not bool(torch.isfinite(flag))
+        if bad:
+            q.clear()
+            raise FloatingPointError("diffusiondepth_amd: a backward pass of the HIP denoiser returned non-finite gradients (NaN / Inf); refusing to continue "
+                                     "training on parameters built from them (DDEPTH_GRAD_GUARD=0 disables this check; dd_set_option('check_finite', 2) names "
+                                     "the first non-finite tensor)")
 
     @staticmethod
     def _hip_device(device) -> torch.device:
@@ -224,18 +232,26 @@ GRAD_GUARD = os.environ.get("DDEPTH_GRAD_GUARD", "1") != "0"
 
 def _note_grads(be, tensors):
     """Always-on guard of the training path (round 6; ADVICE r5 medium: the 16-bit training steps once continued silently on NaN parameters): every
-    backward of the library folds the sum of everything it returns -- parameter gradients, grad_x, grad_cond -- into ONE device scalar on the backend
-    (asynchronous: a handful of reduction kernels, no host synchronisation here).  A NaN / Inf anywhere makes that scalar non-finite, and it stays so.
-    ``HipBound.ensure`` reads it when the NEXT training forward refreshes the parameters (by then the previous step is long complete: the read costs one
-    round trip per iteration) and raises FloatingPointError instead of uploading parameters that an optimizer built from non-finite gradients.
-    DDEPTH_GRAD_GUARD=0 switches it off."""
+    backward of the library folds the sum of everything it returns -- parameter gradients, grad_x, grad_cond -- into ONE device scalar (asynchronous: a
+    handful of reduction kernels) and queues it on the backend with an event recorded behind it.  A NaN / Inf anywhere makes that scalar non-finite.
+    ``HipBound.check_grad_guard`` -- called in front of every refresh of the denoiser's parameters, i.e. once per training iteration -- looks only at the
+    entries whose event has COMPLETED (no host synchronisation: the host keeps running ahead of the device as before; an entry is read one or two
+    iterations after it was made, a queue longer than four entries waits for its oldest) and raises FloatingPointError instead of uploading parameters
+    that an optimizer built from non-finite gradients.  DDEPTH_GRAD_GUARD=0 switches it off."""
     if not GRAD_GUARD:
         return
     parts = [t.sum() for t in tensors if t is not None]
     if not parts:
         return
     s = torch.stack(parts).sum()
-    be._grad_guard = s if getattr(be, "_grad_guard", None) is None else be._grad_guard + s
+    ev = None
+    if s.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(s.device))
+    q = getattr(be, "_grad_guard", None)
+    if q is None:
+        q = be._grad_guard = []
+    q.append((s, ev))
 
 
 class _DenoiseOnceFn(torch.autograd.Function):
