@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libddepth_hip.so"
 _lib = None
 
-# "f16x3": split f16 (DD_PREC_F16X3, include/ddepth.h) -- the abs-1e-3-on-depth inference mode (forward only)
+# "f16x3": split f16 (DD_PREC_F16X3, include/ddepth.h) -- the abs-1e-3-on-depth mode; its backward (round 6) sends f16 gradients behind the split forward
 # "f16r": refined f16 (DD_PREC_F16R) -- f16 operands with one MFMA per product on the two large convolutions, the thin layers / the once-per-image
 # term / the y3 hand-over made (near-)exact: the 16-bit inference mode that holds 1e-3 depth RMSE at KITTI's depth range (Res denoiser, forward only)
 PRECISIONS = {"naive_fp32": 0, "fp32": 1, "bf16": 2, "f16": 3, "fp16": 3, "f16x3": 4, "split_f16": 4, "f16r": 5, "refined_f16": 5}

@@ -117,6 +117,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->bf16_pure = value != 0;
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
+  else if (k == "x3_grad_fp32") h->x3_grad_fp32 = value != 0;
   else if (k == "keep_trajectory") h->keep_traj = value != 0;
   else if (k == "use_trajectory") h->use_traj = value;
   else if (k == "adjoint_tiled") h->adjoint_tiled = value != 0;
@@ -422,13 +423,15 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
   }
 
   // A plan that KEEPS its trajectory -- the forward of a training step -- is enqueued eagerly (option "train_graphs" = 1 restores the graph).  Round 5
-  // found 16-bit training steps producing non-finite values intermittently (3 of 8 processes within 40 iterations, always in iterations 20..34 of
-  // a process; never with fp32 operands, never forward-only, never with ANY host synchronisation, extra kernel or serialisation added between
-  // the stages -- every observation made the symptom go away) and the one switch that separates clean from failing runs with no other change is
-  // whether this forward is a replayed hipGraph: 0 of 12 processes fail with eager launches, 9 of 21 with the graph (A/B alternating on one
-  // box: profiles/r05_experiments.md section 4).  The cause inside the graph replay next to the backward's ~600-launch eager bursts was not
-  // established; the eager form costs the 59-ms training step nothing measurable and the inference plans (hundreds of replays per bench run,
-  // parity-checked) are not affected.
+  // found 16-bit training steps of a whole head producing non-finite values intermittently (3 of 8 processes within 40 iterations, always in iterations
+  // 20..34; never with fp32 operands, never forward-only) and the one library switch that separates clean from failing runs is whether this forward is a
+  // replayed hipGraph (0 of 12 processes fail with eager launches, 9 of 21 with the graph: profiles/r05_experiments.md section 4).  Round 6 localised it
+  // OUTSIDE the library (profiles/r06_experiments.md section 5): a torch-free driver of these very calls never fails (0 of 64 processes), the library alone
+  // from Python never fails (0 of 24), the head fails only while PyTorch's MIOpen convolutions AND batch-norm training kernels run between the calls
+  // (either half taken away: 0 of 10), and not with a host synchronisation on either side of hipGraphLaunch (option "graph_fence") or with the HIP
+  // runtime's graph fast path off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: 0 of 8 against 6 of 8) -- the runtime's packet-captured graph launch next to those
+  // kernels.  The eager form costs the 59-ms training step nothing measurable; the inference plans (hundreds of replays per bench run, parity-checked,
+  // no MIOpen kernel in between) are not affected.
   const bool want_graph = h->use_graph && !h->layer_timing && !h->debug_sync && !pl->capture_failed && (!keep || h->train_graphs);
   bool launched = false;
   if (want_graph) {

@@ -131,6 +131,7 @@ struct Plan {
   DevBuf a1, f, a3, eps;   // naive path only: normalised activations
   DevBuf sa, sf;           // Swin variant: convA / convB outputs (256 ch)
   DevBuf bX, bA1, bF, bA3; // fused backward: the four convs' input activations, materialised for the weight gradients
+  DevBuf bSa, bSf;         // Swin, split-f16 forward with f16 gradients: the fuse convolutions' raw results as f16 operands
   DevBuf xstash;           // loop backward: the T states entering each step + the running gradient, fp32 NHWC16
   int64_t traj_ticket = 0;         // key.keep plans: ticket of the dd_denoise call whose states x_0 .. x_{T-1} xstash holds (0 = none)
   int64_t traj_weights = -1;       // ... and the parameter generation (dd_handle_s::weights_serial) they were computed with
@@ -263,6 +264,7 @@ struct dd_handle_s {
   bool adjoint_tiled = true;  // Swin backward: tiled separable kernel for the adjoint of the condition upsampling (0 = the one-thread-per-piece kernel, A/B check)
   int64_t traj_serial = 0, use_traj = 0, weights_serial = 0, n_traj_reuse = 0;
   int naive_wgrad = 0;        // backward: 1 = weight gradients by the unfused kernel in every mode (A/B check of dd_wgrad.hip)
+  int x3_grad_fp32 = 0;       // DD_PREC_F16X3's backward: 0 = f16 gradients behind the split forward (the f16 mode's MFMA kernels), 1 = fp32 gradients (the fp32 mode's kernels)
   std::map<PlanKey, std::unique_ptr<Plan>> plans;
   DevBuf wgrad_ws[MAX_LANES]; // per-slab partial weight gradients of dd_wgrad.hip (one workspace per concurrent lane)
   // parameter gradients (fp32, reference shapes), accumulated like torch .grad in set 0; sets 1.. are the scratch of the concurrent lanes of

@@ -72,7 +72,13 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   const bool naive = precision == DD_PREC_NAIVE_FP32;
   const long long HW = (long long)lat_h * lat_w;
   const int mode = pl->ek;                  // kernels of the recomputed forward pass and of the data gradients
-  const int ek = opnd_kind(mode);           // gradients, materialised activations, weight-gradient operands: bf16 in the mode EK_BF16M
+  // gradients, materialised activations, weight-gradient operands: bf16 in the mode EK_BF16M.  Split f16 (DD_PREC_F16X3, round 6): the forward the
+  // backward differentiates -- recomputed here or kept by the forward call -- runs the split kernels (fp32 tensors in the fp32 mode's layouts, every
+  // product as three f16 MFMAs: the values the loss sees hold the 1e-3 absolute depth bound, the ReLU masks and GroupNorm statistics are the exact
+  // forward's); the gradients BEHIND it travel as f16 through the f16 mode's kernels (MFMA data and weight gradients; the GroupNorm-backward kernels read
+  // the fp32 y / condition map and write f16) -- or, option "x3_grad_fp32" = 1, as fp32 through the fp32 mode's (unfused weight gradient: ~60x slower,
+  // the parity form)
+  const int ek = mode == EK_F16S ? (h->x3_grad_fp32 ? (int)EK_F32 : (int)EK_F16) : opnd_kind(mode);
   const int yk = store_kind(mode);          // the stored conv outputs y1..y3 and the condition map (f16 in that mode)
   int rc = DD_OK;
   // option "check_finite" (debug): after a stage, count the non-finite elements of what it wrote; the first hit fails the call by name
@@ -96,7 +102,7 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
                                       std::to_string(lane) + ") holds " + std::to_string(c) + " non-finite values of " + std::to_string(n));
     return DD_OK;
   };
-  const int kk = (opnd_kind(pl->ek) == EK_F32) ? 0 : (opnd_kind(pl->ek) == EK_BF16 ? 1 : 2);
+  const int kk = (ek == EK_F32) ? 0 : (ek == EK_BF16 ? 1 : 2);
   if (!kept) DD_HIP(hipMemsetAsync(pl->stat_ptr(0, 0), 0, (size_t)4 * B * STAT_SLOTS * STAT_STRIDE * sizeof(double), s));
   const int lay = naive ? 0 : 1;                    // activation layout flag of the views: plain NHWC fp32 / channel-blocked
   const ActView nothing{nullptr, EK_F32, 0, 1, HW};
@@ -131,6 +137,14 @@ int bwd_core(dd_handle_t h, Plan* pl, const float* x_nhwc, const long long* tv, 
   const void* sf_buf = src->slot(src->sf, sstep);
   const bool swin = h->variant == DD_VARIANT_SWIN;     // fused modes only (checked by the callers)
   // the conv's input activation; Swin: pred.0 reads the raw convB output sf (and convB reads sa, convA reads bF = u)
+  if (swin && mode == EK_F16S && ek != EK_F32) {
+    // split f16 with f16 gradients: the fuse convolutions' raw results (fp32 in this mode) as f16 operands of their weight gradients
+    const size_t bytes = (size_t)B * COND_C * HW * 2;
+    if (pl->bSa.bytes < bytes) { DD_HIP(pl->bSa.alloc(bytes)); DD_HIP(pl->bSf.alloc(bytes)); }
+    DD_HIP(launch_view_copy(ActView{sa_buf, EK_F32, 1, COND_C, HW}, ActView{pl->bSa.p, ek, 1, COND_C, HW}, B, s));
+    DD_HIP(launch_view_copy(ActView{sf_buf, EK_F32, 1, COND_C, HW}, ActView{pl->bSf.p, ek, 1, COND_C, HW}, B, s));
+    sa_buf = pl->bSa.p; sf_buf = pl->bSf.p;
+  }
   const void* inbuf[4] = {naive ? (const void*)x_nhwc : pl->bX.p, naive ? pl->a1.p : pl->bA1.p,
                           naive ? pl->f.p : (swin ? sf_buf : pl->bF.p), naive ? pl->a3.p : pl->bA3.p};
   hipError_t e = hipSuccess;
@@ -258,9 +272,9 @@ int check_bwd(dd_handle_t h, int precision, const char* who) {
   if (h->variant == DD_VARIANT_SWIN && precision == DD_PREC_NAIVE_FP32)
     return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_VARIANT_SWIN has no unfused path (use fp32 / bf16 / f16)");
   if (precision < DD_PREC_NAIVE_FP32 || precision > DD_PREC_LAST) return h->fail(DD_ERR_INVALID_ARG, std::string(who) + ": unknown precision");
-  if (precision == DD_PREC_F16X3 || precision == DD_PREC_F16R)
-    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16X3 (split f16) and DD_PREC_F16R (refined f16) are forward-only modes; train in fp32 / bf16 / f16");
-  return DD_OK;
+  if (precision == DD_PREC_F16R)
+    return h->fail(DD_ERR_UNSUPPORTED, std::string(who) + ": DD_PREC_F16R (refined f16) is a forward-only mode; train in fp32 / f16x3 (the forward's abs-1e-3 modes) or bf16 / f16");
+  return check_split(h, precision, who);
 }
 
 }  // namespace ddapi

@@ -191,12 +191,35 @@ hipError_t launch_channel_sum(const ActView& v, float* out, const long long* row
 // ------------------------------------------------------------------------------------------------
 template <int EK>
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) { Piece<EK>::unpack(v, f); }
+// eight consecutive channels of a channel-blocked tensor of kind K at ELEMENT offset `off`: one 16-byte piece of a 2-byte kind, two of fp32 (the stored
+// conv outputs and the condition map of the split-f16 mode, whose gradients travel as f16: DD_PREC_F16X3's backward)
+template <int K> struct Raw8 {
+  uint4 v[K == EK_F32 ? 2 : 1];
+  __device__ __forceinline__ void load(const void* p, size_t off) {
+    if constexpr (K == EK_F32) {
+      const uint4* q = reinterpret_cast<const uint4*>(static_cast<const float*>(p) + off);
+      v[0] = q[0]; v[1] = q[1];
+    } else {
+      v[0] = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p) + off);
+    }
+  }
+  __device__ __forceinline__ void unpack(float (&f)[8]) const {
+    if constexpr (K == EK_F32) {
+      float a[4], b[4];
+      Piece<EK_F32>::unpack(v[0], a); Piece<EK_F32>::unpack(v[1], b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { f[i] = a[i]; f[4 + i] = b[i]; }
+    } else {
+      Piece<K>::unpack(v[0], f);
+    }
+  }
+};
 
 // per (b, c):  out[0] += sum g_z,  out[1] += sum g_z * yh,  out[2] += sum y  (for the analytic conv-bias gradient),
 // out[3] += sum g_a (unmasked: the time-embedding gradient when g_a is dLoss/df)
 // EK = kind of the gradient tensor, YK = kind of the stored conv output (they differ in the mode EK_BF16M: bf16 gradients, f16 y)
 template <int EK, int YK>
-__global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16_t* __restrict__ ga, const uint16_t* __restrict__ y,
+__global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16_t* __restrict__ ga, const void* __restrict__ y,
                                                                     const double* __restrict__ stats, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, double* __restrict__ out, int C,
                                                                     long long HW, int slab) {
@@ -221,9 +244,9 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16
   const long long p0 = (long long)blockIdx.x * slab, p1 = min(p0 + slab, HW);
   for (long long p = p0 + pl; p < p1; p += 64) {
     const uint4 gv = *reinterpret_cast<const uint4*>(ga + base + (size_t)p * ACT_CB);
-    const uint4 yv = *reinterpret_cast<const uint4*>(y + base + (size_t)p * ACT_CB);
+    Raw8<YK> yv; yv.load(y, base + (size_t)p * ACT_CB);
     float g[8], yy[8];
-    unpack8<EK>(gv, g); unpack8<YK>(yv, yy);
+    unpack8<EK>(gv, g); yv.unpack(yy);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float yh = (yy[k] - mean) * rstd;
@@ -243,26 +266,28 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_blocked_kernel(const uint16
 }
 hipError_t launch_gn_bwd_reduce_blocked(const void* ga, const void* y, int ek, int yk, const double* stats, const float* gamma, const float* beta,
                                         double* out_bc4, int B, int C, long long HW, hipStream_t s) {
-  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16))) return hipErrorInvalidValue;
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16) || (ek == EK_F16 && yk == EK_F32))) return hipErrorInvalidValue;
   const int slab = 1024;                                   // 16 passes of 64 pixels: fp32 partials of <= 16 values per thread
   dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
   if (ek == EK_BF16 && yk == EK_F16) hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_BF16, EK_F16>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
-                                        reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
+                                        y, stats, gamma, beta, out_bc4, C, HW, slab);
   else if (ek == EK_BF16) hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_BF16, EK_BF16>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
-                                        reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
+                                        y, stats, gamma, beta, out_bc4, C, HW, slab);
+  else if (yk == EK_F32) hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_F16, EK_F32>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
+                                        y, stats, gamma, beta, out_bc4, C, HW, slab);      // split-f16 mode: fp32 y, f16 gradients
   else hipLaunchKernelGGL((gn_bwd_reduce_blocked_kernel<EK_F16, EK_F16>), grid, dim3(256), 0, s, reinterpret_cast<const uint16_t*>(ga),
-                          reinterpret_cast<const uint16_t*>(y), stats, gamma, beta, out_bc4, C, HW, slab);
+                          y, stats, gamma, beta, out_bc4, C, HW, slab);
   return hipGetLastError();
 }
 
 // g_y = A_c g_z + P_g + Q_g y   with A_c = gamma_c rstd_g,  Q_g = -rstd^2 S2/N,  P_g = -rstd S1/N - mean Q_g  (the same
 // expression as gn_bwd_apply_kernel, regrouped);  optional  act = relu(A_c y + B_c) [+ cond + E[t]].   sums: [b][c][4].
 template <int EK, int YK>      // EK: g_a, g_y and act;  YK: y and cond
-__global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_t* __restrict__ ga, const uint16_t* __restrict__ y,
+__global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_t* __restrict__ ga, const void* __restrict__ y,
                                                                    const double* __restrict__ stats, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, const double* __restrict__ sums,
                                                                    uint16_t* __restrict__ gy, uint16_t* __restrict__ act,
-                                                                   const uint16_t* __restrict__ cond, const float* __restrict__ emb,
+                                                                   const void* __restrict__ cond, const float* __restrict__ emb,
                                                                    const long long* __restrict__ tvec, int t_base, int t_bstride, int C,
                                                                    long long HW, int slab) {
   __shared__ float s_mean[GN_GROUPS], s_rstd[GN_GROUPS], s_p[GN_GROUPS], s_q[GN_GROUPS];
@@ -306,18 +331,19 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
   for (long long p = p0 + pl; p < p1; p += 128) {
     const bool two = p + 64 < p1;
     const size_t off[2] = {base + (size_t)p * ACT_CB, base + (size_t)(two ? p + 64 : p) * ACT_CB};
-    uint4 ry[2], rg[2], rc[2];
+    Raw8<YK> ry[2], rc[2];
+    uint4 rg[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      ry[j] = *reinterpret_cast<const uint4*>(y + off[j]);
+      ry[j].load(y, off[j]);
       if (gy) rg[j] = *reinterpret_cast<const uint4*>(ga + off[j]);
-      if (act && cond) rc[j] = *reinterpret_cast<const uint4*>(cond + off[j]);
+      if (act && cond) rc[j].load(cond, off[j]);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j == 1 && !two) break;
       float yy[8];
-      unpack8<YK>(ry[j], yy);
+      ry[j].unpack(yy);
       if (gy) {
         float g[8], o[8];
         unpack8<EK>(rg[j], g);
@@ -334,7 +360,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
         for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaf(ta[k], yy[k], tb[k]), 0.f);
         if (cond) {
           float cv[8];
-          unpack8<YK>(rc[j], cv);
+          rc[j].unpack(cv);
 #pragma unroll
           for (int k = 0; k < 8; ++k) o[k] = o[k] + (cv[k] + te[k]);
         }
@@ -346,16 +372,18 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_blocked_kernel(const uint16_
 hipError_t launch_gn_bwd_apply_blocked(const void* ga, const void* y, int ek, int yk, const double* stats, const float* gamma, const float* beta,
                                        const double* sums_bc4, void* gy, void* act, const void* cond, const float* emb,
                                        const long long* tvec, int t_base, int t_bstride, int B, int C, long long HW, hipStream_t s) {
-  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16))) return hipErrorInvalidValue;
+  if (C % ACT_CB != 0 || (ek != EK_BF16 && ek != EK_F16) || !(yk == ek || (ek == EK_BF16 && yk == EK_F16) || (ek == EK_F16 && yk == EK_F32))) return hipErrorInvalidValue;
   const int slab = 2048;      // the per-workgroup prologue (group moments, gamma-weighted sums over C/4 channels in fp64) costs as much as 512 pixels of streaming
   dim3 grid((unsigned)((HW + slab - 1) / slab), (unsigned)(C / ACT_CB), (unsigned)B);
   auto U16 = [](const void* p) { return reinterpret_cast<const uint16_t*>(p); };
-  if (ek == EK_BF16 && yk == EK_F16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_F16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
-                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
-  else if (ek == EK_BF16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_BF16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
-                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
-  else hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_F16, EK_F16>), grid, dim3(256), 0, s, U16(ga), U16(y), stats, gamma, beta, sums_bc4,
-                          reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), U16(cond), emb, tvec, t_base, t_bstride, C, HW, slab);
+  if (ek == EK_BF16 && yk == EK_F16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_F16>), grid, dim3(256), 0, s, U16(ga), y, stats, gamma, beta, sums_bc4,
+                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), cond, emb, tvec, t_base, t_bstride, C, HW, slab);
+  else if (ek == EK_BF16) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_BF16, EK_BF16>), grid, dim3(256), 0, s, U16(ga), y, stats, gamma, beta, sums_bc4,
+                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), cond, emb, tvec, t_base, t_bstride, C, HW, slab);
+  else if (yk == EK_F32) hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_F16, EK_F32>), grid, dim3(256), 0, s, U16(ga), y, stats, gamma, beta, sums_bc4,
+                                        reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), cond, emb, tvec, t_base, t_bstride, C, HW, slab);
+  else hipLaunchKernelGGL((gn_bwd_apply_blocked_kernel<EK_F16, EK_F16>), grid, dim3(256), 0, s, U16(ga), y, stats, gamma, beta, sums_bc4,
+                          reinterpret_cast<uint16_t*>(gy), reinterpret_cast<uint16_t*>(act), cond, emb, tvec, t_base, t_bstride, C, HW, slab);
   return hipGetLastError();
 }
 

@@ -58,7 +58,9 @@ typedef enum dd_precision {
   DD_PREC_F16X3 = 4,       /* split f16: every MFMA operand an f16 pair hi + lo (~22 mantissa bits), three MFMAs per product
                               (Whi.Phi + Whi.Plo + Wlo.Phi), fp32 tensors and accumulation -- the mode that meets the
                               1e-3 ABSOLUTE depth tolerance over the whole depth range at ~1/3 of the 16-bit rate;
-                              forward only (dd_denoise / dd_denoise_trace / dd_denoise_once / dd_condition)   */
+                              forward calls dd_denoise / dd_denoise_trace / dd_denoise_once / dd_condition; the backward calls
+                              (round 6) differentiate that forward -- kept or recomputed on the split kernels: its values, ReLU
+                              masks and GroupNorm statistics -- with f16 gradients (option "x3_grad_fp32" = 1: fp32 gradients) */
   DD_PREC_F16R = 5         /* refined f16: the two large convolutions on f16 operands with ONE MFMA per product, everything around
                               them made (near-)exact where it is (near-)free -- conv1 on split operands, conv3(cond) once per image
                               on split operands from the fp32 condition map, y3 and that term handed over as block-scaled int16 (f16's
@@ -223,7 +225,8 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * modes and DD_PREC_F16X3, 1 = also in the fp32 mode, 0 = never; training plans always run the reference's order), "swin_w5" (1 [default] = those plans run
  * pred.0 o convB as ONE 5x5 convolution with a per-step border-ring correction, 0 = as two kernels (DD_PREC_F16X3: the reference's order): A/B switch), "layer_timing", "ablate" (timing experiments; honoured in -DDD_ABLATE=1
  * builds only), "naive_wgrad" (1 = backward weight gradients by the unfused kernel
- * instead of the MFMA kernel, A/B check), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
+ * instead of the MFMA kernel, A/B check), "x3_grad_fp32" (DD_PREC_F16X3's backward: 0 [default] = f16 gradients through the f16 mode's MFMA kernels
+ * behind the split forward, 1 = fp32 gradients through the fp32 mode's kernels, ~60x slower: the parity form), "keep_trajectory" / "use_trajectory" (training: see dd_denoise_backward), "streams" (S > 1:
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
  * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent and every image's result is bit-identical to the one-lane call's as long as both take the same tile form -- since round 6 the Res denoiser's hoisted conv3 pair keeps its 8x32 tiles for every lane count (the Swin 5x5 form moves to 16x32 tiles when its 8x32 tiles exceed the resident slots, whatever the lane count), so they do; option "big_tiles" forces one form;
  * dd_denoise_backward splits the same way, with one parameter-gradient set per lane summed into the caller-visible one at the join;

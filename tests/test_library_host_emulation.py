@@ -27,6 +27,7 @@ from oracle import ddim_oracle as O
 FULL = os.environ.get("DD_EMU_FULL") == "1"
 full_only = pytest.mark.skipif(not FULL, reason="larger emulation case: set DD_EMU_FULL=1")
 LATENT_TOL = {"naive_fp32": 2e-5, "fp32": 2e-5, "f16x3": 2e-5, "f16": 1.5e-3, "bf16": 1e-2, "f16r": 8e-4}        # x max|x_0|: the GPU parity tests' own bounds
+X3_F16_GRAD_REL = 5e-3      # DD_PREC_F16X3 backward with f16 gradients: relative L2 per gradient tensor (measured in emulation: see the test's print)
 EPS_TOL = {"naive_fp32": 5e-5, "fp32": 5e-5, "f16x3": 5e-5, "f16": 1.5e-2, "bf16": 1e-1, "f16r": 1e-2}
 
 
@@ -559,7 +560,7 @@ def test_hahi_neck_on_the_split_f16_kernels(lib):
 
 
 # ---- backward ----------------------------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec", ["naive_fp32"] + (["fp32"] if FULL else []))
+@pytest.mark.parametrize("prec", ["naive_fp32"] + (["fp32", "f16x3"] if FULL else []))      # f16x3 (round 6): the split kernels' forward, the fp32 mode's gradient kernels
 def test_backward_vs_reference_autograd_golden(lib, golden, cases, prec):
     c, g = cases["denoise_bwd_res"], golden("denoise_bwd_res")
     be, _ = backend_for(lib, c)
@@ -570,16 +571,38 @@ def test_backward_vs_reference_autograd_golden(lib, golden, cases, prec):
     gx, gc = np.full_like(x, np.nan), np.full_like(cond, np.nan)
     B, _, h, w = x.shape
     be.timing(order=1, dma_late=1)
-    be.ck(lib.dd_denoise_once_backward(be.h, _p(x), _p(t), _p(cond), _p(ge), _p(gx), _p(gc), B, h, w, h, w, dda.backend.precision_id(prec), None),
-          "dd_denoise_once_backward")
+    if prec == "f16x3":
+        be.set_option("x3_grad_fp32", 1)          # fp32 gradients behind the split forward: held to the fp32 modes' bound
+    try:
+        be.ck(lib.dd_denoise_once_backward(be.h, _p(x), _p(t), _p(cond), _p(ge), _p(gx), _p(gc), B, h, w, h, w, dda.backend.precision_id(prec), None),
+              "dd_denoise_once_backward")
+    finally:
+        be.set_option("x3_grad_fp32", 0)
     assert maxabs(gx, g["grad_x"]) < 1e-4 * np.abs(g["grad_x"]).max()
     assert maxabs(gc[:, :8], g["grad_cond_ch0_8"]) < 1e-4 * np.abs(g["grad_cond_ch0_8"]).max()
-    for name in ("model.pred.0.weight", "model.noise_embedding.1.weight"):
+    names = ("model.pred.0.weight", "model.noise_embedding.1.weight")
+    for name in names:
         key = "grad." + name
         if key in g:
             out = np.full(g[key].shape, np.nan, np.float32)
             be.ck(lib.dd_get_grad(be.h, name.encode(), _p(out), out.size, None), "dd_get_grad")
             assert maxabs(out, g[key]) < 1e-4 * np.abs(g[key]).max(), name
+    if prec == "f16x3":
+        # the default form: f16 gradients through the f16 mode's MFMA kernels behind the SAME forward (exact ReLU masks and statistics): relative L2
+        rel = lambda a, b: float(np.sqrt(((np.asarray(a, np.float64) - b) ** 2).sum()) / np.sqrt((np.asarray(b, np.float64) ** 2).sum()))
+        be.ck(lib.dd_zero_grad(be.h, None), "dd_zero_grad")
+        gx[:], gc[:] = np.nan, np.nan
+        be.ck(lib.dd_denoise_once_backward(be.h, _p(x), _p(t), _p(cond), _p(ge), _p(gx), _p(gc), B, h, w, h, w, dda.backend.precision_id(prec), None),
+              "dd_denoise_once_backward")
+        errs = {"grad_x": rel(gx, g["grad_x"]), "grad_cond": rel(gc[:, :8], g["grad_cond_ch0_8"])}
+        for name in names:
+            key = "grad." + name
+            if key in g:
+                out = np.full(g[key].shape, np.nan, np.float32)
+                be.ck(lib.dd_get_grad(be.h, name.encode(), _p(out), out.size, None), "dd_get_grad")
+                errs[name] = rel(out, g[key])
+        print("f16x3 backward, f16 gradients: relative L2", errs)
+        assert max(errs.values()) < X3_F16_GRAD_REL, errs
 
 
 # ---- NLSPN refinement and the DCNv2 operator (include/ddepth_dcn.h) ------------------------------------------------------------------------------
