@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libddepth_hip.so")
-SOURCES = ["dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_wgrad2.hip", "dd_dcn.hip", "dd_thin.hip"]
+SOURCES = ["dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_wgrad2.hip", "dd_dcn.hip", "dd_thin.hip", "dd_msda.hip"]
 # every header under csrc/ and include/ (a stale-check that misses one -- dd_gcn.h in round 1 -- reuses an old .so after an edit)
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + \
           [os.path.join("..", "..", "include", f) for f in sorted(os.listdir(os.path.join(HERE, "..", "include"))) if f.endswith(".h")]

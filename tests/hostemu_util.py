@@ -62,7 +62,7 @@ def ptr(a):
 
 
 # ---- the whole library for the host: every csrc source + the harness units of tests/host_emul ------------------------------------------------------
-LIB_SOURCES = ("dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_wgrad2.hip", "dd_dcn.hip", "dd_thin.hip")
+LIB_SOURCES = ("dd_api.cpp", "dd_api_weights.cpp", "dd_api_plans.cpp", "dd_api_train.cpp", "dd_igemm2.hip", "dd_misc.hip", "dd_naive.hip", "dd_bwd.hip", "dd_wgrad.hip", "dd_wgrad2.hip", "dd_dcn.hip", "dd_thin.hip", "dd_msda.hip")
 HARNESS_UNITS = ("ddepth_host.cpp", "igemm2_host.cpp")
 _FLAGS = ["-std=c++17", "-O1", "-mf16c", "-x", "c++", "-DDD_HOST_EMULATION", "-Wno-psabi", "-Wno-unused-value", "-fPIC", "-c"]
 
@@ -102,7 +102,8 @@ def _objects():
     hsh = hashlib.sha1()
     deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
     deps += [os.path.join(EMU, u) for u in HARNESS_UNITS] + [os.path.join(EMU, "hip", "hip_runtime.h"),
-                                                              os.path.join(ROOT, "include", "ddepth.h"), os.path.join(ROOT, "include", "ddepth_dcn.h")]
+                                                              os.path.join(ROOT, "include", "ddepth.h"), os.path.join(ROOT, "include", "ddepth_dcn.h"),
+                                                              os.path.join(ROOT, "include", "ddepth_msda.h")]
     for s in deps:
         with open(s, "rb") as f:
             hsh.update(f.read())

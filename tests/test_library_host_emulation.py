@@ -605,6 +605,42 @@ def test_backward_vs_reference_autograd_golden(lib, golden, cases, prec):
         assert max(errs.values()) < X3_F16_GRAD_REL, errs
 
 
+# ---- multi-scale deformable attention of the HAHI neck (include/ddepth_msda.h) --------------------------------------------------------------------
+@pytest.mark.parametrize("seed,B,M,D,shapes,Q,P", [(1, 2, 2, 8, [(5, 7), (3, 4)], 6, 3), (2, 1, 8, 64, [(6, 8), (3, 4), (2, 2), (1, 1)], 5, 2),
+                                                     (3, 2, 3, 5, [(1, 9), (7, 1)], 4, 2), (4, 1, 2, 96, [(3, 3)], 3, 2)])
+def test_msda_forward_backward_vs_oracle(lib, seed, B, M, D, shapes, Q, P):
+    """csrc/dd_msda.hip, work-item by work-item (wave shuffles included), against the fp64 oracle: forward vs the operator's definition, backward vs
+    autograd through the oracle's grid_sample formulation.  Channel counts 8 / 64 / 5 / 96 take the shuffle widths 8 / 64 / 1 / 32."""
+    import torch
+    from oracle import msda_oracle as MO
+    from test_msda_cpu import make_case
+    c_int, c_vp = ctypes.c_int, ctypes.c_void_p
+    lib.dd_msda_last_error.restype = ctypes.c_char_p
+    lib.dd_msda_forward.argtypes = [c_vp] * 6 + [c_int] * 8 + [c_vp]
+    lib.dd_msda_backward.argtypes = [c_vp] * 9 + [c_int] * 8 + [c_vp]
+    value, sh, loc, attn = make_case(seed, B, M, D, shapes, Q, P)
+    starts = np.concatenate([[0], np.cumsum([h * w for h, w in shapes])[:-1]]).astype(np.int64)
+    K, L = value.shape[1], len(shapes)
+    out = np.full((B, Q, M * D), np.nan, np.float32)
+    assert lib.dd_msda_forward(_p(value), _p(sh), _p(starts), _p(loc), _p(attn), _p(out), B, K, M, D, L, Q, P, 64, None) == 0, lib.dd_msda_last_error()
+    want = MO.ms_deform_attn_core(value, sh, loc, attn)
+    assert maxabs(out, want) < 2e-6 * max(1.0, np.abs(want).max())
+    go = np.random.RandomState(seed + 10).standard_normal(out.shape).astype(np.float32)
+    tv, tl, ta = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (value, loc, attn))
+    (MO.ms_deform_attn_core_grid_sample(tv, sh, tl, ta) * torch.from_numpy(go).double()).sum().backward()
+    gv, gl, ga = np.full_like(value, np.nan), np.full_like(loc, np.nan), np.full_like(attn, np.nan)
+    assert lib.dd_msda_backward(_p(value), _p(sh), _p(starts), _p(loc), _p(attn), _p(go), _p(gv), _p(gl), _p(ga), B, K, M, D, L, Q, P, 64, None) == 0, lib.dd_msda_last_error()
+    for got, ref, name in ((gv, tv.grad, "grad_value"), (gl, tl.grad, "grad_sampling_loc"), (ga, ta.grad, "grad_attn_weight")):
+        ref = ref.numpy()
+        assert maxabs(got, ref) < 1e-5 * max(1.0, np.abs(ref).max()), name
+    # outputs nobody asked for are skipped; the others do not change
+    gl2 = np.full_like(loc, np.nan)
+    assert lib.dd_msda_backward(_p(value), _p(sh), _p(starts), _p(loc), _p(attn), _p(go), None, _p(gl2), None, B, K, M, D, L, Q, P, 64, None) == 0
+    assert np.array_equal(gl2, gl)
+    assert lib.dd_msda_forward(_p(value), _p(sh), _p(starts), _p(loc), _p(attn), _p(out), 3, K, M, D, L, Q, P, 2, None) == 1      # batch(3) % im2col_step(2)
+    assert b"im2col_step" in lib.dd_msda_last_error()
+
+
 # ---- NLSPN refinement and the DCNv2 operator (include/ddepth_dcn.h) ------------------------------------------------------------------------------
 def _bind_dcn(lib):
     c_int, c_vp = ctypes.c_int, ctypes.c_void_p
