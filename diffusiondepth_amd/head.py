@@ -128,7 +128,8 @@ class DDIMDepthEstimate_Res(nn.Module):
             bound.register("conv_up.", self.conv_up)
         # the HAHI neck's convolutions run in the library too (dd_neck_condition) for the two pyramids its kernels are built for (Swin-L,
         # MPViT-small); any other widths keep the PyTorch neck in front of the library's FPN
-        self._hip_neck = self._hip_fpn and self._HAHI and list(in_channels) in ([192, 384, 768, 1536], [128, 216, 288, 288])
+        self._hip_neck = (self._hip_fpn and self._HAHI and list(in_channels) in ([192, 384, 768, 1536], [128, 216, 288, 288])
+                          and not (self.hahineck.cross_att or self.hahineck.self_att))        # (dd_neck_condition is the attention-off neck: what every head builds)
         if self._hip_neck:
             bound.register("hahineck.", self.hahineck)
 

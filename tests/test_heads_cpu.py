@@ -53,12 +53,17 @@ def test_hahi_neck_matches_reference_golden(golden, cases):
         assert abs(float(o.abs().max()) - g[f"neck{i}_sum"][1]) < 2e-5, i
 
 
-def test_hahi_attention_is_refused_like_the_reference_cannot_run_it():
-    with pytest.raises(NotImplementedError, match="not runnable in the reference"):
-        dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, cross_att=True, self_att=False)
-    n = dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, cross_att=False, self_att=False)
-    with pytest.raises(NotImplementedError):
-        n.multi_att(torch.zeros(1, 4, 16))
+def test_hahi_attention_with_the_heads_four_inputs_fails_to_broadcast_as_in_the_reference():
+    """Since round 6 the neck carries the attention path (tests/test_msda_cpu.py): what the reference's construction implies for the FOUR inputs the
+    DiffusionDepth heads feed it -- num_levels = 4 against three transformer levels (hahi.py:109-118,176,182) -- is mmcv's broadcasting error, not a
+    result; attention off (what every head builds) runs."""
+    pe = dict(type="SinePositionalEncoding", num_feats=8)
+    n = dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, positional_encoding=pe, cross_att=True, self_att=False).eval()
+    x = [torch.zeros(1, 8, 8 >> i, 8 >> i) for i in range(4)]
+    with pytest.raises(RuntimeError, match="must match the size"):
+        n(x)
+    off = dda.HAHIHeteroNeck([8, 8, 8, 8], [8, 8, 8, 8], 16, positional_encoding=pe, cross_att=False, self_att=False).eval()
+    assert len(off(x)) == 4
 
 
 class _FakeBackend:

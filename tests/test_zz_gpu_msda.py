@@ -142,4 +142,15 @@ def test_operator_rate_at_the_neck_geometry(U):
     us = e0.elapsed_time(e1) / 20 * 1e3
     algo = (value.nbytes + loc.nbytes + attn.nbytes + out.numel() * 4)
     gathered = Q * M * len(shapes) * P * 4 * D * 4
-    U.record("msda_rate", us_per_call=us, algorithmic_GBps=algo / us / 1e3, gathered_GBps=gathered / us / 1e3)
+    # backward (all three gradients): the same gathers plus the scatter of grad_value (fp32 atomics) and the channel sums
+    tv.requires_grad_(True); tl.requires_grad_(True); ta.requires_grad_(True)
+    go = torch.ones_like(out)
+    o2 = f()
+    o2.backward(go, retain_graph=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        o2.backward(go, retain_graph=True)
+    e1.record(); torch.cuda.synchronize()
+    us_b = e0.elapsed_time(e1) / 5 * 1e3
+    U.record("msda_rate", us_per_call=us, algorithmic_GBps=algo / us / 1e3, gathered_GBps=gathered / us / 1e3, backward_us_per_call=us_b)
