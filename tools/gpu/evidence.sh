@@ -31,6 +31,8 @@ line swin_f16x3_b4 --steps 3 --warmup 1 --variant swin --precision f16x3 $X --no
 line c5_swin_f16r_t50_b1 --variant swin --T 50 --batch 1 --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra
 line train_dp_swin_b4 --mode train-dp --variant swin --batch 4 --steps 3 --warmup 1
 line train_dp_res_b4 --mode train-dp --variant res --batch 4 --steps 3 --warmup 1
+line train_dp_swin_f16x3_b4 --mode train-dp --variant swin --precision f16x3 --batch 4 --steps 3 --warmup 1
+line train_dp_res_f16x3_b4 --mode train-dp --variant res --precision f16x3 --batch 4 --steps 3 --warmup 1
 echo "== N=1 under the launcher"; timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline --no-train-extra --no-nlspn-extra --no-head-extra --no-latency-b1 > gpurun_out/bench_launcher_n1.log 2>&1; echo "rc=$?"; tail -n 1 gpurun_out/bench_launcher_n1.log | cut -c1-300
 echo "== rocprof swin f16r (one stream)"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_swin" -o bench --output-format csv -- python "$OLDPWD/bench.py" --variant swin --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-train-extra --no-latency-b1 --no-streams-extra --no-nlspn-extra --no-head-extra > "$OLDPWD/gpurun_out/rocprof_swin.log" 2>&1); echo "rocprof rc=$?"
