@@ -560,7 +560,7 @@ def test_hahi_neck_on_the_split_f16_kernels(lib):
 
 
 # ---- backward ----------------------------------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("prec", ["naive_fp32"] + (["fp32", "f16x3"] if FULL else []))      # f16x3 (round 6): the split kernels' forward, the fp32 mode's gradient kernels
+@pytest.mark.parametrize("prec", ["naive_fp32", "f16x3"] + (["fp32"] if FULL else []))      # f16x3 (round 6): the split kernels' forward; fp32 gradients (option) and f16 gradients (default) behind it
 def test_backward_vs_reference_autograd_golden(lib, golden, cases, prec):
     c, g = cases["denoise_bwd_res"], golden("denoise_bwd_res")
     be, _ = backend_for(lib, c)

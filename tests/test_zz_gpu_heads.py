@@ -295,3 +295,40 @@ def test_head_inference_switches(U, cases):
     assert float(outs["inf"]["ddim_loss"]) == 0.0 and outs["inf"]["ddim_loss"].is_cuda
     lr, ld = float(outs["ref"]["ddim_loss"]), float(outs["dev"]["ddim_loss"])
     assert np.isfinite(ld) and 0.5 * lr < ld < 2.0 * lr
+
+
+def test_training_refuses_to_continue_on_non_finite_gradients(U, cases):
+    """The always-on guard of the training path on the device (modules._note_grads / HipBound.check_grad_guard; the host-emulation twin is
+    tests/test_head_host_emulation.py): a backward of the library that returns NaN makes the next training forward raise before it uploads
+    parameters -- without a host synchronisation on the clean path (only flags whose event has completed are read: the test synchronises by hand
+    so that the poisoned step's flag is visible) -- and a re-seeded torch generator re-seeds the head's private loss-noise generator."""
+    import diffusiondepth_amd as dda
+    from diffusiondepth_amd import modules as M
+    c = cases["head_res"]
+    sd = synth.make_state_dict(c["wseed"], "res", c["decoder_gain"], c["decoder_log_scale"])
+    sd.update(synth.make_fpn_state_dict(c["fseed"]))
+    B, H, W = c["B"], c["H"], c["W"]
+    fp = [U.cu(f) for f in synth.make_backbone_features(c["iseed"], B, H, W)]
+    gt = U.cu(synth.make_gt_depth(c["iseed"] + 1, B, H, W))
+    head = _load(dda.DDIMDepthEstimate_Res(in_channels=[64, 128, 256, 512], inference_steps=3, num_train_timesteps=1000, depth_feature_dim=16, loss_cfgs=[],
+                                           precision="bf16", loss_noise_device="device"), sd).cuda().train()
+
+    def step(poison):
+        out = head([f.clone() for f in fp], gt, gt > 0, gt_depth_map=gt)
+        loss = (out["pred"] - gt).abs().mean() + out["ddim_loss"]
+        (loss * float("nan") if poison else loss).backward()
+        head.zero_grad()
+        torch.cuda.synchronize()
+        return float(out["ddim_loss"])
+    assert M.GRAD_GUARD
+    step(False); step(False)
+    step(True)
+    with pytest.raises(FloatingPointError, match="non-finite gradients"):
+        step(False)
+    step(False)                                    # the raise consumed the flag
+    # the device-side loss noise follows torch.manual_seed (ADVICE r5: the private generator used to be seeded once per process)
+    # (the generator re-seeds when torch.initial_seed() CHANGES: 11 -> 12 -> 11; x_T and the timesteps come from torch's own generator)
+    torch.manual_seed(11); a = step(False)
+    torch.manual_seed(12); d = step(False)
+    torch.manual_seed(11); b = step(False)
+    assert abs(a - b) <= 2e-3 * abs(a) and abs(a - d) > max(5 * abs(a - b), 1e-5 * abs(a)), (a, b, d)
