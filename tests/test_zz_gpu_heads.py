@@ -319,7 +319,7 @@ def test_training_refuses_to_continue_on_non_finite_gradients(U, cases):
         (loss * float("nan") if poison else loss).backward()
         head.zero_grad()
         torch.cuda.synchronize()
-        return float(out["ddim_loss"])
+        return float(out["ddim_loss"].detach())
     assert M.GRAD_GUARD
     step(False); step(False)
     step(True)
