@@ -58,6 +58,7 @@ int dd_destroy(dd_handle_t h) {
     if (h->lane_done[l]) (void)hipEventDestroy(h->lane_done[l]);
   }
   if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
+  for (hipStream_t b : h->burnt_streams) (void)hipStreamDestroy(b);
   delete h;
   return DD_OK;
 }
@@ -117,6 +118,7 @@ int dd_set_option(dd_handle_t h, const char* key, int64_t value) {
     h->bf16_pure = value != 0;
   }
   else if (k == "naive_wgrad") h->naive_wgrad = value != 0;
+  else if (k == "lane_probe") h->lane_probe = value != 0;
   else if (k == "x3_grad_fp32") h->x3_grad_fp32 = value != 0;
   else if (k == "keep_trajectory") h->keep_traj = value != 0;
   else if (k == "use_trajectory") h->use_traj = value;
@@ -180,6 +182,8 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   else if (k == "neck_launches") *value = h->n_neck_launches;
   else if (k == "trajectory_ticket") *value = h->traj_serial;
   else if (k == "lane_calls") *value = h->n_lane_calls;
+  else if (k == "lane_probe_retries") *value = h->n_lane_probe_retries;
+  else if (k == "lane_overlap") *value = h->lane_overlap_seen;
   else if (k == "cond_split_ok") *value = (h->fpn_committed && h->fpn_split_ok ? 1 : 0) | (h->neck_committed && h->neck_split_ok ? 2 : 0);   // bit 0: FPN, bit 1: neck weights fit the split-f16 images
   else if (k == "resident_slots") *value = h->resident_slots;      // workgroup slots at two per CU (2 x multiProcessorCount): what the tile rules compare tile counts with
   else if (k == "trajectory_reuses") *value = h->n_traj_reuse;
@@ -497,6 +501,56 @@ int denoise_lane(dd_handle_t h, const float* x_T, const float* cond, float* x_0,
 }
 }  // namespace ddapi
 
+namespace ddapi {
+// A lane's stream has to run CONCURRENTLY with the caller's.  The HIP runtime multiplexes the streams of a priority level onto GPU_MAX_HW_QUEUES
+// (default 4) hardware queues and, once that many exist, hands a new stream the least-used one -- in a process that created other streams first
+// (an eagerly initialised RCCL communicator: every rank of a data-parallel job; measured in round 6, profiles/r06_experiments.md section 9) that
+// is the caller's own queue, and two lanes in one hardware queue do not overlap: the KITTI B = 4 step ran 23 % slower than with concurrent lanes
+// (and slower than as ONE lane: the fork / join events serialise inside the queue).  So
+// the candidate is PROBED -- one idle ~100-us wavefront on each stream, forked and joined by events: together they take ~100 us when the
+// streams are concurrent, ~200 when they share a queue -- and a candidate that failed is kept alive (the next one then lands on another queue)
+// while another is tried, at most GPU_MAX_HW_QUEUES times.  Once per handle and lane (~0.5 ms); option "lane_probe" = 0 skips it; counters
+// "lane_overlap" (1 / 0 / -1 = not probed) and "lane_probe_retries".
+int acquire_lane_stream(dd_handle_t h, int lane, hipStream_t caller) {
+  hipStream_t cand = nullptr;
+  DD_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+#ifndef DD_HOST_EMULATION
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(caller, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (h->lane_probe && !capturing) {
+    hipEvent_t ea = nullptr, ed = nullptr, ec = nullptr;
+    DD_HIP(hipEventCreate(&ea)); DD_HIP(hipEventCreate(&ed)); DD_HIP(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+    const long long ticks = 10000;       // 100 us of the 100-MHz clock
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      DD_HIP(launch_spin(1, caller)); DD_HIP(launch_spin(1, cand));      // code object loaded, both queues awake
+      DD_HIP(hipStreamSynchronize(caller)); DD_HIP(hipStreamSynchronize(cand));
+      DD_HIP(hipEventRecord(ea, caller));
+      DD_HIP(hipStreamWaitEvent(cand, ea, 0));
+      DD_HIP(launch_spin(ticks, caller)); DD_HIP(launch_spin(ticks, cand));
+      DD_HIP(hipEventRecord(ec, cand));
+      DD_HIP(hipStreamWaitEvent(caller, ec, 0));
+      DD_HIP(hipEventRecord(ed, caller));
+      DD_HIP(hipEventSynchronize(ed));
+      float ms = 0.f;
+      DD_HIP(hipEventElapsedTime(&ms, ea, ed));
+      const bool overlap = ms < 0.160f;
+      h->lane_overlap_seen = overlap ? 1 : 0;
+      if (overlap || attempt == 3) break;
+      h->burnt_streams.push_back(cand);      // stays alive: its queue keeps its reference, the next candidate lands elsewhere
+      h->n_lane_probe_retries++;
+      cand = nullptr;
+      DD_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+    }
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(ed); (void)hipEventDestroy(ec);
+  }
+#else
+  (void)caller;
+#endif
+  h->lane_stream[lane] = cand;
+  return DD_OK;
+}
+}  // namespace ddapi
+
 extern "C" {
 
 int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, int B, int lat_h, int lat_w,
@@ -521,7 +575,7 @@ int dd_denoise(dd_handle_t h, const float* x_T, const float* cond, float* x_0, i
   if (h->variant == DD_VARIANT_SWIN && h->swin_w5 && want_hoist(h, precision, T, h->keep_traj ? 1 : 0)) { rc = ensure_swin_w5(h, s); if (rc) return rc; }
   if (S <= 1) return denoise_lane(h, x_T, cond, x_0, B, lat_h, lat_w, cond_h, cond_w, T, precision, s, 0, 0, B, ticket, 1);
   for (int l = 1; l < S; ++l) {
-    if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    if (!h->lane_stream[l]) { rc = acquire_lane_stream(h, l, s); if (rc) return rc; }
     if (!h->lane_done[l]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
   }
   if (!h->lane_fork) DD_HIP(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));

@@ -258,6 +258,9 @@ struct dd_handle_s {
   DevBuf wmax;                // device route: bits of max |w| over the forward convolution weights (launch_max_abs)
   int resident_slots = 512;   // workgroup slots the chip holds at two per CU (dd_create: 2 x multiProcessorCount): the big-tile rule and thin_slots' default
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipStream_t> burnt_streams;      // lane-stream candidates that did not run concurrently with the caller's stream (kept alive: acquire_lane_stream)
+  int lane_probe = 1;                          // option "lane_probe": 1 = a lane's stream is probed for concurrency with the caller's when it is created
+  int64_t n_lane_probe_retries = 0, lane_overlap_seen = -1;      // counters "lane_probe_retries", "lane_overlap" (-1 = never probed)
   hipEvent_t lane_fork = nullptr, lane_done[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   int64_t n_lane_calls = 0;
   int active_lanes = 1;       // lanes of the dd_denoise_backward call in progress (the weight-gradient kernels size their slab count by it)
@@ -328,6 +331,7 @@ int commit_model_from_device(dd_handle_t h, hipStream_t s);
 int check_common(dd_handle_t h, int B, int lh, int lw, int ch, int cw, bool need_schedule);
 int lane_count(dd_handle_t h, int B, int precision);
 int check_split(dd_handle_t h, int precision, const char* who);
+int acquire_lane_stream(dd_handle_t h, int lane, hipStream_t caller);      // dd_api.cpp: creates h->lane_stream[lane] (probed for concurrency with `caller`)
 int get_cond_buf(dd_handle_t h, int B, int lh, int lw, int precision, std::shared_ptr<DevBuf>* out, int lane = 0);
 int want_hoist(dd_handle_t h, int precision, int T = 1, int keep = 0);
 bool keep2_fits(dd_handle_t h, size_t need);

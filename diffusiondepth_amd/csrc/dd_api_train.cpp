@@ -411,7 +411,7 @@ int dd_denoise_backward(dd_handle_t h, const float* x_T, const float* cond, cons
     return rc ? rc : check_finite_report(h, s);
   }
   for (int l = 1; l < S; ++l) {
-    if (!h->lane_stream[l]) DD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+    if (!h->lane_stream[l]) { rc = acquire_lane_stream(h, l, s); if (rc) return rc; }
     if (!h->lane_done[l]) DD_HIP(hipEventCreateWithFlags(&h->lane_done[l], hipEventDisableTiming));
   }
   if (!h->lane_fork) DD_HIP(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));

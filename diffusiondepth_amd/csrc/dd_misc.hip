@@ -1164,6 +1164,20 @@ __global__ void __launch_bounds__(256) count_nonfinite_kernel(const void* __rest
   }
   if (c) atomicAdd(out, c);
 }
+// One wavefront that does nothing for `ticks` of the constant 100-MHz clock: the two halves of the lane-overlap probe (dd_api.cpp: acquire_lane_stream)
+#ifndef DD_HOST_EMULATION
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_spin(long long ticks, hipStream_t s) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+  return hipGetLastError();
+}
+#else
+hipError_t launch_spin(long long, hipStream_t) { return hipSuccess; }
+#endif
+
 hipError_t launch_count_nonfinite(const void* p, long long n, int kind, unsigned* out, hipStream_t s) {
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(count_nonfinite_kernel, dim3(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb)), dim3(256), 0, s, p, n, kind, out);

@@ -230,7 +230,9 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
  * dd_denoise runs the B images as S concurrent sub-batches -- lane 0 on the caller's stream, the others on streams the handle owns, forked
  * and joined by events on the caller's stream, one plan and hipGraph per lane; the images are independent and every image's result is bit-identical to the one-lane call's as long as both take the same tile form -- since round 6 the Res denoiser's hoisted conv3 pair keeps its 8x32 tiles for every lane count (the Swin 5x5 form moves to 16x32 tiles when its 8x32 tiles exceed the resident slots, whatever the lane count), so they do; option "big_tiles" forces one form;
  * dd_denoise_backward splits the same way, with one parameter-gradient set per lane summed into the caller-visible one at the join;
- * default 1), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
+ * default 1; a lane's stream is probed for concurrency with the caller's when it is created -- two idle ~100-us wavefronts, forked and joined by events --
+ * and replaced when the HIP runtime put both on one hardware queue, as it does in a process that created other streams first, e.g. an eagerly
+ * initialised RCCL communicator: option "lane_probe" = 0 skips the probe, counters "lane_overlap" / "lane_probe_retries" report it), "adjoint_tiled" (0 = the plain kernel for the adjoint of the Swin condition upsampling, A/B check),
  * "keep_activations_mb" (budget of the per-step activation slots kept by "keep_trajectory" forwards, default 65536: ONE figure for the
  * handle -- all lanes and shapes -- also held against the free device memory; stale sets are dropped first, and a forward that cannot
  * keep its activations keeps the states only), "thin_stream" (1 [default] = conv4 runs as the persistent streaming kernel of
