@@ -59,6 +59,7 @@ int dd_destroy(dd_handle_t h) {
   }
   if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
   for (hipStream_t b : h->burnt_streams) (void)hipStreamDestroy(b);
+  for (hipEvent_t e : h->probe_events) (void)hipEventDestroy(e);
   delete h;
   return DD_OK;
 }
@@ -507,8 +508,8 @@ namespace ddapi {
 // (an eagerly initialised RCCL communicator: every rank of a data-parallel job; measured in round 6, profiles/r06_experiments.md section 9) that
 // is the caller's own queue, and two lanes in one hardware queue do not overlap: the KITTI B = 4 step ran 23 % slower than with concurrent lanes
 // (and slower than as ONE lane: the fork / join events serialise inside the queue).  So
-// the candidate is PROBED -- one idle ~100-us wavefront on each stream, forked and joined by events: together they take ~100 us when the
-// streams are concurrent, ~200 when they share a queue -- and a candidate that failed is kept alive (the next one then lands on another queue)
+// the candidate is PROBED -- one idle ~100-us wavefront on each stream, forked and joined by events, each writing its own start / end ticks of the
+// device clock: the two intervals coincide when the streams are concurrent and follow each other when they share a queue -- and a candidate that failed is kept alive (the next one then lands on another queue)
 // while another is tried, at most GPU_MAX_HW_QUEUES times.  Once per handle and lane (~0.5 ms); option "lane_probe" = 0 skips it; counters
 // "lane_overlap" (1 / 0 / -1 = not probed) and "lane_probe_retries".
 int acquire_lane_stream(dd_handle_t h, int lane, hipStream_t caller) {
@@ -518,30 +519,46 @@ int acquire_lane_stream(dd_handle_t h, int lane, hipStream_t caller) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(caller, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
   if (h->lane_probe && !capturing) {
+    // The probe's clock is the DEVICE's: each idle wavefront writes its own start / end ticks.  Not hipEventElapsedTime -- a timing-enabled event that
+    // another stream waits on (the fork below) made the HIP runtime's graph fast path corrupt launches on the caller's stream some 16 000 packets
+    // later (300 back-to-back eval forwards went wrong at forward ~234 in 20 of 30 processes; none of 12 with events created with
+    // hipEventDisableTiming, none with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: profiles/r06_experiments.md section 10).  Every event the library lets a
+    // stream wait on is created with hipEventDisableTiming; these three stay alive with the handle (the configuration that was soaked).
     hipEvent_t ea = nullptr, ed = nullptr, ec = nullptr;
-    DD_HIP(hipEventCreate(&ea)); DD_HIP(hipEventCreate(&ed)); DD_HIP(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+    long long* stamps = nullptr;
+    DD_HIP(hipEventCreateWithFlags(&ea, hipEventDisableTiming)); DD_HIP(hipEventCreateWithFlags(&ed, hipEventDisableTiming)); DD_HIP(hipEventCreateWithFlags(&ec, hipEventDisableTiming));
+    h->probe_events.push_back(ea); h->probe_events.push_back(ed); h->probe_events.push_back(ec);
+    DD_HIP(hipMalloc(&stamps, 4 * sizeof(long long)));
     const long long ticks = 10000;       // 100 us of the 100-MHz clock
+    int rc_ = DD_OK;
     for (int attempt = 0; attempt < 4; ++attempt) {
-      DD_HIP(launch_spin(1, caller)); DD_HIP(launch_spin(1, cand));      // code object loaded, both queues awake
-      DD_HIP(hipStreamSynchronize(caller)); DD_HIP(hipStreamSynchronize(cand));
-      DD_HIP(hipEventRecord(ea, caller));
-      DD_HIP(hipStreamWaitEvent(cand, ea, 0));
-      DD_HIP(launch_spin(ticks, caller)); DD_HIP(launch_spin(ticks, cand));
-      DD_HIP(hipEventRecord(ec, cand));
-      DD_HIP(hipStreamWaitEvent(caller, ec, 0));
-      DD_HIP(hipEventRecord(ed, caller));
-      DD_HIP(hipEventSynchronize(ed));
-      float ms = 0.f;
-      DD_HIP(hipEventElapsedTime(&ms, ea, ed));
-      const bool overlap = ms < 0.160f;
+      hipError_t e = launch_spin(1, nullptr, caller);                                     // code object loaded, both queues awake
+      if (e == hipSuccess) e = launch_spin(1, nullptr, cand);
+      if (e == hipSuccess) e = hipStreamSynchronize(caller);
+      if (e == hipSuccess) e = hipStreamSynchronize(cand);
+      if (e == hipSuccess) e = hipEventRecord(ea, caller);
+      if (e == hipSuccess) e = hipStreamWaitEvent(cand, ea, 0);
+      if (e == hipSuccess) e = launch_spin(ticks, stamps, caller);
+      if (e == hipSuccess) e = launch_spin(ticks, stamps + 2, cand);
+      if (e == hipSuccess) e = hipEventRecord(ec, cand);
+      if (e == hipSuccess) e = hipStreamWaitEvent(caller, ec, 0);
+      if (e == hipSuccess) e = hipEventRecord(ed, caller);
+      if (e == hipSuccess) e = hipEventSynchronize(ed);
+      long long t[4] = {0, 0, 0, 0};
+      if (e == hipSuccess) e = hipMemcpy(t, stamps, sizeof t, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) { rc_ = h->fail(DD_ERR_HIP, std::string("lane-overlap probe: ") + hipGetErrorString(e)); break; }
+      const long long lo = t[0] > t[2] ? t[0] : t[2], hi = t[1] < t[3] ? t[1] : t[3];      // intersection of the two idle intervals
+      const bool overlap = hi - lo > ticks / 2;
       h->lane_overlap_seen = overlap ? 1 : 0;
       if (overlap || attempt == 3) break;
       h->burnt_streams.push_back(cand);      // stays alive: its queue keeps its reference, the next candidate lands elsewhere
       h->n_lane_probe_retries++;
       cand = nullptr;
-      DD_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+      e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+      if (e != hipSuccess) { rc_ = h->fail(DD_ERR_HIP, std::string("lane-overlap probe: ") + hipGetErrorString(e)); break; }
     }
-    (void)hipEventDestroy(ea); (void)hipEventDestroy(ed); (void)hipEventDestroy(ec);
+    (void)hipFree(stamps);
+    if (rc_) { if (cand) (void)hipStreamDestroy(cand); return rc_; }
   }
 #else
   (void)caller;

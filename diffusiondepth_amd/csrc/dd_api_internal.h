@@ -258,6 +258,7 @@ struct dd_handle_s {
   DevBuf wmax;                // device route: bits of max |w| over the forward convolution weights (launch_max_abs)
   int resident_slots = 512;   // workgroup slots the chip holds at two per CU (dd_create: 2 x multiProcessorCount): the big-tile rule and thin_slots' default
   hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> probe_events;
   std::vector<hipStream_t> burnt_streams;      // lane-stream candidates that did not run concurrently with the caller's stream (kept alive: acquire_lane_stream)
   int lane_probe = 1;                          // option "lane_probe": 1 = a lane's stream is probed for concurrency with the caller's when it is created
   int64_t n_lane_probe_retries = 0, lane_overlap_seen = -1;      // counters "lane_probe_retries", "lane_overlap" (-1 = never probed)

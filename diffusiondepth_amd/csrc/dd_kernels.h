@@ -198,7 +198,7 @@ hipError_t launch_pack_weights(const float* src_oihw, void* dst, const PackGeom&
 hipError_t launch_transpose_flip(const float* w, float* wt, int cout, int cin, int kk, hipStream_t s);
 // *out_bits = max(*out_bits, bits of max |w|) (non-negative floats order like their bit patterns; NaN sorts above every finite value)
 hipError_t launch_max_abs(const float* w, long long n, unsigned* out_bits, hipStream_t s);
-hipError_t launch_spin(long long ticks_100mhz, hipStream_t s);       // one idle wavefront for that long (lane-overlap probe)
+hipError_t launch_spin(long long ticks_100mhz, long long* stamp2, hipStream_t s);       // one idle wavefront for that long; its start / end ticks to stamp2 (lane-overlap probe)
 hipError_t launch_count_nonfinite(const void* p, long long n, int kind, unsigned* out, hipStream_t s);      // debug: kind 0 fp32, 1 bf16, 2 f16, 3 fp64
 
 // ---- layout / elementwise / codec kernels (dd_misc.hip) ----------------------------------------

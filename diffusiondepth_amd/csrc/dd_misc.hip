@@ -1166,16 +1166,17 @@ __global__ void __launch_bounds__(256) count_nonfinite_kernel(const void* __rest
 }
 // One wavefront that does nothing for `ticks` of the constant 100-MHz clock: the two halves of the lane-overlap probe (dd_api.cpp: acquire_lane_stream)
 #ifndef DD_HOST_EMULATION
-__global__ void spin_kernel(long long ticks) {
+__global__ void spin_kernel(long long ticks, long long* __restrict__ stamp) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (stamp && threadIdx.x == 0) { stamp[0] = t0; stamp[1] = wall_clock64(); }
 }
-hipError_t launch_spin(long long ticks, hipStream_t s) {
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+hipError_t launch_spin(long long ticks, long long* stamp, hipStream_t s) {
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks, stamp);
   return hipGetLastError();
 }
 #else
-hipError_t launch_spin(long long, hipStream_t) { return hipSuccess; }
+hipError_t launch_spin(long long, long long*, hipStream_t) { return hipSuccess; }
 #endif
 
 hipError_t launch_count_nonfinite(const void* p, long long n, int kind, unsigned* out, hipStream_t s) {
