@@ -45,6 +45,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (before the HIP runtime loads): RCCL across processes needs it on this driver
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")  # the runtime's graph fast path off BEFORE the first HIP call (torch.cuda.set_device below): hipGraph replays stay exact (diffusiondepth_amd/__init__.py)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

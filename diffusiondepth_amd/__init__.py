@@ -5,6 +5,13 @@ head / pipeline / scheduler / depth-transform interfaces; all arithmetic on the 
 ``libddepth_hip.so`` (hand-written HIP for gfx950, C ABI in ``include/ddepth.h``).  There is no CPU
 fallback: importing works anywhere, running needs the built library and a GPU.
 """
+import os as _os
+
+# The HIP 7.0 runtime's graph fast path ("packet capture") corrupts long runs of hipGraph replays next to eager launches (profiles/r06_experiments.md section 10);
+# the runtime reads this switch ONCE, at its first HIP call -- so it is exported here, at import, unless the caller decided otherwise.  A handle created in a
+# process where it is not "0" (HIP initialised before this import, C-ABI callers) enqueues its loops eagerly instead (include/ddepth.h, option "graph").
+_os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 from .scheduler import DDIMScheduler
 from .backend import HipDenoiser, precision_id, library_path, load_library
 from .modules import ScheduledCNNRefine, CNNDDIMPipiline, DeepDepthTransformWithUpsampling

@@ -1,6 +1,7 @@
 // dd_api.cpp -- C ABI (include/ddepth.h) over the HIP kernels: handle, parameter packing, per-shape
 // plans (scratch + schedule tables + captured hipGraph of the T-step loop) and launch sequencing.
 #include "dd_api_internal.h"
+#include <cstdlib>
 
 namespace ddapi {
 thread_local std::string g_create_error;
@@ -39,6 +40,17 @@ int dd_create(dd_handle_t* out, int device, int variant) {
       h->resident_slots = 2 * prop.multiProcessorCount;
       h->thin_slots = h->resident_slots > 4096 ? 4096 : h->resident_slots;
     }
+  }
+  {
+    // hipGraph replay is the DEFAULT only where it is safe.  With the HIP 7.0 runtime's graph fast path ("packet capture": pre-built AQL packets copied into
+    // the hardware queue) long runs of replays next to eager launches on the same stream give WRONG results in windows of ~70 launches every few
+    // thousand packets -- 800 back-to-back eval forwards: 4 of 4 processes wrong from forward ~307 on, 0 of 4 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+    // (profiles/r06_experiments.md section 10; the same switch separates round 5's intermittent training NaN).  The runtime reads that variable once, when it
+    // initialises: the Python package, bench.py and the tests export it = 0 before their first HIP call, and a handle created in a process WITHOUT it
+    // enqueues its loops eagerly (option "graph" = 1 overrides) -- the same kernels in the same order, measured at the same rate (557 vs 557 maps/s).
+    const char* pc = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
+    h->use_graph = pc && pc[0] == '0' && pc[1] == 0;
+    h->graph_off_by_env = !h->use_graph;
   }
   *out = h;
   return DD_OK;
@@ -177,6 +189,7 @@ int dd_get_counter(dd_handle_t h, const char* key, int64_t* value) {
   if (!h || !key || !value) return DD_ERR_INVALID_ARG;
   const std::string k(key);
   if (k == "graph_launches") *value = h->n_graph_launches;
+  else if (k == "graph_default") *value = h->graph_off_by_env ? 0 : 1;       // 0 = this handle defaulted to eager loops: DEBUG_CLR_GRAPH_PACKET_CAPTURE was not "0" when it was created
   else if (k == "eager_loops") *value = h->n_eager_loops;
   else if (k == "graph_capture_failures") *value = h->n_capture_failures;
   else if (k == "plans") *value = (int64_t)h->plans.size();

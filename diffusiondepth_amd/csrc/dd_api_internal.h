@@ -233,6 +233,7 @@ struct dd_handle_s {
   DevBuf d_acp;
   int n_train = 0;
   bool use_graph = true, timing = false, debug_sync = false, layer_timing = false;
+  bool graph_off_by_env = false;      // dd_create: the runtime's graph fast path was not switched off in the environment -> eager loops by default
   int graph_fence = 0;                // option "graph_fence" (diagnosis of the training-graph fault, profiles/r06_experiments.md section 5): bit 0 = hipStreamSynchronize in FRONT of every
                                       // hipGraphLaunch, bit 1 = behind it, bit 2 = the graph is launched on the handle's own capture stream between two events instead of on the caller's stream
   bool train_graphs = false;          // option "train_graphs": 1 = the trajectory-keeping forward of a training step replays a hipGraph too (A/B; default eager)

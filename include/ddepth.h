@@ -217,7 +217,9 @@ int dd_decode(dd_handle_t h, const float* latent, float* depth, int B, int lat_h
 /* ---- introspection (tests, bench) ----------------------------------------------------------------
  * Time of the last dd_denoise graph launch measured with hipEvents recorded on `stream` around
  * the graph (0 if timing is off).  dd_set_option("timing", 1) enables it; other options:
- * "graph" (1 = hipGraph replay [default], 0 = eager launches), "debug_sync" (1 = sync + check
+ * "graph" (1 = hipGraph replay, 0 = eager launches.  Default: 1 in a process whose environment had DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 when the handle was
+ * created, else 0 -- the HIP 7.0 runtime's graph fast path gives wrong results in long runs of replays next to eager launches on one stream, and reads that
+ * variable once, at its own initialisation: export it before the process's first HIP call; counter "graph_default" reports which default a handle took), "debug_sync" (1 = sync + check
  * after every launch), "hoist_cond" (1 = conv3(cond) and conv3(E[t]) are taken out of the DDIM loop by linearity; 0 = the
  * condition map is re-added in conv3's prologue every step; -1 [default] = hoisted in the bf16 and f16 modes of the Res variant.  Swin variant,
  * plans of the loop that keep nothing for a backward: the step-invariant part of pred.0(convB(convA(.))) -- the upsampled condition map through

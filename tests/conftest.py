@@ -8,6 +8,8 @@ if os.environ.get("PYTEST_XDIST_WORKER"):
     os.environ.setdefault("OMP_NUM_THREADS", "2")
     os.environ.setdefault("MKL_NUM_THREADS", "2")
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")      # before any HIP call of the session: what `import diffusiondepth_amd` exports too (profiles/r06_experiments.md section 10)
+
 import numpy as np
 import pytest
 

@@ -559,6 +559,33 @@ def test_hahi_neck_on_the_split_f16_kernels(lib):
     be.close()
 
 
+def test_graph_replay_is_the_default_only_with_the_runtimes_graph_fast_path_off(lib, monkeypatch):
+    """Round 6 (profiles/r06_experiments.md section 10): the HIP 7.0 runtime's graph fast path corrupts long runs of replays next to eager launches; the runtime
+    reads DEBUG_CLR_GRAPH_PACKET_CAPTURE once, when it initialises.  A handle created in a process where that variable is "0" (what importing the package,
+    bench.py and this suite's conftest export) replays its loop as a hipGraph; one created without it enqueues the same kernels eagerly -- bit-identical results;
+    option "graph" overrides either way."""
+    inp = synth.make_inputs(4, 1, 6, 33)
+    sd = synth.make_state_dict(7240)
+    outs = {}
+    for tag, env, force in (("graph", "0", None), ("eager", None, None), ("unset_but_forced", None, 1), ("other_value", "1", None)):
+        if env is None:
+            monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+        else:
+            monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", env)
+        be = EmuDenoiser(lib, "res")
+        be.load_state_dict(sd); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+        assert be.counter("graph_default") == (1 if env == "0" else 0), tag
+        if force is not None:
+            be.set_option("graph", force)
+        for _ in range(2):                      # (the first use of a plan is an eager pass in front of the capture)
+            outs[tag] = be.denoise(inp["x_T"], inp["cond"], 3, "f16")
+        want_graph = env == "0" or force == 1
+        assert (be.counter("graph_launches") > 0) == want_graph and (be.counter("eager_loops") > 0 or want_graph), (tag, be.counter("graph_launches"), be.counter("eager_loops"))
+        be.close()
+    assert all(np.array_equal(outs["graph"], v) for v in outs.values())
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0"      # (monkeypatch restores the session's value afterwards)
+
+
 # ---- backward ----------------------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", ["naive_fp32", "f16x3"] + (["fp32"] if FULL else []))      # f16x3 (round 6): the split kernels' forward; fp32 gradients (option) and f16 gradients (default) behind it
 def test_backward_vs_reference_autograd_golden(lib, golden, cases, prec):
