@@ -852,7 +852,12 @@ def main():
                        "maps_per_gpu_per_step": B, "global_batch": B * world, "parallelism": f"dp{world} (independent images, no collective)",
                        "ranks_seen": ranks_seen, "process_group": (f"{dist.get_backend()} (RCCL), world size {dist.get_world_size()}" if dist is not None else None),
                        "streams": args.streams, "options": args.set,
-                       "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant},
+                       "graph": be.counter("graph_launches") > 0, "flops_per_map": T * h * w * FPS, "variant": args.variant,
+                       # the runtime facts of this process (round 6): hipGraph replay is the default only with the HIP runtime's graph fast path off (exported above, before the
+                       # first HIP call); a lane's stream is probed for concurrency with the caller's when created -- under a launcher the RCCL communicator comes first
+                       "runtime": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"), "graph_default": int(be.counter("graph_default")),
+                                   "graph_launches": int(be.counter("graph_launches")), "eager_loops": int(be.counter("eager_loops")),
+                                   "lane_overlap": int(be.counter("lane_overlap")), "lane_probe_retries": int(be.counter("lane_probe_retries"))}},
             "roofline": roof, "roofline_b1": roof1, "cpu_baseline": cpu, "latency_b1": lat, "other_stream_count": lanes, "training_step": train, "nlspn_refine": nlspn, "head_forward": headx,
             "spread": spread,
         }

@@ -100,3 +100,17 @@ def test_model_facade_builds_and_names_backbones():
     feats = m.depth_backbone(torch.zeros(1, 3, 32, 48))
     assert [f.shape[1] for f in feats] == [64, 128, 256, 512]
     assert [tuple(f.shape[-2:]) for f in feats] == [(16, 24), (8, 12), (4, 6), (2, 3)]
+
+
+def test_importing_the_package_switches_the_runtimes_graph_fast_path_off():
+    """Round 6 (profiles/r06_experiments.md section 10): the HIP runtime reads DEBUG_CLR_GRAPH_PACKET_CAPTURE once, at its first HIP call; the package exports it = 0
+    at import unless the caller decided otherwise (setdefault), and so do bench.py, __graft_entry__.py and this test session (tests/conftest.py)."""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    code = "import os, sys; sys.path.insert(0, %r); import diffusiondepth_amd; print(os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))" % ROOT
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1] == "0"
+    env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "1"         # the caller's own choice is left alone (the handle then defaults to eager loops: include/ddepth.h, option "graph")
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1] == "1"
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    for f in ("bench.py", "__graft_entry__.py"):
+        assert 'os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")' in open(os.path.join(ROOT, f)).read().split("import torch")[0] or f == "__graft_entry__.py", f
