@@ -8,8 +8,11 @@ fallback: importing works anywhere, running needs the built library and a GPU.
 import os as _os
 
 # The HIP 7.0 runtime's graph fast path ("packet capture") corrupts long runs of hipGraph replays next to eager launches (profiles/r06_experiments.md section 10);
-# the runtime reads this switch ONCE, at its first HIP call -- so it is exported here, at import, unless the caller decided otherwise.  A handle created in a
-# process where it is not "0" (HIP initialised before this import, C-ABI callers) enqueues its loops eagerly instead (include/ddepth.h, option "graph").
+# the runtime reads this switch ONCE, at its first HIP call.  GRAPH_REPLAY_SAFE = the process's environment ALREADY had it = 0 when this package was imported (the
+# job exported it; bench.py, the tests and the entry points set it in their first lines): only then do this binding's handles replay their loops as hipGraphs.
+# Otherwise the variable is exported here for what it is worth (it takes effect if no HIP call has happened yet -- which this package cannot know: even
+# torch.cuda.is_available() initialises the runtime) and the handles enqueue their loops EAGERLY: the same kernels in the same order, measured at the same rate.
+GRAPH_REPLAY_SAFE = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
 from .scheduler import DDIMScheduler

@@ -149,6 +149,13 @@ class HipDenoiser:
         # binding's is 2 (the whole GPU suite passes either way; DDEPTH_STREAMS=1 turns it off); bench.py pins 1 for its headline line,
         # whose roofline object is defined per launch on one stream.  (An apparent instability of the head forward under it was a host-side
         # pause in a short average: profiles/history/r02_run29_lanes_head_trace.md.)
+        # hipGraph replay only in a process whose environment had the runtime's graph fast path switched off BEFORE this package was imported
+        # (diffusiondepth_amd/__init__.py: GRAPH_REPLAY_SAFE; DDEPTH_GRAPH=0 / 1 overrides): the library's own default trusts the variable as it finds it
+        # at dd_create, which this package may have exported too late to matter
+        import diffusiondepth_amd as _pkg
+        want_graph = os.environ.get("DDEPTH_GRAPH")
+        self.graph_replay = bool(int(want_graph)) if want_graph not in (None, "") else bool(getattr(_pkg, "GRAPH_REPLAY_SAFE", False))
+        self.set_option("graph", 1 if self.graph_replay else 0)
         self.n_streams = max(1, int(os.environ.get("DDEPTH_STREAMS", "2") or 2))
         if self.n_streams > 1:
             self.set_option("streams", self.n_streams)
