@@ -161,3 +161,41 @@ def test_train_dp_under_the_launcher_takes_the_collective_path_with_one_rank():
     assert d["collectives_launched_in_backward"] >= 1 and d["backward_reads_kept_states"] and d["value"] > 0
     r2, d2 = _bench(["--gpus", "1", "--mode", "train-dp", "--variant", "res", "--size", "nyu", "--batch", "2", "--steps", "2", "--warmup", "1"], launcher=False)
     assert r2.returncode == 0 and not d2["config"]["reducer_active"] and d2["config"]["process_group"] is None
+
+
+GRAPH_RULE_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["DD_ROOT"])
+if os.environ.get("TOUCH_HIP_FIRST") == "1":
+    assert torch.cuda.is_available()              # a first HIP call BEFORE the package is imported: the runtime has read its switches
+import diffusiondepth_amd as dda
+from diffusiondepth_amd import synth
+be = dda.HipDenoiser(torch.device("cuda", 0))
+be.load_state_dict(synth.make_state_dict(7240)); be.set_schedule(dda.DDIMScheduler().alphas_cumprod)
+inp = synth.make_inputs(3, 2, 9, 33)
+x, c = torch.from_numpy(inp["x_T"]).cuda(), torch.from_numpy(inp["cond"]).cuda()
+outs = [be.denoise(x, c, 4, "f16r").cpu() for _ in range(3)]
+assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+print("RULE", dda.GRAPH_REPLAY_SAFE, be.graph_replay, be.counter("graph_default"), be.counter("graph_launches") > 0, be.counter("eager_loops") > 0, float(outs[0].double().sum()))
+"""
+
+
+def test_the_binding_replays_graphs_only_where_the_fast_path_switch_was_in_the_environment():
+    """Round 6: hipGraph replay only in a process whose environment had DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the package was imported (this session: tests/conftest.py);
+    without it -- whether or not a HIP call came first -- the same kernels are enqueued eagerly and give the same numbers; DDEPTH_GRAPH overrides."""
+    base = {k: v for k, v in os.environ.items() if k not in ("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "DDEPTH_GRAPH")}
+    base["DD_ROOT"] = ROOT
+    res = {}
+    for tag, extra in (("exported", {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0"}), ("not_exported", {}), ("hip_first", {"TOUCH_HIP_FIRST": "1"}),
+                       ("fast_path_on", {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "1"}), ("forced_off", {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "0", "DDEPTH_GRAPH": "0"})):
+        r = subprocess.run([sys.executable, "-c", GRAPH_RULE_SCRIPT], env=dict(base, **extra), capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RULE")]
+        assert r.returncode == 0 and line, (tag, r.stdout[-1500:] + r.stderr[-2500:])
+        res[tag] = line[-1].split()[1:]
+    #                          GRAPH_REPLAY_SAFE  binding replays  C default  graph launches  eager loops
+    assert res["exported"][:5] == ["True", "True", "1", "True", "True"] or res["exported"][:4] == ["True", "True", "1", "True"], res      # (a plan's first use is an eager pass in front of the capture)
+    assert res["not_exported"][:2] == ["False", "False"] and res["not_exported"][3] == "False" and res["not_exported"][4] == "True", res
+    assert res["hip_first"][:2] == ["False", "False"] and res["hip_first"][3] == "False", res
+    assert res["fast_path_on"][:3] == ["False", "False", "0"] and res["fast_path_on"][3] == "False", res
+    assert res["forced_off"][0] == "True" and res["forced_off"][1] == "False" and res["forced_off"][3] == "False", res
+    assert len({r[5] for r in res.values()}) == 1, res          # the same numbers every way
